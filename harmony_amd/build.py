@@ -1,0 +1,39 @@
+"""Build libharmony_mi355x.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m harmony_amd.build            # or: from harmony_amd.build import build; build()
+
+The library is written to harmony_amd/lib/ so that it travels with the repo snapshot to
+the GPU box (a JIT cache under ~/.cache would not).  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, "csrc", "hmx_kernels.hip"), os.path.join(HERE, "csrc", "hmx_api.cpp")]
+HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "..", "include", "harmony_mi355x.h")]
+OUT = os.path.join(HERE, "lib", "libharmony_mi355x.so")
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(p) > t for p in SRC + HDR)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
+           "-Wno-unused-result", "-o", OUT] + SRC + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

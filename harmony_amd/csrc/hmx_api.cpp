@@ -1,0 +1,848 @@
+// hmx_api.cpp -- host orchestration behind the C ABI of include/harmony_mi355x.h.
+// Mirrors the reference's `harmony` object (src/harmony.h:20-70): same methods, same
+// per-call operation order, but every pass over the cells is a gfx950
+// kernel (hmx_kernels.hip) and all per-cell state stays in HBM between calls.
+#include "../../include/harmony_mi355x.h"
+#include "hmx_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <numeric>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace hmx;
+
+namespace {
+
+inline uint64_t h_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+inline uint32_t h_fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+int my_ceil(float num) {  // src/utils.cpp:102-108
+  int inum = (int)num;
+  if (num == (float)inum) return inum;
+  return inum + 1;
+}
+constexpr unsigned long long SEED_SENTINEL = 0x7fffffffffffffffull;
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct hmx_ctx {
+  // ---- sharding -------------------------------------------------------------------
+  int rank = 0, world = 1;
+  int64_t goff = 0, N_global = 0;
+  hmx_allreduce_fn ar = nullptr; void* ar_user = nullptr;
+  int (*poll)(void*) = nullptr; void* poll_user = nullptr;
+  // ---- problem --------------------------------------------------------------------
+  int64_t N = 0;  // local cells
+  int d = 0, K = 0, B = 0, C = 0, Q = 0;
+  std::vector<int> B_vec, cov_bounds;
+  std::vector<float> sigma, theta, lambda, Pr_b, sizes;
+  bool lambda_estimation = false;
+  float alpha = 0.2f, block_size = 0.05f, eps_k = 1e-3f, eps_h = 1e-2f, cutoff = 1e-5f;
+  int max_iter_kmeans = 4, window_size = 3, verbose = 0;
+  uint64_t seed = 0, round_counter = 0;
+  int nb = 20; uint64_t cells_per_block = 1;
+  // ---- host-side state --------------------------------------------------------------
+  std::vector<float> Y;  // d x K column-major (reference layout)
+  std::vector<float> W; int W_rows = 0;
+  std::vector<float> obj_kmeans, obj_dist, obj_entropy, obj_cross, obj_harmony;
+  std::vector<int> kmeans_rounds;
+  std::vector<int> qlev, perm;
+  std::deque<std::vector<int64_t>> injected;
+  int64_t subset_clusters = 0, skipped_clusters = 0;
+  std::map<std::string, double> timers;
+  // ---- device -------------------------------------------------------------------------
+  int device = -1;
+  Dev D{}; Launch L{};
+  bool own_stream = false, ran_setup = false, ran_init = false;
+  std::vector<void*> allocs;
+  // profiling of the dominant kernel
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
+  double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0;
+  std::string err, warn;
+};
+
+namespace {
+
+int fail(hmx_ctx* c, int code, const std::string& msg) { c->err = msg; return code; }
+
+#define HIPCHK(expr)                                                                            \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(ctx, HMX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+template <class T> int dalloc(hmx_ctx* ctx, T** p, size_t count) {
+  void* q = nullptr;
+  if (count == 0) count = 1;
+  HIPCHK(hipMalloc(&q, count * sizeof(T)));
+  ctx->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+void free_all(hmx_ctx* ctx) {
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  ctx->allocs.clear();
+  for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  ctx->ev_pool.clear(); ctx->ev_used = 0;
+}
+template <class T> int h2d(hmx_ctx* ctx, T* dst, const T* src, size_t count) {
+  if (count) HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->L.stream));
+  HIPCHK(hipStreamSynchronize(ctx->L.stream));
+  return 0;
+}
+template <class T> int d2h(hmx_ctx* ctx, T* dst, const T* src, size_t count) {
+  if (count) HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->L.stream));
+  HIPCHK(hipStreamSynchronize(ctx->L.stream));
+  return 0;
+}
+int allreduce(hmx_ctx* ctx, void* buf, int64_t count, int dtype) {
+  if (ctx->world <= 1 || !ctx->ar) return 0;
+  int st = ctx->ar(ctx->ar_user, buf, count, dtype, (void*)ctx->L.stream);
+  if (st) return fail(ctx, HMX_ERR_COMM, "all-reduce callback failed");
+  return 0;
+}
+#define CHK(expr) do { int s_ = (expr); if (s_) return s_; } while (0)
+#define KCHK() HIPCHK(hipGetLastError())
+
+void normalise_cols(std::vector<float>& Y, int d, int K) {  // arma::normalise(Y, 2, 0)
+  for (int k = 0; k < K; k++) {
+    float s = 0.f;
+    for (int j = 0; j < d; j++) s += Y[(size_t)k * d + j] * Y[(size_t)k * d + j];
+    float nrm = std::sqrt(s); if (nrm == 0.f) nrm = 1.f;
+    for (int j = 0; j < d; j++) Y[(size_t)k * d + j] /= nrm;
+  }
+}
+int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Yt[j*K+k]
+  std::vector<float> yt((size_t)ctx->d * ctx->K);
+  for (int k = 0; k < ctx->K; k++) for (int j = 0; j < ctx->d; j++) yt[(size_t)j * ctx->K + k] = ctx->Y[(size_t)k * ctx->d + j];
+  return h2d(ctx, ctx->D.Yt, yt.data(), yt.size());
+}
+
+// objective snapshot obj[2..4] -> the four series (src/harmony.cpp:165-168)
+int push_objective(hmx_ctx* ctx) {
+  double o[3];
+  CHK(d2h(ctx, o, ctx->D.obj + 2, 3));
+  const float norm_const = 2000 / ((float)ctx->N_global);
+  ctx->obj_kmeans.push_back((float)((o[0] + o[1] + o[2]) * norm_const));
+  ctx->obj_dist.push_back((float)(o[0] * norm_const));
+  ctx->obj_entropy.push_back((float)(o[1] * norm_const));
+  ctx->obj_cross.push_back((float)(o[2] * norm_const));
+  return 0;
+}
+
+// R, O, E from scratch (src/harmony.cpp:141-150, :221-227); leaves objective partials in obj[0..1]
+int head_pass(hmx_ctx* ctx) {
+  const Dev& D = ctx->D;
+  HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.obj, 0, sizeof(double) * 2, ctx->L.stream));
+  l_head(ctx->L, D, 0); KCHK();
+  CHK(allreduce(ctx, D.O_fx, (int64_t)D.B * D.K, 0));
+  CHK(allreduce(ctx, D.obj, 2, 1));
+  return 0;
+}
+
+bool check_convergence_impl(hmx_ctx* c, int type) {  // src/harmony.cpp:173-205
+  float obj_new, obj_old;
+  if (type == 0) {
+    obj_old = 0; obj_new = 0;
+    for (int i = 0; i < c->window_size; i++) {
+      obj_old += c->obj_kmeans[c->obj_kmeans.size() - 2 - i];
+      obj_new += c->obj_kmeans[c->obj_kmeans.size() - 1 - i];
+    }
+    return std::fabs(obj_old - obj_new) / std::fabs(obj_old) < c->eps_k;
+  } else if (type == 1) {
+    obj_old = c->obj_harmony[c->obj_harmony.size() - 2];
+    obj_new = c->obj_harmony[c->obj_harmony.size() - 1];
+    return (obj_old - obj_new) / std::fabs(obj_old) < c->eps_h;
+  }
+  return true;
+}
+
+// ---- kmeans_centers (src/utils.cpp:10-64) ---------------------------------------------------
+int gather_centres(hmx_ctx* ctx, const std::vector<long long>& gcells, long long* d_gcells, double* d_rows) {
+  const int K = ctx->K, d = ctx->d;
+  CHK(h2d(ctx, d_gcells, gcells.data(), (size_t)K));
+  l_gather_rows(ctx->L, ctx->D, d_gcells, (uint64_t)ctx->goff, d_rows); KCHK();
+  CHK(allreduce(ctx, d_rows, (int64_t)K * d, 1));
+  std::vector<double> rows((size_t)K * d);
+  CHK(d2h(ctx, rows.data(), d_rows, rows.size()));
+  for (size_t i = 0; i < rows.size(); i++) ctx->Y[i] = (float)rows[i];
+  return 0;
+}
+
+int kmeans_centers(hmx_ctx* ctx) {
+  const int K = ctx->K, d = ctx->d;
+  const Dev& D = ctx->D;
+  ctx->Y.assign((size_t)d * K, 0.f);
+  long long* d_gcells; double* d_rows; unsigned* d_excl;
+  CHK(dalloc(ctx, &d_gcells, (size_t)K)); CHK(dalloc(ctx, &d_rows, (size_t)K * d)); CHK(dalloc(ctx, &d_excl, (size_t)K));
+  // random anchors (:12-15): indices = floor(randu * (N-1))
+  std::vector<long long> gcells(K);
+  const float Nm1 = (float)((uint64_t)ctx->N_global - 1);
+  for (int i = 0; i < K; i++) gcells[i] = (long long)std::floor(hmx_u01(ctx->seed, 0, (uint64_t)i) * Nm1);
+  CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
+  CHK(upload_Y(ctx));
+  // exponential race for every anchor in one pass (:24-34)
+  std::vector<unsigned long long> win(K), sentinel(K, SEED_SENTINEL);
+  CHK(h2d(ctx, D.seedmin, sentinel.data(), (size_t)K));
+  l_seed_probe(ctx->L, D, ctx->seed, (uint64_t)ctx->goff, nullptr, 0); KCHK();
+  CHK(allreduce(ctx, D.seedmin, K, 2));
+  CHK(d2h(ctx, win.data(), D.seedmin, (size_t)K));
+  // duplicates are resolved in cluster order (:38-43): re-sample cluster i among cells not yet chosen
+  std::set<unsigned> sup;
+  for (int i = 0; i < K; i++) {
+    unsigned g = (unsigned)(win[i] & 0xffffffffu);
+    if (win[i] == SEED_SENTINEL) return fail(ctx, HMX_ERR_STATE, "centroid seeding found no candidate cell");
+    if (sup.count(g)) {
+      std::vector<unsigned> ex(sup.begin(), sup.end());
+      CHK(h2d(ctx, d_excl, ex.data(), ex.size()));
+      CHK(h2d(ctx, D.seedmin, sentinel.data(), (size_t)K));
+      l_seed_probe(ctx->L, D, ctx->seed, (uint64_t)ctx->goff, d_excl, (int)ex.size()); KCHK();
+      CHK(allreduce(ctx, D.seedmin, K, 2));
+      std::vector<unsigned long long> w2(K);
+      CHK(d2h(ctx, w2.data(), D.seedmin, (size_t)K));
+      if (w2[i] == SEED_SENTINEL) return fail(ctx, HMX_ERR_STATE, "centroid seeding ran out of distinct cells");
+      g = (unsigned)(w2[i] & 0xffffffffu);
+    }
+    sup.insert(g);
+    gcells[i] = (long long)g;
+  }
+  CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
+  // 10 x one Lloyd iteration (:53-64)
+  std::vector<double> sums((size_t)K * d); std::vector<unsigned long long> cnt(K); std::vector<float> yn(K);
+  for (int it = 0; it < 10; it++) {
+    for (int k = 0; k < K; k++) { float s = 0.f; for (int j = 0; j < d; j++) s += ctx->Y[(size_t)k * d + j] * ctx->Y[(size_t)k * d + j]; yn[k] = s; }
+    CHK(upload_Y(ctx));
+    CHK(h2d(ctx, D.ynorm, yn.data(), (size_t)K));
+    HIPCHK(hipMemsetAsync(D.lsum, 0, sizeof(double) * K * d, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.lcnt, 0, sizeof(unsigned long long) * K, ctx->L.stream));
+    l_lloyd(ctx->L, D); KCHK();
+    CHK(allreduce(ctx, D.lsum, (int64_t)K * d, 1));
+    CHK(allreduce(ctx, D.lcnt, K, 0));
+    CHK(d2h(ctx, sums.data(), D.lsum, sums.size()));
+    CHK(d2h(ctx, cnt.data(), D.lcnt, (size_t)K));
+    for (int k = 0; k < K; k++) if (cnt[k] > 0)
+      for (int j = 0; j < d; j++) ctx->Y[(size_t)k * d + j] = (float)(sums[(size_t)k * d + j] / (double)cnt[k]);
+  }
+  return 0;
+}
+
+// ---- update_R (src/harmony.cpp:269-342) ---------------------------------------------------------
+int update_R(hmx_ctx* ctx) {
+  const Dev& D = ctx->D;
+  const double t0 = now_ms();
+  if (!ctx->injected.empty()) {  // host-provided shuffle: block(g) from its position
+    std::vector<int64_t> order = std::move(ctx->injected.front());
+    ctx->injected.pop_front();
+    std::vector<int> pos_blk((size_t)ctx->N);
+    std::vector<int64_t> pos((size_t)ctx->N_global);
+    for (int64_t p = 0; p < ctx->N_global; p++) pos[(size_t)order[p]] = p;
+    for (int64_t i = 0; i < ctx->N; i++) {
+      uint64_t b = (uint64_t)pos[(size_t)(ctx->goff + ctx->perm[i])] / ctx->cells_per_block;
+      pos_blk[i] = (int)std::min<uint64_t>(b, (uint64_t)(ctx->nb - 1));
+    }
+    CHK(h2d(ctx, D.blk, pos_blk.data(), pos_blk.size()));
+  } else {
+    l_blockid(ctx->L, D, ctx->seed, ctx->round_counter, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
+  }
+  ctx->round_counter++;
+  l_sort_blocks(ctx->L, D); KCHK();
+  HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * (size_t)D.nb * D.B * D.K, ctx->L.stream));
+  l_oldsum(ctx->L, D); KCHK();
+  CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0));
+  HIPCHK(hipMemsetAsync(D.obj, 0, sizeof(double) * 2, ctx->L.stream));
+  for (int j = 0; j < D.nb; j++) {
+    l_prepare(ctx->L, D, j); KCHK();
+    if (ctx->profile) {
+      if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+        ctx->ev_pool.emplace_back(a, b);
+      }
+      HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
+    }
+    l_update(ctx->L, D, j); KCHK();
+    if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; }
+    CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.B * D.K, 0));
+  }
+  CHK(allreduce(ctx, D.obj, 2, 1));
+  l_finish_round(ctx->L, D); KCHK();
+  CHK(push_objective(ctx));  // synchronises
+  if (ctx->profile) {
+    for (size_t i = 0; i < ctx->ev_used; i++) {
+      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+      ctx->prof_update_ms += ms;
+    }
+    ctx->prof_update_launches += (int64_t)ctx->ev_used; ctx->prof_update_cells += ctx->N; ctx->ev_used = 0;
+  }
+  ctx->timers["update_R"] += now_ms() - t0;
+  return 0;
+}
+
+// ---- ridge solves (src/harmony.cpp:358-611), fp64, one cluster at a time --------------------------
+bool chol_solve(std::vector<double>& A, int n, std::vector<double>& Bm, int m) {  // column-major, in place
+  for (int c = 0; c < n; c++) {
+    double s = A[(size_t)c * n + c];
+    for (int k = 0; k < c; k++) s -= A[(size_t)k * n + c] * A[(size_t)k * n + c];
+    if (!(s > 0)) return false;
+    const double l = std::sqrt(s);
+    A[(size_t)c * n + c] = l;
+    for (int r = c + 1; r < n; r++) {
+      double t = A[(size_t)c * n + r];
+      for (int k = 0; k < c; k++) t -= A[(size_t)k * n + r] * A[(size_t)k * n + c];
+      A[(size_t)c * n + r] = t / l;
+    }
+  }
+  for (int j = 0; j < m; j++) {
+    double* b = &Bm[(size_t)j * n];
+    for (int r = 0; r < n; r++) { double t = b[r]; for (int k = 0; k < r; k++) t -= A[(size_t)k * n + r] * b[k]; b[r] = t / A[(size_t)r * n + r]; }
+    for (int r = n - 1; r >= 0; r--) { double t = b[r]; for (int k = r + 1; k < n; k++) t -= A[(size_t)r * n + k] * b[k]; b[r] = t / A[(size_t)r * n + r]; }
+  }
+  return true;
+}
+bool lu_solve(std::vector<double>& A, int n, std::vector<double>& Bm, int m) {
+  for (int c = 0; c < n; c++) {
+    int p = c; double best = std::fabs(A[(size_t)c * n + c]);
+    for (int r = c + 1; r < n; r++) if (std::fabs(A[(size_t)c * n + r]) > best) { best = std::fabs(A[(size_t)c * n + r]); p = r; }
+    if (best == 0) return false;
+    if (p != c) {
+      for (int j = 0; j < n; j++) std::swap(A[(size_t)j * n + c], A[(size_t)j * n + p]);
+      for (int j = 0; j < m; j++) std::swap(Bm[(size_t)j * n + c], Bm[(size_t)j * n + p]);
+    }
+    const double inv = 1 / A[(size_t)c * n + c];
+    for (int r = c + 1; r < n; r++) {
+      const double f = A[(size_t)c * n + r] * inv; if (f == 0) continue;
+      for (int j = c + 1; j < n; j++) A[(size_t)j * n + r] -= f * A[(size_t)j * n + c];
+      for (int j = 0; j < m; j++) Bm[(size_t)j * n + r] -= f * Bm[(size_t)j * n + c];
+    }
+  }
+  for (int j = 0; j < m; j++)
+    for (int r = n - 1; r >= 0; r--) {
+      double s = Bm[(size_t)j * n + r];
+      for (int c = r + 1; c < n; c++) s -= A[(size_t)c * n + r] * Bm[(size_t)j * n + c];
+      Bm[(size_t)j * n + r] = s / A[(size_t)r * n + r];
+    }
+  return true;
+}
+
+struct SolveOut { int status = 0; bool skipped = false, subset = false; std::vector<float> W; int m = 0; };
+
+// O, E: K x B column-major floats; Sq [Q][d][K], nq [Q][K] doubles; Wq [Q][K][d] floats (output)
+void solve_cluster(const hmx_ctx* ctx, int k, const std::vector<float>& O, const std::vector<float>& E,
+                   const std::vector<double>& Sq, const std::vector<double>& nq, std::vector<float>& Wq,
+                   std::vector<float>& Ynew, SolveOut& out) {
+  const int K = ctx->K, B = ctx->B, C = ctx->C, d = ctx->d, Q = ctx->Q;
+  std::vector<int> cov_levels(C, 0);
+  for (int b = 0, cov = 0; b < B; b++) {  // :368-380
+    if (!(b < ctx->cov_bounds[cov])) cov++;
+    const float rep = O[(size_t)b * K + k] / ctx->sizes[b];
+    if (rep > ctx->cutoff) cov_levels[cov]++;
+  }
+  std::vector<int> keep;
+  for (int b = 0, cov = 0; b < B; b++) {  // :389-402
+    if (cov < C && !(b < ctx->cov_bounds[cov])) cov++;
+    const float rep = O[(size_t)b * K + k] / ctx->sizes[b];
+    if (rep > ctx->cutoff && cov_levels[cov] > 1) keep.push_back(b);
+  }
+  int active = 0; for (int l : cov_levels) if (l > 1) active++;
+  const bool full = ((int)keep.size() == B);
+  out.subset = !full;
+  for (int q = 0; q < Q; q++) std::fill_n(&Wq[((size_t)q * K + k) * d], d, 0.f);
+  if (!full && active == 0) { out.skipped = true; return; }  // :449-452
+  const int m = (int)keep.size() + 1;
+  std::vector<int> row_of(B, -1);
+  for (int a = 0; a < (int)keep.size(); a++) row_of[keep[a]] = a + 1;
+  std::vector<double> cov((size_t)m * m, 0.0), rhs((size_t)m * d, 0.0);
+  std::vector<int> rows(C + 1);
+  for (int q = 0; q < Q; q++) {
+    int nr = 0; rows[nr++] = 0;
+    for (int c = 0; c < C; c++) { const int ro = row_of[ctx->qlev[(size_t)q * C + c]]; if (ro >= 0) rows[nr++] = ro; }
+    if (nr == 1) continue;  // none of this combination's levels is kept: its cells do not enter (:400,456-460)
+    const double n = nq[(size_t)q * K + k];
+    for (int a = 0; a < nr; a++) for (int b2 = 0; b2 < nr; b2++) cov[(size_t)rows[b2] * m + rows[a]] += n;
+    for (int j = 0; j < d; j++) { const double s = Sq[((size_t)q * d + j) * K + k]; for (int a = 0; a < nr; a++) rhs[(size_t)j * m + rows[a]] += s; }
+  }
+  for (int a = 1; a < m; a++) {  // :434-439, :533-544
+    const float lam = ctx->lambda_estimation ? E[(size_t)keep[a - 1] * K + k] * ctx->alpha : ctx->lambda[keep[a - 1] + 1];
+    cov[(size_t)a * m + a] += (double)lam;
+  }
+  std::vector<double> A = cov, X = rhs;
+  if (!chol_solve(A, m, X, d)) { A = cov; X = rhs; if (!lu_solve(A, m, X, d)) { out.status = HMX_ERR_SOLVE; return; } }
+  for (int j = 0; j < d; j++) { Ynew[(size_t)k * d + j] = (float)X[(size_t)j * m]; X[(size_t)j * m] = 0.0; }  // :610-611
+  out.m = m; out.W.resize((size_t)m * d);
+  for (size_t i = 0; i < out.W.size(); i++) out.W[i] = (float)X[i];
+  for (int q = 0; q < Q; q++) {  // correction of a cell of combination q from cluster k: sum of its kept levels' rows
+    float* w = &Wq[((size_t)q * K + k) * d];
+    for (int c = 0; c < C; c++) { const int ro = row_of[ctx->qlev[(size_t)q * C + c]]; if (ro < 0) continue;
+      for (int j = 0; j < d; j++) w[j] += out.W[(size_t)j * m + ro]; }
+  }
+}
+
+std::vector<float> table_O(const hmx_ctx* ctx, const std::vector<long long>& ofx) {
+  std::vector<float> O(ofx.size());
+  for (size_t i = 0; i < ofx.size(); i++) O[i] = (float)((double)ofx[i] * FX_INV);
+  return O;
+}
+std::vector<float> table_E(const hmx_ctx* ctx, const std::vector<long long>& ofx) {
+  const int K = ctx->K, B = ctx->B;
+  std::vector<float> E((size_t)K * B);
+  for (int k = 0; k < K; k++) {
+    long long rs = 0; for (int b = 0; b < ctx->B_vec[0]; b++) rs += ofx[(size_t)b * K + k];
+    const double rsd = (double)rs * FX_INV;
+    for (int b = 0; b < B; b++) E[(size_t)b * K + k] = (float)(rsd * (double)ctx->Pr_b[b]);
+  }
+  return E;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+hmx_ctx* hmx_create(void) { return new hmx_ctx(); }
+
+void hmx_destroy(hmx_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  free_all(ctx);
+  if (ctx->own_stream && ctx->L.stream) (void)hipStreamDestroy(ctx->L.stream);
+  delete ctx;
+}
+const char* hmx_last_error(hmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null handle"; }
+const char* hmx_last_warning(hmx_ctx* ctx) { return ctx ? ctx->warn.c_str() : ""; }
+
+uint64_t hmx_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g) {
+  int bits = 2;
+  while (((uint64_t)1 << bits) < N) bits += 2;
+  const int half = bits / 2;
+  const uint32_t mask = (uint32_t)(((uint64_t)1 << half) - 1);
+  uint32_t keys[6];
+  for (int r = 0; r < 6; r++)
+    keys[r] = (uint32_t)(h_splitmix64(seed ^ (round * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(r + 1) << 56)) >> 32);
+  uint64_t x = g;
+  do {
+    uint32_t L = (uint32_t)(x >> half), R = (uint32_t)(x & mask);
+    for (int r = 0; r < 6; r++) { uint32_t t = L ^ (h_fmix32(R * 0x9E3779B1u + keys[r]) & mask); L = R; R = t; }
+    x = ((uint64_t)L << half) | R;
+  } while (x >= N);
+  return x;
+}
+float hmx_u01(uint64_t seed, uint64_t stream, uint64_t idx) {
+  const uint64_t h = h_splitmix64(h_splitmix64(seed ^ (stream * 0xD1342543DE82EF95ull)) + idx);
+  return ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+int hmx_set_shard(hmx_ctx* ctx, int32_t rank, int32_t world, int64_t global_offset, int64_t N_global,
+                  hmx_allreduce_fn fn, void* user) {
+  if (!ctx) return HMX_ERR_ARG;
+  if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "hmx_set_shard must precede hmx_setup");
+  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return fail(ctx, HMX_ERR_ARG, "bad shard description");
+  ctx->rank = rank; ctx->world = world; ctx->goff = global_offset; ctx->N_global = N_global; ctx->ar = fn; ctx->ar_user = user;
+  return 0;
+}
+int hmx_set_stream(hmx_ctx* ctx, void* s) {
+  if (!ctx) return HMX_ERR_ARG;
+  if (ctx->own_stream && ctx->L.stream) (void)hipStreamDestroy(ctx->L.stream);
+  ctx->L.stream = (hipStream_t)s; ctx->own_stream = false;
+  return 0;
+}
+int hmx_set_abort_poll(hmx_ctx* ctx, int (*poll)(void*), void* user) {
+  if (!ctx) return HMX_ERR_ARG;
+  ctx->poll = poll; ctx->poll_user = user;
+  return 0;
+}
+int hmx_push_update_order(hmx_ctx* ctx, const int64_t* order) {
+  if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
+  ctx->injected.emplace_back(order, order + ctx->N_global);
+  return 0;
+}
+
+int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
+  if (!ctx || !field) return HMX_ERR_ARG;
+  const std::string f(field);
+  if (f == "max_iter_kmeans") ctx->max_iter_kmeans = (int)v;
+  else if (f == "seed") ctx->seed = (uint64_t)v;
+  else if (f == "device") ctx->device = (int)v;
+  else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; }
+  else if (f == "grid") ctx->L.grid = (int)v;
+  else if (f == "upd_cpw") ctx->D.upd_cpw = (int)v;
+  else return fail(ctx, HMX_ERR_ARG, "unknown or read-only field: " + f);
+  return 0;
+}
+
+// ---- setup (src/harmony.cpp:29-128) -------------------------------------------------------------------
+int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t* phi_i, const int32_t* phi_p,
+              const double* phi_x, int32_t B, const double* sigma, const double* theta, const double* lambda,
+              int32_t n_lambda, double alpha, int32_t max_iter_kmeans, double epsilon_kmeans, double epsilon_harmony,
+              int32_t K, double block_size, const int32_t* B_vec, int32_t C, double cutoff, int32_t verbose) {
+  if (!ctx) return HMX_ERR_ARG;
+  ctx->err.clear(); ctx->warn.clear();
+  if (!Z || !phi_i || !phi_p || !sigma || !theta || !lambda || !B_vec) return fail(ctx, HMX_ERR_ARG, "null argument");
+  if (N <= 0 || d <= 0 || K <= 0 || B <= 0 || C <= 0) return fail(ctx, HMX_ERR_ARG, "non-positive dimension");
+  if (d > 128 || K > 256 || C > 15) return fail(ctx, HMX_ERR_LIMIT, "supported envelope: d <= 128, K <= 256, covariates <= 15");
+  if (N > 2000000000ll) return fail(ctx, HMX_ERR_LIMIT, "at most 2e9 cells per GPU shard");
+  if (ctx->world <= 1) { ctx->N_global = N; ctx->goff = 0; }
+  if (ctx->N_global > 4000000000ll) return fail(ctx, HMX_ERR_LIMIT, "at most 4e9 cells in total");
+  if (ctx->N_global < 6) return fail(ctx, HMX_ERR_TOO_FEW, "Refusing to run with less than 6 cells");
+  if (n_lambda != 1 && n_lambda != B + 1) return fail(ctx, HMX_ERR_ARG, "lambda must have length B+1 (or be the single value -1)");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(ctx, HMX_ERR_DEVICE, "no HIP device available: libharmony_mi355x has no CPU fallback");
+  if (ctx->device < 0) { int cur = 0; (void)hipGetDevice(&cur); ctx->device = cur; }
+  HIPCHK(hipSetDevice(ctx->device));
+  free_all(ctx);
+  if (!ctx->L.stream) { HIPCHK(hipStreamCreateWithFlags(&ctx->L.stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+  if (ctx->L.grid <= 0) {
+    const char* e = getenv("HMX_GRID");
+    ctx->L.grid = e ? atoi(e) : 2048;
+  }
+
+  ctx->N = N; ctx->d = d; ctx->K = K; ctx->B = B; ctx->C = C; ctx->verbose = verbose;
+  ctx->B_vec.assign(B_vec, B_vec + C);
+  ctx->cov_bounds.resize(C);
+  std::partial_sum(ctx->B_vec.begin(), ctx->B_vec.end(), ctx->cov_bounds.begin());
+  if (ctx->cov_bounds.back() != B) return fail(ctx, HMX_ERR_ARG, "sum(B_vec) != nrow(Phi)");
+  ctx->sigma.resize(K); for (int k = 0; k < K; k++) ctx->sigma[k] = (float)sigma[k];
+  ctx->theta.resize(B); for (int b = 0; b < B; b++) ctx->theta[b] = (float)theta[b];
+  if (lambda[0] == -1) { ctx->lambda_estimation = true; ctx->lambda.clear(); }
+  else {
+    if (n_lambda != B + 1) return fail(ctx, HMX_ERR_ARG, "fixed lambda must have length B+1");
+    ctx->lambda_estimation = false; ctx->lambda.resize(B + 1); for (int i = 0; i <= B; i++) ctx->lambda[i] = (float)lambda[i];
+  }
+  ctx->alpha = (float)alpha; ctx->max_iter_kmeans = max_iter_kmeans; ctx->eps_k = (float)epsilon_kmeans;
+  ctx->eps_h = (float)epsilon_harmony; ctx->cutoff = (float)cutoff;
+  if (ctx->N_global < 40) { ctx->warn = "Too few cells. Setting block_size to 0.2"; ctx->block_size = 0.2f; }  // :86-88
+  else ctx->block_size = (float)block_size;
+  ctx->nb = my_ceil(1.0 / ctx->block_size);                                         // :280
+  ctx->cells_per_block = (uint64_t)(unsigned)((float)ctx->N_global * ctx->block_size);  // :281 (fp32 product, truncated)
+  if (ctx->cells_per_block < 1) ctx->cells_per_block = 1;
+  if (ctx->nb < 1) ctx->nb = 1;
+
+  // ---- per-covariate level codes from the C-hot CSC design (src/harmony.cpp:49-65, R/ui.R:210-213)
+  std::vector<int> codes((size_t)C * N);
+  for (int64_t i = 0; i < N; i++) {
+    if (phi_p[i + 1] - phi_p[i] != C) return fail(ctx, HMX_ERR_PHI, "Phi column does not hold exactly one level per covariate");
+    for (int c = 0; c < C; c++) {
+      const int b = phi_i[phi_p[i] + c];
+      if (b < 0 || b >= B || b >= ctx->cov_bounds[c] || (c > 0 && b < ctx->cov_bounds[c - 1]))
+        return fail(ctx, HMX_ERR_PHI, "Phi rows are not grouped by covariate");
+      if (phi_x && phi_x[phi_p[i] + c] != 1.0) return fail(ctx, HMX_ERR_PHI, "Phi must be a 0/1 design");
+      codes[(size_t)c * N + i] = b;
+    }
+  }
+  // ---- level combinations: dense mixed-radix key -> compact id (identical on every rank)
+  double dense = 1; for (int c = 0; c < C; c++) dense *= ctx->B_vec[c];
+  if (dense > 16777216.0) return fail(ctx, HMX_ERR_LIMIT, "product of covariate level counts exceeds 2^24");
+  const int64_t P = (int64_t)dense;
+  std::vector<long long> present((size_t)P, 0);
+  std::vector<int> key((size_t)N);
+  for (int64_t i = 0; i < N; i++) {
+    int64_t kk = 0, mul = 1;
+    for (int c = 0; c < C; c++) { kk += mul * (codes[(size_t)c * N + i] - (c ? ctx->cov_bounds[c - 1] : 0)); mul *= ctx->B_vec[c]; }
+    key[i] = (int)kk; present[(size_t)kk]++;
+  }
+  // global level sizes N_b and global presence (one all-reduce each when sharded)
+  std::vector<long long> nbcount((size_t)B, 0);
+  for (int c = 0; c < C; c++) for (int64_t i = 0; i < N; i++) nbcount[codes[(size_t)c * N + i]]++;
+  if (ctx->world > 1) {
+    long long* dtmp; const size_t cnt = (size_t)P + B;
+    HIPCHK(hipMalloc((void**)&dtmp, cnt * sizeof(long long)));
+    std::vector<long long> tmp(present); tmp.insert(tmp.end(), nbcount.begin(), nbcount.end());
+    int st = h2d(ctx, dtmp, tmp.data(), cnt);
+    if (!st) st = allreduce(ctx, dtmp, (int64_t)cnt, 0);
+    if (!st) st = d2h(ctx, tmp.data(), dtmp, cnt);
+    (void)hipFree(dtmp);
+    if (st) return st;
+    std::copy(tmp.begin(), tmp.begin() + P, present.begin());
+    std::copy(tmp.begin() + P, tmp.end(), nbcount.begin());
+  }
+  std::vector<int> qid((size_t)P, -1);
+  ctx->Q = 0; ctx->qlev.clear();
+  for (int64_t kk = 0; kk < P; kk++) if (present[(size_t)kk] > 0) {
+    qid[(size_t)kk] = ctx->Q++;
+    int64_t rem = kk;
+    for (int c = 0; c < C; c++) { ctx->qlev.push_back((int)(rem % ctx->B_vec[c]) + (c ? ctx->cov_bounds[c - 1] : 0)); rem /= ctx->B_vec[c]; }
+  }
+  const int Q = ctx->Q;
+  ctx->sizes.resize(B); ctx->Pr_b.resize(B);
+  for (int b = 0; b < B; b++) { ctx->sizes[b] = (float)nbcount[b]; ctx->Pr_b[b] = ctx->sizes[b] / (float)ctx->N_global; }  // :67
+  // ---- internal order: cells sorted (stably) by combination
+  std::vector<int> combo_of((size_t)N), start((size_t)Q + 1, 0), invperm((size_t)N), combo_sorted((size_t)N);
+  for (int64_t i = 0; i < N; i++) { combo_of[i] = qid[(size_t)key[i]]; start[(size_t)combo_of[i] + 1]++; }
+  for (int q = 0; q < Q; q++) start[q + 1] += start[q];
+  ctx->perm.assign((size_t)N, 0);
+  { std::vector<int> cur(start.begin(), start.end() - 1);
+    for (int64_t i = 0; i < N; i++) { const int p = cur[combo_of[i]]++; ctx->perm[p] = (int)i; invperm[i] = p; combo_sorted[p] = combo_of[i]; } }
+  std::vector<Item> items, aitems;
+  for (int q = 0; q < Q; q++) {
+    for (int s = start[q]; s < start[q + 1]; s += ITEM_CELLS) items.push_back({q, s, std::min(ITEM_CELLS, start[q + 1] - s)});
+    for (int s = start[q]; s < start[q + 1]; s += APPLY_CELLS) aitems.push_back({q, s, std::min(APPLY_CELLS, start[q + 1] - s)});
+  }
+
+  // ---- device state
+  Dev& D = ctx->D;
+  const int upd_cpw_keep = D.upd_cpw;
+  D = Dev{};
+  D.n = (int)N; D.d = d; D.K = K; D.B = B; D.C = C; D.Q = Q; D.B0 = ctx->B_vec[0];
+  D.KP = (K + 63) / 64 * 64; D.nb = ctx->nb;
+  { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = upd_cpw_keep > 0 ? upd_cpw_keep : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
+  D.nchunks = (int)((N + SORT_CHUNK - 1) / SORT_CHUNK);
+  D.nitems = (int)items.size(); D.naitems = (int)aitems.size();
+  CHK(dalloc(ctx, &D.Zo, (size_t)N * d)); CHK(dalloc(ctx, &D.Zc, (size_t)N * d)); CHK(dalloc(ctx, &D.R, (size_t)N * K));
+  CHK(dalloc(ctx, &D.perm, (size_t)N)); CHK(dalloc(ctx, &D.invperm, (size_t)N)); CHK(dalloc(ctx, &D.combo, (size_t)N));
+  CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
+  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
+  CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
+  CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
+  CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)N)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
+  CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks));
+  CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size()));
+  CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d));
+  CHK(dalloc(ctx, &D.seedmin, (size_t)K)); CHK(dalloc(ctx, &D.lsum, (size_t)K * d)); CHK(dalloc(ctx, &D.lcnt, (size_t)K)); CHK(dalloc(ctx, &D.ynorm, (size_t)K));
+  CHK(h2d(ctx, D.perm, ctx->perm.data(), (size_t)N)); CHK(h2d(ctx, D.invperm, invperm.data(), (size_t)N));
+  CHK(h2d(ctx, D.combo, combo_sorted.data(), (size_t)N)); CHK(h2d(ctx, D.qlev, ctx->qlev.data(), ctx->qlev.size()));
+  CHK(h2d(ctx, D.sigma, ctx->sigma.data(), (size_t)K)); CHK(h2d(ctx, D.theta, ctx->theta.data(), (size_t)B)); CHK(h2d(ctx, D.Pr_b, ctx->Pr_b.data(), (size_t)B));
+  CHK(h2d(ctx, D.items, items.data(), items.size())); CHK(h2d(ctx, D.aitems, aitems.data(), aitems.size()));
+  HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * B * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * B * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.obj, 0, sizeof(double) * 8, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.R, 0, sizeof(float) * (size_t)N * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Wq, 0, sizeof(float) * (size_t)Q * K * d, ctx->L.stream));
+  // Z: double d x N (cell-major) -> fp32 rows in internal order, staged through HBM in slabs (conv_to, :41)
+  {
+    const int64_t slab = std::max<int64_t>(1, (int64_t)(256ll << 20) / (8ll * d));
+    double* dstage; HIPCHK(hipMalloc((void**)&dstage, (size_t)std::min<int64_t>(slab, N) * d * sizeof(double)));
+    for (int64_t s = 0; s < N; s += slab) {
+      const int64_t cnt = std::min<int64_t>(slab, N - s);
+      hipError_t e = hipMemcpyAsync(dstage, Z + s * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, ctx->L.stream);
+      if (e == hipSuccess) { l_convert_in(ctx->L, dstage, D.Zo, D.invperm + s, (int)cnt, d); e = hipGetLastError(); }
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
+      if (e != hipSuccess) { (void)hipFree(dstage); return fail(ctx, HMX_ERR_DEVICE, hipGetErrorString(e)); }
+    }
+    (void)hipFree(dstage);
+  }
+  ctx->W.assign((size_t)(B + 1) * d, 0.f); ctx->W_rows = B + 1;  // allocate_buffers :127
+  ctx->Y.assign((size_t)d * K, 0.f);
+  ctx->ran_setup = true;
+  return hmx_restart(ctx);
+}
+
+int hmx_restart(hmx_ctx* ctx) {
+  if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  const Dev& D = ctx->D;
+  l_copy(ctx->L, D.Zo, D.Zc, (size_t)D.n * D.d); KCHK();
+  l_normalize(ctx->L, D.Zc, D.n, D.d); KCHK();  // Z_corr = normalise(Z_orig) :42
+  HIPCHK(hipStreamSynchronize(ctx->L.stream));
+  ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();
+  ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear();
+  return 0;
+}
+
+int hmx_kmeans_centers(hmx_ctx* ctx, double* Y_out) {
+  if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  CHK(kmeans_centers(ctx));
+  if (Y_out) for (size_t i = 0; i < ctx->Y.size(); i++) Y_out[i] = (double)ctx->Y[i];
+  return 0;
+}
+
+int hmx_init_cluster(hmx_ctx* ctx, const double* Y0) {  // src/harmony.cpp:131-156
+  if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  if (Y0) { ctx->Y.resize((size_t)ctx->d * ctx->K); for (size_t i = 0; i < ctx->Y.size(); i++) ctx->Y[i] = (float)Y0[i]; }
+  else CHK(kmeans_centers(ctx));
+  normalise_cols(ctx->Y, ctx->d, ctx->K);  // :136
+  CHK(upload_Y(ctx));
+  CHK(head_pass(ctx));
+  l_objective_tables(ctx->L, ctx->D); KCHK();
+  CHK(push_objective(ctx));
+  ctx->obj_harmony.push_back(ctx->obj_kmeans.back());
+  ctx->ran_init = true;
+  ctx->timers["init_cluster"] += now_ms() - t0;
+  return 0;
+}
+
+int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the current R, Z_corr, Y, O, E
+  if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemsetAsync(ctx->D.obj, 0, sizeof(double) * 2, ctx->L.stream));
+  l_head(ctx->L, ctx->D, 1); KCHK();
+  CHK(allreduce(ctx, ctx->D.obj, 2, 1));
+  l_objective_tables(ctx->L, ctx->D); KCHK();
+  return push_objective(ctx);
+}
+
+int hmx_check_convergence(hmx_ctx* ctx, int32_t type) {
+  if (!ctx) return -HMX_ERR_ARG;
+  if ((type == 0 && ctx->obj_kmeans.size() < (size_t)ctx->window_size + 1) || (type == 1 && ctx->obj_harmony.size() < 2)) {
+    fail(ctx, HMX_ERR_STATE, "not enough objective values"); return -HMX_ERR_STATE;
+  }
+  return check_convergence_impl(ctx, type) ? 1 : 0;
+}
+
+int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
+  if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  if (ctx->obj_harmony.size() != 1) {  // :214-228
+    l_normalize(ctx->L, ctx->D.Zc, ctx->D.n, ctx->D.d); KCHK();
+    CHK(head_pass(ctx));
+  }
+  int iter;
+  for (iter = 0; iter < ctx->max_iter_kmeans; iter++) {
+    if (ctx->poll && ctx->poll(ctx->poll_user)) return HMX_ABORTED;  // :233-234
+    CHK(update_R(ctx));                                                 // :241 (objective fused, :248)
+    if (iter > ctx->window_size) {                                      // :250-256
+      if (check_convergence_impl(ctx, 0)) { iter++; break; }
+    }
+  }
+  ctx->kmeans_rounds.push_back(iter);
+  ctx->obj_harmony.push_back(ctx->obj_kmeans.back());
+  ctx->timers["cluster"] += now_ms() - t0;
+  return 0;
+}
+
+int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
+  if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->poll && ctx->poll(ctx->poll_user)) return HMX_ABORTED;  // :355-356
+  const double t0 = now_ms();
+  const Dev& D = ctx->D;
+  const int K = ctx->K, B = ctx->B, d = ctx->d, Q = ctx->Q;
+  HIPCHK(hipMemsetAsync(D.Sq, 0, sizeof(double) * (size_t)Q * d * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.nq, 0, sizeof(double) * (size_t)Q * K, ctx->L.stream));
+  l_moe_stats(ctx->L, D); KCHK();
+  CHK(allreduce(ctx, D.Sq, (int64_t)Q * d * K, 1));
+  CHK(allreduce(ctx, D.nq, (int64_t)Q * K, 1));
+  std::vector<double> Sq((size_t)Q * d * K), nq((size_t)Q * K);
+  std::vector<long long> ofx((size_t)B * K);
+  CHK(d2h(ctx, Sq.data(), D.Sq, Sq.size())); CHK(d2h(ctx, nq.data(), D.nq, nq.size())); CHK(d2h(ctx, ofx.data(), D.O_fx, ofx.size()));
+  const double t1 = now_ms();
+  const std::vector<float> O = table_O(ctx, ofx), E = table_E(ctx, ofx);
+  std::vector<float> Wq((size_t)Q * K * d), Ynew = ctx->Y;
+  std::vector<SolveOut> outs(K);
+  {
+    unsigned nt = std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16; if ((int)nt > K) nt = K;
+    if ((size_t)K * (B + 1) * (B + 1) < 200000) nt = 1;
+    std::vector<std::thread> th;
+    auto work = [&](int t) { for (int k = t; k < K; k += (int)nt) solve_cluster(ctx, k, O, E, Sq, nq, Wq, Ynew, outs[k]); };
+    if (nt == 1) work(0);
+    else { for (unsigned t = 0; t < nt; t++) th.emplace_back(work, (int)t); for (auto& x : th) x.join(); }
+  }
+  ctx->subset_clusters = ctx->skipped_clusters = 0;
+  for (int k = 0; k < K; k++) {
+    if (outs[k].status) return fail(ctx, outs[k].status, "singular ridge system");
+    if (outs[k].subset) ctx->subset_clusters++;
+    if (outs[k].skipped) ctx->skipped_clusters++;
+    else { ctx->W = outs[k].W; ctx->W_rows = outs[k].m; }
+  }
+  ctx->timers["moe_solve_host"] += now_ms() - t1;
+  CHK(h2d(ctx, D.Wq, Wq.data(), Wq.size()));
+  l_moe_apply(ctx->L, D); KCHK();   // Z_corr = Z_orig - sum_k R_k W_k[levels]   :347,:615
+  ctx->Y = Ynew;
+  normalise_cols(ctx->Y, d, K);     // :633
+  CHK(upload_Y(ctx));
+  HIPCHK(hipStreamSynchronize(ctx->L.stream));
+  ctx->timers["moe_correct_ridge"] += now_ms() - t0;
+  return 0;
+}
+
+int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
+  if (!ctx || !field) return -1;
+  const std::string f(field);
+  auto scalar = [&](double v) -> int64_t { if (out && cap >= 1) out[0] = v; return 1; };
+  auto vec = [&](const auto& v) -> int64_t {
+    if (out) for (size_t i = 0; i < v.size() && (int64_t)i < cap; i++) out[i] = (double)v[i];
+    return (int64_t)v.size();
+  };
+  if (f == "N") return scalar((double)ctx->N_global);
+  if (f == "N_local") return scalar((double)ctx->N);
+  if (f == "B") return scalar(ctx->B);
+  if (f == "K") return scalar(ctx->K);
+  if (f == "d") return scalar(ctx->d);
+  if (f == "alpha") return scalar(ctx->alpha);
+  if (f == "max_iter_kmeans") return scalar(ctx->max_iter_kmeans);
+  if (f == "block_size") return scalar(ctx->block_size);
+  if (f == "n_blocks") return scalar(ctx->nb);
+  if (f == "cells_per_block") return scalar((double)ctx->cells_per_block);
+  if (f == "W_rows") return scalar(ctx->W_rows);
+  if (f == "n_combos") return scalar(ctx->Q);
+  if (f == "subset_clusters") return scalar((double)ctx->subset_clusters);
+  if (f == "skipped_clusters") return scalar((double)ctx->skipped_clusters);
+  if (f == "prof:update_ms") return scalar(ctx->prof_update_ms);
+  if (f == "prof:update_launches") return scalar((double)ctx->prof_update_launches);
+  if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
+  if (f.rfind("timer:", 0) == 0) { auto it = ctx->timers.find(f.substr(6)); return scalar(it == ctx->timers.end() ? 0.0 : it->second); }
+  if (f == "Y") return vec(ctx->Y);
+  if (f == "W") return vec(ctx->W);
+  if (f == "Pr_b") return vec(ctx->Pr_b);
+  if (f == "theta") return vec(ctx->theta);
+  if (f == "sigma") return vec(ctx->sigma);
+  if (f == "lambda") return vec(ctx->lambda);
+  if (f == "B_vec") return vec(ctx->B_vec);
+  if (f == "objective_kmeans") return vec(ctx->obj_kmeans);
+  if (f == "objective_kmeans_dist") return vec(ctx->obj_dist);
+  if (f == "objective_kmeans_entropy") return vec(ctx->obj_entropy);
+  if (f == "objective_kmeans_cross") return vec(ctx->obj_cross);
+  if (f == "objective_harmony") return vec(ctx->obj_harmony);
+  if (f == "kmeans_rounds") return vec(ctx->kmeans_rounds);
+  if (!ctx->ran_setup) return -1;
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  if (f == "O" || f == "E" || f == "Lambda") {
+    const int K = ctx->K, B = ctx->B;
+    const int64_t cnt = (f == "Lambda") ? (int64_t)K * (B + 1) : (int64_t)K * B;
+    if (!out) return cnt;
+    std::vector<long long> ofx((size_t)B * K);
+    if (d2h(ctx, ofx.data(), ctx->D.O_fx, ofx.size())) return -1;
+    if (f == "O") return vec(table_O(ctx, ofx));
+    const std::vector<float> E = table_E(ctx, ofx);
+    if (f == "E") return vec(E);
+    std::vector<double> L((size_t)K * (B + 1), 0.0);  // getLambda :657-669
+    for (int k = 0; k < K; k++) for (int b = 0; b < B; b++)
+      L[(size_t)(b + 1) * K + k] = ctx->lambda_estimation ? (double)(E[(size_t)b * K + k] * ctx->alpha) : (double)ctx->lambda[b + 1];
+    return vec(L);
+  }
+  if (f == "Z_corr" || f == "Z_orig" || f == "R") {
+    const int w = (f == "R") ? ctx->K : ctx->d;
+    const int64_t cnt = ctx->N * w;
+    if (!out) return cnt;
+    if (cap < cnt) return cnt;
+    const float* src = (f == "R") ? ctx->D.R : (f == "Z_corr" ? ctx->D.Zc : ctx->D.Zo);
+    double* dfull;
+    if (hipMalloc((void**)&dfull, (size_t)cnt * sizeof(double)) != hipSuccess) { ctx->err = "out of device memory in getter"; return -1; }
+    l_convert_out(ctx->L, src, dfull, ctx->D.perm, ctx->D.n, w);
+    hipError_t e = hipMemcpyAsync(out, dfull, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->L.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
+    (void)hipFree(dfull);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
+    return cnt;
+  }
+  return -1;
+}
+
+}  // extern "C"

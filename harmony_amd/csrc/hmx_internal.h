@@ -1,0 +1,93 @@
+// hmx_internal.h -- shared between the host orchestration (hmx_api.cpp) and the gfx950
+// kernels (hmx_kernels.hip).  Not part of the public ABI (see include/harmony_mi355x.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hmx {
+
+constexpr int WAVE = 64;
+constexpr int TPB = 256;            // threads per workgroup (4 waves, one per SIMD)
+constexpr int ITEM_CELLS = 256;     // cells per wave work item in streaming passes
+constexpr int APPLY_CELLS = 1024;   // cells per workgroup work item in the apply pass
+constexpr int SORT_CHUNK = 2048;    // cells per wave in the per-round block counting sort
+constexpr float FX_SCALE = 2147483648.0f;  // R in [0,1] -> 31-bit fixed point (exact int64 sums)
+constexpr double FX_INV = 1.0 / 2147483648.0;
+
+// A run of cells (internal order) that share one covariate-level combination.
+struct Item { int q; int start; int cnt; };
+
+// Everything the kernels need; plain pointers, filled by the host side.
+struct Dev {
+  int n;            // local cells
+  int d, K, B, C, Q;
+  int B0;           // number of levels of covariate 0 (rowsum(R) = sum of its O columns)
+  int upd_cpw;      // cells per wave in the update kernel
+  int KP;           // K rounded up to a multiple of 64
+  int nb;           // blocks per clustering round
+  // cell data, internal (combo-sorted) order, cell-major rows
+  float* Zo;        // [n][d]  Z_orig
+  float* Zc;        // [n][d]  Z_corr (cosine-normalised while clustering)
+  float* R;         // [n][K]
+  int* perm;        // [n] internal -> local original index
+  int* invperm;     // [n] local original -> internal
+  int* combo;       // [n] combination id (non-decreasing)
+  int* qlev;        // [Q][C] global level index of each covariate for combination q
+  // small tables
+  float* Yt;        // [d][K]   centroids, k fastest
+  float* sigma;     // [K]
+  float* theta;     // [B]
+  float* Pr_b;      // [B]
+  long long* O_fx;    // [B][K] fixed-point O (exact sum of quantised R)
+  long long* Snew_fx; // [B][K] contribution of the block being updated
+  long long* Sold_fx; // [nb][B][K] old contribution of every block of this round
+  float* pen;         // [B][K] ((2E+1)/(O+E+1))^theta
+  double* obj;        // [2] accumulators: sum R*dist, sum sigma*R*log R ; [2..5] outputs
+  // per-round block order
+  int* blk;         // [n] block id of each internal cell
+  int* lorder;      // [n] internal cell ids grouped by block (stable)
+  int* boff;        // [nb+1]
+  int* counts;      // [nb][nchunks] scratch of the counting sort
+  int nchunks;
+  // static work lists
+  Item* items; int nitems;        // <= ITEM_CELLS cells each
+  Item* aitems; int naitems;      // <= APPLY_CELLS cells each
+  // MoE
+  double* Sq;       // [Q][d][K]  sum_i R_ki z_ij over cells of combination q
+  double* nq;       // [Q][K]     sum_i R_ki
+  float* Wq;        // [Q][K][d]  correction table
+  // kmeans init
+  unsigned long long* seedmin;  // [K] packed (key bits << 32 | global cell)
+  double* lsum;     // [K][d]
+  unsigned long long* lcnt;  // [K]
+  float* ynorm;     // [K]
+};
+
+struct Launch {
+  hipStream_t stream;
+  int grid;  // workgroups for streaming kernels
+};
+
+// ---- launchers (hmx_kernels.hip) -----------------------------------------------------
+void l_convert_in(const Launch& L, const double* src, float* dst, const int* invperm, int n, int d);
+void l_convert_out(const Launch& L, const float* src, double* dst, const int* perm, int n, int w);
+void l_copy(const Launch& L, const float* src, float* dst, size_t count);
+void l_normalize(const Launch& L, float* Z, int n, int d);
+// mode 0: head (write R, accumulate O_fx, objective partials); mode 1: objective only (read R)
+void l_head(const Launch& L, const Dev& D, int mode);
+void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+               uint64_t cells_per_block);
+void l_sort_blocks(const Launch& L, const Dev& D);
+void l_oldsum(const Launch& L, const Dev& D);
+void l_prepare(const Launch& L, const Dev& D, int j);
+void l_update(const Launch& L, const Dev& D, int j);
+void l_finish_round(const Launch& L, const Dev& D);  // O += Snew, objective outputs -> obj[2..5]
+void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
+void l_moe_stats(const Launch& L, const Dev& D);
+void l_moe_apply(const Launch& L, const Dev& D);
+void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl);
+void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint64_t goff, double* rows);
+void l_lloyd(const Launch& L, const Dev& D);
+size_t lds_bytes_y(const Dev& D);
+
+}  // namespace hmx

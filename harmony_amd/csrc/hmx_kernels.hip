@@ -1,0 +1,929 @@
+// hmx_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the Harmony
+// clustering + correction loop.  MI355X only: no CUDA paths, no portability layer.
+//
+// Data layout (DESIGN.md "HBM layout"): cells are stored cell-major, exactly the
+// reference's column-major d x N / K x N matrices (src/harmony.h:50), but in an
+// internal order sorted by covariate-level combination so that every streaming pass sees
+// long runs of cells sharing one combination.  "Cluster-lane" mapping: lane l of a wave
+// owns clusters l, l+64, ... (KPL per lane); a cell's PCs are broadcast lane->SGPR with
+// v_readlane.  Cross-cell sums (O, E, objective, ridge statistics) are accumulated per
+// lane over a run and flushed with one coalesced atomic per run: 64-bit fixed point for
+// R sums (exact, order-independent => bit-reproducible and shard-count independent),
+// fp64 for the rest.
+#include "hmx_internal.h"
+#include <float.h>
+
+namespace hmx {
+
+// --------------------------------------------------------------------------------------
+// device helpers
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ float rlane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ double wsumd(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wmin64(unsigned long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), m, 64);
+    unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ float trunc_logf_dev(float x) {  // arma::trunc_log (src/utils.cpp:78)
+  return (x > 0.0f) ? logf(x) : logf(FLT_MIN);
+}
+__device__ __forceinline__ unsigned long long fx_of(float r) {  // R in [0,1] -> 31-bit fixed point
+  return (unsigned long long)__float2uint_rn(r * FX_SCALE);
+}
+
+// counter-based generators -- same SPEC as include/harmony_mi355x.h documents
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+struct FeistelKeys { uint32_t k[6]; int half; uint32_t mask; };
+__host__ __device__ __forceinline__ uint64_t feistel_apply(const FeistelKeys& fk, uint64_t N, uint64_t g) {
+  uint64_t x = g;
+  do {
+    uint32_t L = (uint32_t)(x >> fk.half), Rr = (uint32_t)(x & fk.mask);
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      uint32_t t = L ^ (fmix32(Rr * 0x9E3779B1u + fk.k[r]) & fk.mask);
+      L = Rr; Rr = t;
+    }
+    x = ((uint64_t)L << fk.half) | Rr;
+  } while (x >= N);
+  return x;
+}
+static FeistelKeys make_keys(uint64_t seed, uint64_t round, uint64_t N) {
+  FeistelKeys fk;
+  int bits = 2;
+  while (((uint64_t)1 << bits) < N) bits += 2;
+  fk.half = bits / 2;
+  fk.mask = (uint32_t)(((uint64_t)1 << fk.half) - 1);
+  for (int r = 0; r < 6; r++)
+    fk.k[r] = (uint32_t)(splitmix64(seed ^ (round * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(r + 1) << 56)) >> 32);
+  return fk;
+}
+
+// Stage the centroid table Yt[d][K] into LDS as [d][KP] (zero padded), k fastest:
+// lane l then reads ldsY[j*KP + l + 64q] -- consecutive dwords, conflict-free.
+__device__ __forceinline__ void stage_Y(float* ldsY, const float* __restrict__ Yt, int d, int K, int KP) {
+  for (int i = threadIdx.x; i < d * KP; i += blockDim.x) {
+    int j = i / KP, k = i - j * KP;
+    ldsY[i] = (k < K) ? Yt[j * K + k] : 0.0f;
+  }
+  __syncthreads();
+}
+
+// dots of CB cells (rows broadcast from lanes) with all clusters of this lane.
+template <int KPL, int DPL, int CB>
+__device__ __forceinline__ void group_dots(const float* __restrict__ ldsY, int d, int KP, int lane,
+                                           const float (&z)[CB][DPL], float (&acc)[CB][KPL]) {
+#pragma unroll
+  for (int c = 0; c < CB; c++)
+#pragma unroll
+    for (int q = 0; q < KPL; q++) acc[c][q] = 0.0f;
+  const int d0 = d < 64 ? d : 64;
+  for (int j = 0; j < d0; ++j) {
+    float y[KPL];
+#pragma unroll
+    for (int q = 0; q < KPL; q++) y[q] = ldsY[j * KP + lane + 64 * q];
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      const float zj = rlane(z[c][0], j);
+#pragma unroll
+      for (int q = 0; q < KPL; q++) acc[c][q] = fmaf(zj, y[q], acc[c][q]);
+    }
+  }
+  if constexpr (DPL > 1) {
+    for (int j = 64; j < d; ++j) {
+      float y[KPL];
+#pragma unroll
+      for (int q = 0; q < KPL; q++) y[q] = ldsY[j * KP + lane + 64 * q];
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        const float zj = rlane(z[c][DPL - 1], j - 64);
+#pragma unroll
+        for (int q = 0; q < KPL; q++) acc[c][q] = fmaf(zj, y[q], acc[c][q]);
+      }
+    }
+  }
+}
+
+template <int DPL>
+__device__ __forceinline__ void load_row(const float* __restrict__ Z, size_t cell, int d, int lane, float (&z)[DPL]) {
+  z[0] = (lane < d) ? Z[cell * d + lane] : 0.0f;
+  if constexpr (DPL > 1) z[DPL - 1] = (64 + lane < d) ? Z[cell * d + 64 + lane] : 0.0f;
+}
+
+// flush a lane-private fixed-point run sum into a [B][K] table, once per covariate level
+template <int KPL>
+__device__ __forceinline__ void flush_fx(long long* __restrict__ tab, const int* __restrict__ qlev, int q, int C,
+                                         int K, int lane, unsigned long long (&oacc)[KPL]) {
+  for (int c = 0; c < C; c++) {
+    const int b = qlev[q * C + c];
+#pragma unroll
+    for (int qq = 0; qq < KPL; qq++) {
+      const int k = lane + 64 * qq;
+      if (k < K && oacc[qq]) atomicAdd((unsigned long long*)&tab[(size_t)b * K + k], oacc[qq]);
+    }
+  }
+#pragma unroll
+  for (int qq = 0; qq < KPL; qq++) oacc[qq] = 0ull;
+}
+
+// --------------------------------------------------------------------------------------
+// ingest / egress
+// --------------------------------------------------------------------------------------
+// src: [n][d] doubles in local original order -> dst: [n][d] floats in internal order
+__global__ void k_convert_in(const double* __restrict__ src, float* __restrict__ dst, const int* __restrict__ invperm,
+                             int n, int d) {
+  const size_t total = (size_t)n * d;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t cell = i / d; const int j = (int)(i - cell * d);
+    dst[(size_t)invperm[cell] * d + j] = (float)src[i];
+  }
+}
+// src: [n][w] floats internal order -> dst: [n][w] doubles original order
+__global__ void k_convert_out(const float* __restrict__ src, double* __restrict__ dst, const int* __restrict__ perm,
+                              int n, int w) {
+  const size_t total = (size_t)n * w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t cell = i / w; const int j = (int)(i - cell * w);
+    dst[(size_t)perm[cell] * w + j] = (double)src[i];
+  }
+}
+__global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+// arma::normalise(Z, 2, 0) (src/harmony.cpp:42,220): one wave per cell
+__global__ __launch_bounds__(TPB) void k_normalize(float* __restrict__ Z, int n, int d) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  for (int cell = wave; cell < n; cell += nw) {
+    float* z = Z + (size_t)cell * d;
+    float a = (lane < d) ? z[lane] : 0.0f, b = (64 + lane < d) ? z[64 + lane] : 0.0f;
+    float nrm = sqrtf(wsum(a * a + b * b));
+    if (nrm == 0.0f) nrm = 1.0f;
+    if (lane < d) z[lane] = a / nrm;
+    if (64 + lane < d) z[64 + lane] = b / nrm;
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// E-step head: dist = 2(1 - Y^T Z), R = softmax_k(-dist/sigma), O, objective partials
+// (src/harmony.cpp:141-150 and :221-227).  One wave per static work item (a run of cells
+// with one combination).  MODE 0: write R and accumulate O_fx.  MODE 1: objective only,
+// R is read (harmony::compute_objective on the current state).
+// --------------------------------------------------------------------------------------
+template <int KPL, int DPL, int MODE>
+__global__ __launch_bounds__(TPB) void k_head(Dev D) {
+  extern __shared__ __attribute__((aligned(16))) float ldsY[];
+  stage_Y(ldsY, D.Yt, D.d, D.K, D.KP);
+  constexpr int CB = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const int d = D.d, K = D.K;
+  float sig[KPL];
+#pragma unroll
+  for (int q = 0; q < KPL; q++) sig[q] = (lane + 64 * q < K) ? D.sigma[lane + 64 * q] : 1.0f;
+  double od = 0.0, oe = 0.0;
+  for (int it = wave; it < D.nitems; it += nw) {
+    const Item item = D.items[it];
+    unsigned long long oacc[KPL];
+#pragma unroll
+    for (int q = 0; q < KPL; q++) oacc[q] = 0ull;
+    for (int p = 0; p < item.cnt; p += CB) {
+      const int nc = min(CB, item.cnt - p);
+      float z[CB][DPL];
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), d, lane, z[c]);
+        else {
+#pragma unroll
+          for (int t = 0; t < DPL; t++) z[c][t] = 0.0f;
+        }
+      }
+      float acc[CB][KPL];
+      group_dots<KPL, DPL, CB>(ldsY, d, D.KP, lane, z, acc);
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        if (c < nc) {
+          const size_t cell = (size_t)(item.start + p + c);
+          float r[KPL], dist[KPL];
+          if (MODE == 0) {
+            float s = 0.0f;
+#pragma unroll
+            for (int q = 0; q < KPL; q++) {
+              const int k = lane + 64 * q;
+              dist[q] = 2.0f * (1.0f - acc[c][q]);
+              r[q] = (k < K) ? expf(-dist[q] / sig[q]) : 0.0f;
+              s += r[q];
+            }
+            s = wsum(s);
+#pragma unroll
+            for (int q = 0; q < KPL; q++) {
+              const int k = lane + 64 * q;
+              r[q] = r[q] / s;
+              if (k < K) { D.R[cell * K + k] = r[q]; oacc[q] += fx_of(r[q]); }
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < KPL; q++) {
+              const int k = lane + 64 * q;
+              dist[q] = 2.0f * (1.0f - acc[c][q]);
+              r[q] = (k < K) ? D.R[cell * K + k] : 0.0f;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < KPL; q++) {
+            if (lane + 64 * q < K) {
+              od += (double)(r[q] * dist[q]);
+              oe += (double)((r[q] * trunc_logf_dev(r[q])) * sig[q]);
+            }
+          }
+        }
+      }
+    }
+    if (MODE == 0) flush_fx<KPL>(D.O_fx, D.qlev, item.q, D.C, K, lane, oacc);
+  }
+  od = wsumd(od); oe = wsumd(oe);
+  if (lane == 0) { atomicAdd(&D.obj[0], od); atomicAdd(&D.obj[1], oe); }
+}
+
+// --------------------------------------------------------------------------------------
+// per-round block membership + stable counting sort by block
+// --------------------------------------------------------------------------------------
+__global__ void k_blockid(int* __restrict__ blk, const int* __restrict__ perm, int n, FeistelKeys fk, uint64_t Nglob,
+                          uint64_t goff, uint64_t cpb, int nb) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint64_t pos = feistel_apply(fk, Nglob, goff + (uint64_t)perm[i]);
+    uint64_t b = pos / cpb;
+    blk[i] = (int)(b < (uint64_t)(nb - 1) ? b : (uint64_t)(nb - 1));
+  }
+}
+// one wave per chunk of SORT_CHUNK cells; counts[v][chunk]
+__global__ __launch_bounds__(WAVE) void k_sort_hist(const int* __restrict__ blk, int n, int nb, int* __restrict__ counts,
+                                                    int nchunks) {
+  extern __shared__ int cnt[];
+  const int lane = threadIdx.x, chunk = blockIdx.x;
+  for (int v = lane; v < nb; v += WAVE) cnt[v] = 0;
+  __syncthreads();
+  const int s = chunk * SORT_CHUNK, e = min(n, s + SORT_CHUNK);
+  for (int base = s; base < e; base += WAVE) {
+    const int i = base + lane;
+    const int b = (i < e) ? blk[i] : -1;
+    unsigned long long rem = __ballot(b >= 0);
+    while (rem) {
+      const int src = __ffsll((long long)rem) - 1;
+      const int v = __shfl(b, src, 64);
+      const unsigned long long m = __ballot(b == v);
+      if (lane == 0) cnt[v] += __popcll(m);
+      rem &= ~m;
+    }
+  }
+  __syncthreads();
+  for (int v = lane; v < nb; v += WAVE) counts[(size_t)v * nchunks + chunk] = cnt[v];
+}
+// exclusive scan of counts (nb*nchunks ints) in place; boff[v] = start of block v
+__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ counts, int total, int nchunks, int nb,
+                                                    int* __restrict__ boff, int n) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (total + 1023) / 1024;
+  const int s = t * per, e = min(total, s + per);
+  int sum = 0;
+  for (int i = s; i < e; i++) sum += counts[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int i = s; i < e; i++) { int c = counts[i]; counts[i] = run; run += c; }
+  __syncthreads();
+  for (int v = t; v < nb; v += 1024) boff[v] = counts[(size_t)v * nchunks];
+  if (t == 0) boff[nb] = n;
+}
+__global__ __launch_bounds__(WAVE) void k_sort_scatter(const int* __restrict__ blk, int n, int nb,
+                                                       const int* __restrict__ counts, int nchunks,
+                                                       int* __restrict__ lorder) {
+  extern __shared__ int base_[];
+  const int lane = threadIdx.x, chunk = blockIdx.x;
+  for (int v = lane; v < nb; v += WAVE) base_[v] = counts[(size_t)v * nchunks + chunk];
+  __syncthreads();
+  const int s = chunk * SORT_CHUNK, e = min(n, s + SORT_CHUNK);
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int base = s; base < e; base += WAVE) {
+    const int i = base + lane;
+    const int b = (i < e) ? blk[i] : -1;
+    unsigned long long rem = __ballot(b >= 0);
+    while (rem) {
+      const int src = __ffsll((long long)rem) - 1;
+      const int v = __shfl(b, src, 64);
+      const unsigned long long m = __ballot(b == v);
+      const int off = base_[v];  // all lanes read before lane 0 updates
+      if (b == v) lorder[off + __popcll(m & lt)] = i;
+      __syncthreads();
+      if (lane == 0) base_[v] = off + __popcll(m);
+      __syncthreads();
+      rem &= ~m;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// update_R (src/harmony.cpp:269-342) split into:
+//   k_oldsum   one pass: old contribution of EVERY block of this round (:312-313 for all blocks)
+//   k_prepare  tiny: O <- O + new(prev block) - old(this block); penalty table (:322)
+//   k_update   the block's cells: R <- normalise(exp(-dist/sigma)); R *= penalty; normalise;
+//              accumulate the new contribution (:318-330) and the objective partials (:160-161)
+// --------------------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(TPB) void k_oldsum(Dev D) {
+  constexpr int CB = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const int K = D.K;
+  const int per = (D.n + nw - 1) / nw;
+  const int s = wave * per, e = min(D.n, s + per);
+  if (s >= e) return;
+  unsigned long long oacc[KPL];
+#pragma unroll
+  for (int q = 0; q < KPL; q++) oacc[q] = 0ull;
+  int curq = -1, curb = -1;
+  for (int p = s; p < e; p += CB) {
+    const int nc = min(CB, e - p);
+    int cell[CB]; float r[CB][KPL];
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      cell[c] = (c < nc) ? D.lorder[p + c] : 0;
+#pragma unroll
+      for (int q = 0; q < KPL; q++) {
+        const int k = lane + 64 * q;
+        r[c][q] = (c < nc && k < K) ? D.R[(size_t)cell[c] * K + k] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      if (c < nc) {
+        const int b = D.blk[cell[c]], q0 = D.combo[cell[c]];
+        if (b != curb || q0 != curq) {
+          if (curq >= 0) flush_fx<KPL>(D.Sold_fx + (size_t)curb * D.B * K, D.qlev, curq, D.C, K, lane, oacc);
+          curb = b; curq = q0;
+        }
+#pragma unroll
+        for (int q = 0; q < KPL; q++) oacc[q] += fx_of(r[c][q]);
+      }
+    }
+  }
+  if (curq >= 0) flush_fx<KPL>(D.Sold_fx + (size_t)curb * D.B * K, D.qlev, curq, D.C, K, lane, oacc);
+}
+
+// one thread per cluster.  j >= 0: prepare block j.  j < 0: only fold Snew into O.
+__global__ void k_prepare(Dev D, int j) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= D.K) return;
+  const int K = D.K, B = D.B;
+  const long long* sold = (j >= 0) ? D.Sold_fx + (size_t)j * B * K : nullptr;
+  long long rs = 0;
+  for (int b = 0; b < B; b++) {
+    long long o = D.O_fx[(size_t)b * K + k] + D.Snew_fx[(size_t)b * K + k];
+    if (sold) o -= sold[(size_t)b * K + k];
+    D.O_fx[(size_t)b * K + k] = o;
+    D.Snew_fx[(size_t)b * K + k] = 0;
+  }
+  if (j < 0) return;
+  // rowsum(R) over the cells currently "in" = sum over the levels of covariate 0
+  // (every cell has exactly one level per covariate).
+  for (int b = 0; b < D.B0; b++) rs += D.O_fx[(size_t)b * K + k];
+  const double rsd = (double)rs * FX_INV;
+  for (int b = 0; b < B; b++) {
+    const float o = (float)((double)D.O_fx[(size_t)b * K + k] * FX_INV);
+    const float e = (float)(rsd * (double)D.Pr_b[b]);
+    D.pen[(size_t)b * K + k] = powf(((2.0f * e) + 1.0f) / (o + e + 1.0f), D.theta[b]);
+  }
+}
+
+template <int KPL, int DPL>
+__global__ __launch_bounds__(TPB) void k_update(Dev D, int j) {
+  extern __shared__ __attribute__((aligned(16))) float ldsY[];
+  stage_Y(ldsY, D.Yt, D.d, D.K, D.KP);
+  constexpr int CB = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const int d = D.d, K = D.K;
+  const int p0 = D.boff[j], p1 = D.boff[j + 1];
+  const int per = (p1 - p0 + nw - 1) / nw;
+  const int s = p0 + wave * per, e = min(p1, s + per);
+  if (s >= e) return;
+  float sig[KPL], penv[KPL];
+  unsigned long long oacc[KPL];
+#pragma unroll
+  for (int q = 0; q < KPL; q++) { sig[q] = (lane + 64 * q < K) ? D.sigma[lane + 64 * q] : 1.0f; penv[q] = 0.0f; oacc[q] = 0ull; }
+  double od = 0.0, oe = 0.0;
+  int curq = -1;
+  for (int p = s; p < e; p += CB) {
+    const int nc = min(CB, e - p);
+    int cell[CB]; float z[CB][DPL];
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      cell[c] = (c < nc) ? D.lorder[p + c] : 0;
+      if (c < nc) load_row<DPL>(D.Zc, (size_t)cell[c], d, lane, z[c]);
+      else {
+#pragma unroll
+        for (int t = 0; t < DPL; t++) z[c][t] = 0.0f;
+      }
+    }
+    float acc[CB][KPL];
+    group_dots<KPL, DPL, CB>(ldsY, d, D.KP, lane, z, acc);
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      if (c < nc) {
+        const int q0 = D.combo[cell[c]];
+        if (q0 != curq) {
+          if (curq >= 0) flush_fx<KPL>(D.Snew_fx, D.qlev, curq, D.C, K, lane, oacc);
+          curq = q0;
+#pragma unroll
+          for (int q = 0; q < KPL; q++) penv[q] = 0.0f;
+          for (int cc = 0; cc < D.C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
+            const int b = D.qlev[q0 * D.C + cc];
+#pragma unroll
+            for (int q = 0; q < KPL; q++) if (lane + 64 * q < K) penv[q] += D.pen[(size_t)b * K + lane + 64 * q];
+          }
+        }
+        float r[KPL], dist[KPL];
+        float s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) {
+          dist[q] = 2.0f * (1.0f - acc[c][q]);
+          r[q] = (lane + 64 * q < K) ? expf(-dist[q] / sig[q]) : 0.0f;
+          s1 += fabsf(r[q]);
+        }
+        s1 = wsum(s1);
+        if (s1 == 0.0f) s1 = 1.0f;
+        float s2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) { r[q] = (r[q] / s1) * penv[q]; s2 += fabsf(r[q]); }
+        s2 = wsum(s2);
+        if (s2 == 0.0f) s2 = 1.0f;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) {
+          const int k = lane + 64 * q;
+          r[q] = r[q] / s2;
+          if (k < K) {
+            D.R[(size_t)cell[c] * K + k] = r[q];
+            oacc[q] += fx_of(r[q]);
+            od += (double)(r[q] * dist[q]);
+            oe += (double)((r[q] * trunc_logf_dev(r[q])) * sig[q]);
+          }
+        }
+      }
+    }
+  }
+  if (curq >= 0) flush_fx<KPL>(D.Snew_fx, D.qlev, curq, D.C, K, lane, oacc);
+  od = wsumd(od); oe = wsumd(oe);
+  if (lane == 0) { atomicAdd(&D.obj[0], od); atomicAdd(&D.obj[1], oe); }
+}
+
+// cross-entropy term of the objective from the K x B tables alone (src/harmony.cpp:162):
+//   sum_k sigma_k sum_b theta_b log((O+E+1)/(2E+1)) * O[k,b]     (O[k,b] = sum_{i in b} R_ki)
+// single workgroup; obj[2..4] = {dist, entropy, cross} snapshot, obj[0..1] reset.
+__global__ __launch_bounds__(TPB) void k_objective_tables(Dev D, int fold) {
+  __shared__ double red[TPB];
+  const int K = D.K, B = D.B;
+  double cross = 0.0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    long long rs = 0;
+    for (int b = 0; b < B; b++) {
+      if (fold) {
+        D.O_fx[(size_t)b * K + k] += D.Snew_fx[(size_t)b * K + k];
+        D.Snew_fx[(size_t)b * K + k] = 0;
+      }
+      if (b < D.B0) rs += D.O_fx[(size_t)b * K + k];
+    }
+    const double rsd = (double)rs * FX_INV;
+    double ck = 0.0;
+    for (int b = 0; b < B; b++) {
+      const double od = (double)D.O_fx[(size_t)b * K + k] * FX_INV;
+      const float o = (float)od, e = (float)(rsd * (double)D.Pr_b[b]);
+      const float m = D.theta[b] * logf((o + e + 1.0f) / ((2.0f * e) + 1.0f));
+      ck += od * (double)m;
+    }
+    cross += ck * (double)D.sigma[k];
+  }
+  red[threadIdx.x] = cross;
+  __syncthreads();
+  for (int off = TPB / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    D.obj[2] = D.obj[0]; D.obj[3] = D.obj[1]; D.obj[4] = red[0];
+    D.obj[0] = 0.0; D.obj[1] = 0.0;
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// MoE ridge correction (src/harmony.cpp:345-638)
+//   k_moe_stats : per combination q and cluster k:  nq = sum_i R_ki,  Sq = sum_i R_ki z_i
+//                 (the sufficient statistics of Phi* diag(R_k) Phi*^T and Phi* diag(R_k) Z^T)
+//   host        : K small ridge solves in fp64 -> correction table Wq[q][k][:]
+//   k_moe_apply : Z_corr_i = Z_orig_i - sum_k R_ki Wq[q(i)][k][:]
+// --------------------------------------------------------------------------------------
+// grid.y = cluster chunks of 128, grid.z = PC chunks of DP (DP = 4..32 in steps of 4, chosen so that the
+// chunks cover d with little padding: d=50 -> 2 chunks of 28)
+template <int DP>
+__global__ __launch_bounds__(TPB) void k_moe_stats(Dev D) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const int d = D.d, K = D.K;
+  const int k0 = blockIdx.y * 128 + lane, k1 = k0 + 64;
+  const int zoff = blockIdx.z * DP;
+  const int dch = min(DP, d - zoff);
+  for (int it = wave; it < D.nitems; it += nw) {
+    const Item item = D.items[it];
+    float a0[DP], a1[DP];
+#pragma unroll
+    for (int j = 0; j < DP; j++) { a0[j] = 0.0f; a1[j] = 0.0f; }
+    double n0 = 0.0, n1 = 0.0;
+    size_t cell = (size_t)item.start;
+    float zn = (lane < dch) ? D.Zo[cell * d + zoff + lane] : 0.0f;
+    float r0n = (k0 < K) ? D.R[cell * K + k0] : 0.0f;
+    float r1n = (k1 < K) ? D.R[cell * K + k1] : 0.0f;
+    for (int p = 0; p < item.cnt; p++) {
+      const float zr = zn, r0 = r0n, r1 = r1n;
+      if (p + 1 < item.cnt) {  // software prefetch of the next cell's rows
+        cell = (size_t)(item.start + p + 1);
+        zn = (lane < dch) ? D.Zo[cell * d + zoff + lane] : 0.0f;
+        r0n = (k0 < K) ? D.R[cell * K + k0] : 0.0f;
+        r1n = (k1 < K) ? D.R[cell * K + k1] : 0.0f;
+      }
+      n0 += (double)r0; n1 += (double)r1;
+#pragma unroll
+      for (int j = 0; j < DP; j++) {
+        const float zj = rlane(zr, j);
+        a0[j] = fmaf(r0, zj, a0[j]);
+        a1[j] = fmaf(r1, zj, a1[j]);
+      }
+    }
+    double* S = D.Sq + (size_t)item.q * d * K;
+#pragma unroll
+    for (int j = 0; j < DP; j++) {
+      if (j < dch) {
+        if (k0 < K) atomicAdd(&S[(size_t)(zoff + j) * K + k0], (double)a0[j]);
+        if (k1 < K) atomicAdd(&S[(size_t)(zoff + j) * K + k1], (double)a1[j]);
+      }
+    }
+    if (blockIdx.z == 0) {
+      if (k0 < K) atomicAdd(&D.nq[(size_t)item.q * K + k0], n0);
+      if (k1 < K) atomicAdd(&D.nq[(size_t)item.q * K + k1], n1);
+    }
+  }
+}
+
+// one workgroup per apply item (<= APPLY_CELLS cells of one combination); Wq[q] staged in LDS
+// as [K][DS] (DS = 64*DPL); lane = PC.
+template <int KPL, int DPL>
+__global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
+  extern __shared__ __attribute__((aligned(16))) float ldsW[];
+  constexpr int CB = 4;
+  constexpr int DS = 64 * DPL;
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int d = D.d, K = D.K;
+  for (int it = blockIdx.x; it < D.naitems; it += gridDim.x) {
+    const Item item = D.aitems[it];
+    __syncthreads();
+    const float* W = D.Wq + (size_t)item.q * K * d;
+    for (int i = threadIdx.x; i < K * DS; i += blockDim.x) {
+      const int k = i / DS, jj = i - k * DS;
+      ldsW[i] = (jj < d) ? W[(size_t)k * d + jj] : 0.0f;
+    }
+    __syncthreads();
+    const int per = (item.cnt + 3) / 4;
+    const int s = item.start + wib * per, e = min(item.start + item.cnt, s + per);
+    for (int p = s; p < e; p += CB) {
+      const int nc = min(CB, e - p);
+      float rr[CB][KPL], corr[CB][DPL];
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+#pragma unroll
+        for (int q = 0; q < KPL; q++) {
+          const int k = lane + 64 * q;
+          rr[c][q] = (c < nc && k < K) ? D.R[(size_t)(p + c) * K + k] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < DPL; t++) corr[c][t] = 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < KPL; q++) {
+        const int kend = min(64, K - 64 * q);
+        for (int kk = 0; kk < kend; ++kk) {
+          float w[DPL];
+#pragma unroll
+          for (int t = 0; t < DPL; t++) w[t] = ldsW[(64 * q + kk) * DS + 64 * t + lane];
+#pragma unroll
+          for (int c = 0; c < CB; c++) {
+            const float rk = rlane(rr[c][q], kk);
+#pragma unroll
+            for (int t = 0; t < DPL; t++) corr[c][t] = fmaf(rk, w[t], corr[c][t]);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        if (c < nc) {
+          const size_t cell = (size_t)(p + c);
+#pragma unroll
+          for (int t = 0; t < DPL; t++) {
+            const int jj = 64 * t + lane;
+            if (jj < d) D.Zc[cell * d + jj] = D.Zo[cell * d + jj] - corr[c][t];
+          }
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// kmeans_centers (src/utils.cpp:10-64)
+//   k_seed_probe: for every anchor i (= cluster lane) sample a cell with P ~ |2(1 - y_i.x)| via the
+//                 exponential race  argmin_n  -log(u_{i,n}) / dist_{i,n}   (:27-34), all K anchors
+//                 in ONE pass; result = packed (key bits, global cell) min per cluster.
+//   k_lloyd     : one Lloyd iteration: nearest centre (Euclidean), sums and counts.
+// --------------------------------------------------------------------------------------
+template <int KPL, int DPL>
+__global__ __launch_bounds__(TPB) void k_seed_probe(Dev D, uint64_t seed, uint64_t goff, const unsigned* __restrict__ excl,
+                                                    int nexcl) {
+  extern __shared__ __attribute__((aligned(16))) float ldsY[];
+  stage_Y(ldsY, D.Yt, D.d, D.K, D.KP);
+  constexpr int CB = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const int d = D.d, K = D.K;
+  uint64_t sk[KPL]; unsigned long long best[KPL];
+#pragma unroll
+  for (int q = 0; q < KPL; q++) {
+    sk[q] = splitmix64(seed ^ ((uint64_t)(1 + lane + 64 * q) * 0xD1342543DE82EF95ull));
+    best[q] = ~0ull;
+  }
+  for (int it = wave; it < D.nitems; it += nw) {
+    const Item item = D.items[it];
+    for (int p = 0; p < item.cnt; p += CB) {
+      const int nc = min(CB, item.cnt - p);
+      float z[CB][DPL];
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), d, lane, z[c]);
+        else {
+#pragma unroll
+          for (int t = 0; t < DPL; t++) z[c][t] = 0.0f;
+        }
+      }
+      float acc[CB][KPL];
+      group_dots<KPL, DPL, CB>(ldsY, d, D.KP, lane, z, acc);
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        if (c < nc) {
+          const int cell = item.start + p + c;
+          const uint64_t g = goff + (uint64_t)D.perm[cell];
+          bool skip = false;
+          for (int x = 0; x < nexcl; x++) skip |= ((uint64_t)excl[x] == g);
+          if (!skip) {
+#pragma unroll
+            for (int q = 0; q < KPL; q++) {
+              if (lane + 64 * q < K) {
+                const float dis = fabsf(2.0f * (1.0f - acc[c][q]));
+                const uint64_t h = splitmix64(sk[q] + g);
+                const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+                const float key = -logf(u) / dis;  // >= 0 (or +inf / nan when dis == 0)
+                unsigned kb = __float_as_uint(key);
+                if (!(key >= 0.0f)) kb = 0x7f800000u;  // nan -> +inf: never the minimum
+                const unsigned long long pk = ((unsigned long long)kb << 32) | (unsigned long long)(uint32_t)g;
+                best[q] = pk < best[q] ? pk : best[q];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KPL; q++)
+    if (lane + 64 * q < K && best[q] != ~0ull) atomicMin(&D.seedmin[lane + 64 * q], best[q]);
+}
+
+// rows[k][:] = Z_corr row of global cell gcells[k] if it lives on this shard, else 0 (summed across ranks)
+__global__ void k_gather_rows(Dev D, const long long* __restrict__ gcells, uint64_t goff, double* __restrict__ rows) {
+  const int k = blockIdx.x;
+  const long long g = gcells[k];
+  const long long loc = g - (long long)goff;
+  const bool mine = (loc >= 0 && loc < (long long)D.n);
+  for (int j = threadIdx.x; j < D.d; j += blockDim.x)
+    rows[(size_t)k * D.d + j] = mine ? (double)D.Zc[(size_t)D.invperm[loc] * D.d + j] : 0.0;
+}
+
+template <int KPL, int DPL>
+__global__ __launch_bounds__(TPB) void k_lloyd(Dev D) {
+  extern __shared__ __attribute__((aligned(16))) float ldsY[];
+  stage_Y(ldsY, D.Yt, D.d, D.K, D.KP);
+  constexpr int CB = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const int d = D.d, K = D.K;
+  float yn[KPL];
+#pragma unroll
+  for (int q = 0; q < KPL; q++) yn[q] = (lane + 64 * q < K) ? D.ynorm[lane + 64 * q] : 0.0f;
+  for (int it = wave; it < D.nitems; it += nw) {
+    const Item item = D.items[it];
+    for (int p = 0; p < item.cnt; p += CB) {
+      const int nc = min(CB, item.cnt - p);
+      float z[CB][DPL];
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), d, lane, z[c]);
+        else {
+#pragma unroll
+          for (int t = 0; t < DPL; t++) z[c][t] = 0.0f;
+        }
+      }
+      float acc[CB][KPL];
+      group_dots<KPL, DPL, CB>(ldsY, d, D.KP, lane, z, acc);
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        if (c < nc) {
+          unsigned long long best = ~0ull;
+#pragma unroll
+          for (int q = 0; q < KPL; q++) {
+            const int k = lane + 64 * q;
+            if (k < K) {
+              const float sc = yn[q] - 2.0f * acc[c][q];  // ||x-y||^2 - ||x||^2
+              unsigned ub = __float_as_uint(sc);
+              ub = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);  // order-preserving map
+              const unsigned long long pk = ((unsigned long long)ub << 32) | (unsigned)k;
+              best = pk < best ? pk : best;
+            }
+          }
+          best = wmin64(best);
+          const int kb = (int)(best & 0xffffffffu);
+#pragma unroll
+          for (int t = 0; t < DPL; t++) {
+            const int jj = 64 * t + lane;
+            if (jj < d) atomicAdd(&D.lsum[(size_t)kb * d + jj], (double)z[c][t]);
+          }
+          if (lane == 0) atomicAdd(&D.lcnt[kb], 1ull);
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// launchers
+// --------------------------------------------------------------------------------------
+size_t lds_bytes_y(const Dev& D) { return (size_t)D.d * D.KP * sizeof(float); }
+
+#define HMX_DISPATCH_KD(KERNEL, EXTRA, GRID, LDS, ...)                                         \
+  do {                                                                                         \
+    const int kpl_ = D.KP / 64, dpl_ = D.d > 64 ? 2 : 1;                                       \
+    if (dpl_ == 1) {                                                                           \
+      switch (kpl_) {                                                                          \
+        case 1: hipLaunchKernelGGL((KERNEL<1, 1 EXTRA>), GRID, dim3(TPB), LDS, L.stream, __VA_ARGS__); break; \
+        case 2: hipLaunchKernelGGL((KERNEL<2, 1 EXTRA>), GRID, dim3(TPB), LDS, L.stream, __VA_ARGS__); break; \
+        case 3: hipLaunchKernelGGL((KERNEL<3, 1 EXTRA>), GRID, dim3(TPB), LDS, L.stream, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((KERNEL<4, 1 EXTRA>), GRID, dim3(TPB), LDS, L.stream, __VA_ARGS__); break; \
+      }                                                                                        \
+    } else {                                                                                   \
+      switch (kpl_) {                                                                          \
+        case 1: hipLaunchKernelGGL((KERNEL<1, 2 EXTRA>), GRID, dim3(TPB), LDS, L.stream, __VA_ARGS__); break; \
+        case 2: hipLaunchKernelGGL((KERNEL<2, 2 EXTRA>), GRID, dim3(TPB), LDS, L.stream, __VA_ARGS__); break; \
+        case 3: hipLaunchKernelGGL((KERNEL<3, 2 EXTRA>), GRID, dim3(TPB), LDS, L.stream, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((KERNEL<4, 2 EXTRA>), GRID, dim3(TPB), LDS, L.stream, __VA_ARGS__); break; \
+      }                                                                                        \
+    }                                                                                          \
+  } while (0)
+#define HMX_COMMA ,
+
+static int stream_grid(const Launch& L, long long work_waves) {
+  long long blocks = (work_waves + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  if (blocks > L.grid) blocks = L.grid;
+  return (int)blocks;
+}
+
+void l_convert_in(const Launch& L, const double* src, float* dst, const int* invperm, int n, int d) {
+  hipLaunchKernelGGL(k_convert_in, dim3(2048), dim3(256), 0, L.stream, src, dst, invperm, n, d);
+}
+void l_convert_out(const Launch& L, const float* src, double* dst, const int* perm, int n, int w) {
+  hipLaunchKernelGGL(k_convert_out, dim3(2048), dim3(256), 0, L.stream, src, dst, perm, n, w);
+}
+void l_copy(const Launch& L, const float* src, float* dst, size_t count) {
+  hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, L.stream, src, dst, count);
+}
+void l_normalize(const Launch& L, float* Z, int n, int d) {
+  hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, Z, n, d);
+}
+void l_head(const Launch& L, const Dev& D, int mode) {
+  const dim3 grid(stream_grid(L, D.nitems));
+  const size_t lds = lds_bytes_y(D);
+  if (mode == 0) HMX_DISPATCH_KD(k_head, HMX_COMMA 0, grid, lds, D);
+  else HMX_DISPATCH_KD(k_head, HMX_COMMA 1, grid, lds, D);
+}
+void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+               uint64_t cells_per_block) {
+  FeistelKeys fk = make_keys(seed, round, Nglob);
+  hipLaunchKernelGGL(k_blockid, dim3(2048), dim3(256), 0, L.stream, D.blk, D.perm, D.n, fk, Nglob, goff,
+                     cells_per_block, D.nb);
+}
+void l_sort_blocks(const Launch& L, const Dev& D) {
+  const size_t lds = (size_t)D.nb * sizeof(int);
+  hipLaunchKernelGGL(k_sort_hist, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D.blk, D.n, D.nb, D.counts, D.nchunks);
+  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, L.stream, D.counts, D.nb * D.nchunks, D.nchunks, D.nb,
+                     D.boff, D.n);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D.blk, D.n, D.nb, D.counts,
+                     D.nchunks, D.lorder);
+}
+void l_oldsum(const Launch& L, const Dev& D) {
+  const dim3 grid(stream_grid(L, (D.n + 63) / 64));
+  switch (D.KP / 64) {
+    case 1: hipLaunchKernelGGL(k_oldsum<1>, grid, dim3(TPB), 0, L.stream, D); break;
+    case 2: hipLaunchKernelGGL(k_oldsum<2>, grid, dim3(TPB), 0, L.stream, D); break;
+    case 3: hipLaunchKernelGGL(k_oldsum<3>, grid, dim3(TPB), 0, L.stream, D); break;
+    default: hipLaunchKernelGGL(k_oldsum<4>, grid, dim3(TPB), 0, L.stream, D); break;
+  }
+}
+void l_prepare(const Launch& L, const Dev& D, int j) {
+  hipLaunchKernelGGL(k_prepare, dim3((D.K + 63) / 64), dim3(64), 0, L.stream, D, j);
+}
+void l_update(const Launch& L, const Dev& D, int j) {
+  // a block holds ~n/nb cells; D.upd_cpw cells per wave (tunable: HMX_UPD_CPW)
+  const long long waves = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + D.upd_cpw - 1) / D.upd_cpw + 1;
+  const dim3 grid(stream_grid(L, waves));
+  HMX_DISPATCH_KD(k_update, , grid, lds_bytes_y(D), D, j);
+}
+void l_finish_round(const Launch& L, const Dev& D) {
+  hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D, 1);
+}
+void l_objective_tables(const Launch& L, const Dev& D) {
+  hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D, 0);
+}
+void l_moe_stats(const Launch& L, const Dev& D) {
+  const int zch = (D.d + 31) / 32;
+  int dp = (D.d + zch - 1) / zch;
+  dp = (dp + 3) / 4 * 4;
+  const dim3 grid(stream_grid(L, D.nitems), (D.K + 127) / 128, (D.d + dp - 1) / dp);
+  switch (dp) {
+    case 4: hipLaunchKernelGGL(k_moe_stats<4>, grid, dim3(TPB), 0, L.stream, D); break;
+    case 8: hipLaunchKernelGGL(k_moe_stats<8>, grid, dim3(TPB), 0, L.stream, D); break;
+    case 12: hipLaunchKernelGGL(k_moe_stats<12>, grid, dim3(TPB), 0, L.stream, D); break;
+    case 16: hipLaunchKernelGGL(k_moe_stats<16>, grid, dim3(TPB), 0, L.stream, D); break;
+    case 20: hipLaunchKernelGGL(k_moe_stats<20>, grid, dim3(TPB), 0, L.stream, D); break;
+    case 24: hipLaunchKernelGGL(k_moe_stats<24>, grid, dim3(TPB), 0, L.stream, D); break;
+    case 28: hipLaunchKernelGGL(k_moe_stats<28>, grid, dim3(TPB), 0, L.stream, D); break;
+    default: hipLaunchKernelGGL(k_moe_stats<32>, grid, dim3(TPB), 0, L.stream, D); break;
+  }
+}
+void l_moe_apply(const Launch& L, const Dev& D) {
+  const int dpl = D.d > 64 ? 2 : 1;
+  const size_t lds = (size_t)D.K * 64 * dpl * sizeof(float);
+  int g = D.naitems < 4 * L.grid ? D.naitems : 4 * L.grid;
+  if (g < 1) g = 1;
+  const dim3 grid(g);
+  HMX_DISPATCH_KD(k_moe_apply, , grid, lds, D);
+}
+void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl) {
+  const dim3 grid(stream_grid(L, D.nitems));
+  HMX_DISPATCH_KD(k_seed_probe, , grid, lds_bytes_y(D), D, seed, goff, excl, nexcl);
+}
+void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint64_t goff, double* rows) {
+  hipLaunchKernelGGL(k_gather_rows, dim3(D.K), dim3(64), 0, L.stream, D, gcells, goff, rows);
+}
+void l_lloyd(const Launch& L, const Dev& D) {
+  const dim3 grid(stream_grid(L, D.nitems));
+  HMX_DISPATCH_KD(k_lloyd, , grid, lds_bytes_y(D), D);
+}
+
+}  // namespace hmx

@@ -1,0 +1,212 @@
+"""`Harmony`: the Python mirror of the reference's Rcpp-module object.
+
+Same method and field names as ``class_<harmony>`` exposes to R
+(/root/reference/src/harmony.cpp:672-709) -- ``setup``, ``init_cluster_cpp``, ``cluster_cpp``,
+``moe_correct_ridge_cpp``, ``check_convergence``, ``compute_objective``, ``getZcorr``,
+``getZorig``, ``getR``, ``getCentroids``, ``getLambda`` and the fields ``N B K d O E Y Pr_b
+B_vec alpha W R theta sigma lambda kmeans_rounds objective_* max_iter_kmeans`` -- so that the
+driver code (ui.py / utils.py, mirroring R/ui.R and R/utils.R) reads like the reference's.
+Every method is a thin call through the C ABI; all numerics run in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class HarmonyError(RuntimeError):
+    pass
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Harmony(object):
+    """new(harmony)  (R/ui.R:269)."""
+
+    def __init__(self, device=None, seed=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p(self._lib.hmx_create())
+        if not self._h:
+            raise HarmonyError("hmx_create failed")
+        self._keep = []  # keeps ctypes callbacks alive
+        self.warnings = []
+        if device is not None:
+            self._set("device", int(device))
+        if seed is not None:
+            self._set("seed", int(seed))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.hmx_destroy(h)
+
+    # ---- plumbing ----------------------------------------------------------------
+    def _check(self, status, what):
+        if status == 0:
+            return 0
+        if status == -1:
+            return -1
+        msg = self._lib.hmx_last_error(self._h).decode()
+        raise HarmonyError("%s failed (status %d): %s" % (what, status, msg))
+
+    def _set(self, field, value):
+        self._check(self._lib.hmx_set_int(self._h, field.encode(), int(value)), "set " + field)
+
+    def _get(self, field, shape=None):
+        n = self._lib.hmx_get(self._h, field.encode(), None, 0)
+        if n < 0:
+            raise HarmonyError("unknown or unavailable field %r: %s" % (field, self._lib.hmx_last_error(self._h).decode()))
+        out = np.empty(int(n), dtype=np.float64)
+        if n:
+            got = self._lib.hmx_get(self._h, field.encode(), _dptr(out), n)
+            if got != n:
+                raise HarmonyError("getter %r failed: %s" % (field, self._lib.hmx_last_error(self._h).decode()))
+        if shape is not None:
+            out = out.reshape(shape, order="F")
+        return out
+
+    def _scalar(self, field):
+        return self._get(field)[0]
+
+    # ---- distributed / runtime hooks (no reference counterpart) ---------------------------
+    def set_shard(self, rank, world, global_offset, N_global, allreduce_cb):
+        cb = _lib.ALLREDUCE_FN(allreduce_cb)
+        self._keep.append(cb)
+        self._check(self._lib.hmx_set_shard(self._h, rank, world, int(global_offset), int(N_global), cb, None), "set_shard")
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.hmx_set_stream(self._h, C.c_void_p(hip_stream)), "set_stream")
+
+    def set_abort_poll(self, fn):
+        cb = _lib.POLL_FN(lambda _u: int(bool(fn())))
+        self._keep.append(cb)
+        self._check(self._lib.hmx_set_abort_poll(self._h, cb, None), "set_abort_poll")
+
+    def push_update_order(self, order):
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        self._check(self._lib.hmx_push_update_order(self._h, order.ctypes.data_as(C.POINTER(C.c_int64))), "push_update_order")
+
+    def restart(self):
+        self._check(self._lib.hmx_restart(self._h), "restart")
+
+    def set_profile(self, on=True):
+        self._set("profile", 1 if on else 0)
+
+    def timer(self, name):
+        return self._scalar("timer:" + name)
+
+    # ---- the reference's methods -----------------------------------------------------------
+    def setup(self, Z, Phi, sigma, theta, lambda_vec, alpha, max_iter_kmeans, epsilon_kmeans, epsilon_harmony,
+              K, block_size, B_vec, batch_proportion_cutoff, verbose):
+        """harmony::setup (src/harmony.cpp:29-111).  Z: d x N; Phi: (i, p, x, B) CSC of the B x N design."""
+        Z = np.asfortranarray(Z, dtype=np.float64)
+        d, N = Z.shape
+        phi_i, phi_p, phi_x, B = Phi
+        phi_i = np.ascontiguousarray(phi_i, dtype=np.int32)
+        phi_p = np.ascontiguousarray(phi_p, dtype=np.int32)
+        phi_x = None if phi_x is None else np.ascontiguousarray(phi_x, dtype=np.float64)
+        sigma = np.ascontiguousarray(np.atleast_1d(sigma), dtype=np.float64)
+        theta = np.ascontiguousarray(np.atleast_1d(theta), dtype=np.float64)
+        lam = np.ascontiguousarray(np.atleast_1d(lambda_vec), dtype=np.float64)
+        B_vec = np.ascontiguousarray(np.atleast_1d(B_vec), dtype=np.int32)
+        if sigma.size != K:
+            raise HarmonyError("sigma must have one value per cluster")
+        if theta.size != B:
+            raise HarmonyError("theta must have one value per covariate level")
+        st = self._lib.hmx_setup(self._h, _dptr(Z), N, d, _iptr(phi_i), _iptr(phi_p),
+                                 None if phi_x is None else _dptr(phi_x), int(B), _dptr(sigma), _dptr(theta),
+                                 _dptr(lam), lam.size, float(alpha), int(max_iter_kmeans), float(epsilon_kmeans),
+                                 float(epsilon_harmony), int(K), float(block_size), _iptr(B_vec), B_vec.size,
+                                 float(batch_proportion_cutoff), int(bool(verbose)))
+        self._check(st, "setup")
+        w = self._lib.hmx_last_warning(self._h).decode()
+        if w:
+            import warnings
+            self.warnings.append(w)
+            warnings.warn(w)
+
+    def init_cluster_cpp(self, Y0=None):
+        if Y0 is None:
+            st = self._lib.hmx_init_cluster(self._h, None)
+        else:
+            Y0 = np.asfortranarray(Y0, dtype=np.float64)
+            st = self._lib.hmx_init_cluster(self._h, _dptr(Y0))
+        self._check(st, "init_cluster_cpp")
+
+    def kmeans_centers(self):
+        out = np.empty((int(self.d), int(self.K)), dtype=np.float64, order="F")
+        self._check(self._lib.hmx_kmeans_centers(self._h, _dptr(out)), "kmeans_centers")
+        return out
+
+    def cluster_cpp(self):
+        return self._check(self._lib.hmx_cluster(self._h), "cluster_cpp")
+
+    def moe_correct_ridge_cpp(self):
+        return self._check(self._lib.hmx_moe_correct_ridge(self._h), "moe_correct_ridge_cpp")
+
+    def check_convergence(self, type_):
+        r = self._lib.hmx_check_convergence(self._h, int(type_))
+        if r < 0:
+            raise HarmonyError("check_convergence: " + self._lib.hmx_last_error(self._h).decode())
+        return bool(r)
+
+    def compute_objective(self):
+        self._check(self._lib.hmx_compute_objective(self._h), "compute_objective")
+
+    def getZcorr(self):
+        return self._get("Z_corr", (int(self.d), int(self._scalar("N_local"))))
+
+    def getZorig(self):
+        return self._get("Z_orig", (int(self.d), int(self._scalar("N_local"))))
+
+    def getR(self):
+        return self._get("R", (int(self.K), int(self._scalar("N_local"))))
+
+    def getCentroids(self):
+        return self.Y
+
+    def getLambda(self):
+        return self._get("Lambda", (int(self.K), int(self.B) + 1))
+
+    # ---- the reference's fields -----------------------------------------------------------------
+    N = property(lambda s: int(s._scalar("N")))
+    B = property(lambda s: int(s._scalar("B")))
+    K = property(lambda s: int(s._scalar("K")))
+    d = property(lambda s: int(s._scalar("d")))
+    alpha = property(lambda s: float(s._scalar("alpha")))
+    O = property(lambda s: s._get("O", (s.K, s.B)))
+    E = property(lambda s: s._get("E", (s.K, s.B)))
+    Y = property(lambda s: s._get("Y", (s.d, s.K)))
+    R = property(lambda s: s.getR())
+    Pr_b = property(lambda s: s._get("Pr_b"))
+    B_vec = property(lambda s: s._get("B_vec").astype(int))
+    theta = property(lambda s: s._get("theta"))
+    sigma = property(lambda s: s._get("sigma"))
+    kmeans_rounds = property(lambda s: s._get("kmeans_rounds").astype(int))
+    objective_kmeans = property(lambda s: s._get("objective_kmeans"))
+    objective_kmeans_dist = property(lambda s: s._get("objective_kmeans_dist"))
+    objective_kmeans_entropy = property(lambda s: s._get("objective_kmeans_entropy"))
+    objective_kmeans_cross = property(lambda s: s._get("objective_kmeans_cross"))
+    objective_harmony = property(lambda s: s._get("objective_harmony"))
+
+    @property
+    def W(self):
+        return self._get("W", (int(self._scalar("W_rows")), self.d))
+
+    @property
+    def max_iter_kmeans(self):
+        return int(self._scalar("max_iter_kmeans"))
+
+    @max_iter_kmeans.setter
+    def max_iter_kmeans(self, v):  # vignettes/detailedWalkthrough.Rmd:364 writes this field
+        self._set("max_iter_kmeans", v)
+
+
+setattr(Harmony, "lambda", property(lambda s: s._get("lambda")))

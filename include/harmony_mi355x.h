@@ -1,0 +1,141 @@
+/* harmony_mi355x.h -- C ABI of libharmony_mi355x.so
+ *
+ * MI355X-native (gfx950, hand-written HIP) replacement for the reference's Rcpp
+ * module `harmony_module` (class_<harmony>, /root/reference/src/harmony.cpp:672-709;
+ * instantiated by `new(harmony)` at R/ui.R:269 and driven by R/ui.R:271-295 and
+ * R/utils.R:15-46).  One opaque handle == one `harmony` object (for multi-GPU: one
+ * handle per process/GPU holding a contiguous shard of the cells).
+ *
+ * Conventions
+ *   - all matrices cross the boundary exactly as the reference's do: double,
+ *     column-major (Z is d x N, R is K x N, Y is d x K, O/E are K x B, W is (B+1) x d,
+ *     Lambda is K x (B+1)); Phi is a dgCMatrix (CSC i/p/x), B x N, C ones per column,
+ *     rows grouped by covariate in vars_use order (R/ui.R:210-213).
+ *   - inputs are borrowed only for the duration of the call; outputs are written into
+ *     caller-allocated buffers (reference: conv_to copies, src/harmony.cpp:41-45,640-655).
+ *   - no exceptions cross the ABI: every call returns an int status
+ *        0 ok | -1 aborted by the poll callback (reference: Progress::check_abort,
+ *        src/harmony.cpp:233-234) | >0 error class (message: hmx_last_error).
+ *   - state is device-resident between calls; calls are synchronous w.r.t. the host
+ *     (results of getters are complete on return), re-entrant per handle, and there is no
+ *     global state (several handles may coexist).
+ *   - the library REQUIRES a HIP device (gfx950).  There is no CPU fallback: without a
+ *     device hmx_setup fails with HMX_ERR_DEVICE.
+ */
+#ifndef HARMONY_MI355X_H
+#define HARMONY_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hmx_ctx hmx_ctx;
+
+enum {
+  HMX_OK = 0,
+  HMX_ABORTED = -1,
+  HMX_ERR_ARG = 1,      /* bad argument / inconsistent shapes                                  */
+  HMX_ERR_TOO_FEW = 2,  /* "Refusing to run with less than 6 cells" (src/harmony.cpp:83-85)    */
+  HMX_ERR_PHI = 3,      /* Phi is not C-hot / rows not grouped by covariate                    */
+  HMX_ERR_SOLVE = 4,    /* singular ridge system                                               */
+  HMX_ERR_DEVICE = 5,   /* no HIP device / HIP runtime error                                   */
+  HMX_ERR_STATE = 6,    /* method called before setup / init                                   */
+  HMX_ERR_LIMIT = 7,    /* shape outside the supported envelope (d <= 128, K <= 256)           */
+  HMX_ERR_COMM = 8      /* all-reduce callback failed                                          */
+};
+
+/* ---- life cycle ---------------------------------------------------------------------- */
+/* new(harmony): constructor src/harmony.cpp:18-25, R/ui.R:269 */
+hmx_ctx* hmx_create(void);
+/* R external-pointer finalizer (the Rcpp module's XPtr deleter) */
+void hmx_destroy(hmx_ctx* ctx);
+const char* hmx_last_error(hmx_ctx* ctx);
+/* last Rcpp::warning equivalent ("Too few cells. Setting block_size to 0.2", src/harmony.cpp:87); "" if none */
+const char* hmx_last_warning(hmx_ctx* ctx);
+
+/* ---- harmony::setup  (src/harmony.h:25-30, src/harmony.cpp:29-111, called R/ui.R:271-275)
+ * Z: d x N doubles (this rank's cells); phi_i/phi_p/phi_x: CSC of the B x N one-hot design
+ * (phi_x may be NULL = all ones); sigma[K], theta[B]; lambda: B+1 values or a single -1
+ * (n_lambda == 1) meaning automatic estimation (R/ui.R:224-231, src/harmony.cpp:75-79). */
+int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d,
+              const int32_t* phi_i, const int32_t* phi_p, const double* phi_x, int32_t B,
+              const double* sigma, const double* theta, const double* lambda, int32_t n_lambda,
+              double alpha, int32_t max_iter_kmeans, double epsilon_kmeans, double epsilon_harmony,
+              int32_t K, double block_size, const int32_t* B_vec, int32_t C,
+              double batch_proportion_cutoff, int32_t verbose);
+
+/* Return to the state right after hmx_setup without re-uploading the inputs (Z_corr <-
+ * normalise(Z_orig), objective series cleared).  No reference counterpart; used by bench.py
+ * so that every timed step starts from HBM-resident inputs. */
+int hmx_restart(hmx_ctx* ctx);
+
+/* ---- harmony::init_cluster_cpp (src/harmony.cpp:131-156, R/ui.R:281).
+ * Y0 == NULL: centroids come from the on-device kmeans_centers (src/utils.cpp:10-64) using
+ * the documented counter-based generator below and the handle's seed.  Y0 != NULL (d x K):
+ * use these centroids instead (test hook: lets the oracle and the GPU share random choices). */
+int hmx_init_cluster(hmx_ctx* ctx, const double* Y0);
+/* kmeans_centers alone (.Call entry _harmony_kmeans_centers, src/RcppExports.cpp:14-25):
+ * writes the d x K un-normalised centres of the current Z_corr into Y_out. */
+int hmx_kmeans_centers(hmx_ctx* ctx, double* Y_out);
+
+/* ---- harmony::cluster_cpp (src/harmony.cpp:208-262): 0 ok, -1 aborted, >0 error */
+int hmx_cluster(hmx_ctx* ctx);
+/* ---- harmony::moe_correct_ridge_cpp (src/harmony.cpp:345-638) */
+int hmx_moe_correct_ridge(hmx_ctx* ctx);
+/* ---- harmony::check_convergence (src/harmony.cpp:173-205): returns 1/0, or <0 on error */
+int hmx_check_convergence(hmx_ctx* ctx, int32_t type);
+/* ---- harmony::compute_objective (src/harmony.cpp:158-170): appends to the 4 series */
+int hmx_compute_objective(hmx_ctx* ctx);
+
+/* ---- fields and getters (src/harmony.cpp:675-707, 640-669).
+ * `field` is one of: "Z_corr" "Z_orig" "R" "Y" "O" "E" "W" "Lambda" "Pr_b" "theta" "sigma"
+ * "lambda" "B_vec" "objective_kmeans" "objective_kmeans_dist" "objective_kmeans_entropy"
+ * "objective_kmeans_cross" "objective_harmony" "kmeans_rounds" "N" "B" "K" "d" "alpha"
+ * "max_iter_kmeans" "W_rows" (+ diagnostics: "subset_clusters" "skipped_clusters" "n_combos"
+ * and "timer:<phase>" in ms).  Returns the number of doubles the field holds (call with
+ * out == NULL to size), or -1 for an unknown field.  At most `cap` values are written. */
+int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap);
+/* writable fields: "max_iter_kmeans" (vignettes/detailedWalkthrough.Rmd:364), "seed",
+ * "device" (before setup), "deterministic" */
+int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t value);
+
+/* ---- randomness ------------------------------------------------------------------------
+ * The reference draws its per-round cell shuffle (arma::shuffle, src/harmony.cpp:272-273) and
+ * its centroid seeds (fill::randu, src/utils.cpp:12,29) from R's RNG, which is not available
+ * to a C library.  Only block MEMBERSHIP matters mathematically, so the library derives, for
+ * round r, the position of global cell g in the shuffled order from a stateless bijection
+ *      pos = hmx_feistel_pos(seed, r, N_global, g)       (6-round Feistel + cycle walking)
+ * and block(g) = min(pos / cells_per_block, n_blocks-1) exactly as src/harmony.cpp:280-300.
+ * A host that owns an RNG stream (e.g. R's) can inject its own shuffles instead:
+ * each call queues one update_order (N_global entries, update_order[p] = cell at position p,
+ * consumed by the next update_R round). */
+uint64_t hmx_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g);
+float hmx_u01(uint64_t seed, uint64_t stream, uint64_t idx);
+int hmx_push_update_order(hmx_ctx* ctx, const int64_t* update_order);
+
+/* ---- multi-GPU: one handle per process/GPU, cells sharded contiguously --------------------
+ * The all-reduce is a host-provided hook (bench/tests: torch.distributed == RCCL over xGMI;
+ * an R host would bind RCCL directly).  It must SUM (dtype 0: int64, 1: float64) or MIN
+ * (dtype 2: int64) `count` elements in place at device pointer `buf`, enqueued on `stream`
+ * (a hipStream_t) or completed on return.  Return 0 on success. */
+typedef int (*hmx_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, void* stream);
+/* must be called before hmx_setup; global_offset = index of this rank's first cell */
+int hmx_set_shard(hmx_ctx* ctx, int32_t rank, int32_t world, int64_t global_offset,
+                  int64_t N_global, hmx_allreduce_fn fn, void* user);
+/* run all kernels on this hipStream_t (default: the library's own stream) */
+int hmx_set_stream(hmx_ctx* ctx, void* hip_stream);
+/* optional user-interrupt poll, checked once per clustering round and per correction
+ * (Progress::check_abort(), src/harmony.cpp:233,355); non-zero return aborts */
+int hmx_set_abort_poll(hmx_ctx* ctx, int (*poll)(void*), void* user);
+
+/* ---- measurement ----------------------------------------------------------------------------
+ * HIP-event timing of the dominant kernel on the library's stream: after
+ * hmx_set_int(ctx,"profile",1) every launch of the E-step update kernel is bracketed by
+ * events; "prof:update_ms" / "prof:update_launches" / "prof:update_cells" via hmx_get. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HARMONY_MI355X_H */

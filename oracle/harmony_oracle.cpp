@@ -1,0 +1,607 @@
+// =============================================================================
+// TEST INFRASTRUCTURE ONLY -- CPU oracle for the Harmony clustering+correction
+// loop.  Nothing under oracle/ is part of the product: only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+//
+// What it is: a from-scratch C++17 restatement (no Armadillo/Rcpp -- neither is
+// installable here) of the reference engine, following it function by function:
+//   setup / allocate_buffers     /root/reference/src/harmony.cpp:29-128
+//   init_cluster_cpp             src/harmony.cpp:131-156
+//   compute_objective            src/harmony.cpp:158-170, src/utils.cpp:67-81
+//   check_convergence            src/harmony.cpp:173-205
+//   cluster_cpp                  src/harmony.cpp:208-262
+//   update_R                     src/harmony.cpp:269-342
+//   moe_correct_ridge_cpp        src/harmony.cpp:345-638
+//   kmeans_centers et al.        src/utils.cpp:10-108,159-163
+//
+// PARITY UNPINNED: the reference's tests hold no golden numeric vectors
+// (tests/testthat/*.R assert shapes, probability-simplex, finiteness and a chi2
+// ordering only) and the reference cannot be built here (needs R, Rcpp,
+// RcppArmadillo, RcppProgress).  This oracle is therefore pinned only against
+// those invariants on the reference's bundled fixtures (tests/test_oracle.py).
+//
+// Third-party arithmetic whose source is NOT under /root/reference (RcppArmadillo,
+// unpinned version; DESCRIPTION:54) is restated by its published semantics:
+//   arma::normalise(X,p,0)  column / ||column||_p, zero norm -> divide by 1
+//   arma::trunc_log         log(x) with x<=0 -> log(FLT_MIN), +inf -> log(FLT_MAX)
+//   arma::shuffle / randu   replaced by an injectable permutation / a documented
+//                           counter-based generator (R's RNG is not reproducible here)
+//   arma::kmeans(...,keep_existing,1)  ONE Lloyd iteration: assign to the nearest
+//                           mean (Euclidean), new mean = average of members, an
+//                           empty cluster keeps its previous mean  [our definition]
+//   arma::inv               fp32 LU with partial pivoting (faithful mode)
+//
+// Two arithmetic modes (hard part 3):
+//   faithful  fp32 state and fp32 accumulators in the reference's operation order
+//             (sequential fp32 my_accu, fp32 O/E += / -= drift, fp32 inverse)
+//   accurate  same algorithm, but O/E, objective terms and the ridge sufficient
+//             statistics / solve are carried in fp64.  This is the parity target
+//             for the GPU path; the faithful-vs-accurate gap is the noise floor.
+// =============================================================================
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <numeric>
+#include <set>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+typedef void (*sgemm_fn)(int order, int transa, int transb, int M, int N, int K, float alpha,
+                         const float* A, int lda, const float* B, int ldb, float beta, float* C,
+                         int ldc);
+sgemm_fn g_sgemm = nullptr;  // optional cblas_sgemm (OpenBLAS) injected from Python
+
+// ---- documented counter-based generators (shared SPEC with the product; the
+// ---- implementations are independent).  See include/harmony_mi355x.h. --------
+inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+inline float u01(uint64_t seed, uint64_t stream, uint64_t idx) {
+  uint64_t h = splitmix64(splitmix64(seed ^ (stream * 0xD1342543DE82EF95ull)) + idx);
+  return ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+// position of cell g in round `round`'s pseudo-random permutation of [0,N)
+inline uint64_t feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g) {
+  int bits = 2;
+  while (((uint64_t)1 << bits) < N) bits += 2;
+  const int half = bits / 2;
+  const uint32_t mask = (uint32_t)(((uint64_t)1 << half) - 1);
+  uint32_t keys[6];
+  for (int r = 0; r < 6; r++)
+    keys[r] = (uint32_t)(splitmix64(seed ^ (round * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(r + 1) << 56)) >> 32);
+  uint64_t x = g;
+  do {
+    uint32_t L = (uint32_t)(x >> half), R = (uint32_t)(x & mask);
+    for (int r = 0; r < 6; r++) {
+      uint32_t t = L ^ (fmix32(R * 0x9E3779B1u + keys[r]) & mask);
+      L = R; R = t;
+    }
+    x = ((uint64_t)L << half) | R;
+  } while (x >= N);
+  return x;
+}
+
+inline float trunc_logf(float x) {  // arma::trunc_log
+  if (!(x > 0.0f)) return std::log(FLT_MIN);
+  if (std::isinf(x)) return std::log(FLT_MAX);
+  return std::log(x);
+}
+int my_ceil(float num) {  // src/utils.cpp:102-108
+  int inum = (int)num;
+  if (num == (float)inum) return inum;
+  return inum + 1;
+}
+
+struct Timers {
+  std::map<std::string, double> ms;
+  struct Scope {
+    double& acc; std::chrono::steady_clock::time_point t0;
+    Scope(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~Scope() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  };
+};
+
+// C[M x N] = A^T[M x Kd] * B[Kd x N], all column-major (A is Kd x M).
+void gemm_tn(int M, int N, int Kd, const float* A, const float* B, float* C) {
+  if (g_sgemm) {
+    g_sgemm(102 /*ColMajor*/, 112 /*Trans*/, 111 /*NoTrans*/, M, N, Kd, 1.0f, A, Kd, B, Kd, 0.0f, C, M);
+    return;
+  }
+  for (int64_t n = 0; n < N; n++)
+    for (int m = 0; m < M; m++) {
+      float s = 0.0f;
+      const float* a = A + (int64_t)m * Kd; const float* b = B + n * Kd;
+      for (int k = 0; k < Kd; k++) s += a[k] * b[k];
+      C[n * M + m] = s;
+    }
+}
+
+template <class T> void normalise_cols_l2(T* X, int rows, int64_t cols) {
+  for (int64_t c = 0; c < cols; c++) {
+    T* x = X + c * rows; T s = 0;
+    for (int r = 0; r < rows; r++) s += x[r] * x[r];
+    T nrm = std::sqrt(s); if (nrm == 0) nrm = 1;
+    for (int r = 0; r < rows; r++) x[r] /= nrm;
+  }
+}
+
+// dense solve A X = Bm (n x n, n x m) in place, LU with partial pivoting; returns false if singular
+template <class T> bool lu_solve(std::vector<T>& A, int n, std::vector<T>& Bm, int m) {
+  std::vector<int> piv(n);
+  for (int c = 0; c < n; c++) {
+    int p = c; T best = std::fabs(A[c * n + c]);
+    for (int r = c + 1; r < n; r++) if (std::fabs(A[c * n + r]) > best) { best = std::fabs(A[c * n + r]); p = r; }
+    if (best == 0) return false;
+    if (p != c) {
+      for (int j = 0; j < n; j++) std::swap(A[j * n + c], A[j * n + p]);
+      for (int j = 0; j < m; j++) std::swap(Bm[j * n + c], Bm[j * n + p]);
+    }
+    T inv = 1 / A[c * n + c];
+    for (int r = c + 1; r < n; r++) {
+      T f = A[c * n + r] * inv; if (f == 0) continue;
+      A[c * n + r] = f;
+      for (int j = c + 1; j < n; j++) A[j * n + r] -= f * A[j * n + c];
+      for (int j = 0; j < m; j++) Bm[j * n + r] -= f * Bm[j * n + c];
+    }
+  }
+  for (int j = 0; j < m; j++)
+    for (int r = n - 1; r >= 0; r--) {
+      T s = Bm[j * n + r];
+      for (int c = r + 1; c < n; c++) s -= A[c * n + r] * Bm[j * n + c];
+      Bm[j * n + r] = s / A[r * n + r];
+    }
+  return true;
+}
+
+// ACC = float  -> faithful mode;  ACC = double -> accurate mode
+struct OracleBase {
+  virtual ~OracleBase() {}
+  virtual int setup(const double* Z, int64_t N, int d, const int32_t* phi_i, const int32_t* phi_p, int B,
+                    const double* sigma, const double* theta, const double* lambda, int n_lambda,
+                    double alpha, int max_iter_kmeans, double eps_k, double eps_h, int K, double block_size,
+                    const int32_t* B_vec, int C, double cutoff) = 0;
+  virtual int init_cluster(const double* Y0, uint64_t seed) = 0;
+  virtual int cluster() = 0;
+  virtual int moe_correct_ridge() = 0;
+  virtual int check_convergence(int type) = 0;
+  virtual void compute_objective() = 0;
+  virtual int64_t get(const char* what, double* out) = 0;
+  virtual void push_update_order(const int64_t* order) = 0;
+  virtual void set_int(const char* what, int64_t v) = 0;
+  std::string err;
+  Timers timers;
+};
+
+template <class ACC> struct Oracle : OracleBase {
+  int64_t N = 0; int d = 0, K = 0, B = 0, C = 0;
+  std::vector<float> Z_orig, Z_corr, R, dist, Y, W;  // column-major like the reference
+  std::vector<ACC> O, E;                              // K x B, column-major: [b*K + k]
+  std::vector<float> Pr_b, theta, sigma, lambda, sizes;
+  std::vector<int> B_vec, covariate_bounds;
+  std::vector<std::vector<int64_t>> index;            // cells of each level, ascending
+  std::vector<int32_t> codes;                         // [c*N + i] global level of cell i in covariate c
+  std::vector<float> objective_kmeans, objective_kmeans_dist, objective_kmeans_entropy,
+      objective_kmeans_cross, objective_harmony;
+  std::vector<int> kmeans_rounds;
+  float block_size = 0.05f, epsilon_kmeans = 1e-3f, epsilon_harmony = 1e-2f, alpha = 0.2f,
+        batch_proportion_cutoff = 1e-5f;
+  int max_iter_kmeans = 4, window_size = 3;
+  bool lambda_estimation = false;
+  uint64_t seed = 0, round_counter = 0;
+  std::deque<std::vector<int64_t>> injected;
+  int W_rows = 0;
+  int64_t subset_clusters = 0, skipped_clusters = 0;
+
+  // ---- setup: src/harmony.cpp:29-128 ----------------------------------------
+  int setup(const double* Z, int64_t N_, int d_, const int32_t* phi_i, const int32_t* phi_p, int B_,
+            const double* sigma_, const double* theta_, const double* lambda_, int n_lambda, double alpha_,
+            int max_iter_kmeans_, double eps_k, double eps_h, int K_, double block_size_, const int32_t* B_vec_,
+            int C_, double cutoff) override {
+    N = N_; d = d_; B = B_; K = K_; C = C_;
+    if (N < 6) { err = "Refusing to run with less than 6 cells"; return 2; }  // :83-85
+    Z_orig.resize((size_t)d * N);
+    for (size_t i = 0; i < Z_orig.size(); i++) Z_orig[i] = (float)Z[i];          // conv_to :41
+    Z_corr = Z_orig; normalise_cols_l2(Z_corr.data(), d, N);                      // :42
+    B_vec.assign(B_vec_, B_vec_ + C);
+    covariate_bounds.resize(C); std::partial_sum(B_vec.begin(), B_vec.end(), covariate_bounds.begin());
+    if (covariate_bounds.back() != B) { err = "sum(B_vec) != nrow(Phi)"; return 3; }
+    // Phi is C-hot with unit values (R/ui.R:210-213); keep per-covariate level codes + index lists (:49-65)
+    index.assign(B, {}); codes.assign((size_t)C * N, -1);
+    for (int64_t i = 0; i < N; i++) {
+      if (phi_p[i + 1] - phi_p[i] != C) { err = "Phi column is not C-hot"; return 3; }
+      for (int c = 0; c < C; c++) {
+        int b = phi_i[phi_p[i] + c];
+        int cov = 0; while (b >= covariate_bounds[cov]) cov++;
+        if (cov != c) { err = "Phi rows not grouped by covariate"; return 3; }
+        codes[(size_t)c * N + i] = b; index[b].push_back(i);
+      }
+    }
+    sizes.resize(B); Pr_b.resize(B);
+    for (int b = 0; b < B; b++) { sizes[b] = (float)index[b].size(); Pr_b[b] = sizes[b] / (float)N; }  // :67
+    epsilon_kmeans = (float)eps_k; epsilon_harmony = (float)eps_h;
+    if (lambda_[0] == -1) lambda_estimation = true;                               // :75-79
+    else { lambda_estimation = false; lambda.assign(n_lambda, 0.f); for (int i = 0; i < n_lambda; i++) lambda[i] = (float)lambda_[i]; }
+    sigma.resize(K); for (int k = 0; k < K; k++) sigma[k] = (float)sigma_[k];
+    block_size = (N < 40) ? 0.2f : (float)block_size_;                            // :86-91
+    theta.resize(B); for (int b = 0; b < B; b++) theta[b] = (float)theta_[b];
+    max_iter_kmeans = max_iter_kmeans_; alpha = (float)alpha_; batch_proportion_cutoff = (float)cutoff;
+    // allocate_buffers :114-128
+    dist.assign((size_t)K * N, 0.f); R.assign((size_t)K * N, 0.f);
+    O.assign((size_t)K * B, 0); E.assign((size_t)K * B, 0);
+    W.assign((size_t)(B + 1) * d, 0.f); W_rows = B + 1;
+    objective_kmeans.clear(); objective_kmeans_dist.clear(); objective_kmeans_entropy.clear();
+    objective_kmeans_cross.clear(); objective_harmony.clear(); kmeans_rounds.clear();
+    round_counter = 0;
+    return 0;
+  }
+
+  // ---- kmeans_centers: src/utils.cpp:10-64 -----------------------------------
+  void kmeans_centers(uint64_t seed_) {
+    const float* X = Z_corr.data();
+    Y.assign((size_t)d * K, 0.f);
+    // initialize_centroids :10-49
+    const uint64_t Nm1 = (uint64_t)N - 1;
+    for (int i = 0; i < K; i++) {
+      int64_t idx = (int64_t)std::floor(u01(seed_, 0, (uint64_t)i) * (float)Nm1);
+      std::memcpy(&Y[(size_t)i * d], X + idx * d, sizeof(float) * d);
+    }
+    std::set<int64_t> sup;
+    std::vector<float> prob(N);
+    for (int i = 0; i < K; i++) {
+      const float* y = &Y[(size_t)i * d];
+      for (int64_t n = 0; n < N; n++) {
+        float dot = 0.f; const float* x = X + n * d;
+        for (int j = 0; j < d; j++) dot += y[j] * x[j];
+        float dis = std::fabs(2.f * (1.f - dot));
+        prob[n] = -std::log(u01(seed_, 1 + (uint64_t)i, (uint64_t)n)) / dis;
+      }
+      int64_t best = std::min_element(prob.begin(), prob.end()) - prob.begin();
+      while (sup.count(best)) {                                                    // :38-43
+        prob[best] = *std::max_element(prob.begin(), prob.end());
+        best = std::min_element(prob.begin(), prob.end()) - prob.begin();
+      }
+      sup.insert(best);
+      std::memcpy(&Y[(size_t)i * d], X + best * d, sizeof(float) * d);
+    }
+    // 10 x one Lloyd iteration :53-64 (arma::kmeans semantics: see header)
+    std::vector<double> sums((size_t)d * K); std::vector<int64_t> cnt(K); std::vector<float> ynorm(K);
+    for (int it = 0; it < 10; it++) {
+      std::fill(sums.begin(), sums.end(), 0.0); std::fill(cnt.begin(), cnt.end(), 0);
+      for (int k = 0; k < K; k++) { float s = 0.f; for (int j = 0; j < d; j++) s += Y[(size_t)k * d + j] * Y[(size_t)k * d + j]; ynorm[k] = s; }
+      for (int64_t n = 0; n < N; n++) {
+        const float* x = X + n * d; int bk = 0; float bs = FLT_MAX;
+        for (int k = 0; k < K; k++) {
+          float dot = 0.f; const float* y = &Y[(size_t)k * d];
+          for (int j = 0; j < d; j++) dot += y[j] * x[j];
+          float sc = ynorm[k] - 2.f * dot;  // ||x-y||^2 - ||x||^2
+          if (sc < bs) { bs = sc; bk = k; }
+        }
+        cnt[bk]++; for (int j = 0; j < d; j++) sums[(size_t)bk * d + j] += x[j];
+      }
+      for (int k = 0; k < K; k++) if (cnt[k] > 0)
+        for (int j = 0; j < d; j++) Y[(size_t)k * d + j] = (float)(sums[(size_t)k * d + j] / (double)cnt[k]);
+    }
+  }
+
+  // R = softmax_k(-dist/sigma), E, O from scratch: src/harmony.cpp:141-150 and :221-227
+  void dist_R_EO() {
+    gemm_tn(K, (int)N, d, Y.data(), Z_corr.data(), dist.data());
+    for (size_t i = 0; i < dist.size(); i++) dist[i] = 2.f * (1.f - dist[i]);
+    for (int64_t n = 0; n < N; n++) {
+      float* r = &R[n * K]; const float* dm = &dist[n * K]; float s = 0.f;
+      for (int k = 0; k < K; k++) { r[k] = std::exp(-dm[k] / sigma[k]); s += r[k]; }
+      for (int k = 0; k < K; k++) r[k] /= s;
+    }
+    std::vector<ACC> rs(K, 0);
+    for (int64_t n = 0; n < N; n++) for (int k = 0; k < K; k++) rs[k] += R[n * K + k];
+    for (int b = 0; b < B; b++) for (int k = 0; k < K; k++) E[(size_t)b * K + k] = rs[k] * (ACC)Pr_b[b];
+    std::fill(O.begin(), O.end(), (ACC)0);
+    for (int b = 0; b < B; b++) for (int64_t i : index[b]) for (int k = 0; k < K; k++) O[(size_t)b * K + k] += R[i * K + k];
+  }
+
+  int init_cluster(const double* Y0, uint64_t seed_) override {  // :131-156
+    seed = seed_;
+    if (Y0) { Y.resize((size_t)d * K); for (size_t i = 0; i < Y.size(); i++) Y[i] = (float)Y0[i]; }
+    else kmeans_centers(seed_);
+    normalise_cols_l2(Y.data(), d, K);
+    dist_R_EO();
+    compute_objective();
+    objective_harmony.push_back(objective_kmeans.back());
+    return 0;
+  }
+
+  void compute_objective() override {  // :158-170
+    const float norm_const = 2000 / ((float)N);
+    ACC kmeans_error = 0, entropy = 0, cross = 0;
+    std::vector<float> M((size_t)K * B);  // theta_b * log((O+E+1)/(2E+1))
+    for (int b = 0; b < B; b++) for (int k = 0; k < K; k++) {
+      float o = (float)O[(size_t)b * K + k], e = (float)E[(size_t)b * K + k];
+      M[(size_t)b * K + k] = theta[b] * std::log((o + e + 1.f) / ((2.f * e) + 1.f));
+    }
+    for (int64_t n = 0; n < N; n++) for (int k = 0; k < K; k++) kmeans_error += R[n * K + k] * dist[n * K + k];
+    for (int64_t n = 0; n < N; n++) for (int k = 0; k < K; k++) { float r = R[n * K + k]; entropy += (r * trunc_logf(r)) * sigma[k]; }
+    for (int64_t n = 0; n < N; n++) for (int k = 0; k < K; k++) {
+      float m = 0.f; for (int c = 0; c < C; c++) m += M[(size_t)codes[(size_t)c * N + n] * K + k];
+      cross += (R[n * K + k] * sigma[k]) * m;
+    }
+    objective_kmeans.push_back((float)((kmeans_error + entropy + cross) * norm_const));
+    objective_kmeans_dist.push_back((float)(kmeans_error * norm_const));
+    objective_kmeans_entropy.push_back((float)(entropy * norm_const));
+    objective_kmeans_cross.push_back((float)(cross * norm_const));
+  }
+
+  int check_convergence(int type) override {  // :173-205
+    float obj_new, obj_old;
+    if (type == 0) {
+      obj_old = 0; obj_new = 0;
+      for (int i = 0; i < window_size; i++) {
+        obj_old += objective_kmeans[objective_kmeans.size() - 2 - i];
+        obj_new += objective_kmeans[objective_kmeans.size() - 1 - i];
+      }
+      return (std::fabs(obj_old - obj_new) / std::fabs(obj_old) < epsilon_kmeans) ? 1 : 0;
+    } else if (type == 1) {
+      obj_old = objective_harmony[objective_harmony.size() - 2];
+      obj_new = objective_harmony[objective_harmony.size() - 1];
+      return ((obj_old - obj_new) / std::fabs(obj_old) < epsilon_harmony) ? 1 : 0;
+    }
+    return 1;
+  }
+
+  int cluster() override {  // :208-262
+    if (objective_harmony.size() != 1) {
+      normalise_cols_l2(Z_corr.data(), d, N);
+      dist_R_EO();
+    }
+    int iter;
+    for (iter = 0; iter < max_iter_kmeans; iter++) {
+      int st = update_R(); if (st) return st;
+      compute_objective();
+      if (iter > window_size) { if (check_convergence(0)) { iter++; break; } }
+    }
+    kmeans_rounds.push_back(iter);
+    objective_harmony.push_back(objective_kmeans.back());
+    return 0;
+  }
+
+  void push_update_order(const int64_t* order) override { injected.emplace_back(order, order + N); }
+
+  int update_R() {  // :269-342
+    std::vector<int64_t> update_order;
+    if (!injected.empty()) { update_order = std::move(injected.front()); injected.pop_front(); }
+    else {  // documented generator: cell g sits at position feistel_pos(seed, round, N, g)
+      update_order.resize(N);
+      for (int64_t g = 0; g < N; g++) update_order[feistel_pos(seed, round_counter, (uint64_t)N, (uint64_t)g)] = g;
+    }
+    round_counter++;
+    const unsigned n_blocks = (unsigned)my_ceil(1.0 / block_size);
+    const unsigned cells_per_block = (unsigned)(N * block_size);  // fp32 product, truncated :281
+    // physical shuffle :285-291 (the reference gathers R and dist_mat by update_order)
+    std::vector<float> Rr((size_t)K * N), Dr((size_t)K * N);
+    {
+      Timers::Scope t(timers.ms["randomize"]);
+      for (int64_t p = 0; p < N; p++) {
+        std::memcpy(&Rr[p * K], &R[update_order[p] * K], sizeof(float) * K);
+        std::memcpy(&Dr[p * K], &dist[update_order[p] * K], sizeof(float) * K);
+      }
+    }
+    std::vector<float> pen((size_t)K * B); std::vector<ACC> rs(K);
+    for (unsigned blk = 0; blk < n_blocks; blk++) {
+      int64_t idx_min = (int64_t)blk * cells_per_block;
+      int64_t idx_max = (int64_t)(blk + 1) * cells_per_block - 1;
+      if (blk == n_blocks - 1) idx_max = N - 1;
+      if (idx_min > idx_max) continue;  // N*block_size rounding can leave trailing empty blocks
+      {
+        Timers::Scope t(timers.ms["EO_update"]);  // :312-313
+        std::fill(rs.begin(), rs.end(), (ACC)0);
+        for (int64_t p = idx_min; p <= idx_max; p++) for (int k = 0; k < K; k++) rs[k] += Rr[p * K + k];
+        for (int b = 0; b < B; b++) for (int k = 0; k < K; k++) E[(size_t)b * K + k] -= rs[k] * (ACC)Pr_b[b];
+        for (int64_t p = idx_min; p <= idx_max; p++) { int64_t i = update_order[p];
+          for (int c = 0; c < C; c++) { size_t b = codes[(size_t)c * N + i]; for (int k = 0; k < K; k++) O[b * K + k] -= Rr[p * K + k]; } }
+      }
+      {
+        Timers::Scope t(timers.ms["Rcells_update"]);  // :318-323
+        for (int b = 0; b < B; b++) for (int k = 0; k < K; k++) {
+          float o = (float)O[(size_t)b * K + k], e = (float)E[(size_t)b * K + k];
+          pen[(size_t)b * K + k] = std::pow(((2.f * e) + 1.f) / (o + e + 1.f), theta[b]);
+        }
+        for (int64_t p = idx_min; p <= idx_max; p++) {
+          int64_t i = update_order[p]; float* r = &Rr[p * K]; const float* dm = &Dr[p * K];
+          float s = 0.f;
+          for (int k = 0; k < K; k++) { r[k] = std::exp(-dm[k] / sigma[k]); s += std::fabs(r[k]); }
+          if (s == 0.f) s = 1.f;
+          for (int k = 0; k < K; k++) r[k] /= s;
+          s = 0.f;
+          for (int k = 0; k < K; k++) {
+            float m = 0.f; for (int c = 0; c < C; c++) m += pen[(size_t)codes[(size_t)c * N + i] * K + k];
+            r[k] *= m; s += std::fabs(r[k]);
+          }
+          if (s == 0.f) s = 1.f;
+          for (int k = 0; k < K; k++) r[k] /= s;
+        }
+      }
+      {
+        Timers::Scope t(timers.ms["EO_update"]);  // :329-330
+        std::fill(rs.begin(), rs.end(), (ACC)0);
+        for (int64_t p = idx_min; p <= idx_max; p++) for (int k = 0; k < K; k++) rs[k] += Rr[p * K + k];
+        for (int b = 0; b < B; b++) for (int k = 0; k < K; k++) E[(size_t)b * K + k] += rs[k] * (ACC)Pr_b[b];
+        for (int64_t p = idx_min; p <= idx_max; p++) { int64_t i = update_order[p];
+          for (int c = 0; c < C; c++) { size_t b = codes[(size_t)c * N + i]; for (int k = 0; k < K; k++) O[b * K + k] += Rr[p * K + k]; } }
+      }
+    }
+    {
+      Timers::Scope t(timers.ms["randomize"]);  // un-shuffle :338-339
+      for (int64_t p = 0; p < N; p++) std::memcpy(&R[update_order[p] * K], &Rr[p * K], sizeof(float) * K);
+    }
+    return 0;
+  }
+
+  // ---- moe_correct_ridge_cpp: src/harmony.cpp:345-638 -------------------------
+  int moe_correct_ridge() override {
+    Timers::Scope tall(timers.ms["correct_ridge_loop"]);
+    Z_corr = Z_orig;  // :347
+    subset_clusters = skipped_clusters = 0;
+    std::vector<char> in_set(N);
+    for (int k = 0; k < K; k++) {
+      // which levels have support in this cluster :358-402
+      std::vector<int> cov_levels(C, 0);
+      for (int b = 0, cov = 0; b < B; b++) {
+        if (!(b < covariate_bounds[cov])) cov++;
+        float rep = (float)O[(size_t)b * K + k] / sizes[b];
+        if (rep > batch_proportion_cutoff) cov_levels[cov]++;
+      }
+      std::vector<int> keep;
+      for (int b = 0, cov = 0; b < B; b++) {
+        if (cov < C && !(b < covariate_bounds[cov])) cov++;
+        float rep = (float)O[(size_t)b * K + k] / sizes[b];
+        if (rep > batch_proportion_cutoff && cov_levels[cov] > 1) keep.push_back(b);
+      }
+      int active = 0; for (int l : cov_levels) if (l > 1) active++;
+      const bool full = ((int)keep.size() == B);
+      if (!full) { subset_clusters++; if (active == 0) { skipped_clusters++; continue; } }  // :449-452
+      const int m = (int)keep.size() + 1;  // design rows incl. intercept
+      std::vector<int> row_of(B, -1); for (int a = 0; a < (int)keep.size(); a++) row_of[keep[a]] = a + 1;
+      // cells entering the regression = union of kept levels' cells :400,456-460
+      if (full) std::fill(in_set.begin(), in_set.end(), 1);
+      else { std::fill(in_set.begin(), in_set.end(), 0); for (int b : keep) for (int64_t i : index[b]) in_set[i] = 1; }
+      // cov = Phi* diag(R_k) Phi*^T + Lambda ; rhs = Phi* diag(R_k) Z_orig^T   :561-568,592-609
+      std::vector<ACC> cov((size_t)m * m, 0), rhs((size_t)m * d, 0);
+      for (int64_t i = 0; i < N; i++) {
+        if (!in_set[i]) continue;
+        const ACC r = R[i * K + k];
+        int rows[16]; int nr = 0; rows[nr++] = 0;
+        for (int c = 0; c < C; c++) { int ro = row_of[codes[(size_t)c * N + i]]; if (ro >= 0) rows[nr++] = ro; }
+        for (int a = 0; a < nr; a++) for (int b2 = 0; b2 < nr; b2++) cov[(size_t)rows[b2] * m + rows[a]] += r;
+        const float* z = &Z_orig[i * d];
+        for (int j = 0; j < d; j++) { ACC zt = (ACC)(z[j] * (float)r);  // Z_tmp = Z_orig % R_k (fp32 product :592)
+          for (int a = 0; a < nr; a++) rhs[(size_t)j * m + rows[a]] += zt; }
+      }
+      for (int a = 1; a < m; a++) {
+        float lam = lambda_estimation ? (float)E[(size_t)keep[a - 1] * K + k] * alpha : lambda[keep[a - 1] + 1];  // :434-439,533-544
+        cov[(size_t)a * m + a] += (ACC)lam;
+      }
+      // W = inv(cov) * rhs  (:571-609).  Faithful: explicit fp32 inverse (arrowhead closed form for C==1,
+      // LU otherwise) then fp32 products; accurate: fp64 LU solve.
+      std::vector<ACC> Wk((size_t)m * d);
+      bool ok = true;
+      if (std::is_same<ACC, float>::value && C == 1) {
+        std::vector<float> ac(m), bb(m), acb(m);
+        for (int a = 0; a < m; a++) { ac[a] = -(float)cov[(size_t)a * m + 0]; bb[a] = 1.f / (float)cov[(size_t)a * m + a]; }
+        ac[0] = 1.f; float b0 = (float)cov[0]; bb[0] = 0.f;
+        float u = 0.f; for (int a = 0; a < m; a++) u += (ac[a] * ac[a]) * bb[a]; u = b0 - u;
+        for (int a = 0; a < m; a++) acb[a] = ac[a] * bb[a]; acb[0] = 1.f;
+        std::vector<float> inv((size_t)m * m);
+        for (int c2 = 0; c2 < m; c2++) for (int r2 = 0; r2 < m; r2++) inv[(size_t)c2 * m + r2] = (1.f / u) * (acb[r2] * acb[c2]);
+        for (int a = 0; a < m; a++) inv[(size_t)a * m + a] += bb[a];
+        for (int j = 0; j < d; j++) for (int r2 = 0; r2 < m; r2++) {
+          float s = 0.f; for (int c2 = 0; c2 < m; c2++) s += inv[(size_t)c2 * m + r2] * (float)rhs[(size_t)j * m + c2];
+          Wk[(size_t)j * m + r2] = s; }
+      } else if (std::is_same<ACC, float>::value) {
+        std::vector<ACC> A = cov, I((size_t)m * m, 0); for (int a = 0; a < m; a++) I[(size_t)a * m + a] = 1;
+        ok = lu_solve(A, m, I, m);
+        for (int j = 0; j < d; j++) for (int r2 = 0; r2 < m; r2++) {
+          ACC s = 0; for (int c2 = 0; c2 < m; c2++) s += I[(size_t)c2 * m + r2] * rhs[(size_t)j * m + c2];
+          Wk[(size_t)j * m + r2] = s; }
+      } else {
+        std::vector<ACC> A = cov; Wk = rhs; ok = lu_solve(A, m, Wk, d);
+      }
+      if (!ok) { err = "singular ridge system"; return 4; }
+      for (int j = 0; j < d; j++) { Y[(size_t)k * d + j] = (float)Wk[(size_t)j * m]; Wk[(size_t)j * m] = 0; }  // :610-611
+      // Z_corr -= W^T Phi* diag(R_k)  :615
+      for (int64_t i = 0; i < N; i++) {
+        if (!in_set[i]) continue;
+        const float r = R[i * K + k]; float* z = &Z_corr[i * d];
+        for (int j = 0; j < d; j++) { float w = 0.f;
+          for (int c = 0; c < C; c++) { int ro = row_of[codes[(size_t)c * N + i]]; if (ro >= 0) w += (float)Wk[(size_t)j * m + ro]; }
+          z[j] -= w * r; }
+      }
+      W.assign((size_t)m * d, 0.f); W_rows = m;
+      for (size_t i = 0; i < W.size(); i++) W[i] = (float)Wk[i];
+    }
+    normalise_cols_l2(Y.data(), d, K);  // :633
+    return 0;
+  }
+
+  void set_int(const char* what, int64_t v) override {
+    std::string w(what);
+    if (w == "max_iter_kmeans") max_iter_kmeans = (int)v;
+    else if (w == "seed") seed = (uint64_t)v;
+  }
+
+  template <class T> static int64_t copy_out(const std::vector<T>& v, double* out) {
+    if (out) for (size_t i = 0; i < v.size(); i++) out[i] = (double)v[i];
+    return (int64_t)v.size();
+  }
+  int64_t get(const char* what, double* out) override {
+    std::string w(what);
+    if (w == "Z_corr") return copy_out(Z_corr, out);
+    if (w == "Z_orig") return copy_out(Z_orig, out);
+    if (w == "R") return copy_out(R, out);
+    if (w == "dist") return copy_out(dist, out);
+    if (w == "Y") return copy_out(Y, out);
+    if (w == "O") return copy_out(O, out);
+    if (w == "E") return copy_out(E, out);
+    if (w == "W") return copy_out(W, out);
+    if (w == "W_rows") { if (out) out[0] = W_rows; return 1; }
+    if (w == "Pr_b") return copy_out(Pr_b, out);
+    if (w == "theta") return copy_out(theta, out);
+    if (w == "sigma") return copy_out(sigma, out);
+    if (w == "lambda") return copy_out(lambda, out);
+    if (w == "objective_kmeans") return copy_out(objective_kmeans, out);
+    if (w == "objective_kmeans_dist") return copy_out(objective_kmeans_dist, out);
+    if (w == "objective_kmeans_entropy") return copy_out(objective_kmeans_entropy, out);
+    if (w == "objective_kmeans_cross") return copy_out(objective_kmeans_cross, out);
+    if (w == "objective_harmony") return copy_out(objective_harmony, out);
+    if (w == "kmeans_rounds") return copy_out(kmeans_rounds, out);
+    if (w == "subset_clusters") { if (out) out[0] = (double)subset_clusters; return 1; }
+    if (w == "skipped_clusters") { if (out) out[0] = (double)skipped_clusters; return 1; }
+    if (w == "Lambda") {  // getLambda :657-669  (K x (B+1), column-major)
+      if (out) for (int k = 0; k < K; k++) { out[k] = 0;
+        for (int b = 0; b < B; b++) out[(size_t)(b + 1) * K + k] = lambda_estimation ? (double)((float)E[(size_t)b * K + k] * alpha) : (double)lambda[b + 1]; }
+      return (int64_t)K * (B + 1);
+    }
+    if (w.rfind("timer:", 0) == 0) { if (out) out[0] = timers.ms[w.substr(6)]; return 1; }
+    return -1;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+void* orc_create(int accurate) { return accurate ? (OracleBase*)new Oracle<double>() : (OracleBase*)new Oracle<float>(); }
+void orc_destroy(void* h) { delete (OracleBase*)h; }
+void orc_set_sgemm(void* fn) { g_sgemm = (sgemm_fn)fn; }
+int orc_setup(void* h, const double* Z, int64_t N, int d, const int32_t* phi_i, const int32_t* phi_p, int B,
+              const double* sigma, const double* theta, const double* lambda, int n_lambda, double alpha,
+              int max_iter_kmeans, double eps_k, double eps_h, int K, double block_size, const int32_t* B_vec,
+              int C, double cutoff) {
+  return ((OracleBase*)h)->setup(Z, N, d, phi_i, phi_p, B, sigma, theta, lambda, n_lambda, alpha, max_iter_kmeans,
+                                 eps_k, eps_h, K, block_size, B_vec, C, cutoff);
+}
+int orc_init_cluster(void* h, const double* Y0, uint64_t seed) { return ((OracleBase*)h)->init_cluster(Y0, seed); }
+int orc_cluster(void* h) { return ((OracleBase*)h)->cluster(); }
+int orc_moe_correct_ridge(void* h) { return ((OracleBase*)h)->moe_correct_ridge(); }
+int orc_check_convergence(void* h, int type) { return ((OracleBase*)h)->check_convergence(type); }
+void orc_compute_objective(void* h) { ((OracleBase*)h)->compute_objective(); }
+int64_t orc_get(void* h, const char* what, double* out) { return ((OracleBase*)h)->get(what, out); }
+void orc_push_update_order(void* h, const int64_t* order) { ((OracleBase*)h)->push_update_order(order); }
+void orc_set_int(void* h, const char* what, int64_t v) { ((OracleBase*)h)->set_int(what, v); }
+const char* orc_last_error(void* h) { return ((OracleBase*)h)->err.c_str(); }
+// generator spec probes (used by tests to check the product's implementation of the same spec)
+uint64_t orc_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g) { return feistel_pos(seed, round, N, g); }
+float orc_u01(uint64_t seed, uint64_t stream, uint64_t idx) { return u01(seed, stream, idx); }
+}

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_fixture(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def cell_lines_small():
+    return load_fixture("cell_lines_small")
+
+
+@pytest.fixture(scope="session")
+def cell_lines():
+    return load_fixture("cell_lines")
+
+
+@pytest.fixture(scope="session")
+def pbmc():
+    return load_fixture("pbmc_stim_pcs")
