@@ -1,0 +1,88 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol that
+include/harmony_mi355x.h declares, the documented generators agree with the oracle's independent
+implementation, host-side argument handling mirrors R/ui.R, and the library refuses to run
+without a GPU (no CPU fallback).  No compute calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import harmony_amd
+from harmony_amd import _lib
+from oracle.oracle import load as load_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "harmony_mi355x.h")).read()
+    declared = set(re.findall(r"\b(hmx_[a-z0-9_]+)\s*\(", hdr)) - {"hmx_allreduce_fn"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export: " + name
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+
+
+def test_generators_match_oracle_spec():
+    lib, orc = _lib.load(), load_oracle()
+    for seed, rnd, N in [(1, 0, 300), (7, 3, 2370), (123456789, 17, 1000003), (5, 2, 6), (9, 1, 64), (9, 1, 65)]:
+        gs = np.unique(np.concatenate([np.arange(min(N, 50)), np.random.default_rng(0).integers(0, N, 50)]))
+        for g in gs:
+            assert lib.hmx_feistel_pos(seed, rnd, N, int(g)) == orc.orc_feistel_pos(seed, rnd, N, int(g))
+    for args in [(1, 0, 0), (1, 1, 5), (99, 101, 123456789), (2**40 + 3, 7, 2**33)]:
+        assert lib.hmx_u01(*args) == orc.orc_u01(*args)
+        assert 0.0 < lib.hmx_u01(*args) < 1.0
+
+
+def test_feistel_is_a_permutation():
+    lib = _lib.load()
+    for N in (6, 40, 300, 1000, 4097):
+        pos = np.array([lib.hmx_feistel_pos(11, 2, N, g) for g in range(N)])
+        assert np.array_equal(np.sort(pos), np.arange(N))
+    a = np.array([lib.hmx_feistel_pos(11, 2, 1000, g) for g in range(1000)])
+    b = np.array([lib.hmx_feistel_pos(11, 3, 1000, g) for g in range(1000)])
+    assert (a != b).mean() > 0.9  # a fresh shuffle every round
+    blocks = a // 50
+    assert np.array_equal(np.bincount(blocks), np.full(20, 50))  # balanced blocks (src/harmony.cpp:280-300)
+
+
+def test_prepare_setup_args_mirrors_ui_R():
+    rng = np.random.default_rng(0)
+    Z = rng.normal(size=(90, 5))
+    meta = {"a": np.array(list("xyz") * 30), "b": np.repeat([2, 1], 45)}
+    kw, dm = harmony_amd.prepare_setup_args(Z, meta, ["a", "b"])
+    assert dm.shape == (5, 90)                                   # transposed (R/ui.R:178-183)
+    assert kw["K"] == 3                                          # min(round(N/30), 100)
+    assert list(kw["B_vec"]) == [3, 2] and kw["Phi"][3] == 5
+    assert np.array_equal(kw["theta"], np.full(5, 2.0))          # theta=2 per covariate, expanded per level
+    assert np.array_equal(kw["lambda_vec"], [-1.0])              # automatic lambda
+    assert np.array_equal(kw["sigma"], np.full(3, 0.1))
+    i, p = kw["Phi"][0], kw["Phi"][1]
+    assert np.array_equal(p, np.arange(91) * 2)
+    assert set(i[0::2]) == {0, 1, 2} and set(i[1::2]) == {3, 4}
+    assert i[1] == 3 + 1  # level "2" sorts after "1" (as.factor)
+    kw, _ = harmony_amd.prepare_setup_args(Z, meta, ["a", "b"], lambda_=[1.0, 3.0], theta=[1, 0.5], nclust=7, sigma=0.2,
+                                           options=harmony_amd.harmony_options(tau=5))
+    assert np.array_equal(kw["lambda_vec"], [0, 1, 1, 1, 3, 3])
+    N_b = np.array([30, 30, 30, 45, 45.0])
+    np.testing.assert_allclose(kw["theta"], np.array([1, 1, 1, .5, .5]) * (1 - np.exp(-(N_b / (7 * 5)) ** 2)))
+    kw, _ = harmony_amd.prepare_setup_args(Z, np.repeat([0, 1, 2], 30), None)   # bare vector (R/ui.R:158-162)
+    assert kw["Phi"][3] == 3
+    kw, _ = harmony_amd.prepare_setup_args(Z, meta, "a", early_stop=False)
+    assert kw["epsilon_harmony"] == -np.inf
+    for bad in (dict(vars_use="nope"), dict(vars_use="a", lambda_=[1, 2]), dict(vars_use="a", theta=[1, 2]),
+                dict(vars_use="a", lambda_=-1.0)):
+        with pytest.raises(ValueError):
+            harmony_amd.prepare_setup_args(Z, meta, **bad)
+    with pytest.raises(ValueError):
+        harmony_amd.harmony_options(block_size=0)
+    with pytest.raises(TypeError):
+        harmony_amd.RunHarmony(Z, meta, "a", max_iter_harmony=3)     # legacy args hard-error (R/harmony_option.R:67-81)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK), reason="a GPU is present")
+def test_no_cpu_fallback():
+    with pytest.raises(harmony_amd.HarmonyError, match="no HIP device"):
+        harmony_amd.RunHarmony(np.random.randn(300, 20), np.repeat([0, 1, 2], 100), verbose=False)

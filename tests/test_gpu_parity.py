@@ -1,0 +1,195 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded inputs -- the reference's fixtures, multi-covariate / subset-path /
+ragged-shape synthetic cases -- plus the reference's own test invariants on the GPU backend and
+size-independent properties at BASELINE's full single-GPU size."""
+import numpy as np
+import pytest
+
+from harmony_amd import Harmony, RunHarmony, harmony_options, prepare_setup_args
+from helpers import chi2, run_backend, synth
+from oracle.oracle import OracleHarmony, feistel_order
+from parity import TOL_R, TOL_TAB, TOL_Z, assert_parity, compare_state, make_pair, relfro, run_both
+
+pytestmark = pytest.mark.gpu
+
+
+def _meta(fx):
+    return {"dataset": fx["dataset_levels"][fx["dataset"]], "cell_type": fx["cell_type_levels"][fx["cell_type"]]}
+
+
+# ---------------------------------------------------------------- stage-by-stage
+def test_ingest_roundtrip_and_normalise(cell_lines_small):
+    g, c = make_pair(cell_lines_small["pcs"], _meta(cell_lines_small), "dataset", nclust=10)
+    np.testing.assert_array_equal(g.getZorig(), c.getZorig())           # double -> fp32 -> double, un-permuted
+    assert relfro(g.getZcorr(), c.getZcorr()) < 1e-6                    # Z_corr = normalise(Z_orig)
+    np.testing.assert_allclose(g.Pr_b, c.Pr_b, rtol=1e-7)
+
+
+def test_init_cluster_stage(cell_lines):
+    g, c = make_pair(cell_lines["pcs"], _meta(cell_lines), "dataset", nclust=50, theta=2)
+    Y0 = np.asfortranarray(cell_lines["pcs"][:50].T)
+    g.init_cluster_cpp(Y0); c.init_cluster_cpp(Y0)
+    s = compare_state(g, c, ("R", "O", "E", "Y", "obj"))
+    assert s["R_maxabs"] < TOL_R and s["argmax_diff_clear"] == 0, s
+    assert s["O_rel"] < 1e-5 and s["E_rel"] < 1e-5 and s["obj_rel"] < 1e-5, s
+    assert s["objective_kmeans_cross_rel"] < 1e-4, s
+
+
+def test_one_cluster_call_then_correction(cell_lines):
+    g, c = make_pair(cell_lines["pcs"], _meta(cell_lines), "dataset", nclust=30, theta=2, seed=5)
+    Y0 = np.asfortranarray(cell_lines["pcs"][100:130].T)
+    g.init_cluster_cpp(Y0); c.init_cluster_cpp(Y0)
+    assert g.cluster_cpp() == 0 and c.cluster_cpp() == 0
+    s = compare_state(g, c, ("R", "O", "E", "obj"))
+    assert s["R_maxabs"] < TOL_R and s["argmax_diff_clear"] == 0 and s["O_rel"] < TOL_TAB and s["obj_rel"] < 1e-4, s
+    g.moe_correct_ridge_cpp(); c.moe_correct_ridge_cpp()
+    s = compare_state(g, c, ("Y", "Z"))
+    assert s["Z_rel"] < TOL_Z and s["Y_rel"] < TOL_TAB, s
+    assert relfro(g.W, c.W) < 1e-3
+    # second iteration exercises the cold-start head of cluster_cpp (src/harmony.cpp:214-228)
+    assert g.cluster_cpp() == 0 and c.cluster_cpp() == 0
+    s = compare_state(g, c, ("R", "O", "E", "obj"))
+    assert s["R_maxabs"] < TOL_R and s["argmax_diff_clear"] == 0 and s["obj_rel"] < 1e-4, s
+
+
+def test_injected_update_order(cell_lines_small):
+    g, c = make_pair(cell_lines_small["pcs"], _meta(cell_lines_small), "dataset", nclust=10, seed=3)
+    Y0 = np.asfortranarray(cell_lines_small["pcs"][:10].T)
+    g.init_cluster_cpp(Y0); c.init_cluster_cpp(Y0)
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        o = rng.permutation(300)
+        g.push_update_order(o); c.push_update_order(o)
+    assert g.cluster_cpp() == 0 and c.cluster_cpp() == 0
+    s = compare_state(g, c, ("R", "O", "E"))
+    assert s["R_maxabs"] < TOL_R and s["argmax_diff_clear"] == 0 and s["O_rel"] < TOL_TAB, s
+
+
+def test_kmeans_centers_vs_oracle(cell_lines):
+    g, c = make_pair(cell_lines["pcs"], _meta(cell_lines), "dataset", nclust=20, seed=11)
+    Yg = g.kmeans_centers()
+    c.init_cluster_cpp()   # oracle: kmeans_centers + normalise
+    Yg_n = Yg / np.linalg.norm(Yg, axis=0, keepdims=True)
+    assert relfro(Yg_n, c.Y) < 1e-4, relfro(Yg_n, c.Y)
+
+
+# ---------------------------------------------------------------- end-to-end on the reference's fixtures
+def test_cell_lines_small_full_run(cell_lines_small):
+    # tests/testthat/test_integration.R:5-7
+    g, c, ig, ic = run_both(cell_lines_small["pcs"], _meta(cell_lines_small), "dataset", max_iter=5, theta=1, nclust=50,
+                            options=harmony_options(max_iter_cluster=10))
+    assert_parity(g, c, ig, ic)
+
+
+def test_cell_lines_two_covariates_full_run(cell_lines):
+    # tests/testthat/test_two_variable.R:5-11 -> multi-covariate ridge (arma::inv branch)
+    g, c, ig, ic = run_both(cell_lines["pcs"], _meta(cell_lines), ["cell_type", "dataset"], max_iter=10, theta=[1, 1],
+                            nclust=50, options=harmony_options(max_iter_cluster=10))
+    assert_parity(g, c, ig, ic)
+
+
+def test_pbmc_default_run(pbmc):
+    meta = {"stim": pbmc["stim_levels"][pbmc["stim"]]}
+    g, c, ig, ic = run_both(pbmc["pcs"].astype(np.float64), meta, "stim", nclust=50)
+    assert_parity(g, c, ig, ic)
+
+
+def test_fixed_lambda_tau_vector_sigma(cell_lines):
+    K = 12
+    g, c, ig, ic = run_both(cell_lines["pcs"], _meta(cell_lines), ["dataset", "cell_type"], max_iter=3, nclust=K,
+                            lambda_=[0.5, 2.0], theta=[2, 1], sigma=np.linspace(0.08, 0.15, K),
+                            options=harmony_options(tau=5, block_size=0.1, max_iter_cluster=6))
+    assert_parity(g, c, ig, ic)
+
+
+@pytest.mark.parametrize("N,d,K,levels,nested", [
+    (5000, 50, 100, (10,), False),      # BASELINE shape, two clusters per lane
+    (3000, 17, 7, (3,), False),         # ragged small shapes
+    (4000, 70, 130, (4,), False),       # d > 64 and three clusters per lane
+    (6000, 30, 200, (5, 7), False),     # crossed covariates, four clusters per lane
+    (6000, 20, 40, (4, 8, 16), True),   # nested 3-covariate: batch-subset path (src/harmony.cpp:440-547)
+])
+def test_synthetic_shapes(N, d, K, levels, nested):
+    Z, meta, _ = synth(N, d=d, levels=levels, seed=N, nested=nested)
+    g, c, ig, ic = run_both(Z, meta, list(meta), max_iter=3, nclust=K, seed=N)
+    assert_parity(g, c, ig, ic)
+    if nested:
+        assert c.subset_clusters > 0 and int(g._scalar("subset_clusters")) == c.subset_clusters
+
+
+def test_tiny_N_block_size_warning():
+    rng = np.random.default_rng(1)
+    Z = rng.normal(size=(30, 8)); meta = {"b": np.arange(30) % 2}
+    with pytest.warns(UserWarning, match="Too few cells"):
+        g, c, ig, ic = run_both(Z, meta, "b", max_iter=2, nclust=3)
+    assert_parity(g, c, ig, ic)
+    with pytest.raises(Exception, match="less than 6 cells"):
+        RunHarmony(Z[:5], meta["b"][:5], verbose=False, nclust=2)
+
+
+def test_100k_cells_against_oracle():
+    Z, meta, _ = synth(100000, d=50, levels=(10,), seed=42)
+    g, c, ig, ic = run_both(Z, meta, "cov0", max_iter=2, nclust=100, seed=42)
+    s = assert_parity(g, c, ig, ic)
+    print("100k parity:", s)
+
+
+# ---------------------------------------------------------------- the reference's own invariants, GPU backend
+def test_reference_invariants_on_gpu(cell_lines_small):
+    m = _meta(cell_lines_small)
+    obj = RunHarmony(cell_lines_small["pcs"], m, "dataset", theta=1, nclust=50, max_iter=5, return_object=True,
+                     verbose=False, options=harmony_options(max_iter_cluster=10), seed=1)
+    assert obj.Y.shape == (obj.d, obj.K) and obj.getZcorr().shape == (obj.d, obj.N) and obj.R.shape == (obj.K, obj.N)
+    R = obj.R
+    assert R.min() >= 0 and R.max() <= 1
+    np.testing.assert_allclose(R.sum(axis=0), 1.0, atol=1e-5)
+    assert np.all(np.isfinite(obj.getZcorr()))
+    o0 = RunHarmony(cell_lines_small["pcs"], m, "dataset", theta=0, nclust=20, max_iter=2, return_object=True, verbose=False, seed=1)
+    o1 = RunHarmony(cell_lines_small["pcs"], m, "dataset", theta=1, nclust=5, max_iter=2, return_object=True, verbose=False, seed=1)
+    assert chi2(o0) > chi2(o1)
+    out = RunHarmony(cell_lines_small["pcs"], m, "dataset", verbose=False)
+    assert out.shape == (300, 20)      # t(Z_corr): cells x PCs, like the input
+
+
+def test_reentrancy_and_max_iter_kmeans_field(cell_lines_small):
+    m = _meta(cell_lines_small)
+    obj = RunHarmony(cell_lines_small["pcs"], m, "dataset", nclust=10, max_iter=1, return_object=True, verbose=False, seed=2)
+    obj.max_iter_kmeans = 2                      # vignettes/detailedWalkthrough.Rmd:364
+    n0 = len(obj.objective_kmeans)
+    assert obj.cluster_cpp() == 0
+    assert len(obj.objective_kmeans) == n0 + 2 and obj.kmeans_rounds[-1] == 2
+    obj.compute_objective()
+    ok = obj.objective_kmeans
+    assert abs(ok[-1] - ok[-2]) / abs(ok[-2]) < 1e-5   # recomputed objective == fused objective of the last round
+    polled = []
+    obj.set_abort_poll(lambda: polled.append(1) or True)
+    assert obj.cluster_cpp() == -1 and polled          # Progress::check_abort -> -1 (src/harmony.cpp:233-234)
+
+
+# ---------------------------------------------------------------- size-independent properties at full size
+def test_full_size_properties():
+    N, K, B = 1000000, 100, 10
+    Z, meta, _ = synth(N, d=50, levels=(B,), seed=7)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
+    g = Harmony(seed=3)
+    g.setup(**skw)
+    g.init_cluster_cpp()
+    assert g.cluster_cpp() == 0
+    O, E = g.O, g.E
+    N_b = np.bincount(meta["cov0"], minlength=B)
+    np.testing.assert_allclose(O.sum(axis=0), N_b, rtol=1e-6)            # sum_k O[k,b] = N_b  (R columns sum to 1)
+    np.testing.assert_allclose(E.sum(axis=0), N_b, rtol=1e-6)
+    np.testing.assert_allclose(E, O.sum(axis=1, keepdims=True) * (N_b / N)[None, :], rtol=1e-5)
+    R = g.R
+    assert R.min() >= 0 and np.abs(R.sum(axis=0) - 1).max() < 1e-5
+    # O is the exact sum of R over each level's cells (fixed-point accumulation == direct fp64 sum)
+    Odirect = np.stack([R[:, meta["cov0"] == b].sum(axis=1) for b in range(B)], axis=1)
+    np.testing.assert_allclose(O, Odirect, rtol=2e-6, atol=1e-3)
+    g.moe_correct_ridge_cpp()
+    Zc = g.getZcorr()
+    assert np.all(np.isfinite(Zc)) and Zc.shape == (50, N)
+    # determinism: restart + identical seed => bit-identical corrected embedding and objective series
+    obj1 = g.objective_kmeans.copy()
+    g.restart(); g.init_cluster_cpp(); assert g.cluster_cpp() == 0; g.moe_correct_ridge_cpp()
+    np.testing.assert_array_equal(g.objective_kmeans, obj1)
+    assert relfro(g.getZcorr(), Zc) < 1e-6
