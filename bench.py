@@ -149,7 +149,9 @@ def main():
                                % (N, d, K, B, "" if world == 1 else ", %d cells/GPU cell-sharded" % n),
                    "parallelism": "cells sharded x%d, RCCL all-reduce of O/E/statistics" % world if world > 1 else "single GPU",
                    "harmony_iterations": iters, "kmeans_rounds_last_step": rounds,
-                   "s_per_iter": 1e-3 * ms_per_step / max(float(np.mean(iters)), 1.0)},
+                   "s_per_iter": 1e-3 * ms_per_step / max(float(np.mean(iters)), 1.0),
+                   "host_phase_ms_per_step": {k: round(obj.timer(k) / (a.steps + a.warmup), 3) for k in
+                                              ("init_cluster", "cluster", "update_R", "moe_correct_ridge", "moe_solve_host")}},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and a.cpu_sample > 0:

@@ -77,6 +77,7 @@ struct hmx_ctx {
   std::vector<void*> allocs;
   // profiling of the dominant kernel
   bool profile = false;
+  int tun_impl = -1, tun_tpw = -1, tun_cpw = -1;  // tunables set through hmx_set_int before setup
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
   double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0;
   std::string err, warn;
@@ -134,10 +135,23 @@ void normalise_cols(std::vector<float>& Y, int d, int K) {  // arma::normalise(Y
     for (int j = 0; j < d; j++) Y[(size_t)k * d + j] /= nrm;
   }
 }
-int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Yt[j*K+k]
-  std::vector<float> yt((size_t)ctx->d * ctx->K);
-  for (int k = 0; k < ctx->K; k++) for (int j = 0; j < ctx->d; j++) yt[(size_t)j * ctx->K + k] = ctx->Y[(size_t)k * ctx->d + j];
-  return h2d(ctx, ctx->D.Yt, yt.data(), yt.size());
+int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Yt[j*K+k] and the MFMA B-operand image
+  const Dev& D = ctx->D;
+  const int d = ctx->d, K = ctx->K;
+  std::vector<float> yt((size_t)d * K);
+  for (int k = 0; k < K; k++) for (int j = 0; j < d; j++) yt[(size_t)j * K + k] = ctx->Y[(size_t)k * d + j];
+  CHK(h2d(ctx, D.Yt, yt.data(), yt.size()));
+  // image[qd][s][p][c][i] = Y[pc(s,p)][16*(4qd+i)+c]; pc(s,p) as the tile kernels assign PCs to MFMA k-slots
+  std::vector<float> img((size_t)D.NQ * D.NS * 256, 0.f);
+  for (int qd = 0; qd < D.NQ; qd++) for (int s = 0; s < D.NS; s++) for (int p = 0; p < 4; p++) {
+    const int j = (s < 4 * D.NT4) ? 16 * (s / 4) + 4 * p + (s % 4) : 16 * D.NT4 + 4 * (s - 4 * D.NT4) + p;
+    if (j >= d) continue;
+    for (int c = 0; c < 16; c++) for (int i = 0; i < 4; i++) {
+      const int k = 16 * (4 * qd + i) + c;
+      if (k < K) img[((((size_t)qd * D.NS + s) * 4 + p) * 16 + c) * 4 + i] = ctx->Y[(size_t)k * d + j];
+    }
+  }
+  return h2d(ctx, D.Yimg, img.data(), img.size());
 }
 
 // objective snapshot obj[2..4] -> the four series (src/harmony.cpp:165-168)
@@ -156,9 +170,10 @@ int push_objective(hmx_ctx* ctx) {
 int head_pass(hmx_ctx* ctx) {
   const Dev& D = ctx->D;
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
-  HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
-  HIPCHK(hipMemsetAsync(D.obj, 0, sizeof(double) * 2, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
   l_head(ctx->L, D, 0); KCHK();
+  l_obj_reduce(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.O_fx, (int64_t)D.B * D.K, 0));
   CHK(allreduce(ctx, D.obj, 2, 1));
   return 0;
@@ -232,20 +247,20 @@ int kmeans_centers(hmx_ctx* ctx) {
   }
   CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
   // 10 x one Lloyd iteration (:53-64)
-  std::vector<double> sums((size_t)K * d); std::vector<unsigned long long> cnt(K); std::vector<float> yn(K);
+  std::vector<long long> sums((size_t)K * d); std::vector<unsigned long long> cnt(K); std::vector<float> yn(K);
   for (int it = 0; it < 10; it++) {
     for (int k = 0; k < K; k++) { float s = 0.f; for (int j = 0; j < d; j++) s += ctx->Y[(size_t)k * d + j] * ctx->Y[(size_t)k * d + j]; yn[k] = s; }
     CHK(upload_Y(ctx));
     CHK(h2d(ctx, D.ynorm, yn.data(), (size_t)K));
-    HIPCHK(hipMemsetAsync(D.lsum, 0, sizeof(double) * K * d, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.lsum, 0, sizeof(long long) * K * d, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.lcnt, 0, sizeof(unsigned long long) * K, ctx->L.stream));
     l_lloyd(ctx->L, D); KCHK();
-    CHK(allreduce(ctx, D.lsum, (int64_t)K * d, 1));
+    CHK(allreduce(ctx, D.lsum, (int64_t)K * d, 0));
     CHK(allreduce(ctx, D.lcnt, K, 0));
     CHK(d2h(ctx, sums.data(), D.lsum, sums.size()));
     CHK(d2h(ctx, cnt.data(), D.lcnt, (size_t)K));
     for (int k = 0; k < K; k++) if (cnt[k] > 0)
-      for (int j = 0; j < d; j++) ctx->Y[(size_t)k * d + j] = (float)(sums[(size_t)k * d + j] / (double)cnt[k]);
+      for (int j = 0; j < d; j++) ctx->Y[(size_t)k * d + j] = (float)(((double)sums[(size_t)k * d + j] * (1.0 / 1073741824.0)) / (double)cnt[k]);
   }
   return 0;
 }
@@ -273,9 +288,18 @@ int update_R(hmx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * (size_t)D.nb * D.B * D.K, ctx->L.stream));
   l_oldsum(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0));
-  HIPCHK(hipMemsetAsync(D.obj, 0, sizeof(double) * 2, ctx->L.stream));
-  for (int j = 0; j < D.nb; j++) {
-    l_prepare(ctx->L, D, j); KCHK();
+  HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
+  for (int j = 0; j <= D.nb; j++) {
+    // fold the previous block's new contribution into O, remove block j's old one (src/harmony.cpp:312-313,329-330)
+    if (ctx->world > 1) {
+      l_fold(ctx->L, D, j, 1); KCHK();
+      CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.B * D.K, 0));
+      l_fold(ctx->L, D, j < D.nb ? j : -1, 2); KCHK();
+    } else {
+      l_fold(ctx->L, D, j < D.nb ? j : -1, 0); KCHK();
+    }
+    if (j == D.nb) break;
+    l_penalty(ctx->L, D); KCHK();
     if (ctx->profile) {
       if (ctx->ev_used == ctx->ev_pool.size()) {
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
@@ -285,10 +309,10 @@ int update_R(hmx_ctx* ctx) {
     }
     l_update(ctx->L, D, j); KCHK();
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; }
-    CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.B * D.K, 0));
   }
+  l_obj_reduce(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.obj, 2, 1));
-  l_finish_round(ctx->L, D); KCHK();
+  l_objective_tables(ctx->L, D); KCHK();
   CHK(push_objective(ctx));  // synchronises
   if (ctx->profile) {
     for (size_t i = 0; i < ctx->ev_used; i++) {
@@ -486,8 +510,11 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "seed") ctx->seed = (uint64_t)v;
   else if (f == "device") ctx->device = (int)v;
   else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; }
-  else if (f == "grid") ctx->L.grid = (int)v;
-  else if (f == "upd_cpw") ctx->D.upd_cpw = (int)v;
+  else if (f == "grid") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "grid must be set before setup"); ctx->L.grid = (int)v; }
+  else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
+  else if (f == "ablate") ctx->D.ablate = (int)v;
+  else if (f == "upd_impl") { ctx->tun_impl = (int)v; if (ctx->ran_setup) ctx->D.upd_impl = (int)v; }
+  else if (f == "upd_tpw") { ctx->tun_tpw = (int)v; if (ctx->ran_setup) ctx->D.upd_tpw = (int)(v < 1 ? 1 : v); }
   else return fail(ctx, HMX_ERR_ARG, "unknown or read-only field: " + f);
   return 0;
 }
@@ -604,20 +631,38 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
 
   // ---- device state
   Dev& D = ctx->D;
-  const int upd_cpw_keep = D.upd_cpw;
   D = Dev{};
   D.n = (int)N; D.d = d; D.K = K; D.B = B; D.C = C; D.Q = Q; D.B0 = ctx->B_vec[0];
   D.KP = (K + 63) / 64 * 64; D.nb = ctx->nb;
-  { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = upd_cpw_keep > 0 ? upd_cpw_keep : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
-  D.nchunks = (int)((N + SORT_CHUNK - 1) / SORT_CHUNK);
+  D.zs = (d + 3) / 4 * 4;
+  { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 16; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
+  { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
+    const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
+  D.lloyd_lds = ((size_t)d * D.KP * 4 + ((size_t)K * d + K) * 8 <= 98304) ? 1 : 0;
+  D.nwmax = 4 * ctx->L.grid; D.objslots = std::min(D.nb, 64);
+  D.pen_lds = ((size_t)D.NQ * 0 + (size_t)B * K * 4 + (size_t)Q * C * 4 <= 24576) ? 1 : 0;
+  D.NQ = (D.NCT + 3) / 4; D.NT4 = D.zs / 16; D.tail = (D.zs - 16 * D.NT4) / 4; D.NS = 4 * D.NT4 + D.tail;
+  { const char* e = getenv("HMX_UPDATE_IMPL"); D.upd_impl = ctx->tun_impl >= 0 ? ctx->tun_impl : ((e && std::string(e) == "v1") ? 1 : 0); }
+  { const char* e = getenv("HMX_UPD_TPW"); D.upd_tpw = ctx->tun_tpw > 0 ? ctx->tun_tpw : (e ? atoi(e) : 1); if (D.upd_tpw < 1) D.upd_tpw = 1; }
+  { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = ctx->tun_cpw > 0 ? ctx->tun_cpw : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
+  std::vector<Item> schunks; std::vector<int> qchunk((size_t)Q + 1, 0);
+  for (int q = 0; q < Q; q++) {
+    qchunk[q] = (int)schunks.size();
+    for (int s = start[q]; s < start[q + 1]; s += SORT_CHUNK) schunks.push_back({q, s, std::min(SORT_CHUNK, start[q + 1] - s)});
+  }
+  qchunk[Q] = (int)schunks.size();
+  D.nchunks = (int)schunks.size();
+  D.npad = (int)std::min<int64_t>((int64_t)N + (int64_t)D.nb * Q * 16, 2147483000ll);
   D.nitems = (int)items.size(); D.naitems = (int)aitems.size();
-  CHK(dalloc(ctx, &D.Zo, (size_t)N * d)); CHK(dalloc(ctx, &D.Zc, (size_t)N * d)); CHK(dalloc(ctx, &D.R, (size_t)N * K));
+  CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, (size_t)N * K));
   CHK(dalloc(ctx, &D.perm, (size_t)N)); CHK(dalloc(ctx, &D.invperm, (size_t)N)); CHK(dalloc(ctx, &D.combo, (size_t)N));
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
-  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
-  CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
+  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
+  CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
-  CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)N)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
+  CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)D.npad)); CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
+  CHK(dalloc(ctx, &D.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
+  CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks));
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d));
@@ -625,11 +670,18 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(h2d(ctx, D.perm, ctx->perm.data(), (size_t)N)); CHK(h2d(ctx, D.invperm, invperm.data(), (size_t)N));
   CHK(h2d(ctx, D.combo, combo_sorted.data(), (size_t)N)); CHK(h2d(ctx, D.qlev, ctx->qlev.data(), ctx->qlev.size()));
   CHK(h2d(ctx, D.sigma, ctx->sigma.data(), (size_t)K)); CHK(h2d(ctx, D.theta, ctx->theta.data(), (size_t)B)); CHK(h2d(ctx, D.Pr_b, ctx->Pr_b.data(), (size_t)B));
+  CHK(h2d(ctx, D.schunks, schunks.data(), schunks.size())); CHK(h2d(ctx, D.qchunk, qchunk.data(), qchunk.size()));
+  { std::vector<float> ce(K), cl(K);
+    for (int k = 0; k < K; k++) { ce[k] = -1.44269504088896341f / ctx->sigma[k]; cl[k] = ctx->sigma[k] * 0.693147180559945309f; }
+    CHK(h2d(ctx, D.ce, ce.data(), (size_t)K)); CHK(h2d(ctx, D.cl, cl.data(), (size_t)K)); }
   CHK(h2d(ctx, D.items, items.data(), items.size())); CHK(h2d(ctx, D.aitems, aitems.data(), aitems.size()));
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * B * K, ctx->L.stream));
-  HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * B * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * B * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.obj, 0, sizeof(double) * 8, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.R, 0, sizeof(float) * (size_t)N * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Zo, 0, sizeof(float) * (size_t)N * D.zs, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Zc, 0, sizeof(float) * (size_t)N * D.zs, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Wq, 0, sizeof(float) * (size_t)Q * K * d, ctx->L.stream));
   // Z: double d x N (cell-major) -> fp32 rows in internal order, staged through HBM in slabs (conv_to, :41)
   {
@@ -638,7 +690,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
     for (int64_t s = 0; s < N; s += slab) {
       const int64_t cnt = std::min<int64_t>(slab, N - s);
       hipError_t e = hipMemcpyAsync(dstage, Z + s * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, ctx->L.stream);
-      if (e == hipSuccess) { l_convert_in(ctx->L, dstage, D.Zo, D.invperm + s, (int)cnt, d); e = hipGetLastError(); }
+      if (e == hipSuccess) { l_convert_in(ctx->L, dstage, D.Zo, D.invperm + s, (int)cnt, d, D.zs); e = hipGetLastError(); }
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
       if (e != hipSuccess) { (void)hipFree(dstage); return fail(ctx, HMX_ERR_DEVICE, hipGetErrorString(e)); }
     }
@@ -654,8 +706,8 @@ int hmx_restart(hmx_ctx* ctx) {
   if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   const Dev& D = ctx->D;
-  l_copy(ctx->L, D.Zo, D.Zc, (size_t)D.n * D.d); KCHK();
-  l_normalize(ctx->L, D.Zc, D.n, D.d); KCHK();  // Z_corr = normalise(Z_orig) :42
+  l_copy(ctx->L, D.Zo, D.Zc, (size_t)D.n * D.zs); KCHK();
+  l_normalize(ctx->L, D.Zc, D.n, D.d, D.zs); KCHK();  // Z_corr = normalise(Z_orig) :42
   HIPCHK(hipStreamSynchronize(ctx->L.stream));
   ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();
   ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear();
@@ -690,8 +742,9 @@ int hmx_init_cluster(hmx_ctx* ctx, const double* Y0) {  // src/harmony.cpp:131-1
 int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the current R, Z_corr, Y, O, E
   if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemsetAsync(ctx->D.obj, 0, sizeof(double) * 2, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(ctx->D.objpart, 0, sizeof(double) * 2 * (size_t)ctx->D.objslots * ctx->D.nwmax, ctx->L.stream));
   l_head(ctx->L, ctx->D, 1); KCHK();
+  l_obj_reduce(ctx->L, ctx->D); KCHK();
   CHK(allreduce(ctx, ctx->D.obj, 2, 1));
   l_objective_tables(ctx->L, ctx->D); KCHK();
   return push_objective(ctx);
@@ -710,7 +763,7 @@ int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
   HIPCHK(hipSetDevice(ctx->device));
   const double t0 = now_ms();
   if (ctx->obj_harmony.size() != 1) {  // :214-228
-    l_normalize(ctx->L, ctx->D.Zc, ctx->D.n, ctx->D.d); KCHK();
+    l_normalize(ctx->L, ctx->D.Zc, ctx->D.n, ctx->D.d, ctx->D.zs); KCHK();
     CHK(head_pass(ctx));
   }
   int iter;
@@ -835,7 +888,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
     const float* src = (f == "R") ? ctx->D.R : (f == "Z_corr" ? ctx->D.Zc : ctx->D.Zo);
     double* dfull;
     if (hipMalloc((void**)&dfull, (size_t)cnt * sizeof(double)) != hipSuccess) { ctx->err = "out of device memory in getter"; return -1; }
-    l_convert_out(ctx->L, src, dfull, ctx->D.perm, ctx->D.n, w);
+    l_convert_out(ctx->L, src, dfull, ctx->D.perm, ctx->D.n, w, (f == "R") ? w : ctx->D.zs);
     hipError_t e = hipMemcpyAsync(out, dfull, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->L.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
     (void)hipFree(dfull);

@@ -24,6 +24,15 @@ struct Dev {
   int B0;           // number of levels of covariate 0 (rowsum(R) = sum of its O columns)
   int upd_cpw;      // cells per wave in the update kernel
   int KP;           // K rounded up to a multiple of 64
+  int zs;           // row stride of Zo/Zc in floats: d rounded up to a multiple of 4 (16-byte rows), pads are 0
+  // MFMA tile path (16 cells x 16 clusters x 4 PCs per v_mfma_f32_16x16x4_f32)
+  int NCT;          // cluster tiles of 16 (template instantiation, >= ceil(K/16))
+  int NQ;           // quads of cluster tiles (ceil(NCT/4))
+  int NT4, tail, NS;  // PC steps: NT4 float4 groups of 4 steps + tail single steps; NS = 4*NT4 + tail
+  float* Yimg;      // [NQ][NS][4][16][4] LDS image of the centroids in MFMA B-operand order
+  int upd_impl;     // 0: MFMA tile kernel, 1: cluster-lane VALU kernel (v1)
+  int upd_tpw;      // tiles per wave target of the MFMA update kernel
+  int ablate;       // timing-only ablation mask of k_update_mfma (tools/ablate.py); 0 in production
   int nb;           // blocks per clustering round
   // cell data, internal (combo-sorted) order, cell-major rows
   float* Zo;        // [n][d]  Z_orig
@@ -36,18 +45,31 @@ struct Dev {
   // small tables
   float* Yt;        // [d][K]   centroids, k fastest
   float* sigma;     // [K]
+  float* ce;        // [K] -log2(e)/sigma_k
+  float* cl;        // [K] sigma_k * ln 2
   float* theta;     // [B]
   float* Pr_b;      // [B]
   long long* O_fx;    // [B][K] fixed-point O (exact sum of quantised R)
-  long long* Snew_fx; // [B][K] contribution of the block being updated
+  long long* Snew_fx; // [nrep][B][K] contribution of the block being updated
   long long* Sold_fx; // [nb][B][K] old contribution of every block of this round
   float* pen;         // [B][K] ((2E+1)/(O+E+1))^theta
-  double* obj;        // [2] accumulators: sum R*dist, sum sigma*R*log R ; [2..5] outputs
+  double* obj;        // [0..1] reduced sums: sum R*dist, sum sigma*R*log R ; [2..4] snapshot incl. cross term
+  double* objpart;    // [objslots][nwmax][2] per-(block,wave) partial sums: private slots, no atomics
+  int objslots, nwmax;
+  double* objrow;     // [objslots][2] per-slot-row sums
+  int pen_lds;        // 1: the penalty table and qlev are staged in LDS by the update kernel
+  int nrep;           // replicas of Snew_fx (power of two) to spread atomic contention
   // per-round block order
   int* blk;         // [n] block id of each internal cell
-  int* lorder;      // [n] internal cell ids grouped by block (stable)
-  int* boff;        // [nb+1]
+  int* lorder;      // [npad] internal cell ids grouped by block (stable); every (block, combination) bin is
+                    //        padded to a multiple of 16 with -1 so that MFMA tiles are combination-pure
+  int* lcombo;      // [npad] combination of position p (valid where lorder[p] >= 0)
+  int npad;         // n + nb*Q*16 (upper bound of the padded length)
+  int* boff;        // [nb+1] padded start of every block (multiples of 16)
   int* counts;      // [nb][nchunks] scratch of the counting sort
+  int* binoff;      // [nb*Q+1] padded start of every (block, combination) bin
+  Item* schunks;    // [nchunks] static sort chunks: <= SORT_CHUNK cells of one combination
+  int* qchunk;      // [Q+1] first sort chunk of every combination
   int nchunks;
   // static work lists
   Item* items; int nitems;        // <= ITEM_CELLS cells each
@@ -58,7 +80,8 @@ struct Dev {
   float* Wq;        // [Q][K][d]  correction table
   // kmeans init
   unsigned long long* seedmin;  // [K] packed (key bits << 32 | global cell)
-  double* lsum;     // [K][d]
+  long long* lsum;  // [K][d] 2^30 fixed-point sums of unit-vector components (exact, order-independent)
+  int lloyd_lds;    // 1: the Lloyd sums are accumulated in an LDS table per workgroup first
   unsigned long long* lcnt;  // [K]
   float* ynorm;     // [K]
 };
@@ -69,19 +92,20 @@ struct Launch {
 };
 
 // ---- launchers (hmx_kernels.hip) -----------------------------------------------------
-void l_convert_in(const Launch& L, const double* src, float* dst, const int* invperm, int n, int d);
-void l_convert_out(const Launch& L, const float* src, double* dst, const int* perm, int n, int w);
+void l_convert_in(const Launch& L, const double* src, float* dst, const int* invperm, int n, int d, int zs);
+void l_convert_out(const Launch& L, const float* src, double* dst, const int* perm, int n, int w, int ws);
 void l_copy(const Launch& L, const float* src, float* dst, size_t count);
-void l_normalize(const Launch& L, float* Z, int n, int d);
+void l_normalize(const Launch& L, float* Z, int n, int d, int zs);
 // mode 0: head (write R, accumulate O_fx, objective partials); mode 1: objective only (read R)
 void l_head(const Launch& L, const Dev& D, int mode);
 void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                uint64_t cells_per_block);
 void l_sort_blocks(const Launch& L, const Dev& D);
 void l_oldsum(const Launch& L, const Dev& D);
-void l_prepare(const Launch& L, const Dev& D, int j);
+void l_fold(const Launch& L, const Dev& D, int j, int mode);
+void l_penalty(const Launch& L, const Dev& D);
+void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
-void l_finish_round(const Launch& L, const Dev& D);  // O += Snew, objective outputs -> obj[2..5]
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
 void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);

@@ -13,6 +13,10 @@
 #include "hmx_internal.h"
 #include <float.h>
 
+#ifndef HMX_USE_DPP
+#define HMX_USE_DPP 1
+#endif
+
 namespace hmx {
 
 // --------------------------------------------------------------------------------------
@@ -130,9 +134,9 @@ __device__ __forceinline__ void group_dots(const float* __restrict__ ldsY, int d
 }
 
 template <int DPL>
-__device__ __forceinline__ void load_row(const float* __restrict__ Z, size_t cell, int d, int lane, float (&z)[DPL]) {
-  z[0] = (lane < d) ? Z[cell * d + lane] : 0.0f;
-  if constexpr (DPL > 1) z[DPL - 1] = (64 + lane < d) ? Z[cell * d + 64 + lane] : 0.0f;
+__device__ __forceinline__ void load_row(const float* __restrict__ Z, size_t cell, int zs, int d, int lane, float (&z)[DPL]) {
+  z[0] = (lane < d) ? Z[cell * zs + lane] : 0.0f;
+  if constexpr (DPL > 1) z[DPL - 1] = (64 + lane < d) ? Z[cell * zs + 64 + lane] : 0.0f;
 }
 
 // flush a lane-private fixed-point run sum into a [B][K] table, once per covariate level
@@ -156,20 +160,20 @@ __device__ __forceinline__ void flush_fx(long long* __restrict__ tab, const int*
 // --------------------------------------------------------------------------------------
 // src: [n][d] doubles in local original order -> dst: [n][d] floats in internal order
 __global__ void k_convert_in(const double* __restrict__ src, float* __restrict__ dst, const int* __restrict__ invperm,
-                             int n, int d) {
+                             int n, int d, int zs) {
   const size_t total = (size_t)n * d;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t cell = i / d; const int j = (int)(i - cell * d);
-    dst[(size_t)invperm[cell] * d + j] = (float)src[i];
+    dst[(size_t)invperm[cell] * zs + j] = (float)src[i];
   }
 }
-// src: [n][w] floats internal order -> dst: [n][w] doubles original order
+// src: [n][ws] floats internal order (first w of each row) -> dst: [n][w] doubles original order
 __global__ void k_convert_out(const float* __restrict__ src, double* __restrict__ dst, const int* __restrict__ perm,
-                              int n, int w) {
+                              int n, int w, int ws) {
   const size_t total = (size_t)n * w;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t cell = i / w; const int j = (int)(i - cell * w);
-    dst[(size_t)perm[cell] * w + j] = (double)src[i];
+    dst[(size_t)perm[cell] * w + j] = (double)src[cell * ws + j];
   }
 }
 __global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, size_t count) {
@@ -177,11 +181,11 @@ __global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, s
     dst[i] = src[i];
 }
 // arma::normalise(Z, 2, 0) (src/harmony.cpp:42,220): one wave per cell
-__global__ __launch_bounds__(TPB) void k_normalize(float* __restrict__ Z, int n, int d) {
+__global__ __launch_bounds__(TPB) void k_normalize(float* __restrict__ Z, int n, int d, int zs) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
   for (int cell = wave; cell < n; cell += nw) {
-    float* z = Z + (size_t)cell * d;
+    float* z = Z + (size_t)cell * zs;
     float a = (lane < d) ? z[lane] : 0.0f, b = (64 + lane < d) ? z[64 + lane] : 0.0f;
     float nrm = sqrtf(wsum(a * a + b * b));
     if (nrm == 0.0f) nrm = 1.0f;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(TPB) void k_head(Dev D) {
       float z[CB][DPL];
 #pragma unroll
       for (int c = 0; c < CB; c++) {
-        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), d, lane, z[c]);
+        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), D.zs, d, lane, z[c]);
         else {
 #pragma unroll
           for (int t = 0; t < DPL; t++) z[c][t] = 0.0f;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(TPB) void k_head(Dev D) {
     if (MODE == 0) flush_fx<KPL>(D.O_fx, D.qlev, item.q, D.C, K, lane, oacc);
   }
   od = wsumd(od); oe = wsumd(oe);
-  if (lane == 0) { atomicAdd(&D.obj[0], od); atomicAdd(&D.obj[1], oe); }
+  if (lane == 0) { D.objpart[2 * wave] += od; D.objpart[2 * wave + 1] += oe; }  // private slot (slot row 0): no atomics
 }
 
 // --------------------------------------------------------------------------------------
@@ -282,17 +286,21 @@ __global__ void k_blockid(int* __restrict__ blk, const int* __restrict__ perm, i
     blk[i] = (int)(b < (uint64_t)(nb - 1) ? b : (uint64_t)(nb - 1));
   }
 }
-// one wave per chunk of SORT_CHUNK cells; counts[v][chunk]
-__global__ __launch_bounds__(WAVE) void k_sort_hist(const int* __restrict__ blk, int n, int nb, int* __restrict__ counts,
-                                                    int nchunks) {
+// Stable counting sort of the cells by block, with every (block, combination) bin padded to a multiple of
+// 16 positions (dummy entries = -1) so that a 16-cell MFMA tile never straddles two combinations.
+// Sort chunks are static runs of <= SORT_CHUNK cells of ONE combination (D.schunks, built at setup), so the
+// per-chunk histogram counts[blk][chunk] also yields the per-(block, combination) bin sizes.
+// one wave per sort chunk
+__global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D) {
   extern __shared__ int cnt[];
-  const int lane = threadIdx.x, chunk = blockIdx.x;
+  const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb;
   for (int v = lane; v < nb; v += WAVE) cnt[v] = 0;
   __syncthreads();
-  const int s = chunk * SORT_CHUNK, e = min(n, s + SORT_CHUNK);
+  const Item ch = D.schunks[chunk];
+  const int s = ch.start, e = ch.start + ch.cnt;
   for (int base = s; base < e; base += WAVE) {
     const int i = base + lane;
-    const int b = (i < e) ? blk[i] : -1;
+    const int b = (i < e) ? D.blk[i] : -1;
     unsigned long long rem = __ballot(b >= 0);
     while (rem) {
       const int src = __ffsll((long long)rem) - 1;
@@ -303,50 +311,69 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(const int* __restrict__ blk,
     }
   }
   __syncthreads();
-  for (int v = lane; v < nb; v += WAVE) counts[(size_t)v * nchunks + chunk] = cnt[v];
+  for (int v = lane; v < nb; v += WAVE) D.counts[(size_t)v * D.nchunks + chunk] = cnt[v];
 }
-// exclusive scan of counts (nb*nchunks ints) in place; boff[v] = start of block v
-__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ counts, int total, int nchunks, int nb,
-                                                    int* __restrict__ boff, int n) {
+// single workgroup: bin sizes -> padded bin starts -> per-(block, chunk) destination offsets (in place in counts);
+// boff[v] = padded start of block v, boff[nb] = padded total.
+__global__ __launch_bounds__(1024) void k_sort_scan(Dev D) {
   __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const int per = (total + 1023) / 1024;
-  const int s = t * per, e = min(total, s + per);
+  const int t = threadIdx.x, nb = D.nb, Q = D.Q, nbins = nb * Q, nch = D.nchunks;
+  int* bins = D.binoff;  // [nb*Q + 1]
+  // phase A: padded size of bin (v, q) = sum of its chunks' counts rounded up to 16
+  for (int bin = t; bin < nbins; bin += 1024) {
+    const int v = bin / Q, q = bin - v * Q;
+    int sum = 0;
+    for (int c = D.qchunk[q]; c < D.qchunk[q + 1]; c++) sum += D.counts[(size_t)v * nch + c];
+    bins[bin] = (sum + 15) & ~15;
+  }
+  __syncthreads();
+  // phase B: exclusive scan of the padded bin sizes (block-major, combination-minor)
+  const int per = (nbins + 1023) / 1024;
+  const int s = t * per, e = min(nbins, s + per);
   int sum = 0;
-  for (int i = s; i < e; i++) sum += counts[i];
+  for (int i = s; i < e; i++) sum += bins[i];
   part[t] = sum;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    int v = (t >= off) ? part[t - off] : 0;
+    const int v = (t >= off) ? part[t - off] : 0;
     __syncthreads();
     part[t] += v;
     __syncthreads();
   }
   int run = part[t] - sum;
-  for (int i = s; i < e; i++) { int c = counts[i]; counts[i] = run; run += c; }
+  for (int i = s; i < e; i++) { const int c = bins[i]; bins[i] = run; run += c; }
+  if (t == 1023) bins[nbins] = part[1023];
   __syncthreads();
-  for (int v = t; v < nb; v += 1024) boff[v] = counts[(size_t)v * nchunks];
-  if (t == 0) boff[nb] = n;
+  // phase C: destination offset of every (block, chunk): bin start + cells of earlier chunks of the same bin
+  for (int bin = t; bin < nbins; bin += 1024) {
+    const int v = bin / Q, q = bin - v * Q;
+    int o = bins[bin];
+    for (int c = D.qchunk[q]; c < D.qchunk[q + 1]; c++) {
+      const int n = D.counts[(size_t)v * nch + c];
+      D.counts[(size_t)v * nch + c] = o;
+      o += n;
+    }
+  }
+  for (int v = t; v <= nb; v += 1024) D.boff[v] = bins[v < nb ? v * Q : nbins];
 }
-__global__ __launch_bounds__(WAVE) void k_sort_scatter(const int* __restrict__ blk, int n, int nb,
-                                                       const int* __restrict__ counts, int nchunks,
-                                                       int* __restrict__ lorder) {
+__global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   extern __shared__ int base_[];
-  const int lane = threadIdx.x, chunk = blockIdx.x;
-  for (int v = lane; v < nb; v += WAVE) base_[v] = counts[(size_t)v * nchunks + chunk];
+  const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb;
+  for (int v = lane; v < nb; v += WAVE) base_[v] = D.counts[(size_t)v * D.nchunks + chunk];
   __syncthreads();
-  const int s = chunk * SORT_CHUNK, e = min(n, s + SORT_CHUNK);
+  const Item ch = D.schunks[chunk];
+  const int s = ch.start, e = ch.start + ch.cnt;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int base = s; base < e; base += WAVE) {
     const int i = base + lane;
-    const int b = (i < e) ? blk[i] : -1;
+    const int b = (i < e) ? D.blk[i] : -1;
     unsigned long long rem = __ballot(b >= 0);
     while (rem) {
       const int src = __ffsll((long long)rem) - 1;
       const int v = __shfl(b, src, 64);
       const unsigned long long m = __ballot(b == v);
       const int off = base_[v];  // all lanes read before lane 0 updates
-      if (b == v) lorder[off + __popcll(m & lt)] = i;
+      if (b == v) { const int dst = off + __popcll(m & lt); D.lorder[dst] = i; D.lcombo[dst] = ch.q; }
       __syncthreads();
       if (lane == 0) base_[v] = off + __popcll(m);
       __syncthreads();
@@ -368,8 +395,9 @@ __global__ __launch_bounds__(TPB) void k_oldsum(Dev D) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
   const int K = D.K;
-  const int per = (D.n + nw - 1) / nw;
-  const int s = wave * per, e = min(D.n, s + per);
+  const int total = D.boff[D.nb];  // padded length of this round's order
+  const int per = (total + nw - 1) / nw;
+  const int s = wave * per, e = min(total, s + per);
   if (s >= e) return;
   unsigned long long oacc[KPL];
 #pragma unroll
@@ -380,17 +408,17 @@ __global__ __launch_bounds__(TPB) void k_oldsum(Dev D) {
     int cell[CB]; float r[CB][KPL];
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-      cell[c] = (c < nc) ? D.lorder[p + c] : 0;
+      cell[c] = (c < nc) ? D.lorder[p + c] : -1;  // -1: padding slot
 #pragma unroll
       for (int q = 0; q < KPL; q++) {
         const int k = lane + 64 * q;
-        r[c][q] = (c < nc && k < K) ? D.R[(size_t)cell[c] * K + k] : 0.0f;
+        r[c][q] = (cell[c] >= 0 && k < K) ? D.R[(size_t)cell[c] * K + k] : 0.0f;
       }
     }
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-      if (c < nc) {
-        const int b = D.blk[cell[c]], q0 = D.combo[cell[c]];
+      if (cell[c] >= 0) {
+        const int b = D.blk[cell[c]], q0 = D.lcombo[p + c];
         if (b != curb || q0 != curq) {
           if (curq >= 0) flush_fx<KPL>(D.Sold_fx + (size_t)curb * D.B * K, D.qlev, curq, D.C, K, lane, oacc);
           curb = b; curq = q0;
@@ -403,29 +431,54 @@ __global__ __launch_bounds__(TPB) void k_oldsum(Dev D) {
   if (curq >= 0) flush_fx<KPL>(D.Sold_fx + (size_t)curb * D.B * K, D.qlev, curq, D.C, K, lane, oacc);
 }
 
-// one thread per cluster.  j >= 0: prepare block j.  j < 0: only fold Snew into O.
-__global__ void k_prepare(Dev D, int j) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= D.K) return;
-  const int K = D.K, B = D.B;
-  const long long* sold = (j >= 0) ? D.Sold_fx + (size_t)j * B * K : nullptr;
-  long long rs = 0;
-  for (int b = 0; b < B; b++) {
-    long long o = D.O_fx[(size_t)b * K + k] + D.Snew_fx[(size_t)b * K + k];
-    if (sold) o -= sold[(size_t)b * K + k];
-    D.O_fx[(size_t)b * K + k] = o;
-    D.Snew_fx[(size_t)b * K + k] = 0;
+// fold the finished block into O and build the penalty table of block j (j < 0: fold only).
+// Phase 1 (k_fold): O_fx[b][k] += Snew - Sold[j]; Snew = 0.   Phase 2 (k_penalty): pen[b][k].
+// One thread per table entry; two launches because phase 2 reads a column sum of phase 1.
+// mode 0: O += sum_rep Snew[rep] - Sold[j] (single GPU).  mode 1: Snew[0] = sum_rep Snew[rep] only (the
+// sharded path all-reduces Snew[0] next).  mode 2: O += Snew[0] - Sold[j] (after that all-reduce).
+__global__ void k_fold(Dev D, int j, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = D.B * D.K;
+  if (i >= n) return;
+  long long sn = D.Snew_fx[i];
+  if (mode != 2) for (int r = 1; r < D.nrep; r++) { sn += D.Snew_fx[(size_t)r * n + i]; D.Snew_fx[(size_t)r * n + i] = 0; }
+  if (mode == 1) { D.Snew_fx[i] = sn; return; }
+  long long o = D.O_fx[i] + sn;
+  if (j >= 0) o -= D.Sold_fx[(size_t)j * n + i];
+  D.O_fx[i] = o;
+  D.Snew_fx[i] = 0;
+}
+// objective partial slots -> obj[0..1]
+__global__ __launch_bounds__(1024) void k_obj_reduce(Dev D) {
+  __shared__ double ra[1024], rb[1024];
+  double a = 0.0, b = 0.0;
+  double* row = D.objpart + (size_t)blockIdx.x * D.nwmax * 2;
+  for (int i = threadIdx.x; i < D.nwmax; i += 1024) { a += row[2 * i]; b += row[2 * i + 1]; row[2 * i] = 0.0; row[2 * i + 1] = 0.0; }
+  ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { ra[threadIdx.x] += ra[threadIdx.x + off]; rb[threadIdx.x] += rb[threadIdx.x + off]; }
+    __syncthreads();
   }
-  if (j < 0) return;
+  if (threadIdx.x == 0) { D.objrow[2 * blockIdx.x] = ra[0]; D.objrow[2 * blockIdx.x + 1] = rb[0]; }
+}
+// fixed-order sum of the slot rows -> obj[0..1]
+__global__ void k_obj_final(Dev D) {
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < D.objslots; s++) { a += D.objrow[2 * s]; b += D.objrow[2 * s + 1]; }
+  D.obj[0] = a; D.obj[1] = b;
+}
+__global__ void k_penalty(Dev D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.B * D.K) return;
+  const int K = D.K, b = i / K, k = i - b * K;
   // rowsum(R) over the cells currently "in" = sum over the levels of covariate 0
-  // (every cell has exactly one level per covariate).
-  for (int b = 0; b < D.B0; b++) rs += D.O_fx[(size_t)b * K + k];
-  const double rsd = (double)rs * FX_INV;
-  for (int b = 0; b < B; b++) {
-    const float o = (float)((double)D.O_fx[(size_t)b * K + k] * FX_INV);
-    const float e = (float)(rsd * (double)D.Pr_b[b]);
-    D.pen[(size_t)b * K + k] = powf(((2.0f * e) + 1.0f) / (o + e + 1.0f), D.theta[b]);
-  }
+  // (every cell has exactly one level per covariate)
+  long long rs = 0;
+  for (int b0 = 0; b0 < D.B0; b0++) rs += D.O_fx[(size_t)b0 * K + k];
+  const float o = (float)((double)D.O_fx[i] * FX_INV);
+  const float e = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
+  D.pen[i] = powf(((2.0f * e) + 1.0f) / (o + e + 1.0f), D.theta[b]);
 }
 
 template <int KPL, int DPL>
@@ -451,8 +504,8 @@ __global__ __launch_bounds__(TPB) void k_update(Dev D, int j) {
     int cell[CB]; float z[CB][DPL];
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-      cell[c] = (c < nc) ? D.lorder[p + c] : 0;
-      if (c < nc) load_row<DPL>(D.Zc, (size_t)cell[c], d, lane, z[c]);
+      cell[c] = (c < nc) ? D.lorder[p + c] : -1;  // -1: padding slot
+      if (cell[c] >= 0) load_row<DPL>(D.Zc, (size_t)cell[c], D.zs, d, lane, z[c]);
       else {
 #pragma unroll
         for (int t = 0; t < DPL; t++) z[c][t] = 0.0f;
@@ -462,7 +515,7 @@ __global__ __launch_bounds__(TPB) void k_update(Dev D, int j) {
     group_dots<KPL, DPL, CB>(ldsY, d, D.KP, lane, z, acc);
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-      if (c < nc) {
+      if (cell[c] >= 0) {
         const int q0 = D.combo[cell[c]];
         if (q0 != curq) {
           if (curq >= 0) flush_fx<KPL>(D.Snew_fx, D.qlev, curq, D.C, K, lane, oacc);
@@ -506,23 +559,231 @@ __global__ __launch_bounds__(TPB) void k_update(Dev D, int j) {
   }
   if (curq >= 0) flush_fx<KPL>(D.Snew_fx, D.qlev, curq, D.C, K, lane, oacc);
   od = wsumd(od); oe = wsumd(oe);
-  if (lane == 0) { atomicAdd(&D.obj[0], od); atomicAdd(&D.obj[1], oe); }
+  if (lane == 0) { D.objpart[2 * wave] += od; D.objpart[2 * wave + 1] += oe; }  // private slot (slot row 0): no atomics
+}
+
+// --------------------------------------------------------------------------------------
+// MFMA tile variant of the block update (the dominant kernel).
+//
+// One wave owns tiles of 16 gathered cells.  dist(16 cells x 16 clusters) accumulates on the
+// matrix cores with v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain):
+//   A = the cells' embedding rows   lane l supplies A[cell = l&15][k-slot = l>>4]
+//   B = centroids                   lane l supplies B[k-slot = l>>4][cluster = l&15]
+//   D                               lane l holds   D[cell = 4*(l>>4)+reg][cluster = l&15]
+// PCs are assigned to k-slots so that every lane fetches its A operands with 16-byte loads:
+// in float4 group t the lane with slot p holds PCs 16t+4p+{0..3}, used in steps 4t+{0..3};
+// the centroid image D.Yimg is laid out on the host in exactly that order (and as float4 per
+// lane per step -> conflict-free ds_read_b128).  The softmax normalisations are 16-lane DPP
+// row reductions, the penalty is a per-run register vector, O is accumulated per lane in
+// 64-bit fixed point and flushed once per run of equal covariate combination.
+// --------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dpp_f(float v, const int ctrl_id) {
+  // ctrl_id: 0 quad_perm[1,0,3,2]  1 quad_perm[2,3,0,1]  2 row_half_mirror  3 row_mirror
+  const int x = __float_as_int(v);
+  int r;
+  switch (ctrl_id) {
+    case 0: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); break;
+    case 1: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); break;
+    case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); break;
+    default: r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); break;
+  }
+  return __int_as_float(r);
+}
+// sum over the 16 lanes of a DPP row (lanes sharing l>>4); every lane gets the total
+__device__ __forceinline__ float rowsum16(float v) {
+#if HMX_USE_DPP
+  v += dpp_f(v, 0);
+  v += dpp_f(v, 1);
+  v += dpp_f(v, 2);
+  v += dpp_f(v, 3);
+  return v;
+#else
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+#endif
+}
+
+template <int NCT>
+__device__ __forceinline__ void tile_dots(const f32x4* __restrict__ ldsY4, const float* __restrict__ zrow, bool valid,
+                                          int g, int lane, int NS, int NT4, int tail, f32x4 (&acc)[NCT]) {
+  constexpr int NQ = (NCT + 3) / 4;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 zt = valid && NT4 > 0 ? *reinterpret_cast<const f32x4*>(zrow + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT4; ++t) {
+    const f32x4 zc = zt;
+    if (t + 1 < NT4) zt = valid ? *reinterpret_cast<const f32x4*>(zrow + 16 * (t + 1) + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int s = 4 * t + e;
+#pragma unroll
+      for (int qd = 0; qd < NQ; ++qd) {
+        const f32x4 y = ldsY4[(qd * NS + s) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * qd + i < NCT) acc[4 * qd + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc[e], y[i], acc[4 * qd + i], 0, 0, 0);
+      }
+    }
+  }
+  for (int u = 0; u < tail; ++u) {
+    const int s = 4 * NT4 + u;
+    const float zv = valid ? zrow[16 * NT4 + 4 * u + g] : 0.0f;
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) {
+      const f32x4 y = ldsY4[(qd * NS + s) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * qd + i < NCT) acc[4 * qd + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv, y[i], acc[4 * qd + i], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), m, 64);
+  const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// The four 16-lane groups of a wave hold partial sums of the SAME clusters (different cells): add them
+// first, then one atomic per cluster from group 0 -- into one of several table replicas, so that the
+// hundreds of waves of a launch do not serialise on the same few L2 atomic addresses.
+template <int NCT>
+__device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const int* __restrict__ qlev, int q, int C,
+                                              int K, int c, int g, unsigned long long (&oacc)[NCT]) {
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) {
+    unsigned long long v = oacc[ct];
+    v += shfl_xor_u64(v, 16);
+    v += shfl_xor_u64(v, 32);
+    oacc[ct] = v;
+  }
+  if (g == 0) {
+    for (int cc = 0; cc < C; cc++) {
+      const int b = qlev[q * C + cc];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+        const int k = 16 * ct + c;
+        if (k < K && oacc[ct]) atomicAdd((unsigned long long*)&tab[(size_t)b * K + k], oacc[ct]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) oacc[ct] = 0ull;
+}
+
+template <int NCT>
+__global__ __launch_bounds__(TPB) void k_update_mfma(Dev D, int j) {
+  // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits):
+  //   [ centroid image: NQ*NS*64 float4 | penalty table pen[B][K] (if it fits) | qlev[Q][C] (ditto) ]
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
+  const int K = D.K, C = D.C, zs = D.zs;
+  const int p0 = D.boff[j], p1 = D.boff[j + 1];  // padded: multiples of 16, every tile is combination-pure
+  const int nY4 = D.NQ * D.NS * 64;
+  float* ldsPen = reinterpret_cast<float*>(lds4 + nY4);
+  int* ldsQlev = reinterpret_cast<int*>(ldsPen + ((D.B * K + 3) & ~3));
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
+    for (int i = threadIdx.x; i < nY4; i += blockDim.x) lds4[i] = src[i];
+    if (D.pen_lds) {
+      for (int i = threadIdx.x; i < D.B * K; i += blockDim.x) ldsPen[i] = D.pen[i];
+      for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
+    }
+    __syncthreads();
+  }
+  const float* penT = D.pen_lds ? ldsPen : D.pen;
+  const int* qlevT = D.pen_lds ? ldsQlev : D.qlev;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const int ntiles = (p1 - p0) >> 4;
+  const int per = (ntiles + nw - 1) / nw;
+  const int ts = wave * per, te = min(ntiles, ts + per);
+  if (ts >= te) return;
+  long long* snew = D.Snew_fx + (size_t)(wave & (D.nrep - 1)) * D.B * K;  // this wave's table replica
+  // per-lane cluster constants: exp(-dist/sigma) = exp2(dist * ce), ce = -log2(e)/sigma;
+  // sigma r ln r = r log2(r) * cl, cl = sigma ln 2 -> one v_exp_f32 / v_log_f32 per value
+  float ce[NCT], cl[NCT], penv[NCT];
+  unsigned long long oacc[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) {
+    const bool kv = 16 * ct + c < K;
+    ce[ct] = kv ? D.ce[16 * ct + c] : 0.0f;
+    cl[ct] = kv ? D.cl[16 * ct + c] : 0.0f;
+    penv[ct] = 0.0f; oacc[ct] = 0ull;
+  }
+  double od = 0.0, oe = 0.0;
+  int curq = -1;
+  int cellN = D.lorder[p0 + 16 * ts + c];  // A-operand row of this lane (-1: padding), fetched one tile ahead
+  for (int tile = ts; tile < te; ++tile) {
+    const int pbase = p0 + 16 * tile;
+    const int cellA = cellN;
+    if (tile + 1 < te) cellN = D.lorder[pbase + 16 + c];
+    const int q0 = D.lcombo[pbase];  // slot 0 of a tile is always a real cell
+    f32x4 acc[NCT];
+    tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc);
+    if (q0 != curq) {
+      if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+      curq = q0;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
+      for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
+        const int b = qlevT[q0 * C + cc];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) if (16 * ct + c < K) penv[ct] += penT[(size_t)b * K + 16 * ct + c];
+      }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      // row 4g+reg of D: its cell id lives in lane 4g+reg of cellA
+      const int cell = __shfl(cellA, 4 * g + reg, 64);
+      const bool cv = cell >= 0;
+      float* Rrow = D.R + (size_t)(cv ? cell : 0) * K;
+      float r[NCT];
+      float s1 = 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+        r[ct] = (16 * ct + c < K) ? __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]) : 0.0f;
+        s1 += r[ct];
+      }
+      s1 = rowsum16(s1);
+      const float i1 = (s1 == 0.0f) ? 1.0f : 1.0f / s1;
+      float s2 = 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) { r[ct] = (r[ct] * i1) * penv[ct]; s2 += fabsf(r[ct]); }
+      s2 = rowsum16(s2);
+      const float i2 = (s2 == 0.0f) ? 1.0f : 1.0f / s2;
+      float pd = 0.0f, pe = 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+        const float rn = r[ct] * i2;
+        if (cv && 16 * ct + c < K) Rrow[16 * ct + c] = rn;
+        const float rv = cv ? rn : 0.0f;  // exactly 0 for k >= K
+        oacc[ct] += fx_of(rv);
+        pd = fmaf(rv, fmaf(acc[ct][reg], -2.0f, 2.0f), pd);
+        pe = fmaf(rv * __builtin_amdgcn_logf(fmaxf(rv, FLT_MIN)), cl[ct], pe);
+      }
+      od += (double)pd; oe += (double)pe;
+    }
+  }
+  if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+  od = wsumd(od); oe = wsumd(oe);
+  if (lane == 0) {
+    double* slot = D.objpart + ((size_t)(j % D.objslots) * D.nwmax + wave) * 2;
+    if (D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; }        // written once per round: plain store
+    else { slot[0] += od; slot[1] += oe; }
+  }
 }
 
 // cross-entropy term of the objective from the K x B tables alone (src/harmony.cpp:162):
 //   sum_k sigma_k sum_b theta_b log((O+E+1)/(2E+1)) * O[k,b]     (O[k,b] = sum_{i in b} R_ki)
 // single workgroup; obj[2..4] = {dist, entropy, cross} snapshot, obj[0..1] reset.
-__global__ __launch_bounds__(TPB) void k_objective_tables(Dev D, int fold) {
+__global__ __launch_bounds__(TPB) void k_objective_tables(Dev D) {
   __shared__ double red[TPB];
   const int K = D.K, B = D.B;
   double cross = 0.0;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     long long rs = 0;
     for (int b = 0; b < B; b++) {
-      if (fold) {
-        D.O_fx[(size_t)b * K + k] += D.Snew_fx[(size_t)b * K + k];
-        D.Snew_fx[(size_t)b * K + k] = 0;
-      }
       if (b < D.B0) rs += D.O_fx[(size_t)b * K + k];
     }
     const double rsd = (double)rs * FX_INV;
@@ -543,7 +804,6 @@ __global__ __launch_bounds__(TPB) void k_objective_tables(Dev D, int fold) {
   }
   if (threadIdx.x == 0) {
     D.obj[2] = D.obj[0]; D.obj[3] = D.obj[1]; D.obj[4] = red[0];
-    D.obj[0] = 0.0; D.obj[1] = 0.0;
   }
 }
 
@@ -571,14 +831,14 @@ __global__ __launch_bounds__(TPB) void k_moe_stats(Dev D) {
     for (int j = 0; j < DP; j++) { a0[j] = 0.0f; a1[j] = 0.0f; }
     double n0 = 0.0, n1 = 0.0;
     size_t cell = (size_t)item.start;
-    float zn = (lane < dch) ? D.Zo[cell * d + zoff + lane] : 0.0f;
+    float zn = (lane < dch) ? D.Zo[cell * D.zs + zoff + lane] : 0.0f;
     float r0n = (k0 < K) ? D.R[cell * K + k0] : 0.0f;
     float r1n = (k1 < K) ? D.R[cell * K + k1] : 0.0f;
     for (int p = 0; p < item.cnt; p++) {
       const float zr = zn, r0 = r0n, r1 = r1n;
       if (p + 1 < item.cnt) {  // software prefetch of the next cell's rows
         cell = (size_t)(item.start + p + 1);
-        zn = (lane < dch) ? D.Zo[cell * d + zoff + lane] : 0.0f;
+        zn = (lane < dch) ? D.Zo[cell * D.zs + zoff + lane] : 0.0f;
         r0n = (k0 < K) ? D.R[cell * K + k0] : 0.0f;
         r1n = (k1 < K) ? D.R[cell * K + k1] : 0.0f;
       }
@@ -660,7 +920,7 @@ __global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
 #pragma unroll
           for (int t = 0; t < DPL; t++) {
             const int jj = 64 * t + lane;
-            if (jj < d) D.Zc[cell * d + jj] = D.Zo[cell * d + jj] - corr[c][t];
+            if (jj < d) D.Zc[cell * D.zs + jj] = D.Zo[cell * D.zs + jj] - corr[c][t];
           }
         }
       }
@@ -697,7 +957,7 @@ __global__ __launch_bounds__(TPB) void k_seed_probe(Dev D, uint64_t seed, uint64
       float z[CB][DPL];
 #pragma unroll
       for (int c = 0; c < CB; c++) {
-        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), d, lane, z[c]);
+        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), D.zs, d, lane, z[c]);
         else {
 #pragma unroll
           for (int t = 0; t < DPL; t++) z[c][t] = 0.0f;
@@ -743,12 +1003,15 @@ __global__ void k_gather_rows(Dev D, const long long* __restrict__ gcells, uint6
   const long long loc = g - (long long)goff;
   const bool mine = (loc >= 0 && loc < (long long)D.n);
   for (int j = threadIdx.x; j < D.d; j += blockDim.x)
-    rows[(size_t)k * D.d + j] = mine ? (double)D.Zc[(size_t)D.invperm[loc] * D.d + j] : 0.0;
+    rows[(size_t)k * D.d + j] = mine ? (double)D.Zc[(size_t)D.invperm[loc] * D.zs + j] : 0.0;
 }
 
 template <int KPL, int DPL>
 __global__ __launch_bounds__(TPB) void k_lloyd(Dev D) {
+  // LDS: [ centroids d*KP floats | (D.lloyd_lds) K*d 64-bit fixed-point sums + K counts ]
   extern __shared__ __attribute__((aligned(16))) float ldsY[];
+  long long* ltab = reinterpret_cast<long long*>(ldsY + (((size_t)D.d * D.KP + 1) & ~(size_t)1));
+  if (D.lloyd_lds) for (int i = threadIdx.x; i < D.K * D.d + D.K; i += blockDim.x) ltab[i] = 0;
   stage_Y(ldsY, D.Yt, D.d, D.K, D.KP);
   constexpr int CB = 4;
   const int lane = threadIdx.x & 63;
@@ -764,7 +1027,7 @@ __global__ __launch_bounds__(TPB) void k_lloyd(Dev D) {
       float z[CB][DPL];
 #pragma unroll
       for (int c = 0; c < CB; c++) {
-        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), d, lane, z[c]);
+        if (c < nc) load_row<DPL>(D.Zc, (size_t)(item.start + p + c), D.zs, d, lane, z[c]);
         else {
 #pragma unroll
           for (int t = 0; t < DPL; t++) z[c][t] = 0.0f;
@@ -790,14 +1053,30 @@ __global__ __launch_bounds__(TPB) void k_lloyd(Dev D) {
           best = wmin64(best);
           const int kb = (int)(best & 0xffffffffu);
 #pragma unroll
+          // unit-vector components as 2^30 fixed point: exact, order-independent 64-bit sums (LDS-private per
+          // workgroup when the table fits, then one global atomic per entry)
           for (int t = 0; t < DPL; t++) {
             const int jj = 64 * t + lane;
-            if (jj < d) atomicAdd(&D.lsum[(size_t)kb * d + jj], (double)z[c][t]);
+            if (jj < d) {
+              const unsigned long long v = (unsigned long long)__float2ll_rn(z[c][t] * 1073741824.0f);
+              if (D.lloyd_lds) atomicAdd((unsigned long long*)&ltab[kb * d + jj], v);
+              else atomicAdd((unsigned long long*)&D.lsum[(size_t)kb * d + jj], v);
+            }
           }
-          if (lane == 0) atomicAdd(&D.lcnt[kb], 1ull);
+          if (lane == 0) {
+            if (D.lloyd_lds) atomicAdd((unsigned long long*)&ltab[K * d + kb], 1ull);
+            else atomicAdd(&D.lcnt[kb], 1ull);
+          }
         }
       }
     }
+  }
+  if (D.lloyd_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * d; i += blockDim.x)
+      if (ltab[i]) atomicAdd((unsigned long long*)&D.lsum[i], (unsigned long long)ltab[i]);
+    for (int i = threadIdx.x; i < K; i += blockDim.x)
+      if (ltab[K * d + i]) atomicAdd(&D.lcnt[i], (unsigned long long)ltab[K * d + i]);
   }
 }
 
@@ -834,17 +1113,17 @@ static int stream_grid(const Launch& L, long long work_waves) {
   return (int)blocks;
 }
 
-void l_convert_in(const Launch& L, const double* src, float* dst, const int* invperm, int n, int d) {
-  hipLaunchKernelGGL(k_convert_in, dim3(2048), dim3(256), 0, L.stream, src, dst, invperm, n, d);
+void l_convert_in(const Launch& L, const double* src, float* dst, const int* invperm, int n, int d, int zs) {
+  hipLaunchKernelGGL(k_convert_in, dim3(2048), dim3(256), 0, L.stream, src, dst, invperm, n, d, zs);
 }
-void l_convert_out(const Launch& L, const float* src, double* dst, const int* perm, int n, int w) {
-  hipLaunchKernelGGL(k_convert_out, dim3(2048), dim3(256), 0, L.stream, src, dst, perm, n, w);
+void l_convert_out(const Launch& L, const float* src, double* dst, const int* perm, int n, int w, int ws) {
+  hipLaunchKernelGGL(k_convert_out, dim3(2048), dim3(256), 0, L.stream, src, dst, perm, n, w, ws);
 }
 void l_copy(const Launch& L, const float* src, float* dst, size_t count) {
   hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, L.stream, src, dst, count);
 }
-void l_normalize(const Launch& L, float* Z, int n, int d) {
-  hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, Z, n, d);
+void l_normalize(const Launch& L, float* Z, int n, int d, int zs) {
+  hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, Z, n, d, zs);
 }
 void l_head(const Launch& L, const Dev& D, int mode) {
   const dim3 grid(stream_grid(L, D.nitems));
@@ -860,11 +1139,10 @@ void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uin
 }
 void l_sort_blocks(const Launch& L, const Dev& D) {
   const size_t lds = (size_t)D.nb * sizeof(int);
-  hipLaunchKernelGGL(k_sort_hist, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D.blk, D.n, D.nb, D.counts, D.nchunks);
-  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, L.stream, D.counts, D.nb * D.nchunks, D.nchunks, D.nb,
-                     D.boff, D.n);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D.blk, D.n, D.nb, D.counts,
-                     D.nchunks, D.lorder);
+  (void)hipMemsetAsync(D.lorder, 0xFF, sizeof(int) * (size_t)D.npad, L.stream);  // padding slots = -1
+  hipLaunchKernelGGL(k_sort_hist, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
+  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, L.stream, D);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
 }
 void l_oldsum(const Launch& L, const Dev& D) {
   const dim3 grid(stream_grid(L, (D.n + 63) / 64));
@@ -875,20 +1153,40 @@ void l_oldsum(const Launch& L, const Dev& D) {
     default: hipLaunchKernelGGL(k_oldsum<4>, grid, dim3(TPB), 0, L.stream, D); break;
   }
 }
-void l_prepare(const Launch& L, const Dev& D, int j) {
-  hipLaunchKernelGGL(k_prepare, dim3((D.K + 63) / 64), dim3(64), 0, L.stream, D, j);
+void l_fold(const Launch& L, const Dev& D, int j, int mode) {
+  const int n = D.B * D.K;
+  hipLaunchKernelGGL(k_fold, dim3((n + 255) / 256), dim3(256), 0, L.stream, D, j, mode);
+}
+void l_penalty(const Launch& L, const Dev& D) {
+  const int n = D.B * D.K;
+  hipLaunchKernelGGL(k_penalty, dim3((n + 255) / 256), dim3(256), 0, L.stream, D);
+}
+void l_obj_reduce(const Launch& L, const Dev& D) {
+  hipLaunchKernelGGL(k_obj_reduce, dim3(D.objslots), dim3(1024), 0, L.stream, D);
+  hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(1), 0, L.stream, D);
 }
 void l_update(const Launch& L, const Dev& D, int j) {
-  // a block holds ~n/nb cells; D.upd_cpw cells per wave (tunable: HMX_UPD_CPW)
-  const long long waves = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + D.upd_cpw - 1) / D.upd_cpw + 1;
-  const dim3 grid(stream_grid(L, waves));
-  HMX_DISPATCH_KD(k_update, , grid, lds_bytes_y(D), D, j);
-}
-void l_finish_round(const Launch& L, const Dev& D) {
-  hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D, 1);
+  if (D.upd_impl == 1) {
+    // a block holds ~n/nb cells; D.upd_cpw cells per wave (tunable: HMX_UPD_CPW)
+    const long long waves = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + D.upd_cpw - 1) / D.upd_cpw + 1;
+    const dim3 grid(stream_grid(L, waves));
+    HMX_DISPATCH_KD(k_update, , grid, lds_bytes_y(D), D, j);
+    return;
+  }
+  const long long tiles = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + 15) / 16 + 1;
+  const dim3 grid(stream_grid(L, (tiles + D.upd_tpw - 1) / D.upd_tpw));
+  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) +
+                     (D.pen_lds ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
+#define HMX_UPD(N) case N: hipLaunchKernelGGL(k_update_mfma<N>, grid, dim3(TPB), lds, L.stream, D, j); break;
+  switch (D.NCT) {
+    HMX_UPD(1) HMX_UPD(2) HMX_UPD(3) HMX_UPD(4) HMX_UPD(5) HMX_UPD(6) HMX_UPD(7) HMX_UPD(8)
+    HMX_UPD(10) HMX_UPD(12) HMX_UPD(14) HMX_UPD(16)
+    default: break;
+  }
+#undef HMX_UPD
 }
 void l_objective_tables(const Launch& L, const Dev& D) {
-  hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D, 0);
+  hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);
 }
 void l_moe_stats(const Launch& L, const Dev& D) {
   const int zch = (D.d + 31) / 32;
@@ -922,8 +1220,12 @@ void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint6
   hipLaunchKernelGGL(k_gather_rows, dim3(D.K), dim3(64), 0, L.stream, D, gcells, goff, rows);
 }
 void l_lloyd(const Launch& L, const Dev& D) {
-  const dim3 grid(stream_grid(L, D.nitems));
-  HMX_DISPATCH_KD(k_lloyd, , grid, lds_bytes_y(D), D);
+  int blocks = stream_grid(L, D.nitems);
+  if (D.lloyd_lds && blocks > 512) blocks = 512;  // every workgroup flushes a K x d table: keep them few and fat
+  const dim3 grid(blocks);
+  const size_t lds = (((size_t)D.d * D.KP + 1) & ~(size_t)1) * sizeof(float) +
+                     (D.lloyd_lds ? ((size_t)D.K * D.d + D.K) * sizeof(long long) : 0);
+  HMX_DISPATCH_KD(k_lloyd, , grid, lds, D);
 }
 
 }  // namespace hmx
