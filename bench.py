@@ -87,22 +87,33 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
+        # backend "nccl" IS RCCL on ROCm: the accumulators are all-reduced over xGMI through torch.distributed
         dist.init_process_group("nccl", device_id=dev)
 
     n, d, K, B = a.cells_per_gpu, a.pcs, a.clusters, a.batches
     N = n * world
     Z, meta, _ = synth(n, d=d, levels=(B,), seed=a.seed, shard=rank)
+    # harmony_amd is loaded AFTER torch initialised its HIP runtime: both then share ONE runtime in the process,
+    # so torch streams, zero-copy tensor views of the library's buffers and RCCL all interoperate.
     obj = Harmony(device=local_rank, seed=1)
     obj.set_stream(torch.cuda.current_stream().cuda_stream)
     N_b = None
+    comm_kind = "none"
     if world > 1:
-        from harmony_amd.dist import TorchAllReduce
-        ar = TorchAllReduce(device=dev)
-        obj.set_shard(rank, world, rank * n, N, ar)
+        if os.environ.get("HMX_BENCH_COMM", "torch") == "rccl":   # experimental: the library's own communicator
+            uid = [Harmony.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            obj.comm_init(rank, world, uid[0])
+            obj.set_shard(rank, world, rank * n, N, None)
+            comm_kind = "built-in RCCL communicator"
+        else:
+            from harmony_amd.dist import TorchAllReduce
+            obj.set_shard(rank, world, rank * n, N, TorchAllReduce(device=dev))
+            comm_kind = "torch.distributed nccl (RCCL over xGMI)"
         cnt = torch.from_numpy(np.bincount(meta["cov0"], minlength=B).astype(np.int64)).to(dev)
         dist.all_reduce(cnt)
         N_b = cnt.cpu().numpy().astype(float)
-    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K, N_b=N_b)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K, N_b=N_b, levels={"cov0": np.arange(B)})
     obj.setup(**skw)
     del Z
 
@@ -147,7 +158,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic %d cells x %d PCs, K=%d, %d batches%s (BASELINE configs[2] per GPU)"
                                % (N, d, K, B, "" if world == 1 else ", %d cells/GPU cell-sharded" % n),
-                   "parallelism": "cells sharded x%d, RCCL all-reduce of O/E/statistics" % world if world > 1 else "single GPU",
+                   "parallelism": ("cells sharded x%d, all-reduce of O/E/statistics: %s" % (world, comm_kind)) if world > 1 else "single GPU",
                    "harmony_iterations": iters, "kmeans_rounds_last_step": rounds,
                    "s_per_iter": 1e-3 * ms_per_step / max(float(np.mean(iters)), 1.0),
                    "host_phase_ms_per_step": {k: round(obj.timer(k) / (a.steps + a.warmup), 3) for k in

@@ -36,7 +36,9 @@ SIGNATURES = {
     "hmx_feistel_pos": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "hmx_u01": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "hmx_push_update_order": (C.c_int, [C.c_void_p, _lp]),
-    "hmx_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, ALLREDUCE_FN, C.c_void_p]),
+    "hmx_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "hmx_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "hmx_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     "hmx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hmx_set_abort_poll": (C.c_int, [C.c_void_p, POLL_FN, C.c_void_p]),
 }

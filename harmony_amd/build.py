@@ -15,6 +15,19 @@ HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "..", "i
 OUT = os.path.join(HERE, "lib", "libharmony_mi355x.so")
 
 
+def _torch_lib():
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+            if os.path.exists(os.path.join(d, "libamdhip64.so")):
+                return d
+    except Exception:
+        pass
+    return None
+
+
 def _stale():
     if not os.path.exists(OUT):
         return True
@@ -28,7 +41,14 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-Wno-unused-result", "-o", OUT] + SRC + ["-lpthread"]
+           "-Wno-unused-result", "-o", OUT] + SRC + ["-lpthread", "-ldl"]
+    # Share ONE HIP runtime with PyTorch when both live in a process: torch wheels bundle their own
+    # libamdhip64.so (no SONAME).  Linking against that file records DT_NEEDED "libamdhip64.so": if torch is
+    # already imported the loader reuses torch's runtime (device pointers, streams and RCCL then interoperate),
+    # otherwise the name resolves through RUNPATH to /opt/rocm's runtime (R / C hosts without torch).
+    tl = _torch_lib()
+    if tl:
+        cmd += ["-L" + tl]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -5,6 +5,9 @@
 #include "../../include/harmony_mi355x.h"
 #include "hmx_internal.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -39,6 +42,35 @@ int my_ceil(float num) {  // src/utils.cpp:102-108
 }
 constexpr unsigned long long SEED_SENTINEL = 0x7fffffffffffffffull;
 
+// RCCL is bound lazily (dlopen) so that single-GPU users never load the 570 MB library.  It must be the
+// SYSTEM librccl (the one built against the libamdhip64 this library links), not a copy bundled elsewhere.
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl_api(std::string* err) {
+  static RcclApi api; static bool tried = false;
+  if (api.h) return &api;
+  if (tried) { if (err) *err = "librccl could not be loaded"; return nullptr; }
+  tried = true;
+  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  for (const char* n : names) { api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.h) break; }
+  if (!api.h) { if (err) *err = std::string("dlopen(librccl): ") + dlerror(); return nullptr; }
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+  api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) {
+    if (err) *err = "librccl lacks the expected symbols"; dlclose(api.h); api.h = nullptr; return nullptr;
+  }
+  return &api;
+}
+
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -50,6 +82,9 @@ struct hmx_ctx {
   int rank = 0, world = 1;
   int64_t goff = 0, N_global = 0;
   hmx_allreduce_fn ar = nullptr; void* ar_user = nullptr;
+  ncclComm_t comm = nullptr;   // built-in all-reduce: RCCL over xGMI (hmx_comm_init)
+  int64_t comm_calls = 0, comm_bytes = 0;
+  bool comm_force = false;     // test hook: issue the collectives even when world == 1
   int (*poll)(void*) = nullptr; void* poll_user = nullptr;
   // ---- problem --------------------------------------------------------------------
   int64_t N = 0;  // local cells
@@ -119,9 +154,18 @@ template <class T> int d2h(hmx_ctx* ctx, T* dst, const T* src, size_t count) {
   return 0;
 }
 int allreduce(hmx_ctx* ctx, void* buf, int64_t count, int dtype) {
-  if (ctx->world <= 1 || !ctx->ar) return 0;
-  int st = ctx->ar(ctx->ar_user, buf, count, dtype, (void*)ctx->L.stream);
-  if (st) return fail(ctx, HMX_ERR_COMM, "all-reduce callback failed");
+  if (ctx->world <= 1 && !ctx->comm_force) return 0;
+  ctx->comm_calls++; ctx->comm_bytes += count * 8;
+  if (ctx->ar) {
+    int st = ctx->ar(ctx->ar_user, buf, count, dtype, (void*)ctx->L.stream);
+    if (st) return fail(ctx, HMX_ERR_COMM, "all-reduce callback failed");
+    return 0;
+  }
+  if (!ctx->comm) return fail(ctx, HMX_ERR_COMM, "sharded handle without hmx_comm_init or an all-reduce hook");
+  RcclApi* api = rccl_api(nullptr);
+  ncclResult_t r = api->AllReduce(buf, buf, (size_t)count, dtype == 1 ? ncclFloat64 : ncclInt64,
+                                  dtype == 2 ? ncclMin : ncclSum, ctx->comm, ctx->L.stream);
+  if (r != ncclSuccess) return fail(ctx, HMX_ERR_COMM, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(r) : "error"));
   return 0;
 }
 #define CHK(expr) do { int s_ = (expr); if (s_) return s_; } while (0)
@@ -291,7 +335,7 @@ int update_R(hmx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
   for (int j = 0; j <= D.nb; j++) {
     // fold the previous block's new contribution into O, remove block j's old one (src/harmony.cpp:312-313,329-330)
-    if (ctx->world > 1) {
+    if (ctx->world > 1 || ctx->comm_force) {
       l_fold(ctx->L, D, j, 1); KCHK();
       CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.B * D.K, 0));
       l_fold(ctx->L, D, j < D.nb ? j : -1, 2); KCHK();
@@ -450,6 +494,7 @@ hmx_ctx* hmx_create(void) { return new hmx_ctx(); }
 void hmx_destroy(hmx_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  if (ctx->comm) { RcclApi* api = rccl_api(nullptr); if (api) (void)api->CommDestroy(ctx->comm); ctx->comm = nullptr; }
   free_all(ctx);
   if (ctx->own_stream && ctx->L.stream) (void)hipStreamDestroy(ctx->L.stream);
   delete ctx;
@@ -482,8 +527,31 @@ int hmx_set_shard(hmx_ctx* ctx, int32_t rank, int32_t world, int64_t global_offs
                   hmx_allreduce_fn fn, void* user) {
   if (!ctx) return HMX_ERR_ARG;
   if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "hmx_set_shard must precede hmx_setup");
-  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return fail(ctx, HMX_ERR_ARG, "bad shard description");
+  if (world < 1 || rank < 0 || rank >= world) return fail(ctx, HMX_ERR_ARG, "bad shard description");
+  if (world > 1 && !fn && !ctx->comm) return fail(ctx, HMX_ERR_ARG, "a sharded handle needs hmx_comm_init or an all-reduce hook");
   ctx->rank = rank; ctx->world = world; ctx->goff = global_offset; ctx->N_global = N_global; ctx->ar = fn; ctx->ar_user = user;
+  return 0;
+}
+int hmx_comm_unique_id(uint8_t* out) {
+  if (!out) return HMX_ERR_ARG;
+  RcclApi* api = rccl_api(nullptr);
+  if (!api) return HMX_ERR_COMM;
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return HMX_ERR_COMM;
+  std::memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+int hmx_comm_init(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* unique_id) {
+  if (!ctx || !unique_id || world < 1 || rank < 0 || rank >= world) return ctx ? fail(ctx, HMX_ERR_ARG, "bad communicator description") : HMX_ERR_ARG;
+  if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "hmx_comm_init must precede hmx_setup");
+  std::string err;
+  RcclApi* api = rccl_api(&err);
+  if (!api) return fail(ctx, HMX_ERR_COMM, err);
+  if (ctx->device < 0) { int cur = 0; (void)hipGetDevice(&cur); ctx->device = cur; }
+  HIPCHK(hipSetDevice(ctx->device));
+  ncclUniqueId id; std::memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+  ncclResult_t r = api->CommInitRank(&ctx->comm, world, id, rank);
+  if (r != ncclSuccess) { ctx->comm = nullptr; return fail(ctx, HMX_ERR_COMM, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "error")); }
   return 0;
 }
 int hmx_set_stream(hmx_ctx* ctx, void* s) {
@@ -513,6 +581,7 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "grid") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "grid must be set before setup"); ctx->L.grid = (int)v; }
   else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
   else if (f == "ablate") ctx->D.ablate = (int)v;
+  else if (f == "comm_force") ctx->comm_force = v != 0;
   else if (f == "upd_impl") { ctx->tun_impl = (int)v; if (ctx->ran_setup) ctx->D.upd_impl = (int)v; }
   else if (f == "upd_tpw") { ctx->tun_tpw = (int)v; if (ctx->ran_setup) ctx->D.upd_tpw = (int)(v < 1 ? 1 : v); }
   else return fail(ctx, HMX_ERR_ARG, "unknown or read-only field: " + f);
@@ -594,7 +663,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   // global level sizes N_b and global presence (one all-reduce each when sharded)
   std::vector<long long> nbcount((size_t)B, 0);
   for (int c = 0; c < C; c++) for (int64_t i = 0; i < N; i++) nbcount[codes[(size_t)c * N + i]]++;
-  if (ctx->world > 1) {
+  if (ctx->world > 1 || ctx->comm_force) {
     long long* dtmp; const size_t cnt = (size_t)P + B;
     HIPCHK(hipMalloc((void**)&dtmp, cnt * sizeof(long long)));
     std::vector<long long> tmp(present); tmp.insert(tmp.end(), nbcount.begin(), nbcount.end());
@@ -847,6 +916,8 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "n_combos") return scalar(ctx->Q);
   if (f == "subset_clusters") return scalar((double)ctx->subset_clusters);
   if (f == "skipped_clusters") return scalar((double)ctx->skipped_clusters);
+  if (f == "comm:calls") return scalar((double)ctx->comm_calls);
+  if (f == "comm:bytes") return scalar((double)ctx->comm_bytes);
   if (f == "prof:update_ms") return scalar(ctx->prof_update_ms);
   if (f == "prof:update_launches") return scalar((double)ctx->prof_update_launches);
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);

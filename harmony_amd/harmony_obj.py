@@ -76,9 +76,25 @@ class Harmony(object):
         return self._get(field)[0]
 
     # ---- distributed / runtime hooks (no reference counterpart) ---------------------------
-    def set_shard(self, rank, world, global_offset, N_global, allreduce_cb):
-        cb = _lib.ALLREDUCE_FN(allreduce_cb)
-        self._keep.append(cb)
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL unique id (call on rank 0, ship the bytes to the other ranks)."""
+        buf = (C.c_uint8 * 128)()
+        if _lib.load().hmx_comm_unique_id(buf) != 0:
+            raise HarmonyError("hmx_comm_unique_id failed (is the system librccl loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.hmx_comm_init(self._h, int(rank), int(world), buf), "comm_init")
+
+    def set_shard(self, rank, world, global_offset, N_global, allreduce_cb=None):
+        """allreduce_cb None: use the built-in RCCL communicator (comm_init first)."""
+        cb = None
+        if allreduce_cb is not None:
+            cb = _lib.ALLREDUCE_FN(allreduce_cb)
+            self._keep.append(cb)
+            cb = C.cast(cb, C.c_void_p)
         self._check(self._lib.hmx_set_shard(self._h, rank, world, int(global_offset), int(N_global), cb, None), "set_shard")
 
     def set_stream(self, hip_stream):

@@ -21,10 +21,17 @@ def _columns(meta_data):
     return None
 
 
-def as_factor(values):
-    """as.factor(): sorted unique levels, 0-based codes."""
+def as_factor(values, levels=None):
+    """as.factor(): sorted unique levels, 0-based codes.  `levels` (sorted) fixes the level set, e.g. the GLOBAL
+    levels when the cells are sharded over several processes."""
     values = np.asarray(values)
-    levels, codes = np.unique(values, return_inverse=True)
+    if levels is None:
+        levels, codes = np.unique(values, return_inverse=True)
+        return codes.astype(np.int32), levels
+    levels = np.asarray(levels)
+    codes = np.searchsorted(levels, values)
+    if np.any(codes >= len(levels)) or np.any(levels[np.minimum(codes, len(levels) - 1)] != values):
+        raise ValueError("value outside the given factor levels")
     return codes.astype(np.int32), levels
 
 
@@ -41,11 +48,11 @@ def build_phi(factor_codes, n_levels):
 
 
 def prepare_setup_args(data_mat, meta_data, vars_use, theta=None, sigma=0.1, lambda_=None, nclust=None,
-                       early_stop=True, verbose=False, options=None, N_b=None):
+                       early_stop=True, verbose=False, options=None, N_b=None, levels=None):
     """Everything RunHarmony.default computes before `new(harmony)` (R/ui.R:133-258).
 
-    Returns (setup_kwargs, data_mat d x N).  `N_b` lets a sharded caller pass the GLOBAL level
-    sizes for the theta scaling; otherwise they are counted from meta_data.
+    Returns (setup_kwargs, data_mat d x N).  Sharded callers pass the GLOBAL level sizes `N_b` (theta scaling)
+    and the GLOBAL factor levels `levels` ({variable: sorted levels}); otherwise both come from meta_data.
     """
     if options is None:
         options = harmony_options()
@@ -91,7 +98,7 @@ def prepare_setup_args(data_mat, meta_data, vars_use, theta=None, sigma=0.1, lam
 
     codes, n_levels = [], []
     for v in vars_use:
-        c, lv = as_factor(cols[v])
+        c, lv = as_factor(cols[v], None if levels is None else levels.get(v))
         codes.append(c)
         n_levels.append(len(lv))
     phi = build_phi(codes, n_levels)

@@ -116,12 +116,18 @@ float hmx_u01(uint64_t seed, uint64_t stream, uint64_t idx);
 int hmx_push_update_order(hmx_ctx* ctx, const int64_t* update_order);
 
 /* ---- multi-GPU: one handle per process/GPU, cells sharded contiguously --------------------
- * The all-reduce is a host-provided hook (bench/tests: torch.distributed == RCCL over xGMI;
- * an R host would bind RCCL directly).  It must SUM (dtype 0: int64, 1: float64) or MIN
+ * An optional host-provided all-reduce hook must SUM (dtype 0: int64, 1: float64) or MIN
  * (dtype 2: int64) `count` elements in place at device pointer `buf`, enqueued on `stream`
  * (a hipStream_t) or completed on return.  Return 0 on success. */
 typedef int (*hmx_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, void* stream);
-/* must be called before hmx_setup; global_offset = index of this rank's first cell */
+/* Built-in collective: RCCL over xGMI, bound lazily from the system librccl.  Rank 0 creates a 128-byte unique
+ * id (hmx_comm_unique_id) and the host ships it to the other ranks by any means (MPI, torch.distributed/gloo,
+ * a file, an R socket); every rank then calls hmx_comm_init before hmx_set_shard / hmx_setup.  With a
+ * communicator, hmx_set_shard may pass fn == NULL. */
+int hmx_comm_unique_id(uint8_t* out128);
+int hmx_comm_init(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* unique_id128);
+/* must be called before hmx_setup; global_offset = index of this rank's first cell.  fn != NULL overrides the
+ * built-in RCCL all-reduce with a host-provided hook (tests: thread rendezvous, gloo). */
 int hmx_set_shard(hmx_ctx* ctx, int32_t rank, int32_t world, int64_t global_offset,
                   int64_t N_global, hmx_allreduce_fn fn, void* user);
 /* run all kernels on this hipStream_t (default: the library's own stream) */

@@ -1,0 +1,110 @@
+/* harmony_mi355x_glue.c -- .Call glue between R and libharmony_mi355x.so.
+ *
+ * NOT COMPILED IN THIS REPOSITORY'S CI: the build container has no R (no Rinternals.h).  This file is the
+ * binding a maintainer of the reference would add in place of the Rcpp module
+ * (/root/reference/src/harmony.cpp:672-709, registered at src/RcppExports.cpp:57-70); it only marshals
+ * SEXPs to the plain-pointer C ABI of include/harmony_mi355x.h.  See INTEGRATION.md.
+ *
+ *   R CMD SHLIB harmony_mi355x_glue.c -I../include -L../harmony_amd/lib -lharmony_mi355x
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <stdint.h>
+#include "harmony_mi355x.h"
+
+static void hmx_finalizer(SEXP ptr) {
+  hmx_ctx* h = (hmx_ctx*)R_ExternalPtrAddr(ptr);
+  if (h) { hmx_destroy(h); R_ClearExternalPtr(ptr); }
+}
+static hmx_ctx* handle(SEXP ptr) {
+  hmx_ctx* h = (hmx_ctx*)R_ExternalPtrAddr(ptr);
+  if (!h) Rf_error("harmony object has been destroyed");
+  return h;
+}
+static void check(hmx_ctx* h, int status, const char* what) {
+  if (status > 0) Rf_error("%s: %s", what, hmx_last_error(h));          /* Rcpp::stop equivalent */
+  const char* w = hmx_last_warning(h);
+  if (w && w[0]) Rf_warning("%s", w);                                    /* Rcpp::warning equivalent */
+}
+static int poll_interrupt(void* unused) {                                 /* Progress::check_abort() */
+  (void)unused;
+  return R_ToplevelExec((void (*)(void*))R_CheckUserInterrupt, NULL) == FALSE;
+}
+
+SEXP C_hmx_new(void) {                                                    /* new(harmony), R/ui.R:269 */
+  hmx_ctx* h = hmx_create();
+  hmx_set_abort_poll(h, poll_interrupt, NULL);
+  SEXP ptr = PROTECT(R_MakeExternalPtr(h, R_NilValue, R_NilValue));
+  R_RegisterCFinalizerEx(ptr, hmx_finalizer, TRUE);
+  UNPROTECT(1);
+  return ptr;
+}
+
+/* harmonyObj$setup(data_mat, phi, sigma, theta, lambda_vec, alpha, max.iter.cluster, epsilon.cluster,
+ *                  epsilon.harmony, nclust, block.size, B_vec, batch.prop.cutoff, verbose)   R/ui.R:271-275
+ * phi is a dgCMatrix: pass phi@i, phi@p, phi@x, nrow(phi). */
+SEXP C_hmx_setup(SEXP ptr, SEXP Z, SEXP phi_i, SEXP phi_p, SEXP phi_x, SEXP B, SEXP sigma, SEXP theta, SEXP lambda,
+                 SEXP alpha, SEXP max_iter_kmeans, SEXP eps_k, SEXP eps_h, SEXP K, SEXP block_size, SEXP B_vec,
+                 SEXP cutoff, SEXP verbose) {
+  hmx_ctx* h = handle(ptr);
+  SEXP dim = Rf_getAttrib(Z, R_DimSymbol);
+  const int d = INTEGER(dim)[0];
+  const int64_t N = INTEGER(dim)[1];
+  int st = hmx_setup(h, REAL(Z), N, d, INTEGER(phi_i), INTEGER(phi_p), REAL(phi_x), Rf_asInteger(B), REAL(sigma),
+                     REAL(theta), REAL(lambda), LENGTH(lambda), Rf_asReal(alpha), Rf_asInteger(max_iter_kmeans),
+                     Rf_asReal(eps_k), Rf_asReal(eps_h), Rf_asInteger(K), Rf_asReal(block_size), INTEGER(B_vec),
+                     LENGTH(B_vec), Rf_asReal(cutoff), Rf_asLogical(verbose));
+  check(h, st, "setup");
+  return R_NilValue;
+}
+SEXP C_hmx_set_seed(SEXP ptr, SEXP seed) { hmx_set_int(handle(ptr), "seed", (int64_t)Rf_asReal(seed)); return R_NilValue; }
+SEXP C_hmx_init_cluster(SEXP ptr) { hmx_ctx* h = handle(ptr); check(h, hmx_init_cluster(h, NULL), "init_cluster_cpp"); return R_NilValue; }
+SEXP C_hmx_cluster(SEXP ptr) {
+  hmx_ctx* h = handle(ptr);
+  int st = hmx_cluster(h);
+  if (st > 0) check(h, st, "cluster_cpp");
+  return Rf_ScalarInteger(st);                                            /* 0 ok, -1 user interrupt (R/utils.R:26-32) */
+}
+SEXP C_hmx_moe_correct_ridge(SEXP ptr) { hmx_ctx* h = handle(ptr); int st = hmx_moe_correct_ridge(h); if (st > 0) check(h, st, "moe_correct_ridge_cpp"); return R_NilValue; }
+SEXP C_hmx_check_convergence(SEXP ptr, SEXP type) {
+  hmx_ctx* h = handle(ptr);
+  int r = hmx_check_convergence(h, Rf_asInteger(type));
+  if (r < 0) Rf_error("check_convergence: %s", hmx_last_error(h));
+  return Rf_ScalarLogical(r);
+}
+SEXP C_hmx_compute_objective(SEXP ptr) { hmx_ctx* h = handle(ptr); check(h, hmx_compute_objective(h), "compute_objective"); return R_NilValue; }
+SEXP C_hmx_set_int(SEXP ptr, SEXP field, SEXP value) {
+  hmx_ctx* h = handle(ptr);
+  check(h, hmx_set_int(h, CHAR(STRING_ELT(field, 0)), (int64_t)Rf_asReal(value)), "set");
+  return R_NilValue;
+}
+/* every field / getter: returns a numeric vector; the R side sets dim() */
+SEXP C_hmx_get(SEXP ptr, SEXP field) {
+  hmx_ctx* h = handle(ptr);
+  const char* f = CHAR(STRING_ELT(field, 0));
+  int64_t n = hmx_get(h, f, NULL, 0);
+  if (n < 0) Rf_error("unknown field '%s'", f);
+  SEXP out = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)n));
+  if (n && hmx_get(h, f, REAL(out), n) != n) { UNPROTECT(1); Rf_error("getter '%s': %s", f, hmx_last_error(h)); }
+  UNPROTECT(1);
+  return out;
+}
+
+static const R_CallMethodDef CallEntries[] = {
+  {"C_hmx_new", (DL_FUNC)&C_hmx_new, 0},
+  {"C_hmx_setup", (DL_FUNC)&C_hmx_setup, 18},
+  {"C_hmx_set_seed", (DL_FUNC)&C_hmx_set_seed, 2},
+  {"C_hmx_init_cluster", (DL_FUNC)&C_hmx_init_cluster, 1},
+  {"C_hmx_cluster", (DL_FUNC)&C_hmx_cluster, 1},
+  {"C_hmx_moe_correct_ridge", (DL_FUNC)&C_hmx_moe_correct_ridge, 1},
+  {"C_hmx_check_convergence", (DL_FUNC)&C_hmx_check_convergence, 2},
+  {"C_hmx_compute_objective", (DL_FUNC)&C_hmx_compute_objective, 1},
+  {"C_hmx_set_int", (DL_FUNC)&C_hmx_set_int, 3},
+  {"C_hmx_get", (DL_FUNC)&C_hmx_get, 2},
+  {NULL, NULL, 0}
+};
+void R_init_harmony(DllInfo* dll) {                                       /* replaces _rcpp_module_boot_harmony_module */
+  R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}

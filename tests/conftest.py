@@ -13,6 +13,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test timeout (pytest-timeout)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # a hung kernel or collective must not eat the GPU budget: hard per-test limit (thread method kills the process)
+    for it in items:
+        if it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(300, method="thread"))
 
 
 def load_fixture(name):

@@ -2,6 +2,10 @@
 the CPU oracle on the same seeded inputs -- the reference's fixtures, multi-covariate / subset-path /
 ragged-shape synthetic cases -- plus the reference's own test invariants on the GPU backend and
 size-independent properties at BASELINE's full single-GPU size."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -193,3 +197,125 @@ def test_full_size_properties():
     g.restart(); g.init_cluster_cpp(); assert g.cluster_cpp() == 0; g.moe_correct_ridge_cpp()
     np.testing.assert_array_equal(g.objective_kmeans, obj1)
     assert relfro(g.getZcorr(), Zc) < 1e-6
+
+
+# ---------------------------------------------------------------- multi-GPU path on one GPU: virtual shards
+def _run_sharded(Z, meta, G, K, seed, max_iter):
+    """G handles (one per thread) each holding a contiguous shard; the all-reduce hook sums the shards' device
+    buffers.  This is the production sharded code path with the collective replaced by a thread rendezvous
+    (device buffers are summed on the host through the same HIP runtime the library links)."""
+    import ctypes
+    import threading
+    from harmony_amd.dist import shard_bounds
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipDeviceSynchronize.argtypes = []
+    N = Z.shape[0]
+    bounds = shard_bounds(N, G)
+    barrier = threading.Barrier(G)
+    slots, results, errors = [None] * G, [None] * G, []
+    N_b = np.bincount(meta["cov0"]).astype(float)
+
+    def hook_for(rank):
+        def hook(user, buf, count, dtype, stream):
+            assert hip.hipDeviceSynchronize() == 0
+            host = np.empty(count, dtype=np.float64 if dtype == 1 else np.int64)
+            assert hip.hipMemcpy(host.ctypes.data, buf, host.nbytes, 2) == 0   # D2H
+            slots[rank] = host
+            barrier.wait()
+            st = np.stack(slots)
+            red = st.min(axis=0) if dtype == 2 else st.sum(axis=0)
+            barrier.wait()
+            assert hip.hipMemcpy(buf, red.ctypes.data, red.nbytes, 1) == 0     # H2D
+            barrier.wait()
+            return 0
+        return hook
+
+    def work(rank):
+        try:
+            lo, hi = bounds[rank]
+            m = {k: v[lo:hi] for k, v in meta.items()}
+            # factor levels must be global: build Phi from the global level set
+            skw, _ = prepare_setup_args(Z[lo:hi], m, "cov0", nclust=K, N_b=N_b, levels={"cov0": np.arange(len(N_b))})
+            g = Harmony(seed=seed)
+            g.set_shard(rank, G, lo, N, hook_for(rank))
+            g.setup(**skw)
+            g.init_cluster_cpp()
+            it = 0
+            for it in range(1, max_iter + 1):
+                assert g.cluster_cpp() == 0
+                g.moe_correct_ridge_cpp()
+                if g.check_convergence(1):
+                    break
+            results[rank] = (g.getZcorr(), g.O, g.objective_kmeans, it, g.R.argmax(axis=0))
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errors:
+        raise errors[0]
+    return results
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_virtual_shards_equal_single_shard(G):
+    Z, meta, _ = synth(30000, d=50, levels=(10,), seed=21)
+    K, seed = 100, 4
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
+    one = Harmony(seed=seed)
+    one.setup(**skw)
+    one.init_cluster_cpp()
+    it1 = 0
+    for it1 in range(1, 4):
+        assert one.cluster_cpp() == 0
+        one.moe_correct_ridge_cpp()
+        if one.check_convergence(1):
+            break
+    res = _run_sharded(Z, meta, G, K, seed, 3)
+    Zs = np.concatenate([r[0] for r in res], axis=1)
+    assert all(r[3] == it1 for r in res)
+    for r in res:                                              # replicated tables are identical on every shard
+        np.testing.assert_array_equal(r[1], res[0][1])
+        np.testing.assert_allclose(r[2], res[0][2], rtol=0, atol=0)
+    np.testing.assert_allclose(res[0][1], one.O, rtol=1e-6, atol=1e-4)   # exact integer sums => shard-count independent
+    np.testing.assert_allclose(res[0][2], one.objective_kmeans, rtol=1e-6)
+    assert relfro(Zs, one.getZcorr()) < 1e-6
+    assert np.array_equal(np.concatenate([r[4] for r in res]), one.R.argmax(axis=0))
+
+
+@pytest.mark.skipif(os.environ.get("HMX_TEST_BUILTIN_RCCL") != "1",
+                    reason="experimental: ncclCommInitRank of the system librccl does not return on the 1-GPU test box")
+def test_builtin_rccl_communicator_single_rank():
+    """The built-in RCCL path (dlopen of the system librccl, ncclCommInitRank, ncclAllReduce on the library's
+    stream) exercised with a 1-rank communicator and forced collectives: results equal the plain run."""
+    Z, meta, _ = synth(20000, d=50, levels=(10,), seed=33)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
+    outs = []
+    for use_comm in (False, True):
+        g = Harmony(seed=5)
+        if use_comm:
+            g.comm_init(0, 1, Harmony.comm_unique_id())
+            g.set_shard(0, 1, 0, Z.shape[0], None)
+            g._set("comm_force", 1)
+        g.setup(**skw)
+        g.init_cluster_cpp()
+        assert g.cluster_cpp() == 0
+        g.moe_correct_ridge_cpp()
+        outs.append((g.getZcorr(), g.O, g.objective_kmeans, g._scalar("comm:calls")))
+    assert outs[0][3] == 0 and outs[1][3] > 80      # >= 20 block all-reduces x 4 rounds
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-6)
+    assert relfro(outs[1][0], outs[0][0]) < 1e-6
+
+
+def test_torch_nccl_hook_single_rank():
+    """torch.distributed (backend nccl == RCCL) all-reduce hook on the library's device buffers: a 1-rank process
+    group with forced collectives must reproduce the plain run.  Separate process because torch has to initialise
+    its HIP runtime BEFORE the library is loaded (they then share one runtime)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "hook_probe.py")], capture_output=True, text=True,
+                       timeout=400, stdin=subprocess.DEVNULL)
+    assert "HOOK_PROBE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
