@@ -216,7 +216,12 @@ int head_pass(hmx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
-  l_head(ctx->L, D, 0); KCHK();
+  if (D.tile_impl && (size_t)D.NQ * D.NS * 1024 <= 160 * 1024) {
+    l_tile_static(ctx->L, D, 1); KCHK();      // MFMA tiles; O contributions land in the Snew replicas
+    l_fold(ctx->L, D, -1, 0); KCHK();         // O = sum of the replicas
+  } else {
+    l_head(ctx->L, D, 0); KCHK();
+  }
   l_obj_reduce(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.O_fx, (int64_t)D.B * D.K, 0));
   CHK(allreduce(ctx, D.obj, 2, 1));
@@ -298,7 +303,8 @@ int kmeans_centers(hmx_ctx* ctx) {
     CHK(h2d(ctx, D.ynorm, yn.data(), (size_t)K));
     HIPCHK(hipMemsetAsync(D.lsum, 0, sizeof(long long) * K * d, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.lcnt, 0, sizeof(unsigned long long) * K, ctx->L.stream));
-    l_lloyd(ctx->L, D); KCHK();
+    if (D.tile_impl && (size_t)D.NQ * D.NS * 1024 + ((size_t)K * d + K) * 8 <= 160 * 1024) { l_tile_static(ctx->L, D, 2); KCHK(); }
+    else { l_lloyd(ctx->L, D); KCHK(); }
     CHK(allreduce(ctx, D.lsum, (int64_t)K * d, 0));
     CHK(allreduce(ctx, D.lcnt, K, 0));
     CHK(d2h(ctx, sums.data(), D.lsum, sums.size()));
@@ -692,10 +698,11 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   ctx->perm.assign((size_t)N, 0);
   { std::vector<int> cur(start.begin(), start.end() - 1);
     for (int64_t i = 0; i < N; i++) { const int p = cur[combo_of[i]]++; ctx->perm[p] = (int)i; invperm[i] = p; combo_sorted[p] = combo_of[i]; } }
-  std::vector<Item> items, aitems;
+  std::vector<Item> items, aitems, titems;
   for (int q = 0; q < Q; q++) {
     for (int s = start[q]; s < start[q + 1]; s += ITEM_CELLS) items.push_back({q, s, std::min(ITEM_CELLS, start[q + 1] - s)});
     for (int s = start[q]; s < start[q + 1]; s += APPLY_CELLS) aitems.push_back({q, s, std::min(APPLY_CELLS, start[q + 1] - s)});
+    for (int s = start[q]; s < start[q + 1]; s += 16) titems.push_back({q, s, std::min(16, start[q + 1] - s)});
   }
 
   // ---- device state
@@ -722,7 +729,8 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   qchunk[Q] = (int)schunks.size();
   D.nchunks = (int)schunks.size();
   D.npad = (int)std::min<int64_t>((int64_t)N + (int64_t)D.nb * Q * 16, 2147483000ll);
-  D.nitems = (int)items.size(); D.naitems = (int)aitems.size();
+  D.nitems = (int)items.size(); D.naitems = (int)aitems.size(); D.ntitems = (int)titems.size();
+  { const char* e = getenv("HMX_TILE_IMPL"); D.tile_impl = (e && std::string(e) == "v1") ? 0 : 1; }
   CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, (size_t)N * K));
   CHK(dalloc(ctx, &D.perm, (size_t)N)); CHK(dalloc(ctx, &D.invperm, (size_t)N)); CHK(dalloc(ctx, &D.combo, (size_t)N));
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
@@ -733,7 +741,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks));
-  CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size()));
+  CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d));
   CHK(dalloc(ctx, &D.seedmin, (size_t)K)); CHK(dalloc(ctx, &D.lsum, (size_t)K * d)); CHK(dalloc(ctx, &D.lcnt, (size_t)K)); CHK(dalloc(ctx, &D.ynorm, (size_t)K));
   CHK(h2d(ctx, D.perm, ctx->perm.data(), (size_t)N)); CHK(h2d(ctx, D.invperm, invperm.data(), (size_t)N));
@@ -743,7 +751,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   { std::vector<float> ce(K), cl(K);
     for (int k = 0; k < K; k++) { ce[k] = -1.44269504088896341f / ctx->sigma[k]; cl[k] = ctx->sigma[k] * 0.693147180559945309f; }
     CHK(h2d(ctx, D.ce, ce.data(), (size_t)K)); CHK(h2d(ctx, D.cl, cl.data(), (size_t)K)); }
-  CHK(h2d(ctx, D.items, items.data(), items.size())); CHK(h2d(ctx, D.aitems, aitems.data(), aitems.size()));
+  CHK(h2d(ctx, D.items, items.data(), items.size())); CHK(h2d(ctx, D.aitems, aitems.data(), aitems.size())); CHK(h2d(ctx, D.titems, titems.data(), titems.size()));
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * B * K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * B * K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));

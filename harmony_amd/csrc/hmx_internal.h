@@ -74,6 +74,8 @@ struct Dev {
   // static work lists
   Item* items; int nitems;        // <= ITEM_CELLS cells each
   Item* aitems; int naitems;      // <= APPLY_CELLS cells each
+  Item* titems; int ntitems;      // <= 16 cells each: static MFMA tiles (head, Lloyd)
+  int tile_impl;                  // 1: head / Lloyd run on the MFMA tile kernel, 0: cluster-lane VALU kernels
   // MoE
   double* Sq;       // [Q][d][K]  sum_i R_ki z_ij over cells of combination q
   double* nq;       // [Q][K]     sum_i R_ki
@@ -98,6 +100,7 @@ void l_copy(const Launch& L, const float* src, float* dst, size_t count);
 void l_normalize(const Launch& L, float* Z, int n, int d, int zs);
 // mode 0: head (write R, accumulate O_fx, objective partials); mode 1: objective only (read R)
 void l_head(const Launch& L, const Dev& D, int mode);
+void l_tile_static(const Launch& L, const Dev& D, int mode);
 void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                uint64_t cells_per_block);
 void l_sort_blocks(const Launch& L, const Dev& D);

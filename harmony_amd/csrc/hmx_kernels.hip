@@ -672,33 +672,40 @@ __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const
   for (int ct = 0; ct < NCT; ct++) oacc[ct] = 0ull;
 }
 
-template <int NCT>
-__global__ __launch_bounds__(TPB) void k_update_mfma(Dev D, int j) {
+// MODE 0: block update (cells gathered through lorder, penalty, second normalisation)      update_R :318-330
+// MODE 1: head (static 16-cell tiles of the internal order, plain softmax)                 :141-150 / :221-227
+// MODE 2: one Lloyd iteration of kmeans_centers (nearest centre, fixed-point sums in LDS)  src/utils.cpp:56-61
+template <int NCT, int MODE>
+__global__ __launch_bounds__(TPB) void k_tile(Dev D, int j) {
   // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits):
-  //   [ centroid image: NQ*NS*64 float4 | penalty table pen[B][K] (if it fits) | qlev[Q][C] (ditto) ]
+  //   [ centroid image: NQ*NS*64 float4 | MODE 0: pen[B][K] + qlev[Q][C] (if they fit) | MODE 2: int64 sums[K][d] + counts[K] ]
   extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
   const int K = D.K, C = D.C, zs = D.zs;
-  const int p0 = D.boff[j], p1 = D.boff[j + 1];  // padded: multiples of 16, every tile is combination-pure
   const int nY4 = D.NQ * D.NS * 64;
   float* ldsPen = reinterpret_cast<float*>(lds4 + nY4);
   int* ldsQlev = reinterpret_cast<int*>(ldsPen + ((D.B * K + 3) & ~3));
+  long long* ltab = reinterpret_cast<long long*>(lds4 + nY4);
+  int p0 = 0, ntiles;
+  if constexpr (MODE == 0) { p0 = D.boff[j]; ntiles = (D.boff[j + 1] - p0) >> 4; }  // padded: combination-pure tiles
+  else ntiles = D.ntitems;
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
     for (int i = threadIdx.x; i < nY4; i += blockDim.x) lds4[i] = src[i];
-    if (D.pen_lds) {
-      for (int i = threadIdx.x; i < D.B * K; i += blockDim.x) ldsPen[i] = D.pen[i];
-      for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
+    if constexpr (MODE == 0) {
+      if (D.pen_lds) {
+        for (int i = threadIdx.x; i < D.B * K; i += blockDim.x) ldsPen[i] = D.pen[i];
+        for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
+      }
     }
+    if constexpr (MODE == 2) for (int i = threadIdx.x; i < K * D.d + K; i += blockDim.x) ltab[i] = 0;
     __syncthreads();
   }
-  const float* penT = D.pen_lds ? ldsPen : D.pen;
-  const int* qlevT = D.pen_lds ? ldsQlev : D.qlev;
+  const float* penT = (MODE == 0 && D.pen_lds) ? ldsPen : D.pen;
+  const int* qlevT = (MODE == 0 && D.pen_lds) ? ldsQlev : D.qlev;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-  const int ntiles = (p1 - p0) >> 4;
   const int per = (ntiles + nw - 1) / nw;
   const int ts = wave * per, te = min(ntiles, ts + per);
-  if (ts >= te) return;
   long long* snew = D.Snew_fx + (size_t)(wave & (D.nrep - 1)) * D.B * K;  // this wave's table replica
   // per-lane cluster constants: exp(-dist/sigma) = exp2(dist * ce), ce = -log2(e)/sigma;
   // sigma r ln r = r log2(r) * cl, cl = sigma ln 2 -> one v_exp_f32 / v_log_f32 per value
@@ -707,70 +714,122 @@ __global__ __launch_bounds__(TPB) void k_update_mfma(Dev D, int j) {
 #pragma unroll
   for (int ct = 0; ct < NCT; ct++) {
     const bool kv = 16 * ct + c < K;
-    ce[ct] = kv ? D.ce[16 * ct + c] : 0.0f;
-    cl[ct] = kv ? D.cl[16 * ct + c] : 0.0f;
-    penv[ct] = 0.0f; oacc[ct] = 0ull;
+    if constexpr (MODE == 2) { ce[ct] = kv ? D.ynorm[16 * ct + c] : 0.0f; cl[ct] = 0.0f; }
+    else { ce[ct] = kv ? D.ce[16 * ct + c] : 0.0f; cl[ct] = kv ? D.cl[16 * ct + c] : 0.0f; }
+    penv[ct] = 1.0f; oacc[ct] = 0ull;
   }
   double od = 0.0, oe = 0.0;
   int curq = -1;
-  int cellN = D.lorder[p0 + 16 * ts + c];  // A-operand row of this lane (-1: padding), fetched one tile ahead
+  int cellN = -1;  // MODE 0: A-operand row of this lane (-1: padding), fetched one tile ahead
+  if constexpr (MODE == 0) { if (ts < te) cellN = D.lorder[p0 + 16 * ts + c]; }
   for (int tile = ts; tile < te; ++tile) {
-    const int pbase = p0 + 16 * tile;
-    const int cellA = cellN;
-    if (tile + 1 < te) cellN = D.lorder[pbase + 16 + c];
-    const int q0 = D.lcombo[pbase];  // slot 0 of a tile is always a real cell
+    int cellA, q0;
+    if constexpr (MODE == 0) {
+      const int pbase = p0 + 16 * tile;
+      cellA = cellN;
+      if (tile + 1 < te) cellN = D.lorder[pbase + 16 + c];
+      q0 = D.lcombo[pbase];  // slot 0 of a tile is always a real cell
+    } else {
+      const Item it = D.titems[tile];  // static tile: <= 16 consecutive cells of one combination
+      cellA = (c < it.cnt) ? it.start + c : -1;
+      q0 = it.q;
+    }
     f32x4 acc[NCT];
     tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc);
-    if (q0 != curq) {
-      if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
-      curq = q0;
+    if constexpr (MODE == 2) {
+      // nearest centre of every cell of the tile: argmin_k ||y_k||^2 - 2 x.y_k ; ties -> smallest k
 #pragma unroll
-      for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
-      for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
-        const int b = qlevT[q0 * C + cc];
+      for (int reg = 0; reg < 4; reg++) {
+        const int cell = __shfl(cellA, 4 * g + reg, 64);
+        unsigned long long best = ~0ull;
 #pragma unroll
-        for (int ct = 0; ct < NCT; ct++) if (16 * ct + c < K) penv[ct] += penT[(size_t)b * K + 16 * ct + c];
+        for (int ct = 0; ct < NCT; ct++) {
+          if (16 * ct + c < K) {
+            const float sc = fmaf(acc[ct][reg], -2.0f, ce[ct]);
+            unsigned ub = __float_as_uint(sc);
+            ub = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);  // order-preserving map
+            const unsigned long long pk = ((unsigned long long)ub << 32) | (unsigned)(16 * ct + c);
+            best = pk < best ? pk : best;
+          }
+        }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { const unsigned long long o = shfl_xor_u64(best, m); best = o < best ? o : best; }
+        if (cell >= 0) {
+          const int kb = (int)(best & 0xffffffffu);
+          const float* zr = D.Zc + (size_t)cell * zs;
+          for (int jj = c; jj < D.d; jj += 16) {  // the 16 lanes of this row group add the cell's PCs (2^30 fixed point)
+            const unsigned long long v = (unsigned long long)__float2ll_rn(zr[jj] * 1073741824.0f);
+            atomicAdd((unsigned long long*)&ltab[kb * D.d + jj], v);
+          }
+          if (c == 0) atomicAdd((unsigned long long*)&ltab[K * D.d + kb], 1ull);
+        }
       }
-    }
+    } else {
+      if (q0 != curq) {
+        if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+        curq = q0;
+        if constexpr (MODE == 0) {
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) {
-      // row 4g+reg of D: its cell id lives in lane 4g+reg of cellA
-      const int cell = __shfl(cellA, 4 * g + reg, 64);
-      const bool cv = cell >= 0;
-      float* Rrow = D.R + (size_t)(cv ? cell : 0) * K;
-      float r[NCT];
-      float s1 = 0.0f;
+          for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
+          for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
+            const int b = qlevT[q0 * C + cc];
 #pragma unroll
-      for (int ct = 0; ct < NCT; ct++) {
-        r[ct] = (16 * ct + c < K) ? __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]) : 0.0f;
-        s1 += r[ct];
+            for (int ct = 0; ct < NCT; ct++) if (16 * ct + c < K) penv[ct] += penT[(size_t)b * K + 16 * ct + c];
+          }
+        }
       }
-      s1 = rowsum16(s1);
-      const float i1 = (s1 == 0.0f) ? 1.0f : 1.0f / s1;
-      float s2 = 0.0f;
 #pragma unroll
-      for (int ct = 0; ct < NCT; ct++) { r[ct] = (r[ct] * i1) * penv[ct]; s2 += fabsf(r[ct]); }
-      s2 = rowsum16(s2);
-      const float i2 = (s2 == 0.0f) ? 1.0f : 1.0f / s2;
-      float pd = 0.0f, pe = 0.0f;
+      for (int reg = 0; reg < 4; reg++) {
+        // row 4g+reg of D: its cell id lives in lane 4g+reg of cellA
+        const int cell = __shfl(cellA, 4 * g + reg, 64);
+        const bool cv = cell >= 0;
+        float* Rrow = D.R + (size_t)(cv ? cell : 0) * K;
+        float r[NCT];
+        float s1 = 0.0f;
 #pragma unroll
-      for (int ct = 0; ct < NCT; ct++) {
-        const float rn = r[ct] * i2;
-        if (cv && 16 * ct + c < K) Rrow[16 * ct + c] = rn;
-        const float rv = cv ? rn : 0.0f;  // exactly 0 for k >= K
-        oacc[ct] += fx_of(rv);
-        pd = fmaf(rv, fmaf(acc[ct][reg], -2.0f, 2.0f), pd);
-        pe = fmaf(rv * __builtin_amdgcn_logf(fmaxf(rv, FLT_MIN)), cl[ct], pe);
+        for (int ct = 0; ct < NCT; ct++) {
+          r[ct] = (16 * ct + c < K) ? __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]) : 0.0f;
+          s1 += r[ct];
+        }
+        s1 = rowsum16(s1);
+        float i2 = (s1 == 0.0f) ? 1.0f : 1.0f / s1;
+        if constexpr (MODE == 0) {
+          float s2 = 0.0f;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ct++) { r[ct] = (r[ct] * i2) * penv[ct]; s2 += fabsf(r[ct]); }
+          s2 = rowsum16(s2);
+          i2 = (s2 == 0.0f) ? 1.0f : 1.0f / s2;
+        }
+        float pd = 0.0f, pe = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) {
+          const float rn = r[ct] * i2;
+          if (cv && 16 * ct + c < K) Rrow[16 * ct + c] = rn;
+          const float rv = cv ? rn : 0.0f;  // exactly 0 for k >= K
+          oacc[ct] += fx_of(rv);
+          pd = fmaf(rv, fmaf(acc[ct][reg], -2.0f, 2.0f), pd);
+          pe = fmaf(rv * __builtin_amdgcn_logf(fmaxf(rv, FLT_MIN)), cl[ct], pe);
+        }
+        od += (double)pd; oe += (double)pe;
       }
-      od += (double)pd; oe += (double)pe;
     }
   }
-  if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
-  od = wsumd(od); oe = wsumd(oe);
-  if (lane == 0) {
-    double* slot = D.objpart + ((size_t)(j % D.objslots) * D.nwmax + wave) * 2;
-    if (D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; }        // written once per round: plain store
-    else { slot[0] += od; slot[1] += oe; }
+  if constexpr (MODE == 2) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * D.d; i += blockDim.x)
+      if (ltab[i]) atomicAdd((unsigned long long*)&D.lsum[i], (unsigned long long)ltab[i]);
+    for (int i = threadIdx.x; i < K; i += blockDim.x)
+      if (ltab[K * D.d + i]) atomicAdd(&D.lcnt[i], (unsigned long long)ltab[K * D.d + i]);
+  } else {
+    if (ts >= te) return;
+    if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+    od = wsumd(od); oe = wsumd(oe);
+    if (lane == 0) {
+      const int slotrow = (MODE == 0) ? (j % D.objslots) : 0;
+      double* slot = D.objpart + ((size_t)slotrow * D.nwmax + wave) * 2;
+      if (MODE == 0 && D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; }  // written once per round: plain store
+      else { slot[0] += od; slot[1] += oe; }
+    }
   }
 }
 
@@ -1125,6 +1184,21 @@ void l_copy(const Launch& L, const float* src, float* dst, size_t count) {
 void l_normalize(const Launch& L, float* Z, int n, int d, int zs) {
   hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, Z, n, d, zs);
 }
+// MFMA tile passes over the static 16-cell tiles: mode 1 = head, mode 2 = Lloyd
+void l_tile_static(const Launch& L, const Dev& D, int mode) {
+  int blocks = stream_grid(L, (D.ntitems + D.upd_tpw - 1) / D.upd_tpw);
+  size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4);
+  if (mode == 2) { lds += ((size_t)D.K * D.d + D.K) * sizeof(long long); if (blocks > 512) blocks = 512; }
+  const dim3 grid(blocks);
+#define HMX_TS(N) case N: if (mode == 1) hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(TPB), lds, L.stream, D, 0); \
+                          else hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(TPB), lds, L.stream, D, 0); break;
+  switch (D.NCT) {
+    HMX_TS(1) HMX_TS(2) HMX_TS(3) HMX_TS(4) HMX_TS(5) HMX_TS(6) HMX_TS(7) HMX_TS(8)
+    HMX_TS(10) HMX_TS(12) HMX_TS(14) HMX_TS(16)
+    default: break;
+  }
+#undef HMX_TS
+}
 void l_head(const Launch& L, const Dev& D, int mode) {
   const dim3 grid(stream_grid(L, D.nitems));
   const size_t lds = lds_bytes_y(D);
@@ -1177,7 +1251,7 @@ void l_update(const Launch& L, const Dev& D, int j) {
   const dim3 grid(stream_grid(L, (tiles + D.upd_tpw - 1) / D.upd_tpw));
   const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) +
                      (D.pen_lds ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
-#define HMX_UPD(N) case N: hipLaunchKernelGGL(k_update_mfma<N>, grid, dim3(TPB), lds, L.stream, D, j); break;
+#define HMX_UPD(N) case N: hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(TPB), lds, L.stream, D, j); break;
   switch (D.NCT) {
     HMX_UPD(1) HMX_UPD(2) HMX_UPD(3) HMX_UPD(4) HMX_UPD(5) HMX_UPD(6) HMX_UPD(7) HMX_UPD(8)
     HMX_UPD(10) HMX_UPD(12) HMX_UPD(14) HMX_UPD(16)
