@@ -317,7 +317,8 @@ int kmeans_centers(hmx_ctx* ctx) {
 
 // ---- update_R (src/harmony.cpp:269-342) ---------------------------------------------------------
 int update_R(hmx_ctx* ctx) {
-  const Dev& D = ctx->D;
+  Dev& D = ctx->D;
+  const bool merged = ctx->world <= 1 && !ctx->comm_force && (size_t)D.B * 128 <= 64 * 1024;
   const double t0 = now_ms();
   if (!ctx->injected.empty()) {  // host-provided shuffle: block(g) from its position
     std::vector<int64_t> order = std::move(ctx->injected.front());
@@ -345,11 +346,15 @@ int update_R(hmx_ctx* ctx) {
       l_fold(ctx->L, D, j, 1); KCHK();
       CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.B * D.K, 0));
       l_fold(ctx->L, D, j < D.nb ? j : -1, 2); KCHK();
+    } else if (merged) {
+      // one launch: O' = O + new(prev) - old(j) and the penalty table; ping-pong so nothing is read while written
+      l_foldpen(ctx->L, D, j < D.nb ? j : -1, D.O_fx, D.O_alt, D.Snew_fx, D.Snew_alt); KCHK();
+      std::swap(D.O_fx, D.O_alt); std::swap(D.Snew_fx, D.Snew_alt);
     } else {
       l_fold(ctx->L, D, j < D.nb ? j : -1, 0); KCHK();
     }
     if (j == D.nb) break;
-    l_penalty(ctx->L, D); KCHK();
+    if (!merged) { l_penalty(ctx->L, D); KCHK(); }
     if (ctx->profile) {
       if (ctx->ev_used == ctx->ev_pool.size()) {
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
@@ -711,7 +716,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   D.n = (int)N; D.d = d; D.K = K; D.B = B; D.C = C; D.Q = Q; D.B0 = ctx->B_vec[0];
   D.KP = (K + 63) / 64 * 64; D.nb = ctx->nb;
   D.zs = (d + 3) / 4 * 4;
-  { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 16; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
+  { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 8; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
   { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
     const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
   D.lloyd_lds = ((size_t)d * D.KP * 4 + ((size_t)K * d + K) * 8 <= 98304) ? 1 : 0;
@@ -735,7 +740,8 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.perm, (size_t)N)); CHK(dalloc(ctx, &D.invperm, (size_t)N)); CHK(dalloc(ctx, &D.combo, (size_t)N));
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
   CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
-  CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
+  CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
+  CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
   CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)D.npad)); CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
   CHK(dalloc(ctx, &D.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
@@ -754,6 +760,8 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(h2d(ctx, D.items, items.data(), items.size())); CHK(h2d(ctx, D.aitems, aitems.data(), aitems.size())); CHK(h2d(ctx, D.titems, titems.data(), titems.size()));
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * B * K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * B * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Snew_alt, 0, sizeof(long long) * (size_t)D.nrep * B * K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.O_alt, 0, sizeof(long long) * B * K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.obj, 0, sizeof(double) * 8, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.R, 0, sizeof(float) * (size_t)N * K, ctx->L.stream));

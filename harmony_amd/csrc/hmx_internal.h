@@ -52,6 +52,8 @@ struct Dev {
   long long* O_fx;    // [B][K] fixed-point O (exact sum of quantised R)
   long long* Snew_fx; // [nrep][B][K] contribution of the block being updated
   long long* Sold_fx; // [nb][B][K] old contribution of every block of this round
+  long long* O_alt;   // ping-pong partners of O_fx / Snew_fx for the single-launch fold+penalty (host swaps)
+  long long* Snew_alt;
   float* pen;         // [B][K] ((2E+1)/(O+E+1))^theta
   double* obj;        // [0..1] reduced sums: sum R*dist, sum sigma*R*log R ; [2..4] snapshot incl. cross term
   double* objpart;    // [objslots][nwmax][2] per-(block,wave) partial sums: private slots, no atomics
@@ -107,6 +109,8 @@ void l_sort_blocks(const Launch& L, const Dev& D);
 void l_oldsum(const Launch& L, const Dev& D);
 void l_fold(const Launch& L, const Dev& D, int j, int mode);
 void l_penalty(const Launch& L, const Dev& D);
+void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long long* Oout, const long long* Sin,
+               long long* Szero);
 void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]

@@ -45,6 +45,12 @@ __device__ __forceinline__ unsigned long long wmin64(unsigned long long v) {
   }
   return v;
 }
+// UNCONDITIONAL load from a clamped (always valid) index, masked afterwards.  `cond ? p[i] : 0` makes hipcc branch
+// around every load and wait vmcnt(0) at each join -- fully serialised memory latency (measured: 2-3x slower).
+template <class T> __device__ __forceinline__ T ld_or(const T* __restrict__ p, size_t safe_idx, bool ok, T dflt) {
+  const T v = p[safe_idx];
+  return ok ? v : dflt;
+}
 __device__ __forceinline__ float trunc_logf_dev(float x) {  // arma::trunc_log (src/utils.cpp:78)
   return (x > 0.0f) ? logf(x) : logf(FLT_MIN);
 }
@@ -93,7 +99,7 @@ static FeistelKeys make_keys(uint64_t seed, uint64_t round, uint64_t N) {
 __device__ __forceinline__ void stage_Y(float* ldsY, const float* __restrict__ Yt, int d, int K, int KP) {
   for (int i = threadIdx.x; i < d * KP; i += blockDim.x) {
     int j = i / KP, k = i - j * KP;
-    ldsY[i] = (k < K) ? Yt[j * K + k] : 0.0f;
+    ldsY[i] = ld_or(Yt, (size_t)j * K + min(k, K - 1), k < K, 0.0f);
   }
   __syncthreads();
 }
@@ -135,8 +141,8 @@ __device__ __forceinline__ void group_dots(const float* __restrict__ ldsY, int d
 
 template <int DPL>
 __device__ __forceinline__ void load_row(const float* __restrict__ Z, size_t cell, int zs, int d, int lane, float (&z)[DPL]) {
-  z[0] = (lane < d) ? Z[cell * zs + lane] : 0.0f;
-  if constexpr (DPL > 1) z[DPL - 1] = (64 + lane < d) ? Z[cell * zs + 64 + lane] : 0.0f;
+  z[0] = ld_or(Z, cell * zs + min(lane, d - 1), lane < d, 0.0f);
+  if constexpr (DPL > 1) z[DPL - 1] = ld_or(Z, cell * zs + min(64 + lane, d - 1), 64 + lane < d, 0.0f);
 }
 
 // flush a lane-private fixed-point run sum into a [B][K] table, once per covariate level
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(TPB) void k_normalize(float* __restrict__ Z, int n,
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
   for (int cell = wave; cell < n; cell += nw) {
     float* z = Z + (size_t)cell * zs;
-    float a = (lane < d) ? z[lane] : 0.0f, b = (64 + lane < d) ? z[64 + lane] : 0.0f;
+    const float a = ld_or(z, (size_t)min(lane, d - 1), lane < d, 0.0f), b = ld_or(z, (size_t)min(64 + lane, d - 1), 64 + lane < d, 0.0f);
     float nrm = sqrtf(wsum(a * a + b * b));
     if (nrm == 0.0f) nrm = 1.0f;
     if (lane < d) z[lane] = a / nrm;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(TPB) void k_head(Dev D) {
   const int d = D.d, K = D.K;
   float sig[KPL];
 #pragma unroll
-  for (int q = 0; q < KPL; q++) sig[q] = (lane + 64 * q < K) ? D.sigma[lane + 64 * q] : 1.0f;
+  for (int q = 0; q < KPL; q++) sig[q] = ld_or(D.sigma, (size_t)min(lane + 64 * q, K - 1), lane + 64 * q < K, 1.0f);
   double od = 0.0, oe = 0.0;
   for (int it = wave; it < D.nitems; it += nw) {
     const Item item = D.items[it];
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(TPB) void k_head(Dev D) {
             for (int q = 0; q < KPL; q++) {
               const int k = lane + 64 * q;
               dist[q] = 2.0f * (1.0f - acc[c][q]);
-              r[q] = (k < K) ? D.R[cell * K + k] : 0.0f;
+              r[q] = ld_or(D.R, cell * K + min(k, K - 1), k < K, 0.0f);
             }
           }
 #pragma unroll
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D) {
   const int s = ch.start, e = ch.start + ch.cnt;
   for (int base = s; base < e; base += WAVE) {
     const int i = base + lane;
-    const int b = (i < e) ? D.blk[i] : -1;
+    const int b = ld_or(D.blk, (size_t)min(i, e - 1), i < e, -1);
     unsigned long long rem = __ballot(b >= 0);
     while (rem) {
       const int src = __ffsll((long long)rem) - 1;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int base = s; base < e; base += WAVE) {
     const int i = base + lane;
-    const int b = (i < e) ? D.blk[i] : -1;
+    const int b = ld_or(D.blk, (size_t)min(i, e - 1), i < e, -1);
     unsigned long long rem = __ballot(b >= 0);
     while (rem) {
       const int src = __ffsll((long long)rem) - 1;
@@ -408,11 +414,11 @@ __global__ __launch_bounds__(TPB) void k_oldsum(Dev D) {
     int cell[CB]; float r[CB][KPL];
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-      cell[c] = (c < nc) ? D.lorder[p + c] : -1;  // -1: padding slot
+      cell[c] = ld_or(D.lorder, (size_t)min(p + c, e - 1), c < nc, -1);  // -1: padding slot
 #pragma unroll
       for (int q = 0; q < KPL; q++) {
         const int k = lane + 64 * q;
-        r[c][q] = (cell[c] >= 0 && k < K) ? D.R[(size_t)cell[c] * K + k] : 0.0f;
+        r[c][q] = ld_or(D.R, (size_t)max(cell[c], 0) * K + min(k, K - 1), cell[c] >= 0 && k < K, 0.0f);
       }
     }
 #pragma unroll
@@ -468,6 +474,39 @@ __global__ void k_obj_final(Dev D) {
   for (int s = 0; s < D.objslots; s++) { a += D.objrow[2 * s]; b += D.objrow[2 * s + 1]; }
   D.obj[0] = a; D.obj[1] = b;
 }
+// Single-launch variant (one GPU): fold + penalty with ping-pong tables, so no thread reads what another writes;
+// one workgroup per 16 clusters, the new O column block goes through LDS for the covariate-0 row sums.
+//   Oin/Sin: O and the replicas filled by the previous block update;  Oout: new O;  Szero: the replica set the NEXT
+//   update accumulates into (zeroed here).  j < 0: fold only.
+__global__ __launch_bounds__(256) void k_foldpen(Dev D, int j, const long long* __restrict__ Oin, long long* __restrict__ Oout,
+                                                 const long long* __restrict__ Sin, long long* __restrict__ Szero) {
+  extern __shared__ long long shO[];  // [B][16] new O of this workgroup's 16 clusters
+  const int K = D.K, B = D.B, n = B * K;
+  const int kk = threadIdx.x & 15, k = blockIdx.x * 16 + kk;
+  const long long* sold = (j >= 0) ? D.Sold_fx + (size_t)j * n : nullptr;
+  for (int b = threadIdx.x >> 4; b < B; b += 16) {
+    long long o = 0;
+    if (k < K) {
+      const size_t i = (size_t)b * K + k;
+      o = Oin[i];
+      for (int r = 0; r < D.nrep; r++) { o += Sin[(size_t)r * n + i]; Szero[(size_t)r * n + i] = 0; }
+      if (sold) o -= sold[i];
+      Oout[i] = o;
+    }
+    shO[b * 16 + kk] = o;
+  }
+  if (j < 0) return;
+  __syncthreads();
+  long long rs = 0;  // rowsum(R) of the cells currently "in" = sum over the levels of covariate 0 of the NEW O
+  for (int b0 = 0; b0 < D.B0; b0++) rs += shO[b0 * 16 + kk];
+  const double rsd = (double)rs * FX_INV;
+  if (k < K)
+    for (int b = threadIdx.x >> 4; b < B; b += 16) {
+      const float of = (float)((double)shO[b * 16 + kk] * FX_INV);
+      const float ef = (float)(rsd * (double)D.Pr_b[b]);
+      D.pen[(size_t)b * K + k] = powf(((2.0f * ef) + 1.0f) / (of + ef + 1.0f), D.theta[b]);
+    }
+}
 __global__ void k_penalty(Dev D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D.B * D.K) return;
@@ -496,7 +535,7 @@ __global__ __launch_bounds__(TPB) void k_update(Dev D, int j) {
   float sig[KPL], penv[KPL];
   unsigned long long oacc[KPL];
 #pragma unroll
-  for (int q = 0; q < KPL; q++) { sig[q] = (lane + 64 * q < K) ? D.sigma[lane + 64 * q] : 1.0f; penv[q] = 0.0f; oacc[q] = 0ull; }
+  for (int q = 0; q < KPL; q++) { sig[q] = ld_or(D.sigma, (size_t)min(lane + 64 * q, K - 1), lane + 64 * q < K, 1.0f); penv[q] = 0.0f; oacc[q] = 0ull; }
   double od = 0.0, oe = 0.0;
   int curq = -1;
   for (int p = s; p < e; p += CB) {
@@ -504,7 +543,7 @@ __global__ __launch_bounds__(TPB) void k_update(Dev D, int j) {
     int cell[CB]; float z[CB][DPL];
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-      cell[c] = (c < nc) ? D.lorder[p + c] : -1;  // -1: padding slot
+      cell[c] = ld_or(D.lorder, (size_t)min(p + c, e - 1), c < nc, -1);  // -1: padding slot
       if (cell[c] >= 0) load_row<DPL>(D.Zc, (size_t)cell[c], D.zs, d, lane, z[c]);
       else {
 #pragma unroll
@@ -611,10 +650,12 @@ __device__ __forceinline__ void tile_dots(const f32x4* __restrict__ ldsY4, const
   constexpr int NQ = (NCT + 3) / 4;
 #pragma unroll
   for (int ct = 0; ct < NCT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 zt = valid && NT4 > 0 ? *reinterpret_cast<const f32x4*>(zrow + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // zrow always points at a real row (row 0 for padding lanes): unconditional loads, masked afterwards
+  f32x4 zt = (NT4 > 0) ? *reinterpret_cast<const f32x4*>(zrow + 4 * g) : zero4;
   for (int t = 0; t < NT4; ++t) {
-    const f32x4 zc = zt;
-    if (t + 1 < NT4) zt = valid ? *reinterpret_cast<const f32x4*>(zrow + 16 * (t + 1) + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zc = valid ? zt : zero4;
+    if (t + 1 < NT4) zt = *reinterpret_cast<const f32x4*>(zrow + 16 * (t + 1) + 4 * g);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int s = 4 * t + e;
@@ -629,7 +670,8 @@ __device__ __forceinline__ void tile_dots(const f32x4* __restrict__ ldsY4, const
   }
   for (int u = 0; u < tail; ++u) {
     const int s = 4 * NT4 + u;
-    const float zv = valid ? zrow[16 * NT4 + 4 * u + g] : 0.0f;
+    const float zl = zrow[16 * NT4 + 4 * u + g];
+    const float zv = valid ? zl : 0.0f;
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) {
       const f32x4 y = ldsY4[(qd * NS + s) * 64 + lane];
@@ -714,8 +756,9 @@ __global__ __launch_bounds__(TPB) void k_tile(Dev D, int j) {
 #pragma unroll
   for (int ct = 0; ct < NCT; ct++) {
     const bool kv = 16 * ct + c < K;
-    if constexpr (MODE == 2) { ce[ct] = kv ? D.ynorm[16 * ct + c] : 0.0f; cl[ct] = 0.0f; }
-    else { ce[ct] = kv ? D.ce[16 * ct + c] : 0.0f; cl[ct] = kv ? D.cl[16 * ct + c] : 0.0f; }
+    const size_t ks = (size_t)min(16 * ct + c, K - 1);
+    if constexpr (MODE == 2) { ce[ct] = ld_or(D.ynorm, ks, kv, 0.0f); cl[ct] = 0.0f; }
+    else { ce[ct] = ld_or(D.ce, ks, kv, 0.0f); cl[ct] = ld_or(D.cl, ks, kv, 0.0f); }
     penv[ct] = 1.0f; oacc[ct] = 0ull;
   }
   double od = 0.0, oe = 0.0;
@@ -774,7 +817,7 @@ __global__ __launch_bounds__(TPB) void k_tile(Dev D, int j) {
           for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
             const int b = qlevT[q0 * C + cc];
 #pragma unroll
-            for (int ct = 0; ct < NCT; ct++) if (16 * ct + c < K) penv[ct] += penT[(size_t)b * K + 16 * ct + c];
+            for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(penT, (size_t)b * K + min(16 * ct + c, K - 1), 16 * ct + c < K, 0.0f);
           }
         }
       }
@@ -890,16 +933,17 @@ __global__ __launch_bounds__(TPB) void k_moe_stats(Dev D) {
     for (int j = 0; j < DP; j++) { a0[j] = 0.0f; a1[j] = 0.0f; }
     double n0 = 0.0, n1 = 0.0;
     size_t cell = (size_t)item.start;
-    float zn = (lane < dch) ? D.Zo[cell * D.zs + zoff + lane] : 0.0f;
-    float r0n = (k0 < K) ? D.R[cell * K + k0] : 0.0f;
-    float r1n = (k1 < K) ? D.R[cell * K + k1] : 0.0f;
+    const int ls = min(lane, dch - 1), k0s = min(k0, K - 1), k1s = min(k1, K - 1);
+    float zn = ld_or(D.Zo, cell * D.zs + zoff + ls, lane < dch, 0.0f);
+    float r0n = ld_or(D.R, cell * K + k0s, k0 < K, 0.0f);
+    float r1n = ld_or(D.R, cell * K + k1s, k1 < K, 0.0f);
     for (int p = 0; p < item.cnt; p++) {
       const float zr = zn, r0 = r0n, r1 = r1n;
       if (p + 1 < item.cnt) {  // software prefetch of the next cell's rows
         cell = (size_t)(item.start + p + 1);
-        zn = (lane < dch) ? D.Zo[cell * D.zs + zoff + lane] : 0.0f;
-        r0n = (k0 < K) ? D.R[cell * K + k0] : 0.0f;
-        r1n = (k1 < K) ? D.R[cell * K + k1] : 0.0f;
+        zn = ld_or(D.Zo, cell * D.zs + zoff + ls, lane < dch, 0.0f);
+        r0n = ld_or(D.R, cell * K + k0s, k0 < K, 0.0f);
+        r1n = ld_or(D.R, cell * K + k1s, k1 < K, 0.0f);
       }
       n0 += (double)r0; n1 += (double)r1;
 #pragma unroll
@@ -939,7 +983,7 @@ __global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
     const float* W = D.Wq + (size_t)item.q * K * d;
     for (int i = threadIdx.x; i < K * DS; i += blockDim.x) {
       const int k = i / DS, jj = i - k * DS;
-      ldsW[i] = (jj < d) ? W[(size_t)k * d + jj] : 0.0f;
+      ldsW[i] = ld_or(W, (size_t)k * d + min(jj, d - 1), jj < d, 0.0f);
     }
     __syncthreads();
     const int per = (item.cnt + 3) / 4;
@@ -952,7 +996,7 @@ __global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
 #pragma unroll
         for (int q = 0; q < KPL; q++) {
           const int k = lane + 64 * q;
-          rr[c][q] = (c < nc && k < K) ? D.R[(size_t)(p + c) * K + k] : 0.0f;
+          rr[c][q] = ld_or(D.R, (size_t)min(p + c, e - 1) * K + min(k, K - 1), c < nc && k < K, 0.0f);
         }
 #pragma unroll
         for (int t = 0; t < DPL; t++) corr[c][t] = 0.0f;
@@ -1078,7 +1122,7 @@ __global__ __launch_bounds__(TPB) void k_lloyd(Dev D) {
   const int d = D.d, K = D.K;
   float yn[KPL];
 #pragma unroll
-  for (int q = 0; q < KPL; q++) yn[q] = (lane + 64 * q < K) ? D.ynorm[lane + 64 * q] : 0.0f;
+  for (int q = 0; q < KPL; q++) yn[q] = ld_or(D.ynorm, (size_t)min(lane + 64 * q, K - 1), lane + 64 * q < K, 0.0f);
   for (int it = wave; it < D.nitems; it += nw) {
     const Item item = D.items[it];
     for (int p = 0; p < item.cnt; p += CB) {
@@ -1230,6 +1274,11 @@ void l_oldsum(const Launch& L, const Dev& D) {
 void l_fold(const Launch& L, const Dev& D, int j, int mode) {
   const int n = D.B * D.K;
   hipLaunchKernelGGL(k_fold, dim3((n + 255) / 256), dim3(256), 0, L.stream, D, j, mode);
+}
+void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long long* Oout, const long long* Sin,
+               long long* Szero) {
+  hipLaunchKernelGGL(k_foldpen, dim3((D.K + 15) / 16), dim3(256), (size_t)D.B * 16 * sizeof(long long), L.stream, D, j, Oin,
+                     Oout, Sin, Szero);
 }
 void l_penalty(const Launch& L, const Dev& D) {
   const int n = D.B * D.K;
