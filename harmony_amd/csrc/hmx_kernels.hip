@@ -714,11 +714,15 @@ __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const
   for (int ct = 0; ct < NCT; ct++) oacc[ct] = 0ull;
 }
 
+// 256-thread workgroups; register budget <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (3 workgroups per CU)
+// are resident and one launch of ~3 workgroups per CU finishes in a single wave of workgroups.
+constexpr int tile_threads(int nct) { return 256; }  // measured: 768-thread workgroups (one per CU) are 30% slower (tail effect)
 // MODE 0: block update (cells gathered through lorder, penalty, second normalisation)      update_R :318-330
 // MODE 1: head (static 16-cell tiles of the internal order, plain softmax)                 :141-150 / :221-227
+// Register budget: <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (12 per CU) are resident.
 // MODE 2: one Lloyd iteration of kmeans_centers (nearest centre, fixed-point sums in LDS)  src/utils.cpp:56-61
 template <int NCT, int MODE>
-__global__ __launch_bounds__(TPB) void k_tile(Dev D, int j) {
+__global__ __launch_bounds__(256, (NCT <= 8 ? 3 : (NCT <= 12 ? 2 : 1))) void k_tile(Dev D, int j) {
   // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits):
   //   [ centroid image: NQ*NS*64 float4 | MODE 0: pen[B][K] + qlev[Q][C] (if they fit) | MODE 2: int64 sums[K][d] + counts[K] ]
   extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
@@ -1230,12 +1234,15 @@ void l_normalize(const Launch& L, float* Z, int n, int d, int zs) {
 }
 // MFMA tile passes over the static 16-cell tiles: mode 1 = head, mode 2 = Lloyd
 void l_tile_static(const Launch& L, const Dev& D, int mode) {
-  int blocks = stream_grid(L, (D.ntitems + D.upd_tpw - 1) / D.upd_tpw);
+  const int wpb = tile_threads(D.NCT) / 64;
+  long long blocks = (((long long)D.ntitems + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
+  if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
   size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4);
-  if (mode == 2) { lds += ((size_t)D.K * D.d + D.K) * sizeof(long long); if (blocks > 512) blocks = 512; }
-  const dim3 grid(blocks);
-#define HMX_TS(N) case N: if (mode == 1) hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(TPB), lds, L.stream, D, 0); \
-                          else hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(TPB), lds, L.stream, D, 0); break;
+  if (mode == 2) { lds += ((size_t)D.K * D.d + D.K) * sizeof(long long); if (blocks > 256) blocks = 256; }
+  if (blocks < 1) blocks = 1;
+  const dim3 grid((unsigned)blocks);
+#define HMX_TS(N) case N: if (mode == 1) hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
+                          else hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); break;
   switch (D.NCT) {
     HMX_TS(1) HMX_TS(2) HMX_TS(3) HMX_TS(4) HMX_TS(5) HMX_TS(6) HMX_TS(7) HMX_TS(8)
     HMX_TS(10) HMX_TS(12) HMX_TS(14) HMX_TS(16)
@@ -1296,11 +1303,15 @@ void l_update(const Launch& L, const Dev& D, int j) {
     HMX_DISPATCH_KD(k_update, , grid, lds_bytes_y(D), D, j);
     return;
   }
-  const long long tiles = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + 15) / 16 + 1;
-  const dim3 grid(stream_grid(L, (tiles + D.upd_tpw - 1) / D.upd_tpw));
+  const long long tiles = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + 15) / 16 + (long long)D.Q + 1;
+  const int wpb = tile_threads(D.NCT) / 64;
+  long long blocks = ((tiles + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
+  if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
+  if (blocks < 1) blocks = 1;
+  const dim3 grid((unsigned)blocks);
   const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) +
                      (D.pen_lds ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
-#define HMX_UPD(N) case N: hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(TPB), lds, L.stream, D, j); break;
+#define HMX_UPD(N) case N: hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(tile_threads(N)), lds, L.stream, D, j); break;
   switch (D.NCT) {
     HMX_UPD(1) HMX_UPD(2) HMX_UPD(3) HMX_UPD(4) HMX_UPD(5) HMX_UPD(6) HMX_UPD(7) HMX_UPD(8)
     HMX_UPD(10) HMX_UPD(12) HMX_UPD(14) HMX_UPD(16)
