@@ -147,8 +147,15 @@ def main():
     upd_cells = obj._scalar("prof:update_cells")  # cells summed over rounds (every round touches every cell once)
     alg_bytes = upd_cells * (4.0 * d + 4.0 * K)
     achieved = alg_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
-    roofline = {"kernel": "k_update", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
+    traffic = None  # HBM bytes per launch from the PMC passes (collected separately, see profiles/r1_pmc_summary.json)
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_update_kernel.json")))
+        if pm["workload"] == {"cells_per_gpu": n, "pcs": d, "clusters": K, "batches": B}:
+            traffic = pm["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    roofline = {"kernel": "k_tile<NCT,0> (block update of update_R)", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "avg_launch_us": 1e3 * upd_ms / max(upd_launches, 1), "launches": int(upd_launches),
                 "alg_bytes_per_launch": alg_bytes / max(upd_launches, 1),
                 "kernel_time_share": upd_ms / (1e3 * dt) if dt > 0 else None}

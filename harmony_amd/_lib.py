@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libharmony_mi355x.so")
+LIB_PATH = os.environ.get("HMX_LIB_PATH") or os.path.join(_HERE, "lib", "libharmony_mi355x.so")
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 POLL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)

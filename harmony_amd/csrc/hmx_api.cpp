@@ -720,6 +720,9 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
     const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
   D.lloyd_lds = ((size_t)d * D.KP * 4 + ((size_t)K * d + K) * 8 <= 98304) ? 1 : 0;
+  { const char* e = getenv("HMX_MOE_IMPL");
+    D.moe_mfma = (K % 4 == 0 && d <= 64 && K <= 128 && !(e && std::string(e) == "v1")) ? 1 : 0;
+    D.wNT4 = K / 16; D.wtail = (K - 16 * D.wNT4) / 4; D.wNS = 4 * D.wNT4 + D.wtail; D.wNQ = ((d + 15) / 16 + 3) / 4; }
   D.nwmax = 4 * ctx->L.grid; D.objslots = std::min(D.nb, 64);
   D.pen_lds = ((size_t)D.NQ * 0 + (size_t)B * K * 4 + (size_t)Q * C * 4 <= 24576) ? 1 : 0;
   D.NQ = (D.NCT + 3) / 4; D.NT4 = D.zs / 16; D.tail = (D.zs - 16 * D.NT4) / 4; D.NS = 4 * D.NT4 + D.tail;
@@ -748,7 +751,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks));
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
-  CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d));
+  CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d)); CHK(dalloc(ctx, &D.Wimg, D.moe_mfma ? (size_t)Q * D.wNQ * D.wNS * 256 : 1));
   CHK(dalloc(ctx, &D.seedmin, (size_t)K)); CHK(dalloc(ctx, &D.lsum, (size_t)K * d)); CHK(dalloc(ctx, &D.lcnt, (size_t)K)); CHK(dalloc(ctx, &D.ynorm, (size_t)K));
   CHK(h2d(ctx, D.perm, ctx->perm.data(), (size_t)N)); CHK(h2d(ctx, D.invperm, invperm.data(), (size_t)N));
   CHK(h2d(ctx, D.combo, combo_sorted.data(), (size_t)N)); CHK(h2d(ctx, D.qlev, ctx->qlev.data(), ctx->qlev.size()));
@@ -874,7 +877,7 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   const int K = ctx->K, B = ctx->B, d = ctx->d, Q = ctx->Q;
   HIPCHK(hipMemsetAsync(D.Sq, 0, sizeof(double) * (size_t)Q * d * K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.nq, 0, sizeof(double) * (size_t)Q * K, ctx->L.stream));
-  l_moe_stats(ctx->L, D); KCHK();
+  if (D.moe_mfma) { l_moe_stats_mfma(ctx->L, D); KCHK(); } else { l_moe_stats(ctx->L, D); KCHK(); }
   CHK(allreduce(ctx, D.Sq, (int64_t)Q * d * K, 1));
   CHK(allreduce(ctx, D.nq, (int64_t)Q * K, 1));
   std::vector<double> Sq((size_t)Q * d * K), nq((size_t)Q * K);
@@ -900,8 +903,22 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
     else { ctx->W = outs[k].W; ctx->W_rows = outs[k].m; }
   }
   ctx->timers["moe_solve_host"] += now_ms() - t1;
-  CHK(h2d(ctx, D.Wq, Wq.data(), Wq.size()));
-  l_moe_apply(ctx->L, D); KCHK();   // Z_corr = Z_orig - sum_k R_k W_k[levels]   :347,:615
+  if (D.moe_mfma) {
+    // image[q][qd][s][p][c][i] = Wq[q][cluster(s,p)][16*(4qd+i)+c], cluster(s,p) as tile_dots assigns reduction slots
+    std::vector<float> img((size_t)Q * D.wNQ * D.wNS * 256, 0.f);
+    for (int q = 0; q < Q; q++) for (int qd = 0; qd < D.wNQ; qd++) for (int s = 0; s < D.wNS; s++) for (int p = 0; p < 4; p++) {
+      const int k = (s < 4 * D.wNT4) ? 16 * (s / 4) + 4 * p + (s % 4) : 16 * D.wNT4 + 4 * (s - 4 * D.wNT4) + p;
+      if (k >= K) continue;
+      const float* w = &Wq[((size_t)q * K + k) * d];
+      float* o = &img[((((size_t)q * D.wNQ + qd) * D.wNS + s) * 4 + p) * 64];
+      for (int c = 0; c < 16; c++) for (int i = 0; i < 4; i++) { const int jj = 16 * (4 * qd + i) + c; if (jj < d) o[c * 4 + i] = w[jj]; }
+    }
+    CHK(h2d(ctx, D.Wimg, img.data(), img.size()));
+    l_moe_apply_mfma(ctx->L, D); KCHK();   // Z_corr = Z_orig - sum_k R_k W_k[levels]   :347,:615
+  } else {
+    CHK(h2d(ctx, D.Wq, Wq.data(), Wq.size()));
+    l_moe_apply(ctx->L, D); KCHK();
+  }
   ctx->Y = Ynew;
   normalise_cols(ctx->Y, d, K);     // :633
   CHK(upload_Y(ctx));

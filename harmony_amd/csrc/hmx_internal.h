@@ -82,6 +82,9 @@ struct Dev {
   double* Sq;       // [Q][d][K]  sum_i R_ki z_ij over cells of combination q
   double* nq;       // [Q][K]     sum_i R_ki
   float* Wq;        // [Q][K][d]  correction table
+  float* Wimg;      // [Q][wNQ][wNS][4][16][4] the same table as MFMA B-operand image (clusters = reduction dim)
+  int wNQ, wNT4, wtail, wNS;  // image geometry for k_moe_apply_mfma (valid when moe_mfma)
+  int moe_mfma;     // 1: MFMA stats/apply kernels (needs K % 4 == 0, d <= 64, K <= 128)
   // kmeans init
   unsigned long long* seedmin;  // [K] packed (key bits << 32 | global cell)
   long long* lsum;  // [K][d] 2^30 fixed-point sums of unit-vector components (exact, order-independent)
@@ -116,6 +119,8 @@ void l_update(const Launch& L, const Dev& D, int j);
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
 void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);
+void l_moe_stats_mfma(const Launch& L, const Dev& D);
+void l_moe_apply_mfma(const Launch& L, const Dev& D);
 void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl);
 void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint64_t goff, double* rows);
 void l_lloyd(const Launch& L, const Dev& D);

@@ -16,6 +16,9 @@
 #ifndef HMX_USE_DPP
 #define HMX_USE_DPP 1
 #endif
+#ifndef HMX_TILE_LB
+#define HMX_TILE_LB(NCT) 1   // waves/SIMD the tile kernel is register-budgeted for; 3 measured slower than unconstrained
+#endif
 
 namespace hmx {
 
@@ -722,7 +725,7 @@ constexpr int tile_threads(int nct) { return 256; }  // measured: 768-thread wor
 // Register budget: <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (12 per CU) are resident.
 // MODE 2: one Lloyd iteration of kmeans_centers (nearest centre, fixed-point sums in LDS)  src/utils.cpp:56-61
 template <int NCT, int MODE>
-__global__ __launch_bounds__(256, (NCT <= 8 ? 3 : (NCT <= 12 ? 2 : 1))) void k_tile(Dev D, int j) {
+__global__ __launch_bounds__(256, HMX_TILE_LB(NCT)) void k_tile(Dev D, int j) {
   // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits):
   //   [ centroid image: NQ*NS*64 float4 | MODE 0: pen[B][K] + qlev[Q][C] (if they fit) | MODE 2: int64 sums[K][d] + counts[K] ]
   extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
@@ -1035,6 +1038,119 @@ __global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
   }
 }
 
+// ---- MFMA variants of the two MoE passes (static 16-cell tiles, rows of a tile are contiguous in HBM) ----
+// k_moe_stats_mfma: Sq[q] (K x d) += R_tile^T (K x 16) * Zo_tile (16 x d): the 16 cells are the MFMA reduction dim.
+//   A[i = cluster 16ct+(l&15)][slot l>>4] = R[cell 4s+(l>>4)][cluster],  B[slot][j = PC 16pt+(l&15)] = Zo[cell][PC]
+//   D: lane l holds clusters 16ct+4(l>>4)+reg x PC 16pt+(l&15); accumulated over a run of tiles, flushed with fp64 atomics.
+// Work split: a workgroup streams a contiguous range of tiles; its wave w owns PC tile w (blockDim = 64*ceil(d/16)),
+// so a wave carries only NCT fp32 MFMA accumulators (folded into fp64 shadows every 4 tiles = 64 cells) and the
+// K x d result of a run is flushed ONCE per workgroup, not once per wave (the fp64 atomics dominated otherwise).
+template <int NCT>
+__global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg) {
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, pt = threadIdx.x >> 6;
+  const int K = D.K, d = D.d, zs = D.zs;
+  const int ts = blockIdx.x * tiles_per_wg, te = min(D.ntitems, ts + tiles_per_wg);
+  if (ts >= te) return;
+  const int jj = 16 * pt + c;           // this lane's PC
+  const bool jv = jj < d;
+  f32x4 acc[NCT];
+  double sh[NCT][4], nsh[NCT];
+  float nacc[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) {
+    acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; nacc[ct] = 0.0f; nsh[ct] = 0.0;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) sh[ct][reg] = 0.0;
+  }
+  auto fold = [&]() {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) sh[ct][reg] += (double)acc[ct][reg];
+      acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      nsh[ct] += (double)nacc[ct]; nacc[ct] = 0.0f;
+    }
+  };
+  auto flush = [&](int q) {
+    double* S = D.Sq + (size_t)q * d * K;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int k = 16 * ct + 4 * g + reg;
+        if (jv && k < K && sh[ct][reg] != 0.0) atomicAdd(&S[(size_t)jj * K + k], sh[ct][reg]);
+        sh[ct][reg] = 0.0;
+      }
+      if (pt == 0) {                            // sum_i R_ki of cluster 16ct+c: add the four cell slots
+        double v = nsh[ct];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (g == 0 && 16 * ct + c < K) atomicAdd(&D.nq[(size_t)q * K + 16 * ct + c], v);
+      }
+      nsh[ct] = 0.0;
+    }
+  };
+  int curq = D.titems[ts].q;
+  for (int tile = ts; tile < te; ++tile) {
+    const Item it = D.titems[tile];
+    if (it.q != curq) { fold(); flush(curq); curq = it.q; }
+    const size_t c0 = (size_t)it.start;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int cell = 4 * st + g;                       // cell slot of this lane in this step
+      const bool cv = cell < it.cnt;
+      const size_t row = c0 + (cv ? cell : 0);
+      float a[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) a[ct] = ld_or(D.R, row * K + min(16 * ct + c, K - 1), cv && 16 * ct + c < K, 0.0f);
+      const float b = ld_or(D.Zo, row * zs + min(jj, zs - 1), cv && jv, 0.0f);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+        nacc[ct] += a[ct];
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], b, acc[ct], 0, 0, 0);
+      }
+    }
+    if (((tile - ts) & 3) == 3) fold();
+  }
+  fold(); flush(curq);
+}
+
+// k_moe_apply_mfma: Z_corr tile (16 x d) = Z_orig tile - R tile (16 x K) * Wq[q] (K x d); clusters are the MFMA reduction
+// dim, so this is tile_dots with (rows = R rows, "centroid image" = Wimg[q] staged in LDS).  One workgroup per apply item.
+template <int NPT>
+__global__ __launch_bounds__(256) void k_moe_apply_mfma(Dev D) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 ldsW4[];
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wib = threadIdx.x >> 6;
+  const int K = D.K, d = D.d, zs = D.zs;
+  const int nW4 = D.wNQ * D.wNS * 64;
+  for (int itx = blockIdx.x; itx < D.naitems; itx += gridDim.x) {
+    const Item item = D.aitems[itx];
+    __syncthreads();
+    const f32x4* src = reinterpret_cast<const f32x4*>(D.Wimg) + (size_t)item.q * nW4;
+    for (int i = threadIdx.x; i < nW4; i += blockDim.x) ldsW4[i] = src[i];
+    __syncthreads();
+    const int ntl = (item.cnt + 15) >> 4;
+    for (int tl = wib; tl < ntl; tl += 4) {
+      const int cell0 = item.start + 16 * tl;
+      const int nvalid = min(16, item.start + item.cnt - cell0);
+      const bool av = c < nvalid;
+      f32x4 acc[NPT];
+      tile_dots<NPT>(ldsW4, D.R + (size_t)(cell0 + (av ? c : 0)) * K, av, g, lane, D.wNS, D.wNT4, D.wtail, acc);
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int cl = 4 * g + reg;
+        const bool cv = cl < nvalid;
+        const size_t row = (size_t)(cell0 + (cv ? cl : 0)) * zs;
+#pragma unroll
+        for (int pt = 0; pt < NPT; pt++) {
+          const int jj = 16 * pt + c;
+          const float zo = D.Zo[row + min(jj, zs - 1)];
+          if (cv && jj < d) D.Zc[row + jj] = zo - acc[pt][reg];
+        }
+      }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------
 // kmeans_centers (src/utils.cpp:10-64)
 //   k_seed_probe: for every anchor i (= cluster lane) sample a cell with P ~ |2(1 - y_i.x)| via the
@@ -1238,7 +1354,7 @@ void l_tile_static(const Launch& L, const Dev& D, int mode) {
   long long blocks = (((long long)D.ntitems + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
   if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
   size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4);
-  if (mode == 2) { lds += ((size_t)D.K * D.d + D.K) * sizeof(long long); if (blocks > 256) blocks = 256; }
+  if (mode == 2) { lds += ((size_t)D.K * D.d + D.K) * sizeof(long long); if (blocks > 512) blocks = 512; }
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
 #define HMX_TS(N) case N: if (mode == 1) hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
@@ -1345,6 +1461,30 @@ void l_moe_apply(const Launch& L, const Dev& D) {
   if (g < 1) g = 1;
   const dim3 grid(g);
   HMX_DISPATCH_KD(k_moe_apply, , grid, lds, D);
+}
+void l_moe_stats_mfma(const Launch& L, const Dev& D) {
+  const int npt = (D.d + 15) / 16;
+  int tpw = (D.ntitems + 2 * 256 - 1) / (2 * 256);   // ~2 workgroups per CU
+  if (tpw < 16) tpw = 16;
+  const dim3 grid((D.ntitems + tpw - 1) / tpw), block(64 * npt);
+#define HMX_MS(N) case N: hipLaunchKernelGGL(k_moe_stats_mfma<N>, grid, block, 0, L.stream, D, tpw); break;
+  switch (D.NCT) {
+    HMX_MS(1) HMX_MS(2) HMX_MS(3) HMX_MS(4) HMX_MS(5) HMX_MS(6) HMX_MS(7) HMX_MS(8)
+    default: break;
+  }
+#undef HMX_MS
+}
+void l_moe_apply_mfma(const Launch& L, const Dev& D) {
+  int g = D.naitems < 4 * L.grid ? D.naitems : 4 * L.grid;
+  if (g < 1) g = 1;
+  const dim3 grid(g);
+  const size_t lds = (size_t)D.wNQ * D.wNS * 64 * sizeof(f32x4);
+  switch ((D.d + 15) / 16) {
+    case 1: hipLaunchKernelGGL(k_moe_apply_mfma<1>, grid, dim3(256), lds, L.stream, D); break;
+    case 2: hipLaunchKernelGGL(k_moe_apply_mfma<2>, grid, dim3(256), lds, L.stream, D); break;
+    case 3: hipLaunchKernelGGL(k_moe_apply_mfma<3>, grid, dim3(256), lds, L.stream, D); break;
+    default: hipLaunchKernelGGL(k_moe_apply_mfma<4>, grid, dim3(256), lds, L.stream, D); break;
+  }
 }
 void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl) {
   const dim3 grid(stream_grid(L, D.nitems));
