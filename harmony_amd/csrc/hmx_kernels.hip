@@ -649,13 +649,16 @@ __device__ __forceinline__ float rowsum16(float v) {
 
 template <int NCT>
 __device__ __forceinline__ void tile_dots(const f32x4* __restrict__ ldsY4, const float* __restrict__ zrow, bool valid,
-                                          int g, int lane, int NS, int NT4, int tail, f32x4 (&acc)[NCT]) {
+                                          int g, int lane, int NS, int NT4, int tail, f32x4 (&acc)[NCT],
+                                          bool have_first = false, f32x4 zfirst = f32x4{0.f, 0.f, 0.f, 0.f}) {
   constexpr int NQ = (NCT + 3) / 4;
 #pragma unroll
   for (int ct = 0; ct < NCT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // zrow always points at a real row (row 0 for padding lanes): unconditional loads, masked afterwards
-  f32x4 zt = (NT4 > 0) ? *reinterpret_cast<const f32x4*>(zrow + 4 * g) : zero4;
+  f32x4 zt = zero4;
+  if (have_first) zt = zfirst;                  // fetched by the caller before its LDS-staging barrier
+  else if (NT4 > 0) zt = *reinterpret_cast<const f32x4*>(zrow + 4 * g);
   for (int t = 0; t < NT4; ++t) {
     const f32x4 zc = valid ? zt : zero4;
     if (t + 1 < NT4) zt = *reinterpret_cast<const f32x4*>(zrow + 16 * (t + 1) + 4 * g);
@@ -737,6 +740,24 @@ __global__ __launch_bounds__(256, HMX_TILE_LB(NCT)) void k_tile(Dev D, int j) {
   int p0 = 0, ntiles;
   if constexpr (MODE == 0) { p0 = D.boff[j]; ntiles = (D.boff[j + 1] - p0) >> 4; }  // padded: combination-pure tiles
   else ntiles = D.ntitems;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  // MODE 0 (short launches, grid capped at the resident capacity): tiles are dealt round-robin, tile = wave + i*nw, so
+  // every wave gets 1-2 tiles and no CU runs a second round of workgroups.  Static modes: contiguous ranges.
+  const int per = (ntiles + nw - 1) / nw;
+  const int ts = (MODE == 0) ? wave : wave * per;
+  const int te = (MODE == 0) ? ntiles : min(ntiles, ts + per);
+  const int tstep = (MODE == 0) ? nw : 1;
+  // MODE 0: the first tile's cell ids and the first 16 bytes of their embedding rows are requested BEFORE the
+  // LDS staging below, so the two dependent HBM round trips overlap with it
+  int cellN = -1;
+  f32x4 zpre = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (MODE == 0) {
+    if (ts < te) {
+      cellN = D.lorder[p0 + 16 * ts + c];
+      if (D.NT4 > 0) zpre = *reinterpret_cast<const f32x4*>(D.Zc + (size_t)(cellN >= 0 ? cellN : 0) * zs + 4 * g);
+    }
+  }
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
     for (int i = threadIdx.x; i < nY4; i += blockDim.x) lds4[i] = src[i];
@@ -751,10 +772,6 @@ __global__ __launch_bounds__(256, HMX_TILE_LB(NCT)) void k_tile(Dev D, int j) {
   }
   const float* penT = (MODE == 0 && D.pen_lds) ? ldsPen : D.pen;
   const int* qlevT = (MODE == 0 && D.pen_lds) ? ldsQlev : D.qlev;
-  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-  const int per = (ntiles + nw - 1) / nw;
-  const int ts = wave * per, te = min(ntiles, ts + per);
   long long* snew = D.Snew_fx + (size_t)(wave & (D.nrep - 1)) * D.B * K;  // this wave's table replica
   // per-lane cluster constants: exp(-dist/sigma) = exp2(dist * ce), ce = -log2(e)/sigma;
   // sigma r ln r = r log2(r) * cl, cl = sigma ln 2 -> one v_exp_f32 / v_log_f32 per value
@@ -770,14 +787,12 @@ __global__ __launch_bounds__(256, HMX_TILE_LB(NCT)) void k_tile(Dev D, int j) {
   }
   double od = 0.0, oe = 0.0;
   int curq = -1;
-  int cellN = -1;  // MODE 0: A-operand row of this lane (-1: padding), fetched one tile ahead
-  if constexpr (MODE == 0) { if (ts < te) cellN = D.lorder[p0 + 16 * ts + c]; }
-  for (int tile = ts; tile < te; ++tile) {
+  for (int tile = ts; tile < te; tile += tstep) {
     int cellA, q0;
     if constexpr (MODE == 0) {
       const int pbase = p0 + 16 * tile;
       cellA = cellN;
-      if (tile + 1 < te) cellN = D.lorder[pbase + 16 + c];
+      if (tile + tstep < te) cellN = D.lorder[pbase + 16 * tstep + c];
       q0 = D.lcombo[pbase];  // slot 0 of a tile is always a real cell
     } else {
       const Item it = D.titems[tile];  // static tile: <= 16 consecutive cells of one combination
@@ -785,7 +800,8 @@ __global__ __launch_bounds__(256, HMX_TILE_LB(NCT)) void k_tile(Dev D, int j) {
       q0 = it.q;
     }
     f32x4 acc[NCT];
-    tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc);
+    tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc,
+                   MODE == 0 && tile == ts && D.NT4 > 0, zpre);
     if constexpr (MODE == 2) {
       // nearest centre of every cell of the tile: argmin_k ||y_k||^2 - 2 x.y_k ; ties -> smallest k
 #pragma unroll
@@ -1422,6 +1438,7 @@ void l_update(const Launch& L, const Dev& D, int j) {
   const long long tiles = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + 15) / 16 + (long long)D.Q + 1;
   const int wpb = tile_threads(D.NCT) / 64;
   long long blocks = ((tiles + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
+  if (blocks > D.upd_maxblocks) blocks = D.upd_maxblocks;   // resident capacity (workgroups per CU x CUs)
   if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
