@@ -185,6 +185,7 @@ int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Yt[j*K+k] and the MFMA 
   std::vector<float> yt((size_t)d * K);
   for (int k = 0; k < K; k++) for (int j = 0; j < d; j++) yt[(size_t)j * K + k] = ctx->Y[(size_t)k * d + j];
   CHK(h2d(ctx, D.Yt, yt.data(), yt.size()));
+  CHK(h2d(ctx, D.Ycur, ctx->Y.data(), ctx->Y.size()));
   // image[qd][s][p][c][i] = Y[pc(s,p)][16*(4qd+i)+c]; pc(s,p) as the tile kernels assign PCs to MFMA k-slots
   std::vector<float> img((size_t)D.NQ * D.NS * 256, 0.f);
   for (int qd = 0; qd < D.NQ; qd++) for (int s = 0; s < D.NS; s++) for (int p = 0; p < 4; p++) {
@@ -295,23 +296,24 @@ int kmeans_centers(hmx_ctx* ctx) {
     gcells[i] = (long long)g;
   }
   CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
-  // 10 x one Lloyd iteration (:53-64)
-  std::vector<long long> sums((size_t)K * d); std::vector<unsigned long long> cnt(K); std::vector<float> yn(K);
-  for (int it = 0; it < 10; it++) {
+  // 10 x one Lloyd iteration (:53-64); the centre update runs on the device, no host round trip per iteration
+  {
+    std::vector<float> yn(K);
     for (int k = 0; k < K; k++) { float s = 0.f; for (int j = 0; j < d; j++) s += ctx->Y[(size_t)k * d + j] * ctx->Y[(size_t)k * d + j]; yn[k] = s; }
     CHK(upload_Y(ctx));
     CHK(h2d(ctx, D.ynorm, yn.data(), (size_t)K));
+  }
+  const bool tile_ok = D.tile_impl && (size_t)D.NQ * D.NS * 1024 + ((size_t)K * d + K) * 8 <= 160 * 1024;
+  for (int it = 0; it < 10; it++) {
     HIPCHK(hipMemsetAsync(D.lsum, 0, sizeof(long long) * K * d, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.lcnt, 0, sizeof(unsigned long long) * K, ctx->L.stream));
-    if (D.tile_impl && (size_t)D.NQ * D.NS * 1024 + ((size_t)K * d + K) * 8 <= 160 * 1024) { l_tile_static(ctx->L, D, 2); KCHK(); }
+    if (tile_ok) { l_tile_static(ctx->L, D, 2); KCHK(); }
     else { l_lloyd(ctx->L, D); KCHK(); }
     CHK(allreduce(ctx, D.lsum, (int64_t)K * d, 0));
     CHK(allreduce(ctx, D.lcnt, K, 0));
-    CHK(d2h(ctx, sums.data(), D.lsum, sums.size()));
-    CHK(d2h(ctx, cnt.data(), D.lcnt, (size_t)K));
-    for (int k = 0; k < K; k++) if (cnt[k] > 0)
-      for (int j = 0; j < d; j++) ctx->Y[(size_t)k * d + j] = (float)(((double)sums[(size_t)k * d + j] * (1.0 / 1073741824.0)) / (double)cnt[k]);
+    l_lloyd_finish(ctx->L, D); KCHK();
   }
+  CHK(d2h(ctx, ctx->Y.data(), D.Ycur, ctx->Y.size()));
   return 0;
 }
 
@@ -428,7 +430,7 @@ bool lu_solve(std::vector<double>& A, int n, std::vector<double>& Bm, int m) {
 
 struct SolveOut { int status = 0; bool skipped = false, subset = false; std::vector<float> W; int m = 0; };
 
-// O, E: K x B column-major floats; Sq [Q][d][K], nq [Q][K] doubles; Wq [Q][K][d] floats (output)
+// O, E: K x B column-major floats; Sq [Q][K][d], nq [Q][K] doubles; Wq [Q][K][d] floats (output)
 void solve_cluster(const hmx_ctx* ctx, int k, const std::vector<float>& O, const std::vector<float>& E,
                    const std::vector<double>& Sq, const std::vector<double>& nq, std::vector<float>& Wq,
                    std::vector<float>& Ynew, SolveOut& out) {
@@ -461,7 +463,8 @@ void solve_cluster(const hmx_ctx* ctx, int k, const std::vector<float>& O, const
     if (nr == 1) continue;  // none of this combination's levels is kept: its cells do not enter (:400,456-460)
     const double n = nq[(size_t)q * K + k];
     for (int a = 0; a < nr; a++) for (int b2 = 0; b2 < nr; b2++) cov[(size_t)rows[b2] * m + rows[a]] += n;
-    for (int j = 0; j < d; j++) { const double s = Sq[((size_t)q * d + j) * K + k]; for (int a = 0; a < nr; a++) rhs[(size_t)j * m + rows[a]] += s; }
+    const double* sq = &Sq[((size_t)q * K + k) * d];
+    for (int j = 0; j < d; j++) { const double s = sq[j]; for (int a = 0; a < nr; a++) rhs[(size_t)j * m + rows[a]] += s; }
   }
   for (int a = 1; a < m; a++) {  // :434-439, :533-544
     const float lam = ctx->lambda_estimation ? E[(size_t)keep[a - 1] * K + k] * ctx->alpha : ctx->lambda[keep[a - 1] + 1];
@@ -743,7 +746,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, (size_t)N * K));
   CHK(dalloc(ctx, &D.perm, (size_t)N)); CHK(dalloc(ctx, &D.invperm, (size_t)N)); CHK(dalloc(ctx, &D.combo, (size_t)N));
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
-  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
+  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
   CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));

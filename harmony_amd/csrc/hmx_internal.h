@@ -45,6 +45,7 @@ struct Dev {
   int* qlev;        // [Q][C] global level index of each covariate for combination q
   // small tables
   float* Yt;        // [d][K]   centroids, k fastest
+  float* Ycur;      // [K][d]   centroids in the reference's layout (device copy used by the on-device Lloyd update)
   float* sigma;     // [K]
   float* ce;        // [K] -log2(e)/sigma_k
   float* cl;        // [K] sigma_k * ln 2
@@ -80,7 +81,7 @@ struct Dev {
   Item* titems; int ntitems;      // <= 16 cells each: static MFMA tiles (head, Lloyd)
   int tile_impl;                  // 1: head / Lloyd run on the MFMA tile kernel, 0: cluster-lane VALU kernels
   // MoE
-  double* Sq;       // [Q][d][K]  sum_i R_ki z_ij over cells of combination q
+  double* Sq;       // [Q][K][d]  sum_i R_ki z_ij over cells of combination q
   double* nq;       // [Q][K]     sum_i R_ki
   float* Wq;        // [Q][K][d]  correction table
   float* Wimg;      // [Q][wNQ][wNS][4][16][4] the same table as MFMA B-operand image (clusters = reduction dim)
@@ -125,6 +126,7 @@ void l_moe_apply_mfma(const Launch& L, const Dev& D);
 void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl);
 void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint64_t goff, double* rows);
 void l_lloyd(const Launch& L, const Dev& D);
+void l_lloyd_finish(const Launch& L, const Dev& D);
 size_t lds_bytes_y(const Dev& D);
 
 }  // namespace hmx

@@ -980,8 +980,8 @@ __global__ __launch_bounds__(TPB) void k_moe_stats(Dev D) {
 #pragma unroll
     for (int j = 0; j < DP; j++) {
       if (j < dch) {
-        if (k0 < K) atomicAdd(&S[(size_t)(zoff + j) * K + k0], (double)a0[j]);
-        if (k1 < K) atomicAdd(&S[(size_t)(zoff + j) * K + k1], (double)a1[j]);
+        if (k0 < K) atomicAdd(&S[(size_t)k0 * d + zoff + j], (double)a0[j]);
+        if (k1 < K) atomicAdd(&S[(size_t)k1 * d + zoff + j], (double)a1[j]);
       }
     }
     if (blockIdx.z == 0) {
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg)
 #pragma unroll
       for (int reg = 0; reg < 4; reg++) {
         const int k = 16 * ct + 4 * g + reg;
-        if (jv && k < K && sh[ct][reg] != 0.0) atomicAdd(&S[(size_t)jj * K + k], sh[ct][reg]);
+        if (jv && k < K && sh[ct][reg] != 0.0) atomicAdd(&S[(size_t)k * d + jj], sh[ct][reg]);
         sh[ct][reg] = 0.0;
       }
       if (pt == 0) {                            // sum_i R_ki of cluster 16ct+c: add the four cell slots
@@ -1319,6 +1319,36 @@ __global__ __launch_bounds__(TPB) void k_lloyd(Dev D) {
   }
 }
 
+// index of centroid entry (PC j, cluster k) in the MFMA B-operand image (inverse of the host builder in upload_Y)
+__device__ __forceinline__ size_t yimg_index(const Dev& D, int j, int k) {
+  int s_, p_;
+  if (j < 16 * D.NT4) { const int t = j >> 4, r = j & 15; p_ = r >> 2; s_ = 4 * t + (r & 3); }
+  else { const int r = j - 16 * D.NT4; s_ = 4 * D.NT4 + (r >> 2); p_ = r & 3; }
+  const int qd = k >> 6, i = (k & 63) >> 4, c = k & 15;
+  return ((((size_t)qd * D.NS + s_) * 4 + p_) * 16 + c) * 4 + i;
+}
+// Lloyd centre update on the device (src/utils.cpp:56-61): mean of the members (2^30 fixed-point sums / counts), an
+// empty cluster keeps its centre; refreshes Ycur [K][d], Yt [d][K], the MFMA image and ||y||^2.  One workgroup per cluster.
+__global__ __launch_bounds__(64) void k_lloyd_finish(Dev D) {
+  const int k = blockIdx.x, lane = threadIdx.x, d = D.d, K = D.K;
+  const unsigned long long cnt = D.lcnt[k];
+  float s2 = 0.0f;
+  for (int j = lane; j < d; j += 64) {
+    float y = D.Ycur[(size_t)k * d + j];
+    if (cnt > 0) y = (float)(((double)D.lsum[(size_t)k * d + j] * (1.0 / 1073741824.0)) / (double)cnt);
+    D.Ycur[(size_t)k * d + j] = y;
+    D.Yt[(size_t)j * K + k] = y;
+    D.Yimg[yimg_index(D, j, k)] = y;
+    s2 += y * y;
+  }
+  // ||y_k||^2 as the host computes it: sequential fp32 sum over j (d <= 128: lane-serial is fine for K blocks)
+  __shared__ float ys[128];
+  for (int j = lane; j < d; j += 64) ys[j] = D.Ycur[(size_t)k * d + j];
+  __syncthreads();
+  if (lane == 0) { float s = 0.0f; for (int j = 0; j < d; j++) s += ys[j] * ys[j]; D.ynorm[k] = s; }
+  (void)s2;
+}
+
 // --------------------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------------------
@@ -1509,6 +1539,9 @@ void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, c
 }
 void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint64_t goff, double* rows) {
   hipLaunchKernelGGL(k_gather_rows, dim3(D.K), dim3(64), 0, L.stream, D, gcells, goff, rows);
+}
+void l_lloyd_finish(const Launch& L, const Dev& D) {
+  hipLaunchKernelGGL(k_lloyd_finish, dim3(D.K), dim3(64), 0, L.stream, D);
 }
 void l_lloyd(const Launch& L, const Dev& D) {
   int blocks = stream_grid(L, D.nitems);
