@@ -753,7 +753,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)D.npad)); CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
   CHK(dalloc(ctx, &D.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
-  CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks));
+  CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d)); CHK(dalloc(ctx, &D.Wimg, D.moe_mfma ? (size_t)Q * D.wNQ * D.wNS * 256 : 1));
   CHK(dalloc(ctx, &D.seedmin, (size_t)K)); CHK(dalloc(ctx, &D.lsum, (size_t)K * d)); CHK(dalloc(ctx, &D.lcnt, (size_t)K)); CHK(dalloc(ctx, &D.ynorm, (size_t)K));

@@ -10,7 +10,7 @@ constexpr int WAVE = 64;
 constexpr int TPB = 256;            // threads per workgroup (4 waves, one per SIMD)
 constexpr int ITEM_CELLS = 256;     // cells per wave work item in streaming passes
 constexpr int APPLY_CELLS = 1024;   // cells per workgroup work item in the apply pass
-constexpr int SORT_CHUNK = 2048;    // cells per wave in the per-round block counting sort
+constexpr int SORT_CHUNK = 512;     // cells per wave in the per-round block counting sort
 constexpr float FX_SCALE = 2147483648.0f;  // R in [0,1] -> 31-bit fixed point (exact int64 sums)
 constexpr double FX_INV = 1.0 / 2147483648.0;
 
@@ -70,7 +70,8 @@ struct Dev {
   int* lcombo;      // [npad] combination of position p (valid where lorder[p] >= 0)
   int npad;         // n + nb*Q*16 (upper bound of the padded length)
   int* boff;        // [nb+1] padded start of every block (multiples of 16)
-  int* counts;      // [nb][nchunks] scratch of the counting sort
+  int* counts;      // [nb][nchunks] histogram of the counting sort
+  int* offs;        // [nb][nchunks] destination offset of every (block, chunk)
   int* binoff;      // [nb*Q+1] padded start of every (block, combination) bin
   Item* schunks;    // [nchunks] static sort chunks: <= SORT_CHUNK cells of one combination
   int* qchunk;      // [Q+1] first sort chunk of every combination

@@ -322,21 +322,31 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D) {
   __syncthreads();
   for (int v = lane; v < nb; v += WAVE) D.counts[(size_t)v * D.nchunks + chunk] = cnt[v];
 }
-// single workgroup: bin sizes -> padded bin starts -> per-(block, chunk) destination offsets (in place in counts);
-// boff[v] = padded start of block v, boff[nb] = padded total.
-__global__ __launch_bounds__(1024) void k_sort_scan(Dev D) {
-  __shared__ int part[1024];
-  const int t = threadIdx.x, nb = D.nb, Q = D.Q, nbins = nb * Q, nch = D.nchunks;
-  int* bins = D.binoff;  // [nb*Q + 1]
-  // phase A: padded size of bin (v, q) = sum of its chunks' counts rounded up to 16
-  for (int bin = t; bin < nbins; bin += 1024) {
-    const int v = bin / Q, q = bin - v * Q;
-    int sum = 0;
-    for (int c = D.qchunk[q]; c < D.qchunk[q + 1]; c++) sum += D.counts[(size_t)v * nch + c];
-    bins[bin] = (sum + 15) & ~15;
+// one wave per (block, combination) bin: exclusive prefix of the bin's chunk counts -> offs (offset inside the bin),
+// padded bin size -> binoff[bin].  The chunks of a combination are contiguous, so the loads are coalesced.
+__global__ __launch_bounds__(WAVE) void k_sort_binscan(Dev D) {
+  const int lane = threadIdx.x, bin = blockIdx.x, Q = D.Q, nch = D.nchunks;
+  const int v = bin / Q, q = bin - v * Q;
+  const int lo = D.qchunk[q], hi = D.qchunk[q + 1];
+  const int* __restrict__ cin = D.counts + (size_t)v * nch;
+  int* __restrict__ cout = D.offs + (size_t)v * nch;
+  int run = 0;
+  for (int base = lo; base < hi; base += WAVE) {
+    const int i = base + lane;
+    const int c = ld_or(cin, (size_t)min(i, hi - 1), i < hi, 0);
+    int incl = c;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
+    if (i < hi) cout[i] = run + incl - c;
+    run += __shfl(incl, 63, 64);
   }
-  __syncthreads();
-  // phase B: exclusive scan of the padded bin sizes (block-major, combination-minor)
+  if (lane == 0) D.binoff[bin] = (run + 15) & ~15;
+}
+// single workgroup: exclusive scan of the padded bin sizes (block-major) -> binoff; boff[v] = padded start of block v
+__global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, nb = D.nb, Q = D.Q, nbins = nb * Q;
+  int* bins = D.binoff;
   const int per = (nbins + 1023) / 1024;
   const int s = t * per, e = min(nbins, s + per);
   int sum = 0;
@@ -353,24 +363,14 @@ __global__ __launch_bounds__(1024) void k_sort_scan(Dev D) {
   for (int i = s; i < e; i++) { const int c = bins[i]; bins[i] = run; run += c; }
   if (t == 1023) bins[nbins] = part[1023];
   __syncthreads();
-  // phase C: destination offset of every (block, chunk): bin start + cells of earlier chunks of the same bin
-  for (int bin = t; bin < nbins; bin += 1024) {
-    const int v = bin / Q, q = bin - v * Q;
-    int o = bins[bin];
-    for (int c = D.qchunk[q]; c < D.qchunk[q + 1]; c++) {
-      const int n = D.counts[(size_t)v * nch + c];
-      D.counts[(size_t)v * nch + c] = o;
-      o += n;
-    }
-  }
   for (int v = t; v <= nb; v += 1024) D.boff[v] = bins[v < nb ? v * Q : nbins];
 }
 __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   extern __shared__ int base_[];
   const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb;
-  for (int v = lane; v < nb; v += WAVE) base_[v] = D.counts[(size_t)v * D.nchunks + chunk];
-  __syncthreads();
   const Item ch = D.schunks[chunk];
+  for (int v = lane; v < nb; v += WAVE) base_[v] = D.binoff[v * D.Q + ch.q] + D.offs[(size_t)v * D.nchunks + chunk];
+  __syncthreads();
   const int s = ch.start, e = ch.start + ch.cnt;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int base = s; base < e; base += WAVE) {
@@ -1428,7 +1428,8 @@ void l_sort_blocks(const Launch& L, const Dev& D) {
   const size_t lds = (size_t)D.nb * sizeof(int);
   (void)hipMemsetAsync(D.lorder, 0xFF, sizeof(int) * (size_t)D.npad, L.stream);  // padding slots = -1
   hipLaunchKernelGGL(k_sort_hist, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
-  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, L.stream, D);
+  hipLaunchKernelGGL(k_sort_binscan, dim3(D.nb * D.Q), dim3(WAVE), 0, L.stream, D);
+  hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
 }
 void l_oldsum(const Launch& L, const Dev& D) {
