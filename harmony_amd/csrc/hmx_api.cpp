@@ -453,6 +453,47 @@ void solve_cluster(const hmx_ctx* ctx, int k, const std::vector<float>& O, const
   for (int q = 0; q < Q; q++) std::fill_n(&Wq[((size_t)q * K + k) * d], d, 0.f);
   if (!full && active == 0) { out.skipped = true; return; }  // :449-452
   const int m = (int)keep.size() + 1;
+  if (C == 1) {
+    // One covariate: Phi* diag(R_k) Phi*^T + Lambda is an arrowhead matrix; solve it in closed form in fp64
+    // (the reference inverts it in closed form too, src/harmony.cpp:575-586).  Combinations == levels here.
+    thread_local std::vector<double> w0, coef;
+    thread_local std::vector<int> qof;
+    w0.assign(d, 0.0); coef.assign(B, 0.0); qof.assign(B, -1);
+    for (int q = 0; q < Q; q++) qof[ctx->qlev[q]] = q;
+    double N = 0.0, u = 0.0;
+    bool ok = true;
+    for (int b : keep) {
+      const int q = qof[b];
+      const double n = (q >= 0) ? nq[(size_t)q * K + k] : 0.0;
+      const float lam = ctx->lambda_estimation ? E[(size_t)b * K + k] * ctx->alpha : ctx->lambda[b + 1];
+      const double den = n + (double)lam;
+      if (!(den > 0.0)) { ok = false; break; }
+      coef[b] = n / den;                       // n_b / (n_b + lambda_b)
+      N += n; u += n * coef[b];
+      if (q >= 0) { const double* sq = &Sq[((size_t)q * K + k) * d]; for (int j = 0; j < d; j++) w0[j] += (1.0 - coef[b]) * sq[j]; }
+    }
+    u = N - u;
+    if (ok && u > 0.0 && std::isfinite(u)) {
+      for (int j = 0; j < d; j++) { w0[j] /= u; Ynew[(size_t)k * d + j] = (float)w0[j]; }          // intercept row :610
+      out.m = m; out.W.assign((size_t)m * d, 0.f);
+      int a = 1;
+      for (int b : keep) {
+        const int q = qof[b];
+        const double n = (q >= 0) ? nq[(size_t)q * K + k] : 0.0;
+        const float lam = ctx->lambda_estimation ? E[(size_t)b * K + k] * ctx->alpha : ctx->lambda[b + 1];
+        const double inv = 1.0 / (n + (double)lam);
+        float* wq = (q >= 0) ? &Wq[((size_t)q * K + k) * d] : nullptr;
+        for (int j = 0; j < d; j++) {
+          const double s = (q >= 0) ? Sq[((size_t)q * K + k) * d + j] : 0.0;
+          const float w = (float)((s - n * w0[j]) * inv);
+          out.W[(size_t)j * m + a] = w;
+          if (wq) wq[j] = w;
+        }
+        a++;
+      }
+      return;
+    }
+  }
   std::vector<int> row_of(B, -1);
   for (int a = 0; a < (int)keep.size(); a++) row_of[keep[a]] = a + 1;
   std::vector<double> cov((size_t)m * m, 0.0), rhs((size_t)m * d, 0.0);
@@ -929,6 +970,21 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   HIPCHK(hipStreamSynchronize(ctx->L.stream));
   ctx->timers["moe_correct_ridge"] += now_ms() - t0;
   return 0;
+}
+
+// host-only micro-benchmark of the ridge solves (no device needed): returns microseconds per call of the full K-cluster loop
+double hmx_debug_solve_bench(int K, int B, int d, int reps) {
+  hmx_ctx c; c.K = K; c.B = B; c.C = 1; c.d = d; c.Q = B; c.B_vec = {B}; c.cov_bounds = {B};
+  c.sizes.assign(B, 1000.f); c.lambda_estimation = true; c.alpha = 0.2f; c.cutoff = 1e-5f;
+  c.qlev.resize(B); for (int b = 0; b < B; b++) c.qlev[b] = b;
+  std::vector<float> O((size_t)K * B, 50.f), E((size_t)K * B, 40.f);
+  std::vector<double> Sq((size_t)B * K * d, 0.3), nq((size_t)B * K, 50.0);
+  for (size_t i = 0; i < Sq.size(); i++) Sq[i] = 0.1 + 1e-3 * (double)(i % 97);
+  std::vector<float> Wq((size_t)B * K * d), Ynew((size_t)K * d);
+  std::vector<SolveOut> outs(K);
+  const double t0 = now_ms();
+  for (int r = 0; r < reps; r++) for (int k = 0; k < K; k++) solve_cluster(&c, k, O, E, Sq, nq, Wq, Ynew, outs[k]);
+  return 1e3 * (now_ms() - t0) / reps;
 }
 
 int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
