@@ -100,16 +100,31 @@ def main():
     N_b = None
     comm_kind = "none"
     if world > 1:
-        if os.environ.get("HMX_BENCH_COMM", "torch") == "rccl":   # experimental: the library's own communicator
+        warm = torch.ones(1, device=dev)
+        dist.all_reduce(warm)                         # torch loads + initialises its RCCL; the library binds to the same one
+        torch.cuda.synchronize()
+        ok = 0
+        if os.environ.get("HMX_BENCH_COMM", "rccl") == "rccl":
+            # built-in communicator: ncclAllReduce issued by the C library on its own stream -- no Python per collective
             uid = [Harmony.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            obj.comm_init(rank, world, uid[0])
-            obj.set_shard(rank, world, rank * n, N, None)
-            comm_kind = "built-in RCCL communicator"
+            dist.broadcast_object_list(uid, src=0, device=dev)
+            try:
+                obj.comm_init(rank, world, uid[0])
+                obj.set_shard(rank, world, rank * n, N, None)
+                ok = 1
+            except Exception as e:                    # pragma: no cover
+                print("rank %d: built-in RCCL communicator failed (%s); using the torch.distributed hook" % (rank, e), file=sys.stderr)
+            flag = torch.tensor([ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            comm_kind = "RCCL over xGMI, ncclAllReduce from the C library (communicator bootstrapped through torch.distributed)"
         else:
             from harmony_amd.dist import TorchAllReduce
+            obj = Harmony(device=local_rank, seed=1)
+            obj.set_stream(torch.cuda.current_stream().cuda_stream)
             obj.set_shard(rank, world, rank * n, N, TorchAllReduce(device=dev))
-            comm_kind = "torch.distributed nccl (RCCL over xGMI)"
+            comm_kind = "torch.distributed nccl all_reduce hook (RCCL over xGMI)"
         cnt = torch.from_numpy(np.bincount(meta["cov0"], minlength=B).astype(np.int64)).to(dev)
         dist.all_reduce(cnt)
         N_b = cnt.cpu().numpy().astype(float)

@@ -57,8 +57,13 @@ RcclApi* rccl_api(std::string* err) {
   if (api.h) return &api;
   if (tried) { if (err) *err = "librccl could not be loaded"; return nullptr; }
   tried = true;
-  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
-  for (const char* n : names) { api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.h) break; }
+  // 1) an RCCL that is ALREADY loaded in the process (PyTorch's bundled librccl.so when the host imported torch first:
+  //    it is the build that matches the HIP runtime this library then shares with torch); 2) the system library.
+  api.h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!api.h) {
+    const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+    for (const char* n : names) { api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.h) break; }
+  }
   if (!api.h) { if (err) *err = std::string("dlopen(librccl): ") + dlerror(); return nullptr; }
   api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
@@ -320,7 +325,8 @@ int kmeans_centers(hmx_ctx* ctx) {
 // ---- update_R (src/harmony.cpp:269-342) ---------------------------------------------------------
 int update_R(hmx_ctx* ctx) {
   Dev& D = ctx->D;
-  const bool merged = ctx->world <= 1 && !ctx->comm_force && (size_t)D.B * 128 <= 64 * 1024;
+  const bool sharded = ctx->world > 1 || ctx->comm_force;
+  const bool merged = (size_t)D.B * 128 <= 64 * 1024;   // LDS budget of k_foldpen
   const double t0 = now_ms();
   if (!ctx->injected.empty()) {  // host-provided shuffle: block(g) from its position
     std::vector<int64_t> order = std::move(ctx->injected.front());
@@ -344,19 +350,19 @@ int update_R(hmx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
   for (int j = 0; j <= D.nb; j++) {
     // fold the previous block's new contribution into O, remove block j's old one (src/harmony.cpp:312-313,329-330)
-    if (ctx->world > 1 || ctx->comm_force) {
+    if (sharded) {  // shard-local replicas -> one table, summed over the ranks (the only collective of a block step)
       l_fold(ctx->L, D, j, 1); KCHK();
       CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.B * D.K, 0));
-      l_fold(ctx->L, D, j < D.nb ? j : -1, 2); KCHK();
-    } else if (merged) {
+    }
+    if (merged) {
       // one launch: O' = O + new(prev) - old(j) and the penalty table; ping-pong so nothing is read while written
       l_foldpen(ctx->L, D, j < D.nb ? j : -1, D.O_fx, D.O_alt, D.Snew_fx, D.Snew_alt); KCHK();
       std::swap(D.O_fx, D.O_alt); std::swap(D.Snew_fx, D.Snew_alt);
     } else {
-      l_fold(ctx->L, D, j < D.nb ? j : -1, 0); KCHK();
+      l_fold(ctx->L, D, j < D.nb ? j : -1, sharded ? 2 : 0); KCHK();
+      if (j < D.nb) { l_penalty(ctx->L, D); KCHK(); }
     }
     if (j == D.nb) break;
-    if (!merged) { l_penalty(ctx->L, D); KCHK(); }
     if (ctx->profile) {
       if (ctx->ev_used == ctx->ev_pool.size()) {
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
@@ -771,7 +777,8 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   D.pen_lds = ((size_t)D.NQ * 0 + (size_t)B * K * 4 + (size_t)Q * C * 4 <= 24576) ? 1 : 0;
   D.NQ = (D.NCT + 3) / 4; D.NT4 = D.zs / 16; D.tail = (D.zs - 16 * D.NT4) / 4; D.NS = 4 * D.NT4 + D.tail;
   { const char* e = getenv("HMX_UPDATE_IMPL"); D.upd_impl = ctx->tun_impl >= 0 ? ctx->tun_impl : ((e && std::string(e) == "v1") ? 1 : 0); }
-  { const char* e = getenv("HMX_UPD_MAXBLOCKS"); D.upd_maxblocks = e ? atoi(e) : 512; if (D.upd_maxblocks < 1) D.upd_maxblocks = 1; }
+  { const char* e = getenv("HMX_UPD_THREADS"); D.upd_threads = (e && atoi(e) == 256) ? 256 : 512; }
+  { const char* e = getenv("HMX_UPD_MAXBLOCKS"); D.upd_maxblocks = e ? atoi(e) : (D.upd_threads == 512 ? 256 : 512); if (D.upd_maxblocks < 1) D.upd_maxblocks = 1; }
   { const char* e = getenv("HMX_UPD_TPW"); D.upd_tpw = ctx->tun_tpw > 0 ? ctx->tun_tpw : (e ? atoi(e) : 1); if (D.upd_tpw < 1) D.upd_tpw = 1; }
   { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = ctx->tun_cpw > 0 ? ctx->tun_cpw : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
   std::vector<Item> schunks; std::vector<int> qchunk((size_t)Q + 1, 0);

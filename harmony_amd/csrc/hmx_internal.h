@@ -32,6 +32,7 @@ struct Dev {
   float* Yimg;      // [NQ][NS][4][16][4] LDS image of the centroids in MFMA B-operand order
   int upd_impl;     // 0: MFMA tile kernel, 1: cluster-lane VALU kernel (v1)
   int upd_tpw;      // tiles per wave target of the MFMA update kernel
+  int upd_threads;   // workgroup size of the update kernel (256 or 512)
   int upd_maxblocks; // grid cap of the update kernel = workgroups resident at once (HMX_UPD_MAXBLOCKS)
   int ablate;       // timing-only ablation mask of k_update_mfma (tools/ablate.py); 0 in production
   int nb;           // blocks per clustering round

@@ -728,7 +728,7 @@ constexpr int tile_threads(int nct) { return 256; }  // measured: 768-thread wor
 // Register budget: <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (12 per CU) are resident.
 // MODE 2: one Lloyd iteration of kmeans_centers (nearest centre, fixed-point sums in LDS)  src/utils.cpp:56-61
 template <int NCT, int MODE>
-__global__ __launch_bounds__(256, HMX_TILE_LB(NCT)) void k_tile(Dev D, int j) {
+__global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits):
   //   [ centroid image: NQ*NS*64 float4 | MODE 0: pen[B][K] + qlev[Q][C] (if they fit) | MODE 2: int64 sums[K][d] + counts[K] ]
   extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
@@ -1467,7 +1467,7 @@ void l_update(const Launch& L, const Dev& D, int j) {
     return;
   }
   const long long tiles = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + 15) / 16 + (long long)D.Q + 1;
-  const int wpb = tile_threads(D.NCT) / 64;
+  const int wpb = D.upd_threads / 64;
   long long blocks = ((tiles + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
   if (blocks > D.upd_maxblocks) blocks = D.upd_maxblocks;   // resident capacity (workgroups per CU x CUs)
   if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
@@ -1475,7 +1475,7 @@ void l_update(const Launch& L, const Dev& D, int j) {
   const dim3 grid((unsigned)blocks);
   const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) +
                      (D.pen_lds ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
-#define HMX_UPD(N) case N: hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(tile_threads(N)), lds, L.stream, D, j); break;
+#define HMX_UPD(N) case N: hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(D.upd_threads), lds, L.stream, D, j); break;
   switch (D.NCT) {
     HMX_UPD(1) HMX_UPD(2) HMX_UPD(3) HMX_UPD(4) HMX_UPD(5) HMX_UPD(6) HMX_UPD(7) HMX_UPD(8)
     HMX_UPD(10) HMX_UPD(12) HMX_UPD(14) HMX_UPD(16)
