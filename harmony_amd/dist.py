@@ -33,6 +33,7 @@ class TorchAllReduce(object):
         self.device = device  # None => host buffers (gloo); else a torch.device("cuda", i)
         self.calls = 0
         self.bytes = 0
+        self._streams = {}
 
     def wrap(self, buf, count, dtype):
         if self.device is None:
@@ -45,7 +46,16 @@ class TorchAllReduce(object):
         try:
             t = self.wrap(buf, count, dtype)
             op = self.dist.ReduceOp.MIN if dtype == 2 else self.dist.ReduceOp.SUM
-            self.dist.all_reduce(t, op=op, group=self.group)
+            if self.device is not None and stream:
+                # order the collective on the LIBRARY's stream: RCCL waits for the kernels queued there and the
+                # library's next kernels wait for the collective -- no host synchronisation
+                ext = self._streams.get(stream)
+                if ext is None:
+                    ext = self._streams[stream] = self.torch.cuda.ExternalStream(int(stream), device=self.device)
+                with self.torch.cuda.stream(ext):
+                    self.dist.all_reduce(t, op=op, group=self.group)
+            else:
+                self.dist.all_reduce(t, op=op, group=self.group)
             self.calls += 1
             self.bytes += int(count) * 8
             return 0
