@@ -117,6 +117,8 @@ struct hmx_ctx {
   std::vector<void*> allocs;
   // profiling of the dominant kernel
   bool profile = false;
+  int round_blocks = 0;        // > 0: the persistent round kernel is usable with this cooperative grid
+  int64_t round_launches = 0, round_fallbacks = 0;
   int tun_impl = -1, tun_tpw = -1, tun_cpw = -1;  // tunables set through hmx_set_int before setup
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
   double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0;
@@ -348,7 +350,30 @@ int update_R(hmx_ctx* ctx) {
   l_oldsum(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
-  for (int j = 0; j <= D.nb; j++) {
+  bool round_done = false;
+  if (!sharded && ctx->round_blocks > 0) {
+    // single GPU: ONE persistent cooperative launch runs the whole chain of block steps (k_round)
+    HIPCHK(hipMemsetAsync(D.Snew_all, 0, sizeof(long long) * (size_t)D.nb * D.nrep * D.B * D.K, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.bar_counter, 0, sizeof(unsigned) * 2, ctx->L.stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->profile) {
+      if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t x, y; HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y)); ctx->ev_pool.emplace_back(x, y); }
+      e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second;
+      HIPCHK(hipEventRecord(e0, ctx->L.stream));
+    }
+    const int st = l_round(ctx->L, D, ctx->round_blocks);
+    if (st == 0) {
+      if (ctx->profile) { HIPCHK(hipEventRecord(e1, ctx->L.stream)); ctx->ev_used++; }
+      unsigned flags[2] = {0, 0};
+      CHK(d2h(ctx, flags, D.bar_counter, 2));   // [0] arrivals, [1] timeout flag (bar_error = bar_counter + 1)
+      if (flags[1] == 0) { round_done = true; ctx->round_launches++; }
+      else return fail(ctx, HMX_ERR_DEVICE, "persistent round kernel: grid barrier timed out");
+    } else {
+      (void)hipGetLastError();
+      ctx->round_blocks = 0; ctx->round_fallbacks++;   // cooperative launch refused: use the step path from now on
+    }
+  }
+  for (int j = 0; j <= D.nb && !round_done; j++) {
     // fold the previous block's new contribution into O, remove block j's old one (src/harmony.cpp:312-313,329-330)
     if (sharded) {  // shard-local replicas -> one table, summed over the ranks (the only collective of a block step)
       l_fold(ctx->L, D, j, 1); KCHK();
@@ -766,7 +791,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   D.n = (int)N; D.d = d; D.K = K; D.B = B; D.C = C; D.Q = Q; D.B0 = ctx->B_vec[0];
   D.KP = (K + 63) / 64 * 64; D.nb = ctx->nb;
   D.zs = (d + 3) / 4 * 4;
-  { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 8; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
+  { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 8; if (want > 8) want = 8; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
   { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
     const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
   D.lloyd_lds = ((size_t)d * D.KP * 4 + ((size_t)K * d + K) * 8 <= 98304) ? 1 : 0;
@@ -796,6 +821,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
   CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
+  CHK(dalloc(ctx, &D.Snew_all, (size_t)D.nb * D.nrep * B * K)); CHK(dalloc(ctx, &D.bar_counter, (size_t)4)); D.bar_error = D.bar_counter + 1;
   CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
   CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)D.npad)); CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
@@ -838,6 +864,11 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   }
   ctx->W.assign((size_t)(B + 1) * d, 0.f); ctx->W_rows = B + 1;  // allocate_buffers :127
   ctx->Y.assign((size_t)d * K, 0.f);
+  { const char* e = getenv("HMX_ROUND_IMPL");
+    // default: one launch per block step.  "round": the persistent cooperative kernel k_round (measured: 5% faster at
+    // 100k cells, equal at 1M, 5% slower at 4M -- its grid barrier + redundant table rebuild cost ~20 us per step)
+    const bool want = (e && std::string(e) == "round") && (size_t)D.nb * D.nrep * B * K * 8 <= (size_t)256 << 20;
+    ctx->round_blocks = want ? round_max_blocks(D) : 0; }
   ctx->ran_setup = true;
   return hmx_restart(ctx);
 }
@@ -1016,6 +1047,9 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "n_combos") return scalar(ctx->Q);
   if (f == "subset_clusters") return scalar((double)ctx->subset_clusters);
   if (f == "skipped_clusters") return scalar((double)ctx->skipped_clusters);
+  if (f == "round:launches") return scalar((double)ctx->round_launches);
+  if (f == "round:fallbacks") return scalar((double)ctx->round_fallbacks);
+  if (f == "round:blocks") return scalar((double)ctx->round_blocks);
   if (f == "comm:calls") return scalar((double)ctx->comm_calls);
   if (f == "comm:bytes") return scalar((double)ctx->comm_bytes);
   if (f == "prof:update_ms") return scalar(ctx->prof_update_ms);

@@ -55,6 +55,8 @@ struct Dev {
   long long* O_fx;    // [B][K] fixed-point O (exact sum of quantised R)
   long long* Snew_fx; // [nrep][B][K] contribution of the block being updated
   long long* Sold_fx; // [nb][B][K] old contribution of every block of this round
+  long long* Snew_all; // [nb][nrep][B][K] per-step replica slabs of the persistent round kernel (k_round)
+  unsigned* bar_counter; unsigned* bar_error;  // grid barrier state of k_round (zeroed before every launch)
   long long* O_alt;   // ping-pong partners of O_fx / Snew_fx for the single-launch fold+penalty (host swaps)
   long long* Snew_alt;
   float* pen;         // [B][K] ((2E+1)/(O+E+1))^theta
@@ -120,6 +122,8 @@ void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long 
                long long* Szero);
 void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
+int l_round(const Launch& L, const Dev& D, int blocks);
+int round_max_blocks(const Dev& D);
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
 void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);

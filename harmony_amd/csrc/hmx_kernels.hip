@@ -744,6 +744,8 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
   // MODE 0 (short launches, grid capped at the resident capacity): tiles are dealt round-robin, tile = wave + i*nw, so
   // every wave gets 1-2 tiles and no CU runs a second round of workgroups.  Static modes: contiguous ranges.
+  // (dealing tiles workgroup-major instead -- equal tiles per CU -- measured 25% SLOWER: the 8 consecutive tiles of a
+  //  workgroup share lorder/lcombo cache lines and the lighter half of the CUs finishing early helps the tail)
   const int per = (ntiles + nw - 1) / nw;
   const int ts = (MODE == 0) ? wave : wave * per;
   const int te = (MODE == 0) ? ntiles : min(ntiles, ts + per);
@@ -897,6 +899,191 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
       else { slot[0] += od; slot[1] += oe; }
     }
   }
+}
+
+// --------------------------------------------------------------------------------------
+// k_round: ONE persistent (cooperative) launch for all nb block steps of a clustering round (single-GPU path).
+//
+// The 20 block steps of update_R are a strict chain (block j's penalty needs the O left by block j-1).  As separate
+// launches every step pays a kernel ramp, a re-staging of the centroid image and a fold+penalty launch; here the
+// workgroups (one per CU, all resident) keep the image, O and the penalty table in LDS for the whole round and
+// meet at ONE grid barrier per step:
+//   step j:  every workgroup recomputes  O_j = O_{j-1} + new(j-1) - old(j)  and pen_j in its own LDS (redundant, ~1000
+//            entries) from the per-step replica slab Snew_all[j-1] -> no table has to be published between workgroups
+//            -> tiles of block j (same MFMA body as k_tile<.,0>), contributions into the slab Snew_all[j] by atomics
+//            -> grid barrier.
+// Cross-workgroup data = the slabs only: written by agent-scope atomics, read after the barrier by agent-scope atomic
+// loads, each slab used in exactly one step and zeroed by a memset before the launch (MI355X_MICROARCH: "8-byte
+// agent atomics on both sides" is a valid hand-off form; every wave drains vmcnt before the workgroup arrives).
+// Spins are bounded: on timeout a flag is raised, every workgroup leaves, and the host falls back to the step path.
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target, unsigned* errflag, int* ldsflag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave: its atomics / stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {  // ldsflag lives in the dynamic LDS object (a static __shared__ would shift its 16-byte base)
+    // NO release fence: the only cross-workgroup payload are agent-scope atomics (already acknowledged, see the
+    // vmcnt(0) above); a buffer_wbl2 here would force the write-back of the ~80 KB of R rows this workgroup just
+    // stored -- data nobody reads before the kernel ends.
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > 2000000u || __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *ldsflag = ok;
+  }
+  __syncthreads();
+  return *ldsflag != 0;
+}
+
+template <int NCT>
+__global__ __launch_bounds__(512) void k_round(Dev D) {
+  // LDS: [ centroid image | O_cur int64 [B][K] | pen float [B][K] | qlev int [Q][C] ]   (one object, see k_tile)
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
+  const int K = D.K, C = D.C, zs = D.zs, B = D.B, nBK = D.B * D.K;
+  const int nY4 = D.NQ * D.NS * 64;
+  long long* ldsO = reinterpret_cast<long long*>(lds4 + nY4);
+  float* ldsPen = reinterpret_cast<float*>(ldsO + nBK);
+  int* ldsQlev = reinterpret_cast<int*>(ldsPen + ((nBK + 3) & ~3));
+  int* ldsFlag = ldsQlev + D.Q * C;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
+    for (int i = threadIdx.x; i < nY4; i += blockDim.x) lds4[i] = src[i];
+    for (int i = threadIdx.x; i < nBK; i += blockDim.x) ldsO[i] = D.O_fx[i];
+    for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
+  }
+  float ce[NCT], cl[NCT], penv[NCT];
+  unsigned long long oacc[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) {
+    const bool kv = 16 * ct + c < K;
+    const size_t ks = (size_t)min(16 * ct + c, K - 1);
+    ce[ct] = ld_or(D.ce, ks, kv, 0.0f); cl[ct] = ld_or(D.cl, ks, kv, 0.0f);
+    penv[ct] = 1.0f; oacc[ct] = 0ull;
+  }
+  double od = 0.0, oe = 0.0;
+  const size_t slab = (size_t)D.nrep * nBK;
+  // first tile of the NEXT step (cell ids + first 16 bytes of their rows): requested before the grid barrier, these
+  // loads depend on nothing another workgroup produces
+  int cellPre = -1;
+  f32x4 zpre = {0.f, 0.f, 0.f, 0.f};
+  {
+    const int p0 = D.boff[0], nt0 = (D.boff[1] - p0) >> 4;
+    if (wave < nt0) {
+      cellPre = D.lorder[p0 + 16 * wave + c];
+      if (D.NT4 > 0) zpre = *reinterpret_cast<const f32x4*>(D.Zc + (size_t)(cellPre >= 0 ? cellPre : 0) * zs + 4 * g);
+    }
+  }
+  for (int j = 0; j <= D.nb; j++) {
+    // ---- O_j and penalty table in LDS (every workgroup computes the same values)
+    __syncthreads();
+    const long long* prev = (j > 0) ? D.Snew_all + (size_t)(j - 1) * slab : nullptr;
+    const long long* sold = (j < D.nb) ? D.Sold_fx + (size_t)j * nBK : nullptr;
+    for (int i = threadIdx.x; i < nBK; i += blockDim.x) {
+      long long o = ldsO[i];
+      if (prev) {
+        long long v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++)   // agent-scope (sc1) loads, issued back to back: "8-byte agent atomics on both sides"
+          v[r] = __hip_atomic_load(&prev[(size_t)min(r, D.nrep - 1) * nBK + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < 8; r++) if (r < D.nrep) o += v[r];
+      }
+      if (sold) o -= sold[i];
+      ldsO[i] = o;
+    }
+    __syncthreads();
+    if (j == D.nb) break;
+    for (int i = threadIdx.x; i < nBK; i += blockDim.x) {
+      const int b = i / K, k = i - b * K;
+      long long rs = 0;
+      for (int b0 = 0; b0 < D.B0; b0++) rs += ldsO[b0 * K + k];
+      const float of = (float)((double)ldsO[i] * FX_INV);
+      const float ef = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
+      ldsPen[i] = powf(((2.0f * ef) + 1.0f) / (of + ef + 1.0f), D.theta[b]);
+    }
+    __syncthreads();
+    // ---- tiles of block j, dealt round-robin over all waves of the grid
+    const int p0 = D.boff[j];
+    const int ntiles = (D.boff[j + 1] - p0) >> 4;
+    long long* snew = D.Snew_all + (size_t)j * slab + (size_t)(wave & (D.nrep - 1)) * nBK;
+    int curq = -1;
+    const int t0 = wave;
+    int cellN = cellPre;
+    for (int tile = t0; tile < ntiles; tile += nw) {
+      const int pbase = p0 + 16 * tile;
+      const int cellA = cellN;
+      if (tile + nw < ntiles) cellN = D.lorder[pbase + 16 * nw + c];
+      const int q0 = D.lcombo[pbase];
+      f32x4 acc[NCT];
+      tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc,
+                     tile == t0 && D.NT4 > 0, zpre);
+      if (q0 != curq) {
+        if (curq >= 0) flush_tile_fx<NCT>(snew, ldsQlev, curq, C, K, c, g, oacc);
+        curq = q0;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
+        for (int cc = 0; cc < C; cc++) {
+          const int b = ldsQlev[q0 * C + cc];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(ldsPen, (size_t)b * K + min(16 * ct + c, K - 1), 16 * ct + c < K, 0.0f);
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int cell = __shfl(cellA, 4 * g + reg, 64);
+        const bool cv = cell >= 0;
+        float* Rrow = D.R + (size_t)(cv ? cell : 0) * K;
+        float r[NCT];
+        float s1 = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) {
+          r[ct] = (16 * ct + c < K) ? __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]) : 0.0f;
+          s1 += r[ct];
+        }
+        s1 = rowsum16(s1);
+        const float i1 = (s1 == 0.0f) ? 1.0f : 1.0f / s1;
+        float s2 = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) { r[ct] = (r[ct] * i1) * penv[ct]; s2 += fabsf(r[ct]); }
+        s2 = rowsum16(s2);
+        const float i2 = (s2 == 0.0f) ? 1.0f : 1.0f / s2;
+        float pd = 0.0f, pe = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) {
+          const float rn = r[ct] * i2;
+          if (cv && 16 * ct + c < K) Rrow[16 * ct + c] = rn;
+          const float rv = cv ? rn : 0.0f;
+          oacc[ct] += fx_of(rv);
+          pd = fmaf(rv, fmaf(acc[ct][reg], -2.0f, 2.0f), pd);
+          pe = fmaf(rv * __builtin_amdgcn_logf(fmaxf(rv, FLT_MIN)), cl[ct], pe);
+        }
+        od += (double)pd; oe += (double)pe;
+      }
+    }
+    if (curq >= 0) flush_tile_fx<NCT>(snew, ldsQlev, curq, C, K, c, g, oacc);
+    cellPre = -1;
+    if (j + 1 < D.nb) {
+      const int pn = D.boff[j + 1], ntn = (D.boff[j + 2] - pn) >> 4;
+      if (wave < ntn) {
+        cellPre = D.lorder[pn + 16 * wave + c];
+        if (D.NT4 > 0) zpre = *reinterpret_cast<const f32x4*>(D.Zc + (size_t)(cellPre >= 0 ? cellPre : 0) * zs + 4 * g);
+      }
+    }
+    if (!grid_barrier(D.bar_counter, (unsigned)gridDim.x * (unsigned)(j + 1), D.bar_error, ldsFlag)) return;
+  }
+  // ldsO now holds the O left by the last block: publish it (next kernels read it after the kernel boundary)
+  if (blockIdx.x == 0) for (int i = threadIdx.x; i < nBK; i += blockDim.x) D.O_fx[i] = ldsO[i];
+  od = wsumd(od); oe = wsumd(oe);
+  if (lane == 0) { D.objpart[2 * wave] += od; D.objpart[2 * wave + 1] += oe; }
 }
 
 // cross-entropy term of the objective from the K x B tables alone (src/harmony.cpp:162):
@@ -1482,6 +1669,41 @@ void l_update(const Launch& L, const Dev& D, int j) {
     default: break;
   }
 #undef HMX_UPD
+}
+// returns hipSuccess, or the launch error (the caller then falls back to the step-by-step path)
+int l_round(const Launch& L, const Dev& D, int blocks) {
+  const size_t nBK = (size_t)D.B * D.K;
+  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + nBK * 8 + ((nBK + 3) & ~(size_t)3) * 4 + (size_t)D.Q * D.C * 4 + 16;
+  Dev Dc = D;
+  void* args[] = {&Dc};
+  const void* fn = nullptr;
+#define HMX_RD(N) case N: fn = (const void*)k_round<N>; break;
+  switch (D.NCT) {
+    HMX_RD(1) HMX_RD(2) HMX_RD(3) HMX_RD(4) HMX_RD(5) HMX_RD(6) HMX_RD(7) HMX_RD(8)
+    HMX_RD(10) HMX_RD(12) HMX_RD(14) HMX_RD(16)
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef HMX_RD
+  return (int)hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(512), args, (unsigned)lds, L.stream);
+}
+// largest cooperative grid (workgroups) for k_round, 0 if it cannot run (LDS budget, occupancy)
+int round_max_blocks(const Dev& D) {
+  const size_t nBK = (size_t)D.B * D.K;
+  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + nBK * 8 + ((nBK + 3) & ~(size_t)3) * 4 + (size_t)D.Q * D.C * 4 + 16;
+  if (lds > 150 * 1024) return 0;
+  const void* fn = nullptr;
+#define HMX_RD(N) case N: fn = (const void*)k_round<N>; break;
+  switch (D.NCT) {
+    HMX_RD(1) HMX_RD(2) HMX_RD(3) HMX_RD(4) HMX_RD(5) HMX_RD(6) HMX_RD(7) HMX_RD(8)
+    HMX_RD(10) HMX_RD(12) HMX_RD(14) HMX_RD(16)
+    default: return 0;
+  }
+#undef HMX_RD
+  int per_cu = 0, dev = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, lds) != hipSuccess || per_cu < 1) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return prop.multiProcessorCount;  // one workgroup per CU (even if more would fit): all resident by construction
 }
 void l_objective_tables(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);
