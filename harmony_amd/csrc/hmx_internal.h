@@ -34,7 +34,6 @@ struct Dev {
   int upd_tpw;      // tiles per wave target of the MFMA update kernel
   int upd_threads;   // workgroup size of the update kernel (256 or 512)
   int upd_maxblocks; // grid cap of the update kernel = workgroups resident at once (HMX_UPD_MAXBLOCKS)
-  int ablate;       // timing-only ablation mask of k_update_mfma (tools/ablate.py); 0 in production
   int nb;           // blocks per clustering round
   // cell data, internal (combo-sorted) order, cell-major rows
   float* Zo;        // [n][d]  Z_orig
