@@ -328,3 +328,16 @@ def test_persistent_round_kernel_parity(cell_lines, monkeypatch):
     monkeypatch.setenv("HMX_ROUND_IMPL", "round")
     g, c, ig, ic = run_both(cell_lines["pcs"], _meta(cell_lines), ["cell_type", "dataset"], max_iter=3, theta=[1, 1], nclust=50)
     assert_parity(g, c, ig, ic)
+
+
+@pytest.mark.parametrize("N,d,K,levels,nested", [
+    (20000, 50, 200, (8, 64, 128), True),   # BASELINE configs[4] scaled down: 3 nested covariates, 200 levels, K=200
+    (3000, 128, 256, (3,), False),          # the envelope's corner: d = 128, K = 256
+    (2500, 64, 128, (2, 3), False),         # exact multiples of the MFMA tile sizes
+])
+def test_envelope_shapes(N, d, K, levels, nested):
+    Z, meta, _ = synth(N, d=d, levels=levels, seed=N + d, nested=nested)
+    g, c, ig, ic = run_both(Z, meta, list(meta), max_iter=2, nclust=K, seed=N)
+    s = assert_parity(g, c, ig, ic)
+    if nested:
+        assert c.subset_clusters > 0 and int(g._scalar("subset_clusters")) == c.subset_clusters
