@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--batches", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=100000, help="cells for the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for smoke tests on one GPU)")
     a = ap.parse_args()
 
     import torch
@@ -83,12 +84,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # (smoke tests may oversubscribe one GPU with gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         # backend "nccl" IS RCCL on ROCm: the accumulators are all-reduced over xGMI through torch.distributed
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
+            os.environ["HMX_BENCH_COMM"] = "torch"     # no RCCL communicator without nccl: use the all-reduce hook
 
     n, d, K, B = a.cells_per_gpu, a.pcs, a.clusters, a.batches
     N = n * world
@@ -124,7 +130,7 @@ def main():
             obj = Harmony(device=local_rank, seed=1)
             obj.set_stream(torch.cuda.current_stream().cuda_stream)
             obj.set_shard(rank, world, rank * n, N, TorchAllReduce(device=dev))
-            comm_kind = "torch.distributed nccl all_reduce hook (RCCL over xGMI)"
+            comm_kind = "torch.distributed %s all_reduce hook%s" % (a.backend, " (RCCL over xGMI)" if a.backend == "nccl" else "")
         cnt = torch.from_numpy(np.bincount(meta["cov0"], minlength=B).astype(np.int64)).to(dev)
         dist.all_reduce(cnt)
         N_b = cnt.cpu().numpy().astype(float)
