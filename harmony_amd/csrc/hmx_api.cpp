@@ -117,6 +117,7 @@ struct hmx_ctx {
   std::vector<void*> allocs;
   // profiling of the dominant kernel
   bool profile = false;
+  bool fused_ok = false;       // k_tile prologue fold usable (LDS budget) and not disabled
   int round_blocks = 0;        // > 0: the persistent round kernel is usable with this cooperative grid
   int64_t round_launches = 0, round_fallbacks = 0;
   int tun_impl = -1, tun_tpw = -1, tun_cpw = -1;  // tunables set through hmx_set_int before setup
@@ -372,6 +373,29 @@ int update_R(hmx_ctx* ctx) {
       (void)hipGetLastError();
       ctx->round_blocks = 0; ctx->round_fallbacks++;   // cooperative launch refused: use the step path from now on
     }
+  }
+  const bool fused = !sharded && !round_done && merged && ctx->fused_ok;
+  if (fused) {
+    // single GPU, default: the fold + penalty of step j happens in the prologue of its own update launch
+    HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * 3 * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
+    long long* const keep_snew = D.Snew_fx;
+    D.fused_fold = 1;
+    for (int j = 0; j < D.nb; j++) {
+      D.fold_prev = D.Snew_set[(j + 2) % 3]; D.Snew_fx = D.Snew_set[j % 3]; D.fold_zero = D.Snew_set[(j + 1) % 3];
+      if (ctx->profile) {
+        if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t x, y; HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y)); ctx->ev_pool.emplace_back(x, y); }
+        HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
+      }
+      l_update(ctx->L, D, j); KCHK();
+      if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; }
+      std::swap(D.O_fx, D.O_alt);   // workgroup 0 published O' into O_alt
+    }
+    D.fused_fold = 0;
+    // O += new(last block): fold-only launch; the set it zeroes is one of the three (re-zeroed next round anyway)
+    l_foldpen(ctx->L, D, -1, D.O_fx, D.O_alt, D.Snew_set[(D.nb - 1) % 3], D.Snew_set[D.nb % 3]); KCHK();
+    std::swap(D.O_fx, D.O_alt);
+    D.Snew_fx = keep_snew;
+    round_done = true;
   }
   for (int j = 0; j <= D.nb && !round_done; j++) {
     // fold the previous block's new contribution into O, remove block j's old one (src/harmony.cpp:312-313,329-330)
@@ -821,6 +845,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
   CHK(dalloc(ctx, &D.Snew_all, (size_t)D.nb * D.nrep * B * K)); CHK(dalloc(ctx, &D.bar_counter, (size_t)4)); D.bar_error = D.bar_counter + 1;
+  { long long* s3; CHK(dalloc(ctx, &s3, (size_t)3 * D.nrep * B * K)); for (int i = 0; i < 3; i++) D.Snew_set[i] = s3 + (size_t)i * D.nrep * B * K; }
   CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
   CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)D.npad)); CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
@@ -863,6 +888,9 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   }
   ctx->W.assign((size_t)(B + 1) * d, 0.f); ctx->W_rows = B + 1;  // allocate_buffers :127
   ctx->Y.assign((size_t)d * K, 0.f);
+  { const char* e = getenv("HMX_FUSED_FOLD");
+    ctx->fused_ok = !(e && std::string(e) == "0") && D.upd_impl == 0 &&
+                    (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024; }
   { const char* e = getenv("HMX_ROUND_IMPL");
     // default: one launch per block step.  "round": the persistent cooperative kernel k_round (measured: 5% faster at
     // 100k cells, equal at 1M, 5% slower at 4M -- its grid barrier + redundant table rebuild cost ~20 us per step)

@@ -56,6 +56,10 @@ struct Dev {
   long long* Sold_fx; // [nb][B][K] old contribution of every block of this round
   long long* Snew_all; // [nb][nrep][B][K] per-step replica slabs of the persistent round kernel (k_round)
   unsigned* bar_counter; unsigned* bar_error;  // grid barrier state of k_round (zeroed before every launch)
+  int fused_fold;      // 1: k_tile<.,0> rebuilds O' and the penalty table in its prologue (no k_foldpen launch per step)
+  const long long* fold_prev;  // replica set written by the previous block update (read in the prologue)
+  long long* fold_zero;        // replica set of the next block update (zeroed by workgroup 0)
+  long long* Snew_set[3];      // the three rotating replica sets of the fused path
   long long* O_alt;   // ping-pong partners of O_fx / Snew_fx for the single-launch fold+penalty (host swaps)
   long long* Snew_alt;
   float* pen;         // [B][K] ((2E+1)/(O+E+1))^theta

@@ -734,8 +734,13 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
   const int K = D.K, C = D.C, zs = D.zs;
   const int nY4 = D.NQ * D.NS * 64;
-  float* ldsPen = reinterpret_cast<float*>(lds4 + nY4);
-  int* ldsQlev = reinterpret_cast<int*>(ldsPen + ((D.B * K + 3) & ~3));
+  // MODE 0 with D.fused_fold: [ image | O' int64 [B][K] | pen | qlev ] -- the fold + penalty of this block step is
+  // recomputed by EVERY workgroup in its own LDS (k_foldpen's launch and its boundary disappear); workgroup 0 also
+  // publishes O' and zeroes the replica set of the NEXT launch (three sets rotate, so nobody reads what is zeroed).
+  const int nBK = D.B * K;
+  long long* ldsO = reinterpret_cast<long long*>(lds4 + nY4);
+  float* ldsPen = (MODE == 0 && D.fused_fold) ? reinterpret_cast<float*>(ldsO + nBK) : reinterpret_cast<float*>(lds4 + nY4);
+  int* ldsQlev = reinterpret_cast<int*>(ldsPen + ((nBK + 3) & ~3));
   long long* ltab = reinterpret_cast<long long*>(lds4 + nY4);
   int p0 = 0, ntiles;
   if constexpr (MODE == 0) { p0 = D.boff[j]; ntiles = (D.boff[j + 1] - p0) >> 4; }  // padded: combination-pure tiles
@@ -764,7 +769,32 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
     const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
     for (int i = threadIdx.x; i < nY4; i += blockDim.x) lds4[i] = src[i];
     if constexpr (MODE == 0) {
-      if (D.pen_lds) {
+      if (D.fused_fold) {
+        const long long* sold = D.Sold_fx + (size_t)j * nBK;
+        for (int i = threadIdx.x; i < nBK; i += blockDim.x) {
+          long long v[8];
+#pragma unroll
+          for (int r = 0; r < 8; r++) v[r] = D.fold_prev[(size_t)min(r, D.nrep - 1) * nBK + i];
+          long long o = D.O_fx[i] - sold[i];
+#pragma unroll
+          for (int r = 0; r < 8; r++) if (r < D.nrep) o += v[r];
+          ldsO[i] = o;
+          if (blockIdx.x == 0) {
+            D.O_alt[i] = o;
+            for (int r = 0; r < D.nrep; r++) D.fold_zero[(size_t)r * nBK + i] = 0;
+          }
+        }
+        for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nBK; i += blockDim.x) {
+          const int b = i / K, k = i - b * K;
+          long long rs = 0;
+          for (int b0 = 0; b0 < D.B0; b0++) rs += ldsO[b0 * K + k];
+          const float of = (float)((double)ldsO[i] * FX_INV);
+          const float ef = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
+          ldsPen[i] = powf(((2.0f * ef) + 1.0f) / (of + ef + 1.0f), D.theta[b]);
+        }
+      } else if (D.pen_lds) {
         for (int i = threadIdx.x; i < D.B * K; i += blockDim.x) ldsPen[i] = D.pen[i];
         for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
       }
@@ -772,8 +802,8 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
     if constexpr (MODE == 2) for (int i = threadIdx.x; i < K * D.d + K; i += blockDim.x) ltab[i] = 0;
     __syncthreads();
   }
-  const float* penT = (MODE == 0 && D.pen_lds) ? ldsPen : D.pen;
-  const int* qlevT = (MODE == 0 && D.pen_lds) ? ldsQlev : D.qlev;
+  const float* penT = (MODE == 0 && (D.pen_lds || D.fused_fold)) ? ldsPen : D.pen;
+  const int* qlevT = (MODE == 0 && (D.pen_lds || D.fused_fold)) ? ldsQlev : D.qlev;
   long long* snew = D.Snew_fx + (size_t)(wave & (D.nrep - 1)) * D.B * K;  // this wave's table replica
   // per-lane cluster constants: exp(-dist/sigma) = exp2(dist * ce), ce = -log2(e)/sigma;
   // sigma r ln r = r log2(r) * cl, cl = sigma ln 2 -> one v_exp_f32 / v_log_f32 per value
@@ -1660,8 +1690,8 @@ void l_update(const Launch& L, const Dev& D, int j) {
   if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
-  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) +
-                     (D.pen_lds ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
+  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + (D.fused_fold ? (size_t)D.B * D.K * 8 : 0) +
+                     ((D.pen_lds || D.fused_fold) ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
 #define HMX_UPD(N) case N: hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(D.upd_threads), lds, L.stream, D, j); break;
   switch (D.NCT) {
     HMX_UPD(1) HMX_UPD(2) HMX_UPD(3) HMX_UPD(4) HMX_UPD(5) HMX_UPD(6) HMX_UPD(7) HMX_UPD(8)
