@@ -329,7 +329,8 @@ int kmeans_centers(hmx_ctx* ctx) {
 int update_R(hmx_ctx* ctx) {
   Dev& D = ctx->D;
   const bool sharded = ctx->world > 1 || ctx->comm_force;
-  const bool merged = (size_t)D.B * 128 <= 64 * 1024;   // LDS budget of k_foldpen
+  const char* fold_env = getenv("HMX_FOLD_IMPL");   // "split": force the two-kernel fold + penalty fallback (tests)
+  const bool merged = (size_t)D.B * 128 <= 64 * 1024 && !(fold_env && std::string(fold_env) == "split");   // LDS budget of k_foldpen
   const double t0 = now_ms();
   if (!ctx->injected.empty()) {  // host-provided shuffle: block(g) from its position
     std::vector<int64_t> order = std::move(ctx->injected.front());

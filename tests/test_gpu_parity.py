@@ -341,3 +341,20 @@ def test_envelope_shapes(N, d, K, levels, nested):
     s = assert_parity(g, c, ig, ic)
     if nested:
         assert c.subset_clusters > 0 and int(g._scalar("subset_clusters")) == c.subset_clusters
+
+
+@pytest.mark.parametrize("env", [
+    {"HMX_UPDATE_IMPL": "v1", "HMX_TILE_IMPL": "v1", "HMX_MOE_IMPL": "v1"},   # first-generation cluster-lane VALU kernels
+    {"HMX_FOLD_IMPL": "split"},                                               # k_fold + k_penalty instead of k_foldpen
+    {"HMX_FUSED_FOLD": "0"},                                                  # separate k_foldpen launch per block step
+    {"HMX_NREP": "1", "HMX_UPD_THREADS": "256", "HMX_UPD_MAXBLOCKS": "64", "HMX_UPD_TPW": "3"},   # launch geometry knobs
+])
+def test_fallback_paths_parity(cell_lines, monkeypatch, env):
+    """Every fallback / tuning path keeps the parity bar (they serve shapes outside the MFMA envelope)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g, c, ig, ic = run_both(cell_lines["pcs"], _meta(cell_lines), ["cell_type", "dataset"], max_iter=3, theta=[1, 1], nclust=50)
+    assert_parity(g, c, ig, ic)
+    Z, meta, _ = synth(20000, d=50, levels=(10,), seed=5)
+    g, c, ig, ic = run_both(Z, meta, "cov0", max_iter=2, nclust=100, seed=8)
+    assert_parity(g, c, ig, ic)
