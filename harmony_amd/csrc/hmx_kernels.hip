@@ -688,6 +688,60 @@ __device__ __forceinline__ void tile_dots(const f32x4* __restrict__ ldsY4, const
   }
 }
 
+// A-operand rows of one tile held in registers (d <= 76: at most 4 float4 groups + 3 single steps), so that the rows of
+// tile i+1 can be requested while tile i is computed.  Loads are unconditional with clamped offsets (see ld_or).
+struct RowRegs { f32x4 v[4]; float t[3]; };
+__device__ __forceinline__ void load_rows(const float* __restrict__ zrow, int g, int NT4, int tail, RowRegs& r) {
+  const int tmax = NT4 > 0 ? NT4 - 1 : 0, umax = tail > 0 ? tail - 1 : 0;
+  if (NT4 > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) r.v[t] = *reinterpret_cast<const f32x4*>(zrow + 16 * min(t, tmax) + 4 * g);
+  }
+  if (tail > 0) {
+#pragma unroll
+    for (int u = 0; u < 3; u++) r.t[u] = zrow[16 * NT4 + 4 * min(u, umax) + g];
+  }
+}
+template <int NCT>
+__device__ __forceinline__ void tile_dots_regs(const f32x4* __restrict__ ldsY4, const RowRegs& r, bool valid, int lane,
+                                               int NS, int NT4, int tail, f32x4 (&acc)[NCT]) {
+  constexpr int NQ = (NCT + 3) / 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) acc[ct] = zero4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < NT4) {
+      const f32x4 zc = valid ? r.v[t] : zero4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * t + e;
+#pragma unroll
+        for (int qd = 0; qd < NQ; ++qd) {
+          const f32x4 y = ldsY4[(qd * NS + s) * 64 + lane];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (4 * qd + i < NCT) acc[4 * qd + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc[e], y[i], acc[4 * qd + i], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    if (u < tail) {
+      const int s = 4 * NT4 + u;
+      const float zv = valid ? r.t[u] : 0.0f;
+#pragma unroll
+      for (int qd = 0; qd < NQ; ++qd) {
+        const f32x4 y = ldsY4[(qd * NS + s) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * qd + i < NCT) acc[4 * qd + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv, y[i], acc[4 * qd + i], 0, 0, 0);
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
   const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), m, 64);
   const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
@@ -757,13 +811,20 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   const int tstep = (MODE == 0) ? nw : 1;
   // MODE 0: the first tile's cell ids and the first 16 bytes of their embedding rows are requested BEFORE the
   // LDS staging below, so the two dependent HBM round trips overlap with it
-  int cellN = -1;
-  f32x4 zpre = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (MODE == 0) {
-    if (ts < te) {
-      cellN = D.lorder[p0 + 16 * ts + c];
-      if (D.NT4 > 0) zpre = *reinterpret_cast<const f32x4*>(D.Zc + (size_t)(cellN >= 0 ? cellN : 0) * zs + 4 * g);
-    }
+  // Software pipeline over tiles (when the rows fit in registers, D.NT4 <= 4): cell ids two tiles ahead, embedding rows
+  // one tile ahead.  MODE 0 requests the first tile's ids and rows BEFORE the LDS staging below.
+  const bool pre = D.NT4 <= 4 && NCT <= 12;   // (K > 192: the extra row registers would spill)
+  int cellN = -1, cellNN = -1;
+  RowRegs rowsN;
+  auto tile_cell = [&](int tile) -> int {      // A-operand cell of this lane for a tile (-1: padding / beyond the end)
+    if (tile >= te) return -1;
+    if constexpr (MODE == 0) return D.lorder[p0 + 16 * tile + c];
+    else { const Item it = D.titems[tile]; return (c < it.cnt) ? it.start + c : -1; }
+  };
+  if (ts < te) {
+    cellN = tile_cell(ts);
+    cellNN = tile_cell(ts + tstep);
+    if (pre) load_rows(D.Zc + (size_t)(cellN >= 0 ? cellN : 0) * zs, g, D.NT4, D.tail, rowsN);
   }
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
@@ -820,20 +881,18 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   double od = 0.0, oe = 0.0;
   int curq = -1;
   for (int tile = ts; tile < te; tile += tstep) {
-    int cellA, q0;
-    if constexpr (MODE == 0) {
-      const int pbase = p0 + 16 * tile;
-      cellA = cellN;
-      if (tile + tstep < te) cellN = D.lorder[pbase + 16 * tstep + c];
-      q0 = D.lcombo[pbase];  // slot 0 of a tile is always a real cell
-    } else {
-      const Item it = D.titems[tile];  // static tile: <= 16 consecutive cells of one combination
-      cellA = (c < it.cnt) ? it.start + c : -1;
-      q0 = it.q;
-    }
+    int q0;
+    if constexpr (MODE == 0) q0 = D.lcombo[p0 + 16 * tile];  // slot 0 of a tile is always a real cell
+    else q0 = D.titems[tile].q;                              // static tile: <= 16 consecutive cells of one combination
+    const int cellA = cellN;
+    const RowRegs rowsA = rowsN;
+    cellN = cellNN;
+    cellNN = tile_cell(tile + 2 * tstep);
+    // rows of the NEXT tile (unconditional: the last iteration re-requests its own rows, nobody waits for them)
+    if (pre) load_rows(D.Zc + (size_t)(cellN >= 0 ? cellN : (cellA >= 0 ? cellA : 0)) * zs, g, D.NT4, D.tail, rowsN);
     f32x4 acc[NCT];
-    tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc,
-                   MODE == 0 && tile == ts && D.NT4 > 0, zpre);
+    if (pre) tile_dots_regs<NCT>(lds4, rowsA, cellA >= 0, lane, D.NS, D.NT4, D.tail, acc);
+    else tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc);
     if constexpr (MODE == 2) {
       // nearest centre of every cell of the tile: argmin_k ||y_k||^2 - 2 x.y_k ; ties -> smallest k
 #pragma unroll
