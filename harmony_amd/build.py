@@ -35,13 +35,19 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in SRC + HDR)
 
 
-def build(force=False, verbose=True):
-    if not force and not _stale():
+def build(force=False, verbose=True, trace=False):
+    """trace=True builds the diagnostics variant (-DHMX_TRACE: per-wave phase stamps in the block-update kernel,
+    see tools/trace_update.py) next to the product library; it is never loaded unless HMX_LIB_PATH points at it."""
+    if trace:
+        out = OUT.replace(".so", "_trace.so")
+    else:
+        out = OUT
+    if not trace and not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-Wno-unused-result", "-o", OUT] + SRC + ["-lpthread", "-ldl"]
+           "-Wno-unused-result", "-o", out] + (["-DHMX_TRACE"] if trace else []) + SRC + ["-lpthread", "-ldl"]
     # Share ONE HIP runtime with PyTorch when both live in a process: torch wheels bundle their own
     # libamdhip64.so (no SONAME).  Linking against that file records DT_NEEDED "libamdhip64.so": if torch is
     # already imported the loader reuses torch's runtime (device pointers, streams and RCCL then interoperate),
@@ -52,8 +58,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, trace="--trace" in sys.argv)

@@ -693,6 +693,7 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
   else if (f == "comm_force") ctx->comm_force = v != 0;
   else if (f == "upd_impl") { ctx->tun_impl = (int)v; if (ctx->ran_setup) ctx->D.upd_impl = (int)v; }
+  else if (f == "upd_debug") { if (ctx->ran_setup) ctx->D.upd_debug = (int)v; }
   else if (f == "upd_tpw") { ctx->tun_tpw = (int)v; if (ctx->ran_setup) ctx->D.upd_tpw = (int)(v < 1 ? 1 : v); }
   else return fail(ctx, HMX_ERR_ARG, "unknown or read-only field: " + f);
   return 0;
@@ -828,6 +829,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   { const char* e = getenv("HMX_UPDATE_IMPL"); D.upd_impl = ctx->tun_impl >= 0 ? ctx->tun_impl : ((e && std::string(e) == "v1") ? 1 : 0); }
   { const char* e = getenv("HMX_UPD_THREADS"); D.upd_threads = (e && atoi(e) == 256) ? 256 : 512; }
   { const char* e = getenv("HMX_UPD_MAXBLOCKS"); D.upd_maxblocks = e ? atoi(e) : (D.upd_threads == 512 ? 256 : 512); if (D.upd_maxblocks < 1) D.upd_maxblocks = 1; }
+  D.upd_debug = 0;
   { const char* e = getenv("HMX_UPD_TPW"); D.upd_tpw = ctx->tun_tpw > 0 ? ctx->tun_tpw : (e ? atoi(e) : 1); if (D.upd_tpw < 1) D.upd_tpw = 1; }
   { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = ctx->tun_cpw > 0 ? ctx->tun_cpw : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
   std::vector<Item> schunks; std::vector<int> qchunk((size_t)Q + 1, 0);
@@ -840,16 +842,18 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   D.npad = (int)std::min<int64_t>((int64_t)N + (int64_t)D.nb * Q * 16, 2147483000ll);
   D.nitems = (int)items.size(); D.naitems = (int)aitems.size(); D.ntitems = (int)titems.size();
   { const char* e = getenv("HMX_TILE_IMPL"); D.tile_impl = (e && std::string(e) == "v1") ? 0 : 1; }
-  CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, (size_t)N * K));
+  CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, ((size_t)N + 1) * K));   // + one dummy row (target of masked stores)
   CHK(dalloc(ctx, &D.perm, (size_t)N)); CHK(dalloc(ctx, &D.invperm, (size_t)N)); CHK(dalloc(ctx, &D.combo, (size_t)N));
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
   CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
   CHK(dalloc(ctx, &D.Snew_all, (size_t)D.nb * D.nrep * B * K)); CHK(dalloc(ctx, &D.bar_counter, (size_t)4)); D.bar_error = D.bar_counter + 1;
   { long long* s3; CHK(dalloc(ctx, &s3, (size_t)3 * D.nrep * B * K)); for (int i = 0; i < 3; i++) D.Snew_set[i] = s3 + (size_t)i * D.nrep * B * K; }
-  CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots)); CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
+  CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots));
+  D.trace = nullptr;
+  if (const char* e = getenv("HMX_TRACE")) if (atoi(e)) { CHK(dalloc(ctx, &D.trace, (size_t)16 * D.nwmax)); HIPCHK(hipMemsetAsync(D.trace, 0, sizeof(unsigned long long) * 16 * (size_t)D.nwmax, ctx->L.stream)); } CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
-  CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)D.npad)); CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
+  CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)D.npad)); CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &D.lpair, (size_t)D.npad));
   CHK(dalloc(ctx, &D.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));
@@ -1080,6 +1084,17 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "round:blocks") return scalar((double)ctx->round_blocks);
   if (f == "comm:calls") return scalar((double)ctx->comm_calls);
   if (f == "comm:bytes") return scalar((double)ctx->comm_bytes);
+  if (f == "trace") {   // HMX_TRACE=1: raw per-wave stamps of the last block-update launch
+    if (!ctx->D.trace) return -1;
+    const int64_t n = (int64_t)ctx->D.nwmax * 16;
+    if (out) {
+      std::vector<unsigned long long> h((size_t)n);
+      (void)hipStreamSynchronize(ctx->L.stream);
+      (void)hipMemcpy(h.data(), ctx->D.trace, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost);
+      for (int64_t i = 0; i < std::min(n, cap); i++) out[i] = (double)(h[(size_t)i] & ((1ull << 52) - 1));
+    }
+    return n;
+  }
   if (f == "prof:update_ms") return scalar(ctx->prof_update_ms);
   if (f == "prof:update_launches") return scalar((double)ctx->prof_update_launches);
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);

@@ -32,6 +32,7 @@ struct Dev {
   float* Yimg;      // [NQ][NS][4][16][4] LDS image of the centroids in MFMA B-operand order
   int upd_impl;     // 0: MFMA tile kernel, 1: cluster-lane VALU kernel (v1)
   int upd_tpw;      // tiles per wave target of the MFMA update kernel
+  int upd_debug;    // diagnostics only (see k_tile)
   int upd_threads;   // workgroup size of the update kernel (256 or 512)
   int upd_maxblocks; // grid cap of the update kernel = workgroups resident at once (HMX_UPD_MAXBLOCKS)
   int nb;           // blocks per clustering round
@@ -66,6 +67,7 @@ struct Dev {
   double* obj;        // [0..1] reduced sums: sum R*dist, sum sigma*R*log R ; [2..4] snapshot incl. cross term
   double* objpart;    // [objslots][nwmax][2] per-(block,wave) partial sums: private slots, no atomics
   int objslots, nwmax;
+  unsigned long long* trace;  // diagnostics (HMX_TRACE=1): [nwmax][16] per-wave phase stamps of the last k_tile<.,0> launch
   double* objrow;     // [objslots][2] per-slot-row sums
   int pen_lds;        // 1: the penalty table and qlev are staged in LDS by the update kernel
   int nrep;           // replicas of Snew_fx (power of two) to spread atomic contention
@@ -74,6 +76,7 @@ struct Dev {
   int* lorder;      // [npad] internal cell ids grouped by block (stable); every (block, combination) bin is
                     //        padded to a multiple of 16 with -1 so that MFMA tiles are combination-pure
   int* lcombo;      // [npad] combination of position p (valid where lorder[p] >= 0)
+  int2* lpair;      // [npad] (lorder, lcombo) interleaved: one 8-byte load per lane in the MFMA update kernel
   int npad;         // n + nb*Q*16 (upper bound of the padded length)
   int* boff;        // [nb+1] padded start of every block (multiples of 16)
   int* counts;      // [nb][nchunks] histogram of the counting sort

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
       const int v = __shfl(b, src, 64);
       const unsigned long long m = __ballot(b == v);
       const int off = base_[v];  // all lanes read before lane 0 updates
-      if (b == v) { const int dst = off + __popcll(m & lt); D.lorder[dst] = i; D.lcombo[dst] = ch.q; }
+      if (b == v) { const int dst = off + __popcll(m & lt); D.lorder[dst] = i; D.lcombo[dst] = ch.q; D.lpair[dst] = make_int2(i, ch.q); }
       __syncthreads();
       if (lane == 0) base_[v] = off + __popcll(m);
       __syncthreads();
@@ -774,6 +774,9 @@ __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const
   for (int ct = 0; ct < NCT; ct++) oacc[ct] = 0ull;
 }
 
+// Instantiated cluster-tile counts are {1..8,10,12,14,16} (hmx_setup picks the smallest >= ceil(K/16)): cluster tiles
+// below this index are always completely inside K, only the ones from it on can hold k >= K.
+constexpr int first_partial_ct(int nct) { return nct <= 8 ? nct - 1 : nct - 2; }
 // 256-thread workgroups; register budget <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (3 workgroups per CU)
 // are resident and one launch of ~3 workgroups per CU finishes in a single wave of workgroups.
 constexpr int tile_threads(int nct) { return 256; }  // measured: 768-thread workgroups (one per CU) are 30% slower (tail effect)
@@ -800,7 +803,17 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   if constexpr (MODE == 0) { p0 = D.boff[j]; ntiles = (D.boff[j + 1] - p0) >> 4; }  // padded: combination-pure tiles
   else ntiles = D.ntitems;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  // wave index as a SCALAR: tile numbers, the tile's combination and all loop control become SALU / s_load work
+  // (lgkmcnt) -- a vector load here would put a loop-carried vmcnt(0), i.e. a drain of the 28 R stores, into every tile
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
+  auto stamp = [&](int slot) {  // diagnostics build only (-DHMX_TRACE, tools/trace_update.py): per-wave phase stamps
+#ifdef HMX_TRACE
+    if constexpr (MODE == 0) {
+      if (D.trace && lane == 0) D.trace[(size_t)wave * 16 + slot] = (slot == 0 || slot == 7) ? wall_clock64() : __builtin_readcyclecounter();
+    }
+#endif
+  };
+  stamp(0); stamp(1);
   // MODE 0 (short launches, grid capped at the resident capacity): tiles are dealt round-robin, tile = wave + i*nw, so
   // every wave gets 1-2 tiles and no CU runs a second round of workgroups.  Static modes: contiguous ranges.
   // (dealing tiles workgroup-major instead -- equal tiles per CU -- measured 25% SLOWER: the 8 consecutive tiles of a
@@ -814,17 +827,20 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   // Software pipeline over tiles (when the rows fit in registers, D.NT4 <= 4): cell ids two tiles ahead, embedding rows
   // one tile ahead.  MODE 0 requests the first tile's ids and rows BEFORE the LDS staging below.
   const bool pre = D.NT4 <= 4 && NCT <= 12;   // (K > 192: the extra row registers would spill)
-  int cellN = -1, cellNN = -1;
+  // (cell id, combination) of this lane's A-operand row, ONE vector load per tile: a separate uniform load of the tile's
+  // combination ends in a readfirstlane right behind the load, i.e. a vmcnt(0) -- a drain of the 28 outstanding R stores
+  // of the previous tile plus a full memory latency -- in every iteration.
+  int2 cellN = make_int2(-1, -1), cellNN = make_int2(-1, -1);
   RowRegs rowsN;
-  auto tile_cell = [&](int tile) -> int {      // A-operand cell of this lane for a tile (-1: padding / beyond the end)
-    if (tile >= te) return -1;
-    if constexpr (MODE == 0) return D.lorder[p0 + 16 * tile + c];
-    else { const Item it = D.titems[tile]; return (c < it.cnt) ? it.start + c : -1; }
+  auto tile_cell = [&](int tile) -> int2 {     // (-1, .): padding slot / beyond the end
+    if (tile >= te) return make_int2(-1, -1);
+    if constexpr (MODE == 0) return D.lpair[p0 + 16 * tile + c];
+    else { const Item it = D.titems[tile]; return make_int2((c < it.cnt) ? it.start + c : -1, it.q); }
   };
   if (ts < te) {
     cellN = tile_cell(ts);
     cellNN = tile_cell(ts + tstep);
-    if (pre) load_rows(D.Zc + (size_t)(cellN >= 0 ? cellN : 0) * zs, g, D.NT4, D.tail, rowsN);
+    if (pre) load_rows(D.Zc + (size_t)(cellN.x >= 0 ? cellN.x : 0) * zs, g, D.NT4, D.tail, rowsN);
   }
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
@@ -863,6 +879,7 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
     if constexpr (MODE == 2) for (int i = threadIdx.x; i < K * D.d + K; i += blockDim.x) ltab[i] = 0;
     __syncthreads();
   }
+  stamp(2);
   const float* penT = (MODE == 0 && (D.pen_lds || D.fused_fold)) ? ldsPen : D.pen;
   const int* qlevT = (MODE == 0 && (D.pen_lds || D.fused_fold)) ? ldsQlev : D.qlev;
   long long* snew = D.Snew_fx + (size_t)(wave & (D.nrep - 1)) * D.B * K;  // this wave's table replica
@@ -880,19 +897,68 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   }
   double od = 0.0, oe = 0.0;
   int curq = -1;
-  for (int tile = ts; tile < te; tile += tstep) {
-    int q0;
-    if constexpr (MODE == 0) q0 = D.lcombo[p0 + 16 * tile];  // slot 0 of a tile is always a real cell
-    else q0 = D.titems[tile].q;                              // static tile: <= 16 consecutive cells of one combination
-    const int cellA = cellN;
-    const RowRegs rowsA = rowsN;
-    cellN = cellNN;
-    cellNN = tile_cell(tile + 2 * tstep);
-    // rows of the NEXT tile (unconditional: the last iteration re-requests its own rows, nobody waits for them)
-    if (pre) load_rows(D.Zc + (size_t)(cellN >= 0 ? cellN : (cellA >= 0 ? cellA : 0)) * zs, g, D.NT4, D.tail, rowsN);
-    f32x4 acc[NCT];
-    if (pre) tile_dots_regs<NCT>(lds4, rowsA, cellA >= 0, lane, D.NS, D.NT4, D.tail, acc);
-    else tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc);
+  // ---- per-tile stages ------------------------------------------------------------------------------------------
+  // the tile's combination: slot 0 of a tile is always a real cell (static tiles: every lane holds it)
+  auto tile_q = [&](const int2 cq) -> int { return __builtin_amdgcn_readfirstlane(cq.y); };
+  // MODE 0/1 epilogue, split so that the fused loop below can interleave it with the next tile's MFMAs:
+  // epi_begin: run change -> flush the O contributions of the finished combination, fetch the new penalty row
+  auto epi_begin = [&](const int q0) {
+    if (q0 != curq) {
+      if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+      curq = q0;
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
+        for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
+          const int b = qlevT[q0 * C + cc];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(penT, (size_t)b * K + min(16 * ct + c, K - 1), 16 * ct + c < K, 0.0f);
+        }
+      }
+    }
+  };
+  // epi_reg: accumulator register `reg` = row 4g+reg of the tile (its cell id lives in lane 4g+reg of cellA).  Branch
+  // free: invalid rows / padded clusters store into the dummy row behind R, so no exec-mask branch splits the region.
+  auto epi_reg = [&](const int reg, const int cellA, f32x4 (&acc)[NCT]) {
+    const int cell = __shfl(cellA, 4 * g + reg, 64);
+    const bool cv = cell >= 0;
+    float* Rrow = D.R + (size_t)(cv ? cell : D.n) * K;
+    float* Rdum = D.R + (size_t)D.n * K;
+    // exp(-dist/sigma) [x penalty], ONE L1 normalisation: the reference normalises, multiplies by the penalty and
+    // normalises again (:141-150, :322-326); the first division cancels in the second, so it is not computed
+    // (identical up to fp32 rounding, ~1e-7 relative).  Only the cluster tiles from first_partial_ct on can hold k >= K.
+    float r[NCT];
+    float s1 = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+      float e = __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]);
+      if constexpr (MODE == 0) e *= penv[ct];
+      if (ct >= first_partial_ct(NCT)) e = (16 * ct + c < K) ? e : 0.0f;
+      r[ct] = e;
+      s1 += e;
+    }
+    s1 = rowsum16(s1);
+    float i2 = __builtin_amdgcn_rcpf(s1);
+    i2 = i2 * fmaf(-s1, i2, 2.0f);               // one Newton step: <= 1 ulp
+    i2 = (s1 == 0.0f) ? 1.0f : i2;
+    float pd = 0.0f, pe = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+      const float rn = r[ct] * i2;
+      float* dst = (ct < first_partial_ct(NCT) || 16 * ct + c < K) ? Rrow + 16 * ct + c : Rdum + c;
+#ifdef HMX_TRACE
+      if (!(D.upd_debug & 4))   // timing experiment: no R stores
+#endif
+      *dst = rn;
+      const float rv = cv ? rn : 0.0f;  // exactly 0 for k >= K
+      oacc[ct] += fx_of(rv);
+      pd = fmaf(rv, fmaf(acc[ct][reg], -2.0f, 2.0f), pd);
+      pe = fmaf(rv * __builtin_amdgcn_logf(fmaxf(rv, FLT_MIN)), cl[ct], pe);
+    }
+    od += (double)pd; oe += (double)pe;
+  };
+  // epilogue of a tile whose distances are in `acc`
+  auto epilogue = [&](const int cellA, const int q0, f32x4 (&acc)[NCT]) {
     if constexpr (MODE == 2) {
       // nearest centre of every cell of the tile: argmin_k ||y_k||^2 - 2 x.y_k ; ties -> smallest k
 #pragma unroll
@@ -922,53 +988,85 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
         }
       }
     } else {
-      if (q0 != curq) {
-        if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
-        curq = q0;
-        if constexpr (MODE == 0) {
+      epi_begin(q0);
 #pragma unroll
-          for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
-          for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
-            const int b = qlevT[q0 * C + cc];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(penT, (size_t)b * K + min(16 * ct + c, K - 1), 16 * ct + c < K, 0.0f);
-          }
-        }
+      for (int reg = 0; reg < 4; reg++) epi_reg(reg, cellA, acc);
+    }
+  };
+  constexpr bool DUAL = NCT <= 8;  // two accumulator sets fit the 256-VGPR budget (2 waves/SIMD) only up to K = 128
+  auto next_rows = [&](const int2 nxt, const int2 cur) {  // row address of the NEXT tile's lane (any valid row if padding)
+    return D.Zc + (size_t)(nxt.x >= 0 ? nxt.x : (cur.x >= 0 ? cur.x : 0)) * zs;
+  };
+  if (pre && !DUAL) {
+    for (int tile = ts; tile < te; tile += tstep) {
+      const int2 cellA = cellN;
+      const RowRegs rowsA = rowsN;
+      cellN = cellNN;
+      cellNN = tile_cell(tile + 2 * tstep);
+      load_rows(next_rows(cellN, cellA), g, D.NT4, D.tail, rowsN);
+      f32x4 acc[NCT];
+      tile_dots_regs<NCT>(lds4, rowsA, cellA.x >= 0, lane, D.NS, D.NT4, D.tail, acc);
+      epilogue(cellA.x, tile_q(cellA), acc);
+    }
+  } else if (pre) {
+    // two accumulator sets: the MFMAs of tile i+1 are issued before the (VALU / transcendental / store) epilogue of tile i
+    if (ts < te) {
+      f32x4 accC[NCT];
+      int2 cellC = cellN;
+      {
+        const RowRegs rowsA = rowsN;
+        cellN = cellNN;
+        cellNN = tile_cell(ts + 2 * tstep);
+        load_rows(next_rows(cellN, cellC), g, D.NT4, D.tail, rowsN);
+        tile_dots_regs<NCT>(lds4, rowsA, cellC.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
       }
+      stamp(3);
+      // every load of the prologue has landed before the loop is entered: hipcc merges the wait state of the two loop
+      // entries conservatively, and row loads still pending on THIS edge would turn the loop-top waits into vmcnt(0..2),
+      // which on the back edge means draining the 28 R stores of the tile just finished
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      for (int tile = ts + tstep; tile < te; tile += tstep) {
+        stamp(8);
+        const int2 cellT = cellN;
+        const RowRegs rowsA = rowsN;
+        cellN = cellNN;
+        cellNN = tile_cell(tile + 2 * tstep);
+        load_rows(next_rows(cellN, cellT), g, D.NT4, D.tail, rowsN);
+        stamp(9);
+        f32x4 accT[NCT];
+#ifdef HMX_TRACE
+        const int dbg = D.upd_debug;   // 1 = no epilogue work, 2 = no MFMAs (WRONG RESULTS; timing experiments only)
+        if (dbg & 2) {
 #pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        // row 4g+reg of D: its cell id lives in lane 4g+reg of cellA
-        const int cell = __shfl(cellA, 4 * g + reg, 64);
-        const bool cv = cell >= 0;
-        float* Rrow = D.R + (size_t)(cv ? cell : 0) * K;
-        float r[NCT];
-        float s1 = 0.0f;
+          for (int ct = 0; ct < NCT; ct++) accT[ct] = rowsA.v[0];
+        } else tile_dots_regs<NCT>(lds4, rowsA, cellT.x >= 0, lane, D.NS, D.NT4, D.tail, accT);
+        stamp(10);
+        if (!(dbg & 1)) epilogue(cellC.x, tile_q(cellC), accC);
+        else {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ct++) {
-          r[ct] = (16 * ct + c < K) ? __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]) : 0.0f;
-          s1 += r[ct];
+          for (int ct = 0; ct < NCT; ct++) od += (double)(accC[ct][0] + accC[ct][1] + accC[ct][2] + accC[ct][3]);
         }
-        s1 = rowsum16(s1);
-        float i2 = (s1 == 0.0f) ? 1.0f : 1.0f / s1;
-        if constexpr (MODE == 0) {
-          float s2 = 0.0f;
+        stamp(11);
+#else
+        tile_dots_regs<NCT>(lds4, rowsA, cellT.x >= 0, lane, D.NS, D.NT4, D.tail, accT);   // MFMA pipe: tile i+1
+        epilogue(cellC.x, tile_q(cellC), accC);                                           // VALU pipe: tile i
+#endif
 #pragma unroll
-          for (int ct = 0; ct < NCT; ct++) { r[ct] = (r[ct] * i2) * penv[ct]; s2 += fabsf(r[ct]); }
-          s2 = rowsum16(s2);
-          i2 = (s2 == 0.0f) ? 1.0f : 1.0f / s2;
-        }
-        float pd = 0.0f, pe = 0.0f;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++) {
-          const float rn = r[ct] * i2;
-          if (cv && 16 * ct + c < K) Rrow[16 * ct + c] = rn;
-          const float rv = cv ? rn : 0.0f;  // exactly 0 for k >= K
-          oacc[ct] += fx_of(rv);
-          pd = fmaf(rv, fmaf(acc[ct][reg], -2.0f, 2.0f), pd);
-          pe = fmaf(rv * __builtin_amdgcn_logf(fmaxf(rv, FLT_MIN)), cl[ct], pe);
-        }
-        od += (double)pd; oe += (double)pe;
+        for (int ct = 0; ct < NCT; ct++) accC[ct] = accT[ct];
+        cellC = cellT;
       }
+      stamp(4);
+      epilogue(cellC.x, tile_q(cellC), accC);
+      stamp(5);
+    }
+  } else {
+    for (int tile = ts; tile < te; tile += tstep) {
+      const int2 cellA = cellN;
+      cellN = cellNN;
+      cellNN = tile_cell(tile + 2 * tstep);
+      f32x4 acc[NCT];
+      tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA.x >= 0 ? cellA.x : 0) * zs, cellA.x >= 0, g, lane, D.NS, D.NT4, D.tail, acc);
+      epilogue(cellA.x, tile_q(cellA), acc);
     }
   }
   if constexpr (MODE == 2) {
@@ -987,6 +1085,8 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
       if (MODE == 0 && D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; }  // written once per round: plain store
       else { slot[0] += od; slot[1] += oe; }
     }
+    stamp(6);
+    stamp(7);
   }
 }
 
@@ -1131,20 +1231,20 @@ __global__ __launch_bounds__(512) void k_round(Dev D) {
         const int cell = __shfl(cellA, 4 * g + reg, 64);
         const bool cv = cell >= 0;
         float* Rrow = D.R + (size_t)(cv ? cell : 0) * K;
-        float r[NCT];
+        float r[NCT];   // same arithmetic as k_tile's epi_reg (bit-identical R: tests compare the two paths exactly)
         float s1 = 0.0f;
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) {
-          r[ct] = (16 * ct + c < K) ? __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]) : 0.0f;
-          s1 += r[ct];
+          float e = __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]);
+          e *= penv[ct];
+          if (ct >= first_partial_ct(NCT)) e = (16 * ct + c < K) ? e : 0.0f;
+          r[ct] = e;
+          s1 += e;
         }
         s1 = rowsum16(s1);
-        const float i1 = (s1 == 0.0f) ? 1.0f : 1.0f / s1;
-        float s2 = 0.0f;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++) { r[ct] = (r[ct] * i1) * penv[ct]; s2 += fabsf(r[ct]); }
-        s2 = rowsum16(s2);
-        const float i2 = (s2 == 0.0f) ? 1.0f : 1.0f / s2;
+        float i2 = __builtin_amdgcn_rcpf(s1);
+        i2 = i2 * fmaf(-s1, i2, 2.0f);
+        i2 = (s1 == 0.0f) ? 1.0f : i2;
         float pd = 0.0f, pe = 0.0f;
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) {
@@ -1703,6 +1803,7 @@ void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uin
 void l_sort_blocks(const Launch& L, const Dev& D) {
   const size_t lds = (size_t)D.nb * sizeof(int);
   (void)hipMemsetAsync(D.lorder, 0xFF, sizeof(int) * (size_t)D.npad, L.stream);  // padding slots = -1
+  (void)hipMemsetAsync(D.lpair, 0xFF, sizeof(int2) * (size_t)D.npad, L.stream);
   hipLaunchKernelGGL(k_sort_hist, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
   hipLaunchKernelGGL(k_sort_binscan, dim3(D.nb * D.Q), dim3(WAVE), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D);
