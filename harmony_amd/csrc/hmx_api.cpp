@@ -118,9 +118,7 @@ struct hmx_ctx {
   // profiling of the dominant kernel
   bool profile = false;
   bool fused_ok = false;       // k_tile prologue fold usable (LDS budget) and not disabled
-  int round_blocks = 0;        // > 0: the persistent round kernel is usable with this cooperative grid
-  int64_t round_launches = 0, round_fallbacks = 0;
-  int tun_impl = -1, tun_tpw = -1, tun_cpw = -1;  // tunables set through hmx_set_int before setup
+  int tun_impl = -1, tun_tpw = -1, tun_cpw = -1, tun_wps = -1;  // tunables set through hmx_set_int before setup
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
   double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0;
   std::string err, warn;
@@ -352,30 +350,8 @@ int update_R(hmx_ctx* ctx) {
   l_oldsum(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
-  bool round_done = false;
-  if (!sharded && ctx->round_blocks > 0) {
-    // single GPU: ONE persistent cooperative launch runs the whole chain of block steps (k_round)
-    HIPCHK(hipMemsetAsync(D.Snew_all, 0, sizeof(long long) * (size_t)D.nb * D.nrep * D.B * D.K, ctx->L.stream));
-    HIPCHK(hipMemsetAsync(D.bar_counter, 0, sizeof(unsigned) * 2, ctx->L.stream));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->profile) {
-      if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t x, y; HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y)); ctx->ev_pool.emplace_back(x, y); }
-      e0 = ctx->ev_pool[ctx->ev_used].first; e1 = ctx->ev_pool[ctx->ev_used].second;
-      HIPCHK(hipEventRecord(e0, ctx->L.stream));
-    }
-    const int st = l_round(ctx->L, D, ctx->round_blocks);
-    if (st == 0) {
-      if (ctx->profile) { HIPCHK(hipEventRecord(e1, ctx->L.stream)); ctx->ev_used++; }
-      unsigned flags[2] = {0, 0};
-      CHK(d2h(ctx, flags, D.bar_counter, 2));   // [0] arrivals, [1] timeout flag (bar_error = bar_counter + 1)
-      if (flags[1] == 0) { round_done = true; ctx->round_launches++; }
-      else return fail(ctx, HMX_ERR_DEVICE, "persistent round kernel: grid barrier timed out");
-    } else {
-      (void)hipGetLastError();
-      ctx->round_blocks = 0; ctx->round_fallbacks++;   // cooperative launch refused: use the step path from now on
-    }
-  }
-  const bool fused = !sharded && !round_done && merged && ctx->fused_ok;
+  bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
+  const bool fused = !sharded && merged && ctx->fused_ok;
   if (fused) {
     // single GPU, default: the fold + penalty of step j happens in the prologue of its own update launch
     HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * 3 * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
@@ -693,6 +669,7 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
   else if (f == "comm_force") ctx->comm_force = v != 0;
   else if (f == "upd_impl") { ctx->tun_impl = (int)v; if (ctx->ran_setup) ctx->D.upd_impl = (int)v; }
+  else if (f == "upd_wps") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "upd_wps must be set before setup"); ctx->tun_wps = (int)v; }
   else if (f == "upd_debug") { if (ctx->ran_setup) ctx->D.upd_debug = (int)v; }
   else if (f == "upd_tpw") { ctx->tun_tpw = (int)v; if (ctx->ran_setup) ctx->D.upd_tpw = (int)(v < 1 ? 1 : v); }
   else return fail(ctx, HMX_ERR_ARG, "unknown or read-only field: " + f);
@@ -828,7 +805,17 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   D.NQ = (D.NCT + 3) / 4; D.NT4 = D.zs / 16; D.tail = (D.zs - 16 * D.NT4) / 4; D.NS = 4 * D.NT4 + D.tail;
   { const char* e = getenv("HMX_UPDATE_IMPL"); D.upd_impl = ctx->tun_impl >= 0 ? ctx->tun_impl : ((e && std::string(e) == "v1") ? 1 : 0); }
   { const char* e = getenv("HMX_UPD_THREADS"); D.upd_threads = (e && atoi(e) == 256) ? 256 : 512; }
-  { const char* e = getenv("HMX_UPD_MAXBLOCKS"); D.upd_maxblocks = e ? atoi(e) : (D.upd_threads == 512 ? 256 : 512); if (D.upd_maxblocks < 1) D.upd_maxblocks = 1; }
+  { // uniform sigma (the reference's default): scalar-constant kernel variants; with K <= 64 they also fit the register
+    // budget of 4 waves per SIMD (1024-thread workgroups) -- measured 16 % faster per launch than 2 waves at K = 64
+    bool usig = true; for (int k = 1; k < K; k++) usig = usig && ctx->sigma[k] == ctx->sigma[0];
+    { const char* e = getenv("HMX_USIG"); if (e && atoi(e) == 0) usig = false; }
+    D.usig = usig ? 1 : 0;
+    const char* e = getenv("HMX_UPD_WPS");
+    int w = ctx->tun_wps > 0 ? ctx->tun_wps : (e ? atoi(e) : 4);
+    if (w != 4 || !usig || D.NCT > 4 || D.upd_impl != 0) w = 2;
+    D.upd_wps = w;
+    if (w == 4) D.upd_threads = 1024; }
+  { const char* e = getenv("HMX_UPD_MAXBLOCKS"); D.upd_maxblocks = e ? atoi(e) : (D.upd_threads >= 512 ? 256 : 512); if (D.upd_maxblocks < 1) D.upd_maxblocks = 1; }
   D.upd_debug = 0;
   { const char* e = getenv("HMX_UPD_TPW"); D.upd_tpw = ctx->tun_tpw > 0 ? ctx->tun_tpw : (e ? atoi(e) : 1); if (D.upd_tpw < 1) D.upd_tpw = 1; }
   { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = ctx->tun_cpw > 0 ? ctx->tun_cpw : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
@@ -847,7 +834,6 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
   CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
-  CHK(dalloc(ctx, &D.Snew_all, (size_t)D.nb * D.nrep * B * K)); CHK(dalloc(ctx, &D.bar_counter, (size_t)4)); D.bar_error = D.bar_counter + 1;
   { long long* s3; CHK(dalloc(ctx, &s3, (size_t)3 * D.nrep * B * K)); for (int i = 0; i < 3; i++) D.Snew_set[i] = s3 + (size_t)i * D.nrep * B * K; }
   CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots));
   D.trace = nullptr;
@@ -896,11 +882,6 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   { const char* e = getenv("HMX_FUSED_FOLD");
     ctx->fused_ok = !(e && std::string(e) == "0") && D.upd_impl == 0 &&
                     (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024; }
-  { const char* e = getenv("HMX_ROUND_IMPL");
-    // default: one launch per block step.  "round": the persistent cooperative kernel k_round (measured: 5% faster at
-    // 100k cells, equal at 1M, 5% slower at 4M -- its grid barrier + redundant table rebuild cost ~20 us per step)
-    const bool want = (e && std::string(e) == "round") && (size_t)D.nb * D.nrep * B * K * 8 <= (size_t)256 << 20;
-    ctx->round_blocks = want ? round_max_blocks(D) : 0; }
   ctx->ran_setup = true;
   return hmx_restart(ctx);
 }
@@ -1079,9 +1060,6 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "n_combos") return scalar(ctx->Q);
   if (f == "subset_clusters") return scalar((double)ctx->subset_clusters);
   if (f == "skipped_clusters") return scalar((double)ctx->skipped_clusters);
-  if (f == "round:launches") return scalar((double)ctx->round_launches);
-  if (f == "round:fallbacks") return scalar((double)ctx->round_fallbacks);
-  if (f == "round:blocks") return scalar((double)ctx->round_blocks);
   if (f == "comm:calls") return scalar((double)ctx->comm_calls);
   if (f == "comm:bytes") return scalar((double)ctx->comm_bytes);
   if (f == "trace") {   // HMX_TRACE=1: raw per-wave stamps of the last block-update launch

@@ -32,6 +32,8 @@ struct Dev {
   float* Yimg;      // [NQ][NS][4][16][4] LDS image of the centroids in MFMA B-operand order
   int upd_impl;     // 0: MFMA tile kernel, 1: cluster-lane VALU kernel (v1)
   int upd_tpw;      // tiles per wave target of the MFMA update kernel
+  int upd_wps;      // waves per SIMD the update/head kernels are built for: 2 | 4 (lean: uniform sigma, K <= 64)
+  int usig;         // all clusters share one sigma (scalar-constant kernel variants)
   int upd_debug;    // diagnostics only (see k_tile)
   int upd_threads;   // workgroup size of the update kernel (256 or 512)
   int upd_maxblocks; // grid cap of the update kernel = workgroups resident at once (HMX_UPD_MAXBLOCKS)
@@ -55,8 +57,6 @@ struct Dev {
   long long* O_fx;    // [B][K] fixed-point O (exact sum of quantised R)
   long long* Snew_fx; // [nrep][B][K] contribution of the block being updated
   long long* Sold_fx; // [nb][B][K] old contribution of every block of this round
-  long long* Snew_all; // [nb][nrep][B][K] per-step replica slabs of the persistent round kernel (k_round)
-  unsigned* bar_counter; unsigned* bar_error;  // grid barrier state of k_round (zeroed before every launch)
   int fused_fold;      // 1: k_tile<.,0> rebuilds O' and the penalty table in its prologue (no k_foldpen launch per step)
   const long long* fold_prev;  // replica set written by the previous block update (read in the prologue)
   long long* fold_zero;        // replica set of the next block update (zeroed by workgroup 0)
@@ -128,8 +128,6 @@ void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long 
                long long* Szero);
 void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
-int l_round(const Launch& L, const Dev& D, int blocks);
-int round_max_blocks(const Dev& D);
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
 void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);

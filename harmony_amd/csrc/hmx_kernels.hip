@@ -623,13 +623,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float dpp_f(float v, const int ctrl_id) {
   // ctrl_id: 0 quad_perm[1,0,3,2]  1 quad_perm[2,3,0,1]  2 row_half_mirror  3 row_mirror
+  // (old = 0 + bound_ctrl: every source lane is in range, and this form lets hipcc fold the move into v_add_f32_dpp)
   const int x = __float_as_int(v);
   int r;
   switch (ctrl_id) {
-    case 0: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); break;
-    case 1: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); break;
-    case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); break;
-    default: r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); break;
+    case 0: r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;
   }
   return __int_as_float(r);
 }
@@ -644,6 +645,24 @@ __device__ __forceinline__ float rowsum16(float v) {
 #else
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
   return v;
+#endif
+}
+
+// N independent row sums, the DPP steps interleaved (ILP N: see epi_rows)
+template <int N>
+__device__ __forceinline__ void rowsum16xN(float (&v)[N]) {
+#if HMX_USE_DPP
+#pragma unroll
+  for (int st = 0; st < 4; st++) {
+    float t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = (st == 0) ? dpp_f(v[i], 0) : (st == 1) ? dpp_f(v[i], 1) : (st == 2) ? dpp_f(v[i], 2) : dpp_f(v[i], 3);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += t[i];
+  }
+#else
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = rowsum16(v[i]);
 #endif
 }
 
@@ -784,8 +803,11 @@ constexpr int tile_threads(int nct) { return 256; }  // measured: 768-thread wor
 // MODE 1: head (static 16-cell tiles of the internal order, plain softmax)                 :141-150 / :221-227
 // Register budget: <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (12 per CU) are resident.
 // MODE 2: one Lloyd iteration of kmeans_centers (nearest centre, fixed-point sums in LDS)  src/utils.cpp:56-61
-template <int NCT, int MODE>
-__global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
+// WPS: waves per SIMD the register budget is cut for (update workgroup = 256*WPS threads).  USIG: one sigma for all clusters
+// (the reference's default, R/ui.R:219-221): ce / cl become scalars, 2-3 register arrays of NCT floats disappear.
+template <int NCT, int MODE, int WPS = 2, bool USIG = false>
+__global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
+  constexpr bool LEAN = WPS > 2;
   // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits):
   //   [ centroid image: NQ*NS*64 float4 | MODE 0: pen[B][K] + qlev[Q][C] (if they fit) | MODE 2: int64 sums[K][d] + counts[K] ]
   extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
@@ -826,7 +848,7 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   // LDS staging below, so the two dependent HBM round trips overlap with it
   // Software pipeline over tiles (when the rows fit in registers, D.NT4 <= 4): cell ids two tiles ahead, embedding rows
   // one tile ahead.  MODE 0 requests the first tile's ids and rows BEFORE the LDS staging below.
-  const bool pre = D.NT4 <= 4 && NCT <= 12;   // (K > 192: the extra row registers would spill)
+  const bool pre = !LEAN && D.NT4 <= 4 && NCT <= 10;   // (K > 160: the extra row registers would spill)
   // (cell id, combination) of this lane's A-operand row, ONE vector load per tile: a separate uniform load of the tile's
   // combination ends in a readfirstlane right behind the load, i.e. a vmcnt(0) -- a drain of the 28 outstanding R stores
   // of the previous tile plus a full memory latency -- in every iteration.
@@ -883,18 +905,25 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   const float* penT = (MODE == 0 && (D.pen_lds || D.fused_fold)) ? ldsPen : D.pen;
   const int* qlevT = (MODE == 0 && (D.pen_lds || D.fused_fold)) ? ldsQlev : D.qlev;
   long long* snew = D.Snew_fx + (size_t)(wave & (D.nrep - 1)) * D.B * K;  // this wave's table replica
-  // per-lane cluster constants: exp(-dist/sigma) = exp2(dist * ce), ce = -log2(e)/sigma;
-  // sigma r ln r = r log2(r) * cl, cl = sigma ln 2 -> one v_exp_f32 / v_log_f32 per value
-  float ce[NCT], cl[NCT], penv[NCT];
+  // per-lane cluster constants: exp(-dist/sigma) = exp2(dist * ce), ce = -log2(e)/sigma;  sigma r ln r = cl r log2 r,
+  // cl = sigma ln 2;  lpen = log2(penalty of the current combination), clp = cl * lpen (general sigma only).
+  constexpr int NSIG = USIG ? 1 : NCT;
+  float ce[NSIG], cl[NSIG], clp[NSIG], lpen[NCT];
   unsigned long long oacc[NCT];
 #pragma unroll
   for (int ct = 0; ct < NCT; ct++) {
     const bool kv = 16 * ct + c < K;
     const size_t ks = (size_t)min(16 * ct + c, K - 1);
-    if constexpr (MODE == 2) { ce[ct] = ld_or(D.ynorm, ks, kv, 0.0f); cl[ct] = 0.0f; }
-    else { ce[ct] = ld_or(D.ce, ks, kv, 0.0f); cl[ct] = ld_or(D.cl, ks, kv, 0.0f); }
-    penv[ct] = 1.0f; oacc[ct] = 0ull;
+    if (ct < NSIG) {
+      if constexpr (MODE == 2) { ce[ct] = ld_or(D.ynorm, ks, kv, 0.0f); cl[ct] = 0.0f; }
+      else if constexpr (USIG) { ce[ct] = D.ce[0]; cl[ct] = D.cl[0]; }
+      else { ce[ct] = ld_or(D.ce, ks, kv, 0.0f); cl[ct] = ld_or(D.cl, ks, kv, 0.0f); }
+      clp[ct] = 0.0f;
+    }
+    lpen[ct] = 0.0f; oacc[ct] = 0ull;
   }
+  auto CE = [&](int ct) -> float { return ce[USIG ? 0 : ct]; };
+  auto CL = [&](int ct) -> float { return cl[USIG ? 0 : ct]; };
   double od = 0.0, oe = 0.0;
   int curq = -1;
   // ---- per-tile stages ------------------------------------------------------------------------------------------
@@ -907,6 +936,7 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
       if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
       curq = q0;
       if constexpr (MODE == 0) {
+        float penv[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
         for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
@@ -914,48 +944,82 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
 #pragma unroll
           for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(penT, (size_t)b * K + min(16 * ct + c, K - 1), 16 * ct + c < K, 0.0f);
         }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) { lpen[ct] = __builtin_amdgcn_logf(fmaxf(penv[ct], FLT_MIN)); if constexpr (!USIG) clp[ct] = cl[ct] * lpen[ct]; }
       }
     }
   };
-  // epi_reg: accumulator register `reg` = row 4g+reg of the tile (its cell id lives in lane 4g+reg of cellA).  Branch
-  // free: invalid rows / padded clusters store into the dummy row behind R, so no exec-mask branch splits the region.
-  auto epi_reg = [&](const int reg, const int cellA, f32x4 (&acc)[NCT]) {
-    const int cell = __shfl(cellA, 4 * g + reg, 64);
-    const bool cv = cell >= 0;
-    float* Rrow = D.R + (size_t)(cv ? cell : D.n) * K;
-    float* Rdum = D.R + (size_t)D.n * K;
-    // exp(-dist/sigma) [x penalty], ONE L1 normalisation: the reference normalises, multiplies by the penalty and
-    // normalises again (:141-150, :322-326); the first division cancels in the second, so it is not computed
-    // (identical up to fp32 rounding, ~1e-7 relative).  Only the cluster tiles from first_partial_ct on can hold k >= K.
-    float r[NCT];
-    float s1 = 0.0f;
+  // epi_rows: the four accumulator registers (rows 4g..4g+3 of the tile; their cell ids live in lanes 4g+reg of cellA)
+  // TOGETHER, stage by stage: a gfx950 wave issues a dependent VALU instruction only every ~26 cycles (measured,
+  // tools/ubench/issue.hip) and few waves share a SIMD here, so the code must carry its own instruction-level
+  // parallelism -- up to 28 independent values per stage instead of one row after the other.
+  //   t_k   = x_k ce_k + log2 pen_k,  e_k = exp2(t_k)      x_k = 2 - 2 z.y_k                   (:141-150, :318-322)
+  //   r_k   = e_k / sum_k e_k                   (ONE L1 normalisation: the reference's first one cancels, :323-326)
+  //   sum_k r_k x_k              = inv * sum e_k x_k                                       (objective_kmeans_dist, :160)
+  //   sum_k sigma_k r_k ln r_k   = inv * sum cl_k e_k (t_k + log2 inv)                     (entropy, :161; log2 r_k = t_k + log2 inv)
+  //        uniform sigma:  = inv cl (ce sum e_k x_k + sum e_k lpen_k + log2(inv) sum e_k)
+  //        general sigma:  = inv (sum e_k clp_k - sum e_k x_k + log2(inv) sum e_k cl_k)     (cl_k ce_k = -1)
+  //   -- no logarithm per value, one per row
+  auto epi_rows = [&](const int cellA, f32x4 (&acc)[NCT]) {
+    constexpr int RB = (NCT <= 7 && !LEAN) ? 4 : 2;   // rows per batch: all four while the registers last
 #pragma unroll
-    for (int ct = 0; ct < NCT; ct++) {
-      float e = __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]);
-      if constexpr (MODE == 0) e *= penv[ct];
-      if (ct >= first_partial_ct(NCT)) e = (16 * ct + c < K) ? e : 0.0f;
-      r[ct] = e;
-      s1 += e;
-    }
-    s1 = rowsum16(s1);
-    float i2 = __builtin_amdgcn_rcpf(s1);
-    i2 = i2 * fmaf(-s1, i2, 2.0f);               // one Newton step: <= 1 ulp
-    i2 = (s1 == 0.0f) ? 1.0f : i2;
-    float pd = 0.0f, pe = 0.0f;
+    for (int r0 = 0; r0 < 4; r0 += RB) {
+      float se[RB], sx[RB], sp[RB], sc[RB];   // sums of e, e x, e lpen (or e clp), e (lane local) (or e cl)
+      float* Rrow[RB];
+      bool cv[RB];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ct++) {
-      const float rn = r[ct] * i2;
-      float* dst = (ct < first_partial_ct(NCT) || 16 * ct + c < K) ? Rrow + 16 * ct + c : Rdum + c;
+      for (int i = 0; i < RB; i++) {
+        const int cell = __shfl(cellA, 4 * g + r0 + i, 64);
+        cv[i] = cell >= 0;
+        Rrow[i] = D.R + (size_t)(cv[i] ? cell : D.n) * K + c;   // invalid rows: the dummy row behind R (zeros)
+        se[i] = 0.0f; sx[i] = 0.0f; sp[i] = 0.0f; sc[i] = 0.0f;
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
+          const float x = fmaf(acc[ct][r0 + i], -2.0f, 2.0f);
+          float e = __builtin_amdgcn_exp2f((MODE == 0) ? fmaf(x, CE(ct), lpen[ct]) : x * CE(ct));
+          if (ct >= first_partial_ct(NCT)) e = (16 * ct + c < K) ? e : 0.0f;
+          acc[ct][r0 + i] = e;
+          se[i] += e;
+          sx[i] = fmaf(e, x, sx[i]);
+          if constexpr (MODE == 0) sp[i] = fmaf(e, USIG ? lpen[ct] : clp[USIG ? 0 : ct], sp[i]);
+          if constexpr (!USIG) sc[i] = fmaf(e, CL(ct), sc[i]);
+        }
+      }
+      if constexpr (USIG) {
+#pragma unroll
+        for (int i = 0; i < RB; i++) sc[i] = se[i];   // this lane's own sum, before the row reduction
+      }
+      rowsum16xN<RB>(se);
+      float inv[RB], pd = 0.0f, pe = 0.0f;
+#pragma unroll
+      for (int i = 0; i < RB; i++) {
+        float i2 = __builtin_amdgcn_rcpf(se[i]);
+        i2 = i2 * fmaf(-se[i], i2, 2.0f);               // one Newton step: <= 1 ulp
+        i2 = (se[i] == 0.0f) ? 1.0f : i2;
+        const float linv = __builtin_amdgcn_logf(i2);
+        i2 = cv[i] ? i2 : 0.0f;                          // padding rows contribute exactly nothing
+        inv[i] = i2;
+        pd = fmaf(i2, sx[i], pd);
+        if constexpr (USIG) pe = fmaf(i2 * CL(0), fmaf(CE(0), sx[i], fmaf(linv, sc[i], sp[i])), pe);
+        else pe = fmaf(i2, fmaf(linv, sc[i], sp[i] - sx[i]), pe);
+      }
+      od += (double)pd; oe += (double)pe;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
+          const float rn = acc[ct][r0 + i] * inv[i];
 #ifdef HMX_TRACE
-      if (!(D.upd_debug & 4))   // timing experiment: no R stores
+          if (!(D.upd_debug & 4))   // timing experiment: no R stores
 #endif
-      *dst = rn;
-      const float rv = cv ? rn : 0.0f;  // exactly 0 for k >= K
-      oacc[ct] += fx_of(rv);
-      pd = fmaf(rv, fmaf(acc[ct][reg], -2.0f, 2.0f), pd);
-      pe = fmaf(rv * __builtin_amdgcn_logf(fmaxf(rv, FLT_MIN)), cl[ct], pe);
+          if (ct < first_partial_ct(NCT) || 16 * ct + c < K) Rrow[i][16 * ct] = rn;
+          oacc[ct] += fx_of(rn);
+        }
+      }
     }
-    od += (double)pd; oe += (double)pe;
   };
   // epilogue of a tile whose distances are in `acc`
   auto epilogue = [&](const int cellA, const int q0, f32x4 (&acc)[NCT]) {
@@ -989,11 +1053,10 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
       }
     } else {
       epi_begin(q0);
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) epi_reg(reg, cellA, acc);
+      epi_rows(cellA, acc);
     }
   };
-  constexpr bool DUAL = NCT <= 8;  // two accumulator sets fit the 256-VGPR budget (2 waves/SIMD) only up to K = 128
+  constexpr bool DUAL = !LEAN && NCT <= 7;  // two accumulator sets fit the 256-VGPR budget (2 waves/SIMD) only up to K = 112
   auto next_rows = [&](const int2 nxt, const int2 cur) {  // row address of the NEXT tile's lane (any valid row if padding)
     return D.Zc + (size_t)(nxt.x >= 0 ? nxt.x : (cur.x >= 0 ? cur.x : 0)) * zs;
   };
@@ -1090,190 +1153,7 @@ __global__ __launch_bounds__(512) void k_tile(Dev D, int j) {
   }
 }
 
-// --------------------------------------------------------------------------------------
-// k_round: ONE persistent (cooperative) launch for all nb block steps of a clustering round (single-GPU path).
-//
-// The 20 block steps of update_R are a strict chain (block j's penalty needs the O left by block j-1).  As separate
-// launches every step pays a kernel ramp, a re-staging of the centroid image and a fold+penalty launch; here the
-// workgroups (one per CU, all resident) keep the image, O and the penalty table in LDS for the whole round and
-// meet at ONE grid barrier per step:
-//   step j:  every workgroup recomputes  O_j = O_{j-1} + new(j-1) - old(j)  and pen_j in its own LDS (redundant, ~1000
-//            entries) from the per-step replica slab Snew_all[j-1] -> no table has to be published between workgroups
-//            -> tiles of block j (same MFMA body as k_tile<.,0>), contributions into the slab Snew_all[j] by atomics
-//            -> grid barrier.
-// Cross-workgroup data = the slabs only: written by agent-scope atomics, read after the barrier by agent-scope atomic
-// loads, each slab used in exactly one step and zeroed by a memset before the launch (MI355X_MICROARCH: "8-byte
-// agent atomics on both sides" is a valid hand-off form; every wave drains vmcnt before the workgroup arrives).
-// Spins are bounded: on timeout a flag is raised, every workgroup leaves, and the host falls back to the step path.
-// --------------------------------------------------------------------------------------
-__device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target, unsigned* errflag, int* ldsflag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave: its atomics / stores have been acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) {  // ldsflag lives in the dynamic LDS object (a static __shared__ would shift its 16-byte base)
-    // NO release fence: the only cross-workgroup payload are agent-scope atomics (already acknowledged, see the
-    // vmcnt(0) above); a buffer_wbl2 here would force the write-back of the ~80 KB of R rows this workgroup just
-    // stored -- data nobody reads before the kernel ends.
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    int ok = 1;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > 2000000u || __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    *ldsflag = ok;
-  }
-  __syncthreads();
-  return *ldsflag != 0;
-}
 
-template <int NCT>
-__global__ __launch_bounds__(512) void k_round(Dev D) {
-  // LDS: [ centroid image | O_cur int64 [B][K] | pen float [B][K] | qlev int [Q][C] ]   (one object, see k_tile)
-  extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
-  const int K = D.K, C = D.C, zs = D.zs, B = D.B, nBK = D.B * D.K;
-  const int nY4 = D.NQ * D.NS * 64;
-  long long* ldsO = reinterpret_cast<long long*>(lds4 + nY4);
-  float* ldsPen = reinterpret_cast<float*>(ldsO + nBK);
-  int* ldsQlev = reinterpret_cast<int*>(ldsPen + ((nBK + 3) & ~3));
-  int* ldsFlag = ldsQlev + D.Q * C;
-  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
-    for (int i = threadIdx.x; i < nY4; i += blockDim.x) lds4[i] = src[i];
-    for (int i = threadIdx.x; i < nBK; i += blockDim.x) ldsO[i] = D.O_fx[i];
-    for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
-  }
-  float ce[NCT], cl[NCT], penv[NCT];
-  unsigned long long oacc[NCT];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ct++) {
-    const bool kv = 16 * ct + c < K;
-    const size_t ks = (size_t)min(16 * ct + c, K - 1);
-    ce[ct] = ld_or(D.ce, ks, kv, 0.0f); cl[ct] = ld_or(D.cl, ks, kv, 0.0f);
-    penv[ct] = 1.0f; oacc[ct] = 0ull;
-  }
-  double od = 0.0, oe = 0.0;
-  const size_t slab = (size_t)D.nrep * nBK;
-  // first tile of the NEXT step (cell ids + first 16 bytes of their rows): requested before the grid barrier, these
-  // loads depend on nothing another workgroup produces
-  int cellPre = -1;
-  f32x4 zpre = {0.f, 0.f, 0.f, 0.f};
-  {
-    const int p0 = D.boff[0], nt0 = (D.boff[1] - p0) >> 4;
-    if (wave < nt0) {
-      cellPre = D.lorder[p0 + 16 * wave + c];
-      if (D.NT4 > 0) zpre = *reinterpret_cast<const f32x4*>(D.Zc + (size_t)(cellPre >= 0 ? cellPre : 0) * zs + 4 * g);
-    }
-  }
-  for (int j = 0; j <= D.nb; j++) {
-    // ---- O_j and penalty table in LDS (every workgroup computes the same values)
-    __syncthreads();
-    const long long* prev = (j > 0) ? D.Snew_all + (size_t)(j - 1) * slab : nullptr;
-    const long long* sold = (j < D.nb) ? D.Sold_fx + (size_t)j * nBK : nullptr;
-    for (int i = threadIdx.x; i < nBK; i += blockDim.x) {
-      long long o = ldsO[i];
-      if (prev) {
-        long long v[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++)   // agent-scope (sc1) loads, issued back to back: "8-byte agent atomics on both sides"
-          v[r] = __hip_atomic_load(&prev[(size_t)min(r, D.nrep - 1) * nBK + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int r = 0; r < 8; r++) if (r < D.nrep) o += v[r];
-      }
-      if (sold) o -= sold[i];
-      ldsO[i] = o;
-    }
-    __syncthreads();
-    if (j == D.nb) break;
-    for (int i = threadIdx.x; i < nBK; i += blockDim.x) {
-      const int b = i / K, k = i - b * K;
-      long long rs = 0;
-      for (int b0 = 0; b0 < D.B0; b0++) rs += ldsO[b0 * K + k];
-      const float of = (float)((double)ldsO[i] * FX_INV);
-      const float ef = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
-      ldsPen[i] = powf(((2.0f * ef) + 1.0f) / (of + ef + 1.0f), D.theta[b]);
-    }
-    __syncthreads();
-    // ---- tiles of block j, dealt round-robin over all waves of the grid
-    const int p0 = D.boff[j];
-    const int ntiles = (D.boff[j + 1] - p0) >> 4;
-    long long* snew = D.Snew_all + (size_t)j * slab + (size_t)(wave & (D.nrep - 1)) * nBK;
-    int curq = -1;
-    const int t0 = wave;
-    int cellN = cellPre;
-    for (int tile = t0; tile < ntiles; tile += nw) {
-      const int pbase = p0 + 16 * tile;
-      const int cellA = cellN;
-      if (tile + nw < ntiles) cellN = D.lorder[pbase + 16 * nw + c];
-      const int q0 = D.lcombo[pbase];
-      f32x4 acc[NCT];
-      tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA >= 0 ? cellA : 0) * zs, cellA >= 0, g, lane, D.NS, D.NT4, D.tail, acc,
-                     tile == t0 && D.NT4 > 0, zpre);
-      if (q0 != curq) {
-        if (curq >= 0) flush_tile_fx<NCT>(snew, ldsQlev, curq, C, K, c, g, oacc);
-        curq = q0;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
-        for (int cc = 0; cc < C; cc++) {
-          const int b = ldsQlev[q0 * C + cc];
-#pragma unroll
-          for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(ldsPen, (size_t)b * K + min(16 * ct + c, K - 1), 16 * ct + c < K, 0.0f);
-        }
-      }
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int cell = __shfl(cellA, 4 * g + reg, 64);
-        const bool cv = cell >= 0;
-        float* Rrow = D.R + (size_t)(cv ? cell : 0) * K;
-        float r[NCT];   // same arithmetic as k_tile's epi_reg (bit-identical R: tests compare the two paths exactly)
-        float s1 = 0.0f;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++) {
-          float e = __builtin_amdgcn_exp2f(fmaf(acc[ct][reg], -2.0f, 2.0f) * ce[ct]);
-          e *= penv[ct];
-          if (ct >= first_partial_ct(NCT)) e = (16 * ct + c < K) ? e : 0.0f;
-          r[ct] = e;
-          s1 += e;
-        }
-        s1 = rowsum16(s1);
-        float i2 = __builtin_amdgcn_rcpf(s1);
-        i2 = i2 * fmaf(-s1, i2, 2.0f);
-        i2 = (s1 == 0.0f) ? 1.0f : i2;
-        float pd = 0.0f, pe = 0.0f;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++) {
-          const float rn = r[ct] * i2;
-          if (cv && 16 * ct + c < K) Rrow[16 * ct + c] = rn;
-          const float rv = cv ? rn : 0.0f;
-          oacc[ct] += fx_of(rv);
-          pd = fmaf(rv, fmaf(acc[ct][reg], -2.0f, 2.0f), pd);
-          pe = fmaf(rv * __builtin_amdgcn_logf(fmaxf(rv, FLT_MIN)), cl[ct], pe);
-        }
-        od += (double)pd; oe += (double)pe;
-      }
-    }
-    if (curq >= 0) flush_tile_fx<NCT>(snew, ldsQlev, curq, C, K, c, g, oacc);
-    cellPre = -1;
-    if (j + 1 < D.nb) {
-      const int pn = D.boff[j + 1], ntn = (D.boff[j + 2] - pn) >> 4;
-      if (wave < ntn) {
-        cellPre = D.lorder[pn + 16 * wave + c];
-        if (D.NT4 > 0) zpre = *reinterpret_cast<const f32x4*>(D.Zc + (size_t)(cellPre >= 0 ? cellPre : 0) * zs + 4 * g);
-      }
-    }
-    if (!grid_barrier(D.bar_counter, (unsigned)gridDim.x * (unsigned)(j + 1), D.bar_error, ldsFlag)) return;
-  }
-  // ldsO now holds the O left by the last block: publish it (next kernels read it after the kernel boundary)
-  if (blockIdx.x == 0) for (int i = threadIdx.x; i < nBK; i += blockDim.x) D.O_fx[i] = ldsO[i];
-  od = wsumd(od); oe = wsumd(oe);
-  if (lane == 0) { D.objpart[2 * wave] += od; D.objpart[2 * wave + 1] += oe; }
-}
 
 // cross-entropy term of the objective from the K x B tables alone (src/harmony.cpp:162):
 //   sum_k sigma_k sum_b theta_b log((O+E+1)/(2E+1)) * O[k,b]     (O[k,b] = sum_{i in b} R_ki)
@@ -1779,14 +1659,25 @@ void l_tile_static(const Launch& L, const Dev& D, int mode) {
   if (mode == 2) { lds += ((size_t)D.K * D.d + D.K) * sizeof(long long); if (blocks > 512) blocks = 512; }
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
-#define HMX_TS(N) case N: if (mode == 1) hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
-                          else hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); break;
+  // head / Lloyd.  Head variants: general sigma | uniform sigma (D.usig) | uniform sigma at 4 waves per SIMD (K <= 64)
+#define HMX_TS(N) case N: if (mode == 2) hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
+                          else if (D.usig) hipLaunchKernelGGL((k_tile<N, 1, 2, true>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
+                          else hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); break;
+#define HMX_TSL(N) case N: hipLaunchKernelGGL((k_tile<N, 1, 4, true>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); break;
+  if (mode == 1 && D.upd_wps == 4) {
+    switch (D.NCT) {
+      HMX_TSL(1) HMX_TSL(2) HMX_TSL(3) HMX_TSL(4)
+      default: break;
+    }
+    return;
+  }
   switch (D.NCT) {
     HMX_TS(1) HMX_TS(2) HMX_TS(3) HMX_TS(4) HMX_TS(5) HMX_TS(6) HMX_TS(7) HMX_TS(8)
     HMX_TS(10) HMX_TS(12) HMX_TS(14) HMX_TS(16)
     default: break;
   }
 #undef HMX_TS
+#undef HMX_TSL
 }
 void l_head(const Launch& L, const Dev& D, int mode) {
   const dim3 grid(stream_grid(L, D.nitems));
@@ -1852,48 +1743,23 @@ void l_update(const Launch& L, const Dev& D, int j) {
   const dim3 grid((unsigned)blocks);
   const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + (D.fused_fold ? (size_t)D.B * D.K * 8 : 0) +
                      ((D.pen_lds || D.fused_fold) ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
-#define HMX_UPD(N) case N: hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(D.upd_threads), lds, L.stream, D, j); break;
+#define HMX_UPDL(N) case N: hipLaunchKernelGGL((k_tile<N, 0, 4, true>), grid, dim3(1024), lds, L.stream, D, j); break;
+  if (D.upd_wps == 4) {   // hmx_setup: upd_threads == 1024, uniform sigma, K <= 64
+    switch (D.NCT) {
+      HMX_UPDL(1) HMX_UPDL(2) HMX_UPDL(3) HMX_UPDL(4)
+      default: break;
+    }
+    return;
+  }
+#undef HMX_UPDL
+#define HMX_UPD(N) case N: if (D.usig) hipLaunchKernelGGL((k_tile<N, 0, 2, true>), grid, dim3(D.upd_threads), lds, L.stream, D, j); \
+                           else hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(D.upd_threads), lds, L.stream, D, j); break;
   switch (D.NCT) {
     HMX_UPD(1) HMX_UPD(2) HMX_UPD(3) HMX_UPD(4) HMX_UPD(5) HMX_UPD(6) HMX_UPD(7) HMX_UPD(8)
     HMX_UPD(10) HMX_UPD(12) HMX_UPD(14) HMX_UPD(16)
     default: break;
   }
 #undef HMX_UPD
-}
-// returns hipSuccess, or the launch error (the caller then falls back to the step-by-step path)
-int l_round(const Launch& L, const Dev& D, int blocks) {
-  const size_t nBK = (size_t)D.B * D.K;
-  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + nBK * 8 + ((nBK + 3) & ~(size_t)3) * 4 + (size_t)D.Q * D.C * 4 + 16;
-  Dev Dc = D;
-  void* args[] = {&Dc};
-  const void* fn = nullptr;
-#define HMX_RD(N) case N: fn = (const void*)k_round<N>; break;
-  switch (D.NCT) {
-    HMX_RD(1) HMX_RD(2) HMX_RD(3) HMX_RD(4) HMX_RD(5) HMX_RD(6) HMX_RD(7) HMX_RD(8)
-    HMX_RD(10) HMX_RD(12) HMX_RD(14) HMX_RD(16)
-    default: return (int)hipErrorInvalidValue;
-  }
-#undef HMX_RD
-  return (int)hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(512), args, (unsigned)lds, L.stream);
-}
-// largest cooperative grid (workgroups) for k_round, 0 if it cannot run (LDS budget, occupancy)
-int round_max_blocks(const Dev& D) {
-  const size_t nBK = (size_t)D.B * D.K;
-  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + nBK * 8 + ((nBK + 3) & ~(size_t)3) * 4 + (size_t)D.Q * D.C * 4 + 16;
-  if (lds > 150 * 1024) return 0;
-  const void* fn = nullptr;
-#define HMX_RD(N) case N: fn = (const void*)k_round<N>; break;
-  switch (D.NCT) {
-    HMX_RD(1) HMX_RD(2) HMX_RD(3) HMX_RD(4) HMX_RD(5) HMX_RD(6) HMX_RD(7) HMX_RD(8)
-    HMX_RD(10) HMX_RD(12) HMX_RD(14) HMX_RD(16)
-    default: return 0;
-  }
-#undef HMX_RD
-  int per_cu = 0, dev = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, lds) != hipSuccess || per_cu < 1) return 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  return prop.multiProcessorCount;  // one workgroup per CU (even if more would fit): all resident by construction
 }
 void l_objective_tables(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);

@@ -306,30 +306,6 @@ def test_torch_nccl_hook_single_rank():
     assert "HOOK_PROBE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
 
 
-def test_persistent_round_kernel_parity(cell_lines, monkeypatch):
-    """HMX_ROUND_IMPL=round: all block steps of a clustering round in ONE cooperative launch (k_round, grid barrier
-    per step).  Same parity bar as the default step-by-step path, and bit-identical O tables."""
-    Z, meta, _ = synth(60000, d=50, levels=(10,), seed=77)
-    res = {}
-    for impl in ("steps", "round"):
-        monkeypatch.setenv("HMX_ROUND_IMPL", impl)
-        skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
-        g = Harmony(seed=9)
-        g.setup(**skw)
-        g.init_cluster_cpp()
-        assert g.cluster_cpp() == 0
-        g.moe_correct_ridge_cpp()
-        assert g.cluster_cpp() == 0
-        res[impl] = (g.O, g.getZcorr(), g.objective_kmeans, int(g._scalar("round:launches")))
-    assert res["steps"][3] == 0 and res["round"][3] == 8
-    np.testing.assert_array_equal(res["steps"][0], res["round"][0])
-    np.testing.assert_allclose(res["steps"][2], res["round"][2], rtol=1e-6)
-    assert relfro(res["round"][1], res["steps"][1]) < 1e-6
-    monkeypatch.setenv("HMX_ROUND_IMPL", "round")
-    g, c, ig, ic = run_both(cell_lines["pcs"], _meta(cell_lines), ["cell_type", "dataset"], max_iter=3, theta=[1, 1], nclust=50)
-    assert_parity(g, c, ig, ic)
-
-
 @pytest.mark.parametrize("N,d,K,levels,nested", [
     (20000, 50, 200, (8, 64, 128), True),   # BASELINE configs[4] scaled down: 3 nested covariates, 200 levels, K=200
     (3000, 128, 256, (3,), False),          # the envelope's corner: d = 128, K = 256

@@ -42,7 +42,7 @@ def report():
 
 g.cluster_cpp()
 print(f"N={N} K={K} B={B}")
-for dbg in (0, 4, 6, 2):
+for dbg in (0, 4, 6, 2, 3, 1):
     g._set("upd_debug", dbg)
     g._set("profile", 1)
     g.cluster_cpp()
