@@ -817,6 +817,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
     if (w == 4) D.upd_threads = 1024; }
   { const char* e = getenv("HMX_UPD_MAXBLOCKS"); D.upd_maxblocks = e ? atoi(e) : (D.upd_threads >= 512 ? 256 : 512); if (D.upd_maxblocks < 1) D.upd_maxblocks = 1; }
   D.upd_debug = 0;
+  { const char* e = getenv("HMX_OLDSUM_IMPL"); D.oldsum_stream = (e && std::string(e) == "gather") ? 0 : (e && std::string(e) == "stream1") ? 2 : 1; }   // 1: 16-byte stream, 2: dword stream
   { const char* e = getenv("HMX_UPD_TPW"); D.upd_tpw = ctx->tun_tpw > 0 ? ctx->tun_tpw : (e ? atoi(e) : 1); if (D.upd_tpw < 1) D.upd_tpw = 1; }
   { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = ctx->tun_cpw > 0 ? ctx->tun_cpw : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
   std::vector<Item> schunks; std::vector<int> qchunk((size_t)Q + 1, 0);
@@ -1073,6 +1074,8 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
     }
     return n;
   }
+  if (f == "usig") return scalar((double)ctx->D.usig);
+  if (f == "upd_wps") return scalar((double)ctx->D.upd_wps);
   if (f == "prof:update_ms") return scalar(ctx->prof_update_ms);
   if (f == "prof:update_launches") return scalar((double)ctx->prof_update_launches);
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);

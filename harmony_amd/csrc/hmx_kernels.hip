@@ -21,6 +21,7 @@
 #endif
 
 namespace hmx {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // --------------------------------------------------------------------------------------
 // device helpers
@@ -59,6 +60,15 @@ __device__ __forceinline__ float trunc_logf_dev(float x) {  // arma::trunc_log (
 }
 __device__ __forceinline__ unsigned long long fx_of(float r) {  // R in [0,1] -> 31-bit fixed point
   return (unsigned long long)__float2uint_rn(r * FX_SCALE);
+}
+
+// diversity penalty ((2E+1)/(O+E+1))^theta (src/harmony.cpp:319-321) with a SHORT dependent chain: rcp, mul, log2, mul, exp2
+// (~2e-7 relative; powf's ~100 dependent instructions cost >1 us in the serial prologue of every block step at gfx950's
+// 26-cycle dependent-issue latency).  ONE definition for the fused and the stand-alone fold kernels: the sharded and the
+// single-GPU paths must produce bit-identical penalty tables.
+__device__ __forceinline__ float pen_pow(float num, float den, float theta) {
+  const float x = num * __builtin_amdgcn_rcpf(den);
+  return __builtin_amdgcn_exp2f(theta * __builtin_amdgcn_logf(x));
 }
 
 // counter-based generators -- same SPEC as include/harmony_mi355x.h documents
@@ -398,9 +408,12 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
 //   k_update   the block's cells: R <- normalise(exp(-dist/sigma)); R *= penalty; normalise;
 //              accumulate the new contribution (:318-330) and the objective partials (:160-161)
 // --------------------------------------------------------------------------------------
+#ifndef HMX_OLDSUM_CB
+#define HMX_OLDSUM_CB 4
+#endif
 template <int KPL>
 __global__ __launch_bounds__(TPB) void k_oldsum(Dev D) {
-  constexpr int CB = 4;
+  constexpr int CB = HMX_OLDSUM_CB;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
   const int K = D.K;
@@ -438,6 +451,128 @@ __global__ __launch_bounds__(TPB) void k_oldsum(Dev D) {
     }
   }
   if (curq >= 0) flush_fx<KPL>(D.Sold_fx + (size_t)curb * D.B * K, D.qlev, curq, D.C, K, lane, oacc);
+}
+
+// k_oldsum_stream: the same sums, but R is read in INTERNAL cell order -- a pure sequential stream of the K-float rows
+// instead of a gather through this round's sorted order.  The target table of a cell depends on its block id, so the
+// accumulators live in LDS ([nb][K] 64-bit fixed point, ds_add_u64; the 64 lanes of a wave hit 64 different clusters of
+// one block: conflict free) and are flushed with global atomics when the combination changes and at the end of the
+// workgroup's contiguous range of sort chunks (<= SORT_CHUNK cells of one combination each).  Integer sums: exact,
+// order independent, identical to k_oldsum's.
+template <int KPL>
+__global__ __launch_bounds__(256) void k_oldsum_stream(Dev D) {
+  extern __shared__ unsigned long long otab[];   // [nb][K]
+  const int K = D.K, nT = D.nb * K;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cpw = (D.nchunks + gridDim.x - 1) / gridDim.x;
+  const int c0 = blockIdx.x * cpw, c1 = min(D.nchunks, c0 + cpw);
+  if (c0 >= c1) return;
+  for (int i = threadIdx.x; i < nT; i += blockDim.x) otab[i] = 0ull;
+  __syncthreads();
+  auto flush = [&](int q) {   // + zero
+    for (int i = threadIdx.x; i < nT; i += blockDim.x) {
+      const unsigned long long v = otab[i];
+      if (v) {
+        const int blk = i / K, k = i - blk * K;
+        for (int cc = 0; cc < D.C; cc++)
+          atomicAdd((unsigned long long*)&D.Sold_fx[((size_t)blk * D.B + D.qlev[q * D.C + cc]) * K + k], v);
+        otab[i] = 0ull;
+      }
+    }
+  };
+  int curq = D.schunks[c0].q;
+  for (int ch = c0; ch < c1; ch++) {
+    const Item it = D.schunks[ch];
+    if (it.q != curq) { __syncthreads(); flush(curq); __syncthreads(); curq = it.q; }
+    const int per = (it.cnt + 3) >> 2;                          // the chunk's cells: one contiguous quarter per wave
+    const int s = it.start + w * per, e = min(it.start + it.cnt, s + per);
+    for (int base = s; base < e; base += 64) {
+      const int n = min(64, e - base);
+      const int bv = D.blk[min(base + lane, e - 1)];           // block ids of the next 64 cells, one per lane
+      for (int u = 0; u < n; u += 8) {                          // eight rows (3.2 KB at K = 100) in flight per wave
+        float r[8][KPL];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const size_t row = (size_t)min(base + u + c, e - 1) * K;
+#pragma unroll
+          for (int q = 0; q < KPL; q++) r[c][q] = D.R[row + min(lane + 64 * q, K - 1)];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          if (u + c < n) {
+            const int b = __builtin_amdgcn_readlane(bv, u + c);
+#pragma unroll
+            for (int q = 0; q < KPL; q++)
+              if (lane + 64 * q < K) atomicAdd(&otab[b * K + lane + 64 * q], fx_of(r[c][q]));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  flush(curq);
+}
+
+// k_oldsum_stream4: as k_oldsum_stream for K % 4 == 0 -- the rows of a sort chunk are ONE contiguous run of floats, read
+// with 16-byte loads (four in flight per lane); a lane's four floats belong to one cell, whose block id selects the LDS row.
+// 1024-thread workgroups over ~4 chunks each: full occupancy with a quarter of the flush atomics (measured: the 4M global
+// atomics of one-chunk workgroups cost 32 of 128 us).
+__global__ __launch_bounds__(1024) void k_oldsum_stream4(Dev D) {
+  extern __shared__ unsigned long long otab[];   // [nb][K]
+  const int K = D.K, nT = D.nb * K;
+  const int cpw = (D.nchunks + gridDim.x - 1) / gridDim.x;
+  const int c0 = blockIdx.x * cpw, c1 = min(D.nchunks, c0 + cpw);
+  if (c0 >= c1) return;
+  for (int i = threadIdx.x; i < nT; i += blockDim.x) otab[i] = 0ull;
+  __syncthreads();
+  auto flush = [&](int q) {   // + zero
+    for (int i = threadIdx.x; i < nT; i += blockDim.x) {
+      const unsigned long long v = otab[i];
+      if (v) {
+        const int blk = i / K, k = i - blk * K;
+#ifndef HMX_OS_NOFLUSH
+        for (int cc = 0; cc < D.C; cc++)
+          atomicAdd((unsigned long long*)&D.Sold_fx[((size_t)blk * D.B + D.qlev[q * D.C + cc]) * K + k], v);
+#endif
+        otab[i] = 0ull;
+      }
+    }
+  };
+  const unsigned magic = (unsigned)((0x100000000ull + (unsigned)K - 1) / (unsigned)K);   // floor(n / K) = umulhi(n, magic), n < 2^32 / K
+  int curq = D.schunks[c0].q;
+  for (int ch = c0; ch < c1; ch++) {
+    const Item it = D.schunks[ch];
+    if (it.q != curq) { __syncthreads(); flush(curq); __syncthreads(); curq = it.q; }
+    const f32x4* src = reinterpret_cast<const f32x4*>(D.R + (size_t)it.start * K);
+    const int n4 = it.cnt * (K >> 2);                            // float4 groups of this chunk
+    for (int base = 0; base < n4; base += 4 * (int)blockDim.x) {
+      f32x4 v[4]; int bl[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int f = min(base + u * (int)blockDim.x + (int)threadIdx.x, n4 - 1);
+        v[u] = src[f];
+        bl[u] = D.blk[it.start + (int)__umulhi((unsigned)(4 * f), magic)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int f = base + u * (int)blockDim.x + (int)threadIdx.x;
+        if (f < n4) {
+          const int cell = (int)__umulhi((unsigned)(4 * f), magic);
+          unsigned long long* row = otab + bl[u] * K + (4 * f - cell * K);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+#ifdef HMX_OS_NOATOM   // timing experiment (tools/oldsum_cmp.sh): no LDS atomics
+            if (fx_of(v[u][e]) == 0x123456789ull) row[e] = 1;
+#else
+            atomicAdd(&row[e], fx_of(v[u][e]));
+#endif
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  flush(curq);
 }
 
 // fold the finished block into O and build the penalty table of block j (j < 0: fold only).
@@ -507,7 +642,7 @@ __global__ __launch_bounds__(256) void k_foldpen(Dev D, int j, const long long* 
     for (int b = threadIdx.x >> 4; b < B; b += 16) {
       const float of = (float)((double)shO[b * 16 + kk] * FX_INV);
       const float ef = (float)(rsd * (double)D.Pr_b[b]);
-      D.pen[(size_t)b * K + k] = powf(((2.0f * ef) + 1.0f) / (of + ef + 1.0f), D.theta[b]);
+      D.pen[(size_t)b * K + k] = pen_pow((2.0f * ef) + 1.0f, of + ef + 1.0f, D.theta[b]);
     }
 }
 __global__ void k_penalty(Dev D) {
@@ -520,7 +655,7 @@ __global__ void k_penalty(Dev D) {
   for (int b0 = 0; b0 < D.B0; b0++) rs += D.O_fx[(size_t)b0 * K + k];
   const float o = (float)((double)D.O_fx[i] * FX_INV);
   const float e = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
-  D.pen[i] = powf(((2.0f * e) + 1.0f) / (o + e + 1.0f), D.theta[b]);
+  D.pen[i] = pen_pow((2.0f * e) + 1.0f, o + e + 1.0f, D.theta[b]);
 }
 
 template <int KPL, int DPL>
@@ -619,7 +754,6 @@ __global__ __launch_bounds__(TPB) void k_update(Dev D, int j) {
 // row reductions, the penalty is a per-run register vector, O is accumulated per lane in
 // 64-bit fixed point and flushed once per run of equal covariate combination.
 // --------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float dpp_f(float v, const int ctrl_id) {
   // ctrl_id: 0 quad_perm[1,0,3,2]  1 quad_perm[2,3,0,1]  2 row_half_mirror  3 row_mirror
@@ -857,41 +991,97 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   auto tile_cell = [&](int tile) -> int2 {     // (-1, .): padding slot / beyond the end
     if (tile >= te) return make_int2(-1, -1);
     if constexpr (MODE == 0) return D.lpair[p0 + 16 * tile + c];
-    else { const Item it = D.titems[tile]; return make_int2((c < it.cnt) ? it.start + c : -1, it.q); }
+    else {
+      // keep this a per-lane (vector) load: with the uniform tile index hipcc would emit load + readfirstlane, i.e. a
+      // vmcnt(0) -- a full memory latency per tile that also drains the prefetched rows
+      const Item* tp = D.titems + tile;
+      asm volatile("" : "+v"(tp));
+      const Item it = *tp;
+      return make_int2((c < it.cnt) ? it.start + c : -1, it.q);
+    }
   };
-  if (ts < te) {
-    cellN = tile_cell(ts);
-    cellNN = tile_cell(ts + tstep);
-    if (pre) load_rows(D.Zc + (size_t)(cellN.x >= 0 ? cellN.x : 0) * zs, g, D.NT4, D.tail, rowsN);
-  }
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
-    for (int i = threadIdx.x; i < nY4; i += blockDim.x) lds4[i] = src[i];
-    if constexpr (MODE == 0) {
-      if (D.fused_fold) {
-        const long long* sold = D.Sold_fx + (size_t)j * nBK;
-        for (int i = threadIdx.x; i < nBK; i += blockDim.x) {
-          long long v[8];
+    // Staging.  Every global load of this prologue is ISSUED before the first one is consumed (the launch is a link of
+    // the block-step chain, its prologue a serial section): first the fold inputs -- replica tables written by the
+    // previous launch's atomics, i.e. L2 misses -- then the centroid image, then they are consumed in the same order.
+    constexpr int FE = 2;                     // fold entries per thread and chunk (B*K <= 2 * blockDim in one chunk)
+    const bool fold = (MODE == 0) && D.fused_fold;
+    const int bd = blockDim.x, tid = threadIdx.x;
+    long long fv[FE][10];
+    float fth[FE], fpr[FE];
+    const long long* sold = fold ? D.Sold_fx + (size_t)j * nBK : nullptr;
+    auto fold_issue = [&](int base) {
 #pragma unroll
-          for (int r = 0; r < 8; r++) v[r] = D.fold_prev[(size_t)min(r, D.nrep - 1) * nBK + i];
-          long long o = D.O_fx[i] - sold[i];
+      for (int e = 0; e < FE; e++) {
+        const int ic = min(base + tid + e * bd, nBK - 1);
 #pragma unroll
-          for (int r = 0; r < 8; r++) if (r < D.nrep) o += v[r];
+        for (int r = 0; r < 8; r++) fv[e][r] = D.fold_prev[(size_t)min(r, D.nrep - 1) * nBK + ic];
+        fv[e][8] = D.O_fx[ic]; fv[e][9] = sold[ic];
+        const int b = ic / K;
+        fth[e] = D.theta[b]; fpr[e] = D.Pr_b[b];
+      }
+    };
+    auto fold_consume = [&](int base) {
+#pragma unroll
+      for (int e = 0; e < FE; e++) {
+        const int i = base + tid + e * bd;
+        if (i < nBK) {
+          long long o = fv[e][8] - fv[e][9];
+#pragma unroll
+          for (int r = 0; r < 8; r++) if (r < D.nrep) o += fv[e][r];
           ldsO[i] = o;
           if (blockIdx.x == 0) {
             D.O_alt[i] = o;
             for (int r = 0; r < D.nrep; r++) D.fold_zero[(size_t)r * nBK + i] = 0;
           }
         }
-        for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
+      }
+    };
+    auto pen_entry = [&](int i, float th, float pr) {   // same arithmetic as k_foldpen (sharded path): tables must agree bitwise
+      const int b = i / K, k = i - b * K;
+      long long rs = 0;
+      for (int b0 = 0; b0 < D.B0; b0++) rs += ldsO[b0 * K + k];
+      const float of = (float)((double)ldsO[i] * FX_INV);
+      const float ef = (float)(((double)rs * FX_INV) * (double)pr);
+      ldsPen[i] = pen_pow((2.0f * ef) + 1.0f, of + ef + 1.0f, th);
+    };
+    if (fold) fold_issue(0);
+    const int nQC = D.Q * C;
+    int qlv0 = 0;
+    if (fold) qlv0 = D.qlev[min(tid, nQC - 1)];
+    if (ts < te) { cellN = tile_cell(ts); cellNN = tile_cell(ts + tstep); }   // first tiles' (cell, combination) pairs
+    const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
+    {   // first chunk straight-line (a loop header here would make hipcc drain the loads above before the first image load)
+      f32x4 t[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) t[k] = src[min(tid + k * bd, nY4 - 1)];
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (tid + k * bd < nY4) lds4[tid + k * bd] = t[k];
+    }
+    stamp(12);
+    if (ts < te && pre) load_rows(D.Zc + (size_t)(cellN.x >= 0 ? cellN.x : 0) * zs, g, D.NT4, D.tail, rowsN);
+    stamp(13);
+    for (int base = 4 * bd; base < nY4; base += 4 * bd) {
+      f32x4 t[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) t[k] = src[min(base + tid + k * bd, nY4 - 1)];
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (base + tid + k * bd < nY4) lds4[base + tid + k * bd] = t[k];
+    }
+    if constexpr (MODE == 0) {
+      if (D.fused_fold) {
+        fold_consume(0);
+        for (int base = FE * bd; base < nBK; base += FE * bd) { fold_issue(base); fold_consume(base); }
+        if (tid < nQC) ldsQlev[tid] = qlv0;
+        for (int i = tid + bd; i < nQC; i += bd) ldsQlev[i] = D.qlev[i];
+        stamp(14);
         __syncthreads();
-        for (int i = threadIdx.x; i < nBK; i += blockDim.x) {
-          const int b = i / K, k = i - b * K;
-          long long rs = 0;
-          for (int b0 = 0; b0 < D.B0; b0++) rs += ldsO[b0 * K + k];
-          const float of = (float)((double)ldsO[i] * FX_INV);
-          const float ef = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
-          ldsPen[i] = powf(((2.0f * ef) + 1.0f) / (of + ef + 1.0f), D.theta[b]);
+        stamp(15);
+        if (nBK <= FE * bd) {
+#pragma unroll
+          for (int e = 0; e < FE; e++) if (tid + e * bd < nBK) pen_entry(tid + e * bd, fth[e], fpr[e]);
+        } else {
+          for (int i = tid; i < nBK; i += bd) pen_entry(i, D.theta[i / K], D.Pr_b[i / K]);
         }
       } else if (D.pen_lds) {
         for (int i = threadIdx.x; i < D.B * K; i += blockDim.x) ldsPen[i] = D.pen[i];
@@ -931,7 +1121,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   auto tile_q = [&](const int2 cq) -> int { return __builtin_amdgcn_readfirstlane(cq.y); };
   // MODE 0/1 epilogue, split so that the fused loop below can interleave it with the next tile's MFMAs:
   // epi_begin: run change -> flush the O contributions of the finished combination, fetch the new penalty row
-  auto epi_begin = [&](const int q0) {
+  auto epi_begin = [&](const int q0) __attribute__((always_inline)) {
     if (q0 != curq) {
       if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
       curq = q0;
@@ -960,7 +1150,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   //        uniform sigma:  = inv cl (ce sum e_k x_k + sum e_k lpen_k + log2(inv) sum e_k)
   //        general sigma:  = inv (sum e_k clp_k - sum e_k x_k + log2(inv) sum e_k cl_k)     (cl_k ce_k = -1)
   //   -- no logarithm per value, one per row
-  auto epi_rows = [&](const int cellA, f32x4 (&acc)[NCT]) {
+  auto epi_rows = [&](const int cellA, f32x4 (&acc)[NCT]) __attribute__((always_inline)) {
     constexpr int RB = (NCT <= 7 && !LEAN) ? 4 : 2;   // rows per batch: all four while the registers last
 #pragma unroll
     for (int r0 = 0; r0 < 4; r0 += RB) {
@@ -1022,35 +1212,77 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     }
   };
   // epilogue of a tile whose distances are in `acc`
-  auto epilogue = [&](const int cellA, const int q0, f32x4 (&acc)[NCT]) {
+  auto epilogue = [&](const int cellA, const int q0, f32x4 (&acc)[NCT]) __attribute__((always_inline)) {
     if constexpr (MODE == 2) {
-      // nearest centre of every cell of the tile: argmin_k ||y_k||^2 - 2 x.y_k ; ties -> smallest k
+      // nearest centre of every cell of the tile: argmin_k ||y_k||^2 - 2 x.y_k ; ties -> smallest k.  All four rows
+      // together (ILP), the 16-lane reductions by DPP: first the minimum score, then the smallest k that attains it.
+      float bs[4]; int bk[4];
 #pragma unroll
       for (int reg = 0; reg < 4; reg++) {
-        const int cell = __shfl(cellA, 4 * g + reg, 64);
-        unsigned long long best = ~0ull;
+        bs[reg] = INFINITY; bk[reg] = 0x7fffffff;
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) {
-          if (16 * ct + c < K) {
-            const float sc = fmaf(acc[ct][reg], -2.0f, ce[ct]);
-            unsigned ub = __float_as_uint(sc);
-            ub = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);  // order-preserving map
-            const unsigned long long pk = ((unsigned long long)ub << 32) | (unsigned)(16 * ct + c);
-            best = pk < best ? pk : best;
-          }
-        }
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) { const unsigned long long o = shfl_xor_u64(best, m); best = o < best ? o : best; }
-        if (cell >= 0) {
-          const int kb = (int)(best & 0xffffffffu);
-          const float* zr = D.Zc + (size_t)cell * zs;
-          for (int jj = c; jj < D.d; jj += 16) {  // the 16 lanes of this row group add the cell's PCs (2^30 fixed point)
-            const unsigned long long v = (unsigned long long)__float2ll_rn(zr[jj] * 1073741824.0f);
-            atomicAdd((unsigned long long*)&ltab[kb * D.d + jj], v);
-          }
-          if (c == 0) atomicAdd((unsigned long long*)&ltab[K * D.d + kb], 1ull);
+          const float sc = (ct < first_partial_ct(NCT) || 16 * ct + c < K) ? fmaf(acc[ct][reg], -2.0f, ce[ct]) : INFINITY;
+          const bool lt = sc < bs[reg];               // strict: the smaller k (ct ascending) wins a tie
+          bs[reg] = lt ? sc : bs[reg];
+          bk[reg] = lt ? 16 * ct + c : bk[reg];
         }
       }
+      float m[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) m[reg] = bs[reg];
+#pragma unroll
+      for (int st = 0; st < 4; st++) {
+        float t[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) t[reg] = (st == 0) ? dpp_f(m[reg], 0) : (st == 1) ? dpp_f(m[reg], 1) : (st == 2) ? dpp_f(m[reg], 2) : dpp_f(m[reg], 3);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) m[reg] = fminf(m[reg], t[reg]);
+      }
+      int kb[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) kb[reg] = (bs[reg] == m[reg]) ? bk[reg] : 0x7fffffff;
+#pragma unroll
+      for (int st = 0; st < 4; st++) {
+        int t[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const float kf = __int_as_float(kb[reg]);
+          t[reg] = __float_as_int((st == 0) ? dpp_f(kf, 0) : (st == 1) ? dpp_f(kf, 1) : (st == 2) ? dpp_f(kf, 2) : dpp_f(kf, 3));
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) kb[reg] = min(kb[reg], t[reg]);
+      }
+      // the 16 lanes of a row group add the row's PCs (2^30 fixed point) to the LDS table of its centre: ALL loads of the
+      // tile are issued before the first is used (they hit L1/L2 -- the rows were just read as MFMA operands)
+      const int dd = D.d;          // locals: after the first LDS atomic hipcc would re-read D's fields from a spilled copy
+      const float* const Zcp = D.Zc;
+      int cellr[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) cellr[reg] = __shfl(cellA, 4 * g + reg, 64);
+      for (int j0 = 0; j0 < dd; j0 += 64) {
+        float z[4][4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const float* zr = Zcp + (size_t)max(cellr[reg], 0) * zs;
+#pragma unroll
+          for (int u = 0; u < 4; u++) z[reg][u] = zr[min(j0 + 16 * u + c, dd - 1)];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int jj = j0 + 16 * u + c;
+            if (cellr[reg] >= 0 && jj < dd) {
+              const unsigned long long v = (unsigned long long)__float2ll_rn(z[reg][u] * 1073741824.0f);
+              atomicAdd((unsigned long long*)&ltab[kb[reg] * dd + jj], v);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++)
+        if (c == 0 && cellr[reg] >= 0) atomicAdd((unsigned long long*)&ltab[K * dd + kb[reg]], 1ull);
     } else {
       epi_begin(q0);
       epi_rows(cellA, acc);
@@ -1701,6 +1933,23 @@ void l_sort_blocks(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
 }
 void l_oldsum(const Launch& L, const Dev& D) {
+  const size_t tab = (size_t)D.nb * D.K * sizeof(unsigned long long);
+  if (D.oldsum_stream && tab <= 64 * 1024) {   // sequential pass over R with LDS accumulators
+    const int wgs = tab <= 20 * 1024 ? 2048 : 512;   // 8 workgroups (32 waves) per CU while the LDS tables allow it
+    const dim3 sg((unsigned)std::min(wgs, D.nchunks));
+    if (D.K % 4 == 0 && D.oldsum_stream == 1) {
+      const dim3 g4((unsigned)std::min(tab <= 20 * 1024 ? 512 : 256, D.nchunks));
+      hipLaunchKernelGGL(k_oldsum_stream4, g4, dim3(1024), tab, L.stream, D);
+      return;
+    }
+    switch (D.KP / 64) {
+      case 1: hipLaunchKernelGGL(k_oldsum_stream<1>, sg, dim3(256), tab, L.stream, D); break;
+      case 2: hipLaunchKernelGGL(k_oldsum_stream<2>, sg, dim3(256), tab, L.stream, D); break;
+      case 3: hipLaunchKernelGGL(k_oldsum_stream<3>, sg, dim3(256), tab, L.stream, D); break;
+      default: hipLaunchKernelGGL(k_oldsum_stream<4>, sg, dim3(256), tab, L.stream, D); break;
+    }
+    return;
+  }
   const dim3 grid(stream_grid(L, (D.n + 63) / 64));
   switch (D.KP / 64) {
     case 1: hipLaunchKernelGGL(k_oldsum<1>, grid, dim3(TPB), 0, L.stream, D); break;

@@ -306,6 +306,25 @@ def test_torch_nccl_hook_single_rank():
     assert "HOOK_PROBE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
 
 
+def test_per_cluster_sigma_vector():
+    """sigma as a length-K vector (R/ui.R:219-221 allows it): the general-sigma kernel variants (per-lane ce / cl arrays)
+    instead of the scalar-constant ones the default uniform sigma selects."""
+    Z, meta, _ = synth(6000, d=30, levels=(4,), seed=11)
+    K = 40
+    sig = np.linspace(0.08, 0.16, K)
+    g, c, ig, ic = run_both(Z, meta, list(meta), max_iter=3, nclust=K, seed=3, sigma=sig)
+    assert int(g._scalar("usig")) == 0
+    assert_parity(g, c, ig, ic)
+
+
+def test_small_K_uses_four_waves_per_simd():
+    """K <= 64 with the default uniform sigma: the 1024-thread (4 waves per SIMD) variants; same parity bar."""
+    Z, meta, _ = synth(8000, d=50, levels=(6,), seed=5)
+    g, c, ig, ic = run_both(Z, meta, list(meta), max_iter=3, nclust=48, seed=4)
+    assert int(g._scalar("usig")) == 1 and int(g._scalar("upd_wps")) == 4
+    assert_parity(g, c, ig, ic)
+
+
 @pytest.mark.parametrize("N,d,K,levels,nested", [
     (20000, 50, 200, (8, 64, 128), True),   # BASELINE configs[4] scaled down: 3 nested covariates, 200 levels, K=200
     (3000, 128, 256, (3,), False),          # the envelope's corner: d = 128, K = 256
@@ -324,6 +343,7 @@ def test_envelope_shapes(N, d, K, levels, nested):
     {"HMX_FOLD_IMPL": "split"},                                               # k_fold + k_penalty instead of k_foldpen
     {"HMX_FUSED_FOLD": "0"},                                                  # separate k_foldpen launch per block step
     {"HMX_NREP": "1", "HMX_UPD_THREADS": "256", "HMX_UPD_MAXBLOCKS": "64", "HMX_UPD_TPW": "3"},   # launch geometry knobs
+    {"HMX_OLDSUM_IMPL": "gather", "HMX_USIG": "0", "HMX_UPD_WPS": "2"},       # gather k_oldsum, general-sigma variants
 ])
 def test_fallback_paths_parity(cell_lines, monkeypatch, env):
     """Every fallback / tuning path keeps the parity bar (they serve shapes outside the MFMA envelope)."""

@@ -37,12 +37,16 @@ def report():
         e = np.diff(it[:, 8:12], axis=1)
         for i, nme in enumerate(["last iter: ids/rows issue", "last iter: MFMAs (waits for rows)", "last iter: epilogue (+stores issue)"]):
             print(f"    {nme:36s} median {np.median(e[:, i]):9.0f} clk   p90 {np.percentile(e[:, i], 90):9.0f}   max {e[:, i].max():9.0f}")
+    if t[:, 12].max() > 0:
+        sg = np.stack([t[:, 12] - t[:, 1], t[:, 13] - t[:, 12], t[:, 14] - t[:, 13], t[:, 15] - t[:, 14], t[:, 2] - t[:, 15]], axis=1)
+        for i, nme in enumerate(["stg: entry -> image in LDS", "stg: wait pairs, issue rows", "stg: fold consumed (O in LDS)", "stg: barrier 1", "stg: penalty + barrier 2"]):
+            print(f"    {nme:36s} median {np.median(sg[:, i]):9.0f} clk   p90 {np.percentile(sg[:, i], 90):9.0f}   max {sg[:, i].max():9.0f}")
     print(f"    {'total':36s} median {np.median(tot):9.0f} clk   p90 {np.percentile(tot, 90):9.0f}   max {tot.max():9.0f}")
 
 
 g.cluster_cpp()
 print(f"N={N} K={K} B={B}")
-for dbg in (0, 4, 6, 2, 3, 1):
+for dbg in (0,):
     g._set("upd_debug", dbg)
     g._set("profile", 1)
     g.cluster_cpp()
