@@ -346,15 +346,14 @@ int update_R(hmx_ctx* ctx) {
   }
   ctx->round_counter++;
   l_sort_blocks(ctx->L, D); KCHK();
-  HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * (size_t)D.nb * D.B * D.K, ctx->L.stream));
+  HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
   l_oldsum(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0));
-  HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
+  // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
   const bool fused = !sharded && merged && ctx->fused_ok;
   if (fused) {
     // single GPU, default: the fold + penalty of step j happens in the prologue of its own update launch
-    HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * 3 * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
     long long* const keep_snew = D.Snew_fx;
     D.fused_fold = 1;
     for (int j = 0; j < D.nb; j++) {
@@ -835,12 +834,14 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
   CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
-  { long long* s3; CHK(dalloc(ctx, &s3, (size_t)3 * D.nrep * B * K)); for (int i = 0; i < 3; i++) D.Snew_set[i] = s3 + (size_t)i * D.nrep * B * K; }
+  // Sold_fx [nb][B][K] and the three rotating replica sets of the fused path share one buffer: one memset per round
+  { long long* s3; CHK(dalloc(ctx, &s3, (size_t)D.nb * B * K + (size_t)3 * D.nrep * B * K)); D.Sold_fx = s3;
+    for (int i = 0; i < 3; i++) D.Snew_set[i] = s3 + (size_t)D.nb * B * K + (size_t)i * D.nrep * B * K; }
   CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots));
   D.trace = nullptr;
-  if (const char* e = getenv("HMX_TRACE")) if (atoi(e)) { CHK(dalloc(ctx, &D.trace, (size_t)16 * D.nwmax)); HIPCHK(hipMemsetAsync(D.trace, 0, sizeof(unsigned long long) * 16 * (size_t)D.nwmax, ctx->L.stream)); } CHK(dalloc(ctx, &D.Sold_fx, (size_t)D.nb * B * K));
+  if (const char* e = getenv("HMX_TRACE")) if (atoi(e)) { CHK(dalloc(ctx, &D.trace, (size_t)16 * D.nwmax)); HIPCHK(hipMemsetAsync(D.trace, 0, sizeof(unsigned long long) * 16 * (size_t)D.nwmax, ctx->L.stream)); }
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
-  CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)D.npad)); CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &D.lpair, (size_t)D.npad));
+  CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)3 * D.npad + 2)); D.lpair = reinterpret_cast<int2*>(D.lorder + (((size_t)D.npad + 1) & ~(size_t)1)); /* lorder + lpair: one 0xFF memset per round */ CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
   CHK(dalloc(ctx, &D.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));

@@ -1593,10 +1593,20 @@ __global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg)
       nsh[ct] = 0.0;
     }
   };
-  int curq = D.titems[ts].q;
+  // tile descriptors one tile ahead and as per-lane loads (a uniform load becomes load + readfirstlane + vmcnt(0): one more
+  // serial memory latency per tile in front of the operand loads)
+  auto item_at = [&](int tile) -> Item {
+    const Item* tp = D.titems + min(tile, te - 1);
+    asm volatile("" : "+v"(tp));
+    return *tp;
+  };
+  Item itN = item_at(ts);
+  int curq = __builtin_amdgcn_readfirstlane(itN.q);
   for (int tile = ts; tile < te; ++tile) {
-    const Item it = D.titems[tile];
-    if (it.q != curq) { fold(); flush(curq); curq = it.q; }
+    const Item it = itN;
+    itN = item_at(tile + 1);
+    const int tq = __builtin_amdgcn_readfirstlane(it.q);
+    if (tq != curq) { fold(); flush(curq); curq = tq; }
     const size_t c0 = (size_t)it.start;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -1925,8 +1935,7 @@ void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uin
 }
 void l_sort_blocks(const Launch& L, const Dev& D) {
   const size_t lds = (size_t)D.nb * sizeof(int);
-  (void)hipMemsetAsync(D.lorder, 0xFF, sizeof(int) * (size_t)D.npad, L.stream);  // padding slots = -1
-  (void)hipMemsetAsync(D.lpair, 0xFF, sizeof(int2) * (size_t)D.npad, L.stream);
+  (void)hipMemsetAsync(D.lorder, 0xFF, sizeof(int) * ((size_t)3 * D.npad + 2), L.stream);  // padding slots = -1 (lorder and lpair: one buffer)
   hipLaunchKernelGGL(k_sort_hist, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
   hipLaunchKernelGGL(k_sort_binscan, dim3(D.nb * D.Q), dim3(WAVE), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D);
