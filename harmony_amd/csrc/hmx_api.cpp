@@ -330,6 +330,7 @@ int update_R(hmx_ctx* ctx) {
   const char* fold_env = getenv("HMX_FOLD_IMPL");   // "split": force the two-kernel fold + penalty fallback (tests)
   const bool merged = (size_t)D.B * 128 <= 64 * 1024 && !(fold_env && std::string(fold_env) == "split");   // LDS budget of k_foldpen
   const double t0 = now_ms();
+  bool gen_blocks = false;
   if (!ctx->injected.empty()) {  // host-provided shuffle: block(g) from its position
     std::vector<int64_t> order = std::move(ctx->injected.front());
     ctx->injected.pop_front();
@@ -341,11 +342,9 @@ int update_R(hmx_ctx* ctx) {
       pos_blk[i] = (int)std::min<uint64_t>(b, (uint64_t)(ctx->nb - 1));
     }
     CHK(h2d(ctx, D.blk, pos_blk.data(), pos_blk.size()));
-  } else {
-    l_blockid(ctx->L, D, ctx->seed, ctx->round_counter, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
-  }
+  } else gen_blocks = true;   // block ids from the Feistel bijection, computed inside the sort's histogram kernel
+  l_sort_blocks(ctx->L, D, gen_blocks, ctx->seed, ctx->round_counter, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
   ctx->round_counter++;
-  l_sort_blocks(ctx->L, D); KCHK();
   HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
   l_oldsum(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0));

@@ -121,7 +121,8 @@ void l_head(const Launch& L, const Dev& D, int mode);
 void l_tile_static(const Launch& L, const Dev& D, int mode);
 void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                uint64_t cells_per_block);
-void l_sort_blocks(const Launch& L, const Dev& D);
+void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+                   uint64_t cells_per_block);
 void l_oldsum(const Launch& L, const Dev& D);
 void l_fold(const Launch& L, const Dev& D, int j, int mode);
 void l_penalty(const Launch& L, const Dev& D);

@@ -309,8 +309,12 @@ __global__ void k_blockid(int* __restrict__ blk, const int* __restrict__ perm, i
 // 16 positions (dummy entries = -1) so that a 16-cell MFMA tile never straddles two combinations.
 // Sort chunks are static runs of <= SORT_CHUNK cells of ONE combination (D.schunks, built at setup), so the
 // per-chunk histogram counts[blk][chunk] also yields the per-(block, combination) bin sizes.
-// one wave per sort chunk
-__global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D) {
+// one wave per sort chunk.  FUSED: the block id is computed here from the Feistel bijection (k_blockid's work: saves a
+// launch and a write + read of blk); the histogram is one ds_add_u32 per 64 cells instead of a ballot loop over the
+// distinct block values.
+struct BlockIdArgs { FeistelKeys fk; uint64_t Nglob, goff, cpb; };
+template <bool FUSED>
+__global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
   extern __shared__ int cnt[];
   const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb;
   for (int v = lane; v < nb; v += WAVE) cnt[v] = 0;
@@ -319,14 +323,15 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D) {
   const int s = ch.start, e = ch.start + ch.cnt;
   for (int base = s; base < e; base += WAVE) {
     const int i = base + lane;
-    const int b = ld_or(D.blk, (size_t)min(i, e - 1), i < e, -1);
-    unsigned long long rem = __ballot(b >= 0);
-    while (rem) {
-      const int src = __ffsll((long long)rem) - 1;
-      const int v = __shfl(b, src, 64);
-      const unsigned long long m = __ballot(b == v);
-      if (lane == 0) cnt[v] += __popcll(m);
-      rem &= ~m;
+    int b = -1;
+    if (i < e) {
+      if constexpr (FUSED) {
+        const uint64_t pos = feistel_apply(A.fk, A.Nglob, A.goff + (uint64_t)D.perm[i]);
+        const uint64_t bb = pos / A.cpb;
+        b = (int)(bb < (uint64_t)(nb - 1) ? bb : (uint64_t)(nb - 1));
+        D.blk[i] = b;
+      } else b = D.blk[i];
+      atomicAdd(&cnt[b], 1);
     }
   }
   __syncthreads();
@@ -1933,10 +1938,15 @@ void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uin
   hipLaunchKernelGGL(k_blockid, dim3(2048), dim3(256), 0, L.stream, D.blk, D.perm, D.n, fk, Nglob, goff,
                      cells_per_block, D.nb);
 }
-void l_sort_blocks(const Launch& L, const Dev& D) {
+// fused = true: D.blk is produced by the histogram kernel from (seed, round) -- l_blockid is not needed
+void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+                   uint64_t cells_per_block) {
   const size_t lds = (size_t)D.nb * sizeof(int);
   (void)hipMemsetAsync(D.lorder, 0xFF, sizeof(int) * ((size_t)3 * D.npad + 2), L.stream);  // padding slots = -1 (lorder and lpair: one buffer)
-  hipLaunchKernelGGL(k_sort_hist, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
+  BlockIdArgs A;
+  A.fk = make_keys(seed, round, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
+  if (fused) hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
+  else hipLaunchKernelGGL(k_sort_hist<false>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
   hipLaunchKernelGGL(k_sort_binscan, dim3(D.nb * D.Q), dim3(WAVE), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);

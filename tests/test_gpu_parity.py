@@ -112,6 +112,8 @@ def test_fixed_lambda_tau_vector_sigma(cell_lines):
     (4000, 70, 130, (4,), False),       # d > 64 and three clusters per lane
     (6000, 30, 200, (5, 7), False),     # crossed covariates, four clusters per lane
     (6000, 20, 40, (4, 8, 16), True),   # nested 3-covariate: batch-subset path (src/harmony.cpp:440-547)
+    (2011, 3, 5, (2,), False),          # d < 4 (one partial MFMA k-step), K < 16 (one partial cluster tile), ragged N
+    (4099, 64, 16, (3,), False),        # d and K exact multiples of the tile sizes, prime N
 ])
 def test_synthetic_shapes(N, d, K, levels, nested):
     Z, meta, _ = synth(N, d=d, levels=levels, seed=N, nested=nested)
@@ -304,6 +306,15 @@ def test_torch_nccl_hook_single_rank():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "hook_probe.py")], capture_output=True, text=True,
                        timeout=400, stdin=subprocess.DEVNULL)
     assert "HOOK_PROBE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
+
+
+def test_theta_zero_and_strong_theta():
+    """theta = 0 switches the diversity penalty off (pen^0 = 1, src/harmony.cpp:319-321); theta = 6 makes it dominant:
+    both ends of the range the fast penalty power exp2(theta * log2(x)) has to cover."""
+    Z, meta, _ = synth(6000, d=20, levels=(5,), seed=21)
+    for th in (0.0, 6.0):
+        g, c, ig, ic = run_both(Z, meta, list(meta), max_iter=3, nclust=30, seed=2, theta=th)
+        assert_parity(g, c, ig, ic)
 
 
 def test_per_cluster_sigma_vector():
