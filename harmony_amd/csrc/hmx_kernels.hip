@@ -787,6 +787,43 @@ __device__ __forceinline__ float rowsum16(float v) {
 #endif
 }
 
+// arma::normalise(Z, 2, 0) with 16-byte accesses: 16 lanes per row (lane c: float4 c [and c + 16]), four rows per wave instruction, four
+// instructions in flight; the row's sum of squares is a 16-lane DPP reduction.  Rows are zero beyond d (zs = d rounded up to 4).
+template <int NF>
+__global__ __launch_bounds__(TPB) void k_normalize4(float* __restrict__ Z, int n, int nq) {
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (long long base = (long long)wave * 16; base < n; base += (long long)nw * 16) {
+    f32x4 v[4][NF];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const long long cell = min(base + 4 * u + g, (long long)n - 1);
+      const f32x4* row = reinterpret_cast<const f32x4*>(Z) + cell * nq;
+#pragma unroll
+      for (int f = 0; f < NF; f++) v[u][f] = row[min(c + 16 * f, nq - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      float ss = 0.0f;
+#pragma unroll
+      for (int f = 0; f < NF; f++) {
+        if (c + 16 * f >= nq) v[u][f] = zero4;
+        ss += v[u][f][0] * v[u][f][0] + v[u][f][1] * v[u][f][1] + v[u][f][2] * v[u][f][2] + v[u][f][3] * v[u][f][3];
+      }
+      float nrm = sqrtf(rowsum16(ss));
+      if (nrm == 0.0f) nrm = 1.0f;
+      const long long cell = base + 4 * u + g;
+      if (cell < n) {
+        f32x4* row = reinterpret_cast<f32x4*>(Z) + cell * nq;
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+          if (c + 16 * f < nq) { f32x4 o; for (int e = 0; e < 4; e++) o[e] = v[u][f][e] / nrm; row[c + 16 * f] = o; }
+      }
+    }
+  }
+}
+
 // N independent row sums, the DPP steps interleaved (ILP N: see epi_rows)
 template <int N>
 __device__ __forceinline__ void rowsum16xN(float (&v)[N]) {
@@ -1279,7 +1316,8 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           for (int u = 0; u < 4; u++) {
             const int jj = j0 + 16 * u + c;
             if (cellr[reg] >= 0 && jj < dd) {
-              const unsigned long long v = (unsigned long long)__float2ll_rn(z[reg][u] * 1073741824.0f);
+              // |z| <= 1 (normalised rows): the 2^30 fixed-point value fits int32 -> rndne + cvt + sign extension
+              const unsigned long long v = (unsigned long long)(long long)__float2int_rn(z[reg][u] * 1073741824.0f);
               atomicAdd((unsigned long long*)&ltab[kb[reg] * dd + jj], v);
             }
           }
@@ -1895,7 +1933,10 @@ void l_copy(const Launch& L, const float* src, float* dst, size_t count) {
   hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, L.stream, src, dst, count);
 }
 void l_normalize(const Launch& L, float* Z, int n, int d, int zs) {
-  hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, Z, n, d, zs);
+  const int nq = zs / 4;
+  if (nq <= 16) hipLaunchKernelGGL(k_normalize4<1>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, Z, n, nq);
+  else if (nq <= 32) hipLaunchKernelGGL(k_normalize4<2>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, Z, n, nq);
+  else hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, Z, n, d, zs);
 }
 // MFMA tile passes over the static 16-cell tiles: mode 1 = head, mode 2 = Lloyd
 void l_tile_static(const Launch& L, const Dev& D, int mode) {
