@@ -1690,6 +1690,15 @@ __global__ __launch_bounds__(256) void k_moe_apply_mfma(Dev D) {
       const int cell0 = item.start + 16 * tl;
       const int nvalid = min(16, item.start + item.cnt - cell0);
       const bool av = c < nvalid;
+      // Z_orig of the tile is requested BEFORE the MFMA chain (its latency hides behind the 100 MFMAs instead of following them)
+      float zo[4][NPT];
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int cl = 4 * g + reg;
+        const size_t row = (size_t)(cell0 + (cl < nvalid ? cl : 0)) * zs;
+#pragma unroll
+        for (int pt = 0; pt < NPT; pt++) zo[reg][pt] = D.Zo[row + min(16 * pt + c, zs - 1)];
+      }
       f32x4 acc[NPT];
       tile_dots<NPT>(ldsW4, D.R + (size_t)(cell0 + (av ? c : 0)) * K, av, g, lane, D.wNS, D.wNT4, D.wtail, acc);
 #pragma unroll
@@ -1700,8 +1709,7 @@ __global__ __launch_bounds__(256) void k_moe_apply_mfma(Dev D) {
 #pragma unroll
         for (int pt = 0; pt < NPT; pt++) {
           const int jj = 16 * pt + c;
-          const float zo = D.Zo[row + min(jj, zs - 1)];
-          if (cv && jj < d) D.Zc[row + jj] = zo - acc[pt][reg];
+          if (cv && jj < d) D.Zc[row + jj] = zo[reg][pt] - acc[pt][reg];
         }
       }
     }
