@@ -359,9 +359,12 @@ int update_R(hmx_ctx* ctx) {
   CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0));
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
-  const bool fused = !sharded && merged && ctx->fused_ok;
+  const bool fused = merged && ctx->fused_ok;
   if (fused) {
-    // single GPU, default: the fold + penalty of step j happens in the prologue of its own update launch
+    // default: the fold + penalty of step j happens in the prologue of its own update launch.  Sharded: the replica set a
+    // launch has filled is all-reduced IN PLACE (nrep*B*K int64, 64 KB at C4: latency-bound like the 8 KB of one table), so
+    // the next launch's prologue sums global replicas exactly as it sums local ones -- one kernel + one collective per block
+    // step instead of three kernels + one collective.
     long long* const keep_snew = D.Snew_fx;
     D.fused_fold = 1;
     for (int j = 0; j < D.nb; j++) {
@@ -372,6 +375,7 @@ int update_R(hmx_ctx* ctx) {
       }
       l_update(ctx->L, D, j); KCHK();
       if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; }
+      if (sharded) CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.nrep * D.B * D.K, 0));   // this block's new contribution, all ranks
       std::swap(D.O_fx, D.O_alt);   // workgroup 0 published O' into O_alt
     }
     D.fused_fold = 0;

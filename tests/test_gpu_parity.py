@@ -262,8 +262,11 @@ def _run_sharded(Z, meta, G, K, seed, max_iter):
     return results
 
 
-@pytest.mark.parametrize("G", [2, 3])
-def test_virtual_shards_equal_single_shard(G):
+@pytest.mark.parametrize("G,fused", [(2, "1"), (3, "1"), (2, "0")])
+def test_virtual_shards_equal_single_shard(G, fused, monkeypatch):
+    """fused = "1": block steps = update kernel (fold in its prologue) + in-place all-reduce of the replica set (default);
+    "0": the step-by-step sharded path (k_fold, all-reduce of one table, k_foldpen, update)."""
+    monkeypatch.setenv("HMX_FUSED_FOLD", fused)
     Z, meta, _ = synth(30000, d=50, levels=(10,), seed=21)
     K, seed = 100, 4
     skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
