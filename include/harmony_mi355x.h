@@ -93,12 +93,17 @@ int hmx_compute_objective(hmx_ctx* ctx);
  * `field` is one of: "Z_corr" "Z_orig" "R" "Y" "O" "E" "W" "Lambda" "Pr_b" "theta" "sigma"
  * "lambda" "B_vec" "objective_kmeans" "objective_kmeans_dist" "objective_kmeans_entropy"
  * "objective_kmeans_cross" "objective_harmony" "kmeans_rounds" "N" "B" "K" "d" "alpha"
- * "max_iter_kmeans" "W_rows" (+ diagnostics: "subset_clusters" "skipped_clusters" "n_combos"
- * and "timer:<phase>" in ms).  Returns the number of doubles the field holds (call with
+ * "max_iter_kmeans" "W_rows" (+ diagnostics: "subset_clusters" "skipped_clusters" "n_combos" "usig"
+ * "upd_wps" "comm:calls" "comm:bytes" and "timer:<phase>" in ms).  Returns the number of doubles the field holds (call with
  * out == NULL to size), or -1 for an unknown field.  At most `cap` values are written. */
 int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap);
 /* writable fields: "max_iter_kmeans" (vignettes/detailedWalkthrough.Rmd:364), "seed",
- * "device" (before setup), "deterministic" */
+ * "device" (before setup), "profile" (HIP-event timing of the update kernel, see below).
+ * Tuning / fallback selectors (tests and measurements; the defaults are the measured best):
+ *   fields "grid", "upd_wps" (before setup), "upd_tpw", "upd_cpw", "upd_impl", "comm_force";
+ *   environment, read by hmx_setup: HMX_GRID, HMX_NREP, HMX_UPD_WPS (2|4), HMX_USIG=0 (general-sigma kernels),
+ *   HMX_UPD_THREADS, HMX_UPD_MAXBLOCKS, HMX_UPD_TPW, HMX_UPD_CPW, HMX_FUSED_FOLD=0, HMX_FOLD_IMPL=split,
+ *   HMX_OLDSUM_IMPL=gather|stream1, HMX_UPDATE_IMPL=v1, HMX_TILE_IMPL=v1, HMX_MOE_IMPL=v1 (first-generation kernels). */
 int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t value);
 
 /* ---- randomness ------------------------------------------------------------------------
