@@ -114,12 +114,26 @@ def main():
             # built-in communicator: ncclAllReduce issued by the C library on its own stream -- no Python per collective
             uid = [Harmony.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0, device=dev)
-            try:
-                obj.comm_init(rank, world, uid[0])
-                obj.set_shard(rank, world, rank * n, N, None)
-                ok = 1
-            except Exception as e:                    # pragma: no cover
-                print("rank %d: built-in RCCL communicator failed (%s); using the torch.distributed hook" % (rank, e), file=sys.stderr)
+            # ncclCommInitRank runs in a watchdog thread: if the bootstrap of the extra communicator never returns on this
+            # node, every rank falls back to the torch.distributed hook instead of hanging the whole job
+            import threading
+            res = {}
+
+            def _init():
+                try:
+                    obj.comm_init(rank, world, uid[0])
+                    obj.set_shard(rank, world, rank * n, N, None)
+                    res["ok"] = 1
+                except Exception as e:                # pragma: no cover
+                    res["err"] = e
+
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("HMX_COMM_INIT_TIMEOUT", "120")))
+            ok = 1 if res.get("ok") else 0
+            if not ok:                                # pragma: no cover
+                print("rank %d: built-in RCCL communicator failed (%s); using the torch.distributed hook"
+                      % (rank, res.get("err", "ncclCommInitRank timed out")), file=sys.stderr)
             flag = torch.tensor([ok], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())

@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // LDS staging below, so the two dependent HBM round trips overlap with it
   // Software pipeline over tiles (when the rows fit in registers, D.NT4 <= 4): cell ids two tiles ahead, embedding rows
   // one tile ahead.  MODE 0 requests the first tile's ids and rows BEFORE the LDS staging below.
-  const bool pre = !LEAN && D.NT4 <= 4 && NCT <= 10;   // (K > 160: the extra row registers would spill)
+  const bool pre = !LEAN && D.NT4 <= 4 && NCT <= 8;    // (K > 128: the extra row registers would spill)
   // (cell id, combination) of this lane's A-operand row, ONE vector load per tile: a separate uniform load of the tile's
   // combination ends in a readfirstlane right behind the load, i.e. a vmcnt(0) -- a drain of the 28 outstanding R stores
   // of the previous tile plus a full memory latency -- in every iteration.
