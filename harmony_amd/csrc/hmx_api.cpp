@@ -279,7 +279,17 @@ int kmeans_centers(hmx_ctx* ctx) {
   // exponential race for every anchor in one pass (:24-34)
   std::vector<unsigned long long> win(K), sentinel(K, SEED_SENTINEL);
   CHK(h2d(ctx, D.seedmin, sentinel.data(), (size_t)K));
-  l_seed_probe(ctx->L, D, ctx->seed, (uint64_t)ctx->goff, nullptr, 0); KCHK();
+  // the race on the matrix cores (k_tile mode 3) when the centroid image fits; else the cluster-lane VALU kernel
+  const bool seed_tile = D.tile_impl && (size_t)D.NQ * D.NS * 1024 <= 150 * 1024;
+  auto seed_probe = [&](const unsigned* excl, int nexcl) -> int {
+    if (seed_tile) {
+      ctx->D.seed_key = ctx->seed; ctx->D.seed_goff = (unsigned long long)ctx->goff; ctx->D.seed_excl = excl; ctx->D.seed_nexcl = nexcl;
+      l_tile_static(ctx->L, ctx->D, 3);
+    } else l_seed_probe(ctx->L, D, ctx->seed, (uint64_t)ctx->goff, excl, nexcl);
+    KCHK();
+    return 0;
+  };
+  CHK(seed_probe(nullptr, 0));
   CHK(allreduce(ctx, D.seedmin, K, 2));
   CHK(d2h(ctx, win.data(), D.seedmin, (size_t)K));
   // duplicates are resolved in cluster order (:38-43): re-sample cluster i among cells not yet chosen
@@ -291,7 +301,7 @@ int kmeans_centers(hmx_ctx* ctx) {
       std::vector<unsigned> ex(sup.begin(), sup.end());
       CHK(h2d(ctx, d_excl, ex.data(), ex.size()));
       CHK(h2d(ctx, D.seedmin, sentinel.data(), (size_t)K));
-      l_seed_probe(ctx->L, D, ctx->seed, (uint64_t)ctx->goff, d_excl, (int)ex.size()); KCHK();
+      CHK(seed_probe(d_excl, (int)ex.size()));
       CHK(allreduce(ctx, D.seedmin, K, 2));
       std::vector<unsigned long long> w2(K);
       CHK(d2h(ctx, w2.data(), D.seedmin, (size_t)K));

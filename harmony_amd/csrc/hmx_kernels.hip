@@ -979,6 +979,7 @@ constexpr int tile_threads(int nct) { return 256; }  // measured: 768-thread wor
 // MODE 1: head (static 16-cell tiles of the internal order, plain softmax)                 :141-150 / :221-227
 // Register budget: <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (12 per CU) are resident.
 // MODE 2: one Lloyd iteration of kmeans_centers (nearest centre, fixed-point sums in LDS)  src/utils.cpp:56-61
+// MODE 3: the seeding race of kmeans_centers: for every anchor k  argmin_n -log(u_kn) / |2(1 - y_k.x_n)|  src/utils.cpp:24-34
 // WPS: waves per SIMD the register budget is cut for (update workgroup = 256*WPS threads).  USIG: one sigma for all clusters
 // (the reference's default, R/ui.R:219-221): ce / cl become scalars, 2-3 register arrays of NCT floats disappear.
 template <int NCT, int MODE, int WPS = 2, bool USIG = false>
@@ -1154,6 +1155,15 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     }
     lpen[ct] = 0.0f; oacc[ct] = 0ull;
   }
+  // MODE 3: per-lane running minima of the packed (key bits, global cell) race values and the per-anchor hash keys
+  unsigned long long best[MODE == 3 ? NCT : 1], sk[MODE == 3 ? NCT : 1];
+  if constexpr (MODE == 3) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+      best[ct] = ~0ull;
+      sk[ct] = splitmix64(D.seed_key ^ ((uint64_t)(1 + 16 * ct + c) * 0xD1342543DE82EF95ull));
+    }
+  }
   auto CE = [&](int ct) -> float { return ce[USIG ? 0 : ct]; };
   auto CL = [&](int ct) -> float { return cl[USIG ? 0 : ct]; };
   double od = 0.0, oe = 0.0;
@@ -1326,6 +1336,33 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #pragma unroll
       for (int reg = 0; reg < 4; reg++)
         if (c == 0 && cellr[reg] >= 0) atomicAdd((unsigned long long*)&ltab[K * dd + kb[reg]], 1ull);
+    } else if constexpr (MODE == 3) {
+      // same arithmetic per (cell, anchor) as k_seed_probe: u from splitmix64(anchor key + global cell), key = -log(u) / dist
+      int gc[4]; bool ok[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int cell = __shfl(cellA, 4 * g + reg, 64);
+        ok[reg] = cell >= 0;
+        gc[reg] = D.perm[max(cell, 0)];
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const uint64_t gg = D.seed_goff + (uint64_t)gc[reg];
+        bool skip = !ok[reg];
+        for (int x = 0; x < D.seed_nexcl; x++) skip |= ((uint64_t)D.seed_excl[x] == gg);   // re-probe passes only
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) {
+          const float dis = fabsf(2.0f * (1.0f - acc[ct][reg]));
+          const uint64_t h = splitmix64(sk[ct] + gg);
+          const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+          const float key = -logf(u) / dis;  // >= 0 (or +inf / nan when dis == 0)
+          unsigned kb = __float_as_uint(key);
+          if (!(key >= 0.0f)) kb = 0x7f800000u;  // nan -> +inf: never the minimum
+          const unsigned long long pk = ((unsigned long long)kb << 32) | (unsigned long long)(uint32_t)gg;
+          const bool take = !skip && (ct < first_partial_ct(NCT) || 16 * ct + c < K) && pk < best[ct];
+          best[ct] = take ? pk : best[ct];
+        }
+      }
     } else {
       epi_begin(q0);
       epi_rows(cellA, acc);
@@ -1413,6 +1450,14 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       if (ltab[i]) atomicAdd((unsigned long long*)&D.lsum[i], (unsigned long long)ltab[i]);
     for (int i = threadIdx.x; i < K; i += blockDim.x)
       if (ltab[K * D.d + i]) atomicAdd(&D.lcnt[i], (unsigned long long)ltab[K * D.d + i]);
+  } else if constexpr (MODE == 3) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {   // the four row groups hold candidates for the same anchors
+      unsigned long long v = best[ct];
+      unsigned long long o = shfl_xor_u64(v, 16); v = o < v ? o : v;
+      o = shfl_xor_u64(v, 32); v = o < v ? o : v;
+      if (g == 0 && 16 * ct + c < K && v != ~0ull) atomicMin(&D.seedmin[16 * ct + c], v);
+    }
   } else {
     if (ts >= te) return;
     if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
@@ -1946,7 +1991,7 @@ void l_normalize(const Launch& L, float* Z, int n, int d, int zs) {
   else if (nq <= 32) hipLaunchKernelGGL(k_normalize4<2>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, Z, n, nq);
   else hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, Z, n, d, zs);
 }
-// MFMA tile passes over the static 16-cell tiles: mode 1 = head, mode 2 = Lloyd
+// MFMA tile passes over the static 16-cell tiles: mode 1 = head, mode 2 = Lloyd, mode 3 = seeding race
 void l_tile_static(const Launch& L, const Dev& D, int mode) {
   const int wpb = tile_threads(D.NCT) / 64;
   long long blocks = (((long long)D.ntitems + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
@@ -1956,7 +2001,8 @@ void l_tile_static(const Launch& L, const Dev& D, int mode) {
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
   // head / Lloyd.  Head variants: general sigma | uniform sigma (D.usig) | uniform sigma at 4 waves per SIMD (K <= 64)
-#define HMX_TS(N) case N: if (mode == 2) hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
+#define HMX_TS(N) case N: if (mode == 3) hipLaunchKernelGGL((k_tile<N, 3>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
+                          else if (mode == 2) hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
                           else if (D.usig) hipLaunchKernelGGL((k_tile<N, 1, 2, true>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
                           else hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); break;
 #define HMX_TSL(N) case N: hipLaunchKernelGGL((k_tile<N, 1, 4, true>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); break;
