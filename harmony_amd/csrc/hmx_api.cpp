@@ -321,12 +321,10 @@ int kmeans_centers(hmx_ctx* ctx) {
   }
   const bool tile_ok = D.tile_impl && (size_t)D.NQ * D.NS * 1024 + ((size_t)K * d + K) * 8 <= 160 * 1024;
   for (int it = 0; it < 10; it++) {
-    HIPCHK(hipMemsetAsync(D.lsum, 0, sizeof(long long) * K * d, ctx->L.stream));
-    HIPCHK(hipMemsetAsync(D.lcnt, 0, sizeof(unsigned long long) * K, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.lsum, 0, sizeof(long long) * ((size_t)K * d + K), ctx->L.stream));   // sums + counts: one buffer
     if (tile_ok) { l_tile_static(ctx->L, D, 2); KCHK(); }
     else { l_lloyd(ctx->L, D); KCHK(); }
-    CHK(allreduce(ctx, D.lsum, (int64_t)K * d, 0));
-    CHK(allreduce(ctx, D.lcnt, K, 0));
+    CHK(allreduce(ctx, D.lsum, (int64_t)K * d + K, 0));   // sums and counts in one collective
     l_lloyd_finish(ctx->L, D); KCHK();
   }
   CHK(d2h(ctx, ctx->Y.data(), D.Ycur, ctx->Y.size()));
@@ -869,7 +867,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d)); CHK(dalloc(ctx, &D.Wimg, D.moe_mfma ? (size_t)Q * D.wNQ * D.wNS * 256 : 1));
-  CHK(dalloc(ctx, &D.seedmin, (size_t)K)); CHK(dalloc(ctx, &D.lsum, (size_t)K * d)); CHK(dalloc(ctx, &D.lcnt, (size_t)K)); CHK(dalloc(ctx, &D.ynorm, (size_t)K));
+  CHK(dalloc(ctx, &D.seedmin, (size_t)K)); CHK(dalloc(ctx, &D.lsum, (size_t)K * d + K)); D.lcnt = reinterpret_cast<unsigned long long*>(D.lsum + (size_t)K * d); CHK(dalloc(ctx, &D.ynorm, (size_t)K));
   CHK(h2d(ctx, D.perm, ctx->perm.data(), (size_t)N)); CHK(h2d(ctx, D.invperm, invperm.data(), (size_t)N));
   CHK(h2d(ctx, D.combo, combo_sorted.data(), (size_t)N)); CHK(h2d(ctx, D.qlev, ctx->qlev.data(), ctx->qlev.size()));
   CHK(h2d(ctx, D.sigma, ctx->sigma.data(), (size_t)K)); CHK(h2d(ctx, D.theta, ctx->theta.data(), (size_t)B)); CHK(h2d(ctx, D.Pr_b, ctx->Pr_b.data(), (size_t)B));
