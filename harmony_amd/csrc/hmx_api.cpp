@@ -817,7 +817,7 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
     const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
   D.lloyd_lds = ((size_t)d * D.KP * 4 + ((size_t)K * d + K) * 8 <= 98304) ? 1 : 0;
   { const char* e = getenv("HMX_MOE_IMPL");
-    D.moe_mfma = (K % 4 == 0 && d <= 64 && K <= 128 && !(e && std::string(e) == "v1")) ? 1 : 0;
+    D.moe_mfma = (K % 4 == 0 && d <= 64 && K <= 256 && !(e && std::string(e) == "v1")) ? 1 : 0;   // K > 128: split statistics kernel
     D.wNT4 = K / 16; D.wtail = (K - 16 * D.wNT4) / 4; D.wNS = 4 * D.wNT4 + D.wtail; D.wNQ = ((d + 15) / 16 + 3) / 4; }
   D.nwmax = 4 * ctx->L.grid; D.objslots = std::min(D.nb, 64);
   D.pen_lds = ((size_t)D.NQ * 0 + (size_t)B * K * 4 + (size_t)Q * C * 4 <= 24576) ? 1 : 0;

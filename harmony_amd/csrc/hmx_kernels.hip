@@ -1637,9 +1637,14 @@ __global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
 // Work split: a workgroup streams a contiguous range of tiles; its wave w owns PC tile w (blockDim = 64*ceil(d/16)),
 // so a wave carries only NCT fp32 MFMA accumulators (folded into fp64 shadows every 4 tiles = 64 cells) and the
 // K x d result of a run is flushed ONCE per workgroup, not once per wave (the fp64 atomics dominated otherwise).
-template <int NCT>
-__global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg) {
-  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, pt = threadIdx.x >> 6;
+// CTS > 1 (K > 128): the cluster tiles are split over CTS groups of waves (wave = PC tile pt x cluster-tile group), each wave
+// carrying NCTT / CTS accumulators + fp64 shadows.  (For K <= 128 the split was measured SLOWER -- 597 vs 355 us: the
+// operand loads, not the registers, limit this kernel -- so it is only used where one wave cannot hold all cluster tiles.)
+template <int NCTT, int CTS>
+__global__ __launch_bounds__(512) void k_moe_stats_mfma(Dev D, int tiles_per_wg, int npt) {
+  constexpr int NCT = (NCTT + CTS - 1) / CTS;   // cluster tiles of this wave
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wv = threadIdx.x >> 6, pt = wv % npt, ct0 = (wv / npt) * NCT;   // first cluster tile of this wave
   const int K = D.K, d = D.d, zs = D.zs;
   const int ts = blockIdx.x * tiles_per_wg, te = min(D.ntitems, ts + tiles_per_wg);
   if (ts >= te) return;
@@ -1669,14 +1674,14 @@ __global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg)
     for (int ct = 0; ct < NCT; ct++) {
 #pragma unroll
       for (int reg = 0; reg < 4; reg++) {
-        const int k = 16 * ct + 4 * g + reg;
+        const int k = 16 * (ct0 + ct) + 4 * g + reg;
         if (jv && k < K && sh[ct][reg] != 0.0) atomicAdd(&S[(size_t)k * d + jj], sh[ct][reg]);
         sh[ct][reg] = 0.0;
       }
       if (pt == 0) {                            // sum_i R_ki of cluster 16ct+c: add the four cell slots
         double v = nsh[ct];
         v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        if (g == 0 && 16 * ct + c < K) atomicAdd(&D.nq[(size_t)q * K + 16 * ct + c], v);
+        if (g == 0 && 16 * (ct0 + ct) + c < K) atomicAdd(&D.nq[(size_t)q * K + 16 * (ct0 + ct) + c], v);
       }
       nsh[ct] = 0.0;
     }
@@ -1703,7 +1708,7 @@ __global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg)
       const size_t row = c0 + (cv ? cell : 0);
       float a[NCT];
 #pragma unroll
-      for (int ct = 0; ct < NCT; ct++) a[ct] = ld_or(D.R, row * K + min(16 * ct + c, K - 1), cv && 16 * ct + c < K, 0.0f);
+      for (int ct = 0; ct < NCT; ct++) a[ct] = ld_or(D.R, row * K + min(16 * (ct0 + ct) + c, K - 1), cv && 16 * (ct0 + ct) + c < K, 0.0f);
       const float b = ld_or(D.Zo, row * zs + min(jj, zs - 1), cv && jv, 0.0f);
 #pragma unroll
       for (int ct = 0; ct < NCT; ct++) {
@@ -2155,13 +2160,17 @@ void l_moe_stats_mfma(const Launch& L, const Dev& D) {
   const int npt = (D.d + 15) / 16;
   int tpw = (D.ntitems + 2 * 256 - 1) / (2 * 256);   // ~2 workgroups per CU
   if (tpw < 16) tpw = 16;
-  const dim3 grid((D.ntitems + tpw - 1) / tpw), block(64 * npt);
-#define HMX_MS(N) case N: hipLaunchKernelGGL(k_moe_stats_mfma<N>, grid, block, 0, L.stream, D, tpw); break;
+  const bool split = D.NCT > 8;                       // K > 128: two cluster-tile groups of waves (d <= 64: 8 waves)
+  const dim3 grid((D.ntitems + tpw - 1) / tpw), block(64 * npt * (split ? 2 : 1));
+#define HMX_MS(N) case N: hipLaunchKernelGGL((k_moe_stats_mfma<N, 1>), grid, block, 0, L.stream, D, tpw, npt); break;
+#define HMX_MS2(N) case N: hipLaunchKernelGGL((k_moe_stats_mfma<N, 2>), grid, block, 0, L.stream, D, tpw, npt); break;
   switch (D.NCT) {
     HMX_MS(1) HMX_MS(2) HMX_MS(3) HMX_MS(4) HMX_MS(5) HMX_MS(6) HMX_MS(7) HMX_MS(8)
+    HMX_MS2(10) HMX_MS2(12) HMX_MS2(14) HMX_MS2(16)
     default: break;
   }
 #undef HMX_MS
+#undef HMX_MS2
 }
 void l_moe_apply_mfma(const Launch& L, const Dev& D) {
   int g = D.naitems < 4 * L.grid ? D.naitems : 4 * L.grid;
