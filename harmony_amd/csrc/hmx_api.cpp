@@ -836,6 +836,9 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
     if (w == 4) D.upd_threads = 1024; }
   { const char* e = getenv("HMX_UPD_MAXBLOCKS"); D.upd_maxblocks = e ? atoi(e) : (D.upd_threads >= 512 ? 256 : 512); if (D.upd_maxblocks < 1) D.upd_maxblocks = 1; }
   D.upd_debug = 0;
+  // static-tile launches (head / Lloyd / seeding): one resident generation of 256-thread workgroups (2 per CU at the 2 waves
+  // per SIMD the K > 64 kernels get) re-stages the centroid image once instead of four times: head 213 -> 200 us at 1M
+  { const char* e = getenv("HMX_STATIC_MAXBLOCKS"); D.static_maxblocks = e ? atoi(e) : (D.NCT >= 5 ? 512 : D.NCT >= 3 ? 768 : 1024); }
   { const char* e = getenv("HMX_OLDSUM_IMPL"); D.oldsum_stream = (e && std::string(e) == "gather") ? 0 : (e && std::string(e) == "stream1") ? 2 : 1; }   // 1: 16-byte stream, 2: dword stream
   { const char* e = getenv("HMX_UPD_TPW"); D.upd_tpw = ctx->tun_tpw > 0 ? ctx->tun_tpw : (e ? atoi(e) : 1); if (D.upd_tpw < 1) D.upd_tpw = 1; }
   { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = ctx->tun_cpw > 0 ? ctx->tun_cpw : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }

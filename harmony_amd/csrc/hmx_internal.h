@@ -34,6 +34,7 @@ struct Dev {
   int upd_tpw;      // tiles per wave target of the MFMA update kernel
   int upd_wps;      // waves per SIMD the update/head kernels are built for: 2 | 4 (lean: uniform sigma, K <= 64)
   int usig;         // all clusters share one sigma (scalar-constant kernel variants)
+  int static_maxblocks; // cap of the static-tile launches (head / Lloyd / seeding); 0 = nwmax / waves per workgroup
   // seeding race (k_tile mode 3): hash key, first global cell of this shard, cells already chosen (re-probe passes)
   unsigned long long seed_key, seed_goff; const unsigned* seed_excl; int seed_nexcl;
   int oldsum_stream; // 1: k_oldsum_stream (sequential R pass, LDS accumulators) | 0: k_oldsum (gather through the sorted order)

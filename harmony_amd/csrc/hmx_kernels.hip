@@ -1637,16 +1637,18 @@ __global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
 // Work split: a workgroup streams a contiguous range of tiles; its wave w owns PC tile w (blockDim = 64*ceil(d/16)),
 // so a wave carries only NCT fp32 MFMA accumulators (folded into fp64 shadows every 4 tiles = 64 cells) and the
 // K x d result of a run is flushed ONCE per workgroup, not once per wave (the fp64 atomics dominated otherwise).
-// CTS > 1 (K > 128): the cluster tiles are split over CTS groups of waves (wave = PC tile pt x cluster-tile group), each wave
-// carrying NCTT / CTS accumulators + fp64 shadows.  (For K <= 128 the split was measured SLOWER -- 597 vs 355 us: the
+// CTS > 1 (K > 128): the cluster tiles are split over CTS workgroups per tile range (blockIdx % CTS = cluster-tile group),
+// each wave carrying NCTT / CTS accumulators + fp64 shadows.  (For K <= 128 the split was measured SLOWER -- 597 vs 355 us: the
 // operand loads, not the registers, limit this kernel -- so it is only used where one wave cannot hold all cluster tiles.)
+// (launch bounds 256 = one wave per SIMD with the whole 512-entry register file: with a 256-register budget hipcc serialises
+//  the 32 operand loads of a tile with a wait after each, 355 -> 800 us -- hence the split across workgroups, not waves)
 template <int NCTT, int CTS>
-__global__ __launch_bounds__(512) void k_moe_stats_mfma(Dev D, int tiles_per_wg, int npt) {
+__global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg, int npt) {
   constexpr int NCT = (NCTT + CTS - 1) / CTS;   // cluster tiles of this wave
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int wv = threadIdx.x >> 6, pt = wv % npt, ct0 = (wv / npt) * NCT;   // first cluster tile of this wave
+  const int pt = threadIdx.x >> 6, grp = (CTS > 1) ? (int)(blockIdx.x % CTS) : 0, ct0 = grp * NCT;   // first cluster tile of this workgroup
   const int K = D.K, d = D.d, zs = D.zs;
-  const int ts = blockIdx.x * tiles_per_wg, te = min(D.ntitems, ts + tiles_per_wg);
+  const int ts = (int)(blockIdx.x / CTS) * tiles_per_wg, te = min(D.ntitems, ts + tiles_per_wg);
   if (ts >= te) return;
   const int jj = 16 * pt + c;           // this lane's PC
   const bool jv = jj < d;
@@ -2001,6 +2003,7 @@ void l_tile_static(const Launch& L, const Dev& D, int mode) {
   const int wpb = tile_threads(D.NCT) / 64;
   long long blocks = (((long long)D.ntitems + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
   if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
+  if (D.static_maxblocks > 0 && blocks > D.static_maxblocks) blocks = D.static_maxblocks;
   size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4);
   if (mode == 2) { lds += ((size_t)D.K * D.d + D.K) * sizeof(long long); if (blocks > 512) blocks = 512; }
   if (blocks < 1) blocks = 1;
@@ -2160,8 +2163,8 @@ void l_moe_stats_mfma(const Launch& L, const Dev& D) {
   const int npt = (D.d + 15) / 16;
   int tpw = (D.ntitems + 2 * 256 - 1) / (2 * 256);   // ~2 workgroups per CU
   if (tpw < 16) tpw = 16;
-  const bool split = D.NCT > 8;                       // K > 128: two cluster-tile groups of waves (d <= 64: 8 waves)
-  const dim3 grid((D.ntitems + tpw - 1) / tpw), block(64 * npt * (split ? 2 : 1));
+  const bool split = D.NCT > 8;                       // K > 128: two workgroups (cluster-tile halves) per tile range
+  const dim3 grid(((D.ntitems + tpw - 1) / tpw) * (split ? 2 : 1)), block(64 * npt);
 #define HMX_MS(N) case N: hipLaunchKernelGGL((k_moe_stats_mfma<N, 1>), grid, block, 0, L.stream, D, tpw, npt); break;
 #define HMX_MS2(N) case N: hipLaunchKernelGGL((k_moe_stats_mfma<N, 2>), grid, block, 0, L.stream, D, tpw, npt); break;
   switch (D.NCT) {

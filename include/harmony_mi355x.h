@@ -102,7 +102,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap);
  * Tuning / fallback selectors (tests and measurements; the defaults are the measured best):
  *   fields "grid", "upd_wps" (before setup), "upd_tpw", "upd_cpw", "upd_impl", "comm_force";
  *   environment, read by hmx_setup: HMX_GRID, HMX_NREP, HMX_UPD_WPS (2|4), HMX_USIG=0 (general-sigma kernels),
- *   HMX_UPD_THREADS, HMX_UPD_MAXBLOCKS, HMX_UPD_TPW, HMX_UPD_CPW, HMX_FUSED_FOLD=0, HMX_FOLD_IMPL=split,
+ *   HMX_UPD_THREADS, HMX_UPD_MAXBLOCKS, HMX_STATIC_MAXBLOCKS, HMX_UPD_TPW, HMX_UPD_CPW, HMX_FUSED_FOLD=0, HMX_FOLD_IMPL=split,
  *   HMX_OLDSUM_IMPL=gather|stream1, HMX_UPDATE_IMPL=v1, HMX_TILE_IMPL=v1, HMX_MOE_IMPL=v1 (first-generation kernels). */
 int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t value);
 
