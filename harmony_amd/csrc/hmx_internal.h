@@ -122,8 +122,6 @@ void l_normalize(const Launch& L, float* Z, int n, int d, int zs);
 // mode 0: head (write R, accumulate O_fx, objective partials); mode 1: objective only (read R)
 void l_head(const Launch& L, const Dev& D, int mode);
 void l_tile_static(const Launch& L, const Dev& D, int mode);
-void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
-               uint64_t cells_per_block);
 void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                    uint64_t cells_per_block);
 void l_oldsum(const Launch& L, const Dev& D);

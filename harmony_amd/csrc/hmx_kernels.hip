@@ -297,19 +297,11 @@ __global__ __launch_bounds__(TPB) void k_head(Dev D) {
 // --------------------------------------------------------------------------------------
 // per-round block membership + stable counting sort by block
 // --------------------------------------------------------------------------------------
-__global__ void k_blockid(int* __restrict__ blk, const int* __restrict__ perm, int n, FeistelKeys fk, uint64_t Nglob,
-                          uint64_t goff, uint64_t cpb, int nb) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t pos = feistel_apply(fk, Nglob, goff + (uint64_t)perm[i]);
-    uint64_t b = pos / cpb;
-    blk[i] = (int)(b < (uint64_t)(nb - 1) ? b : (uint64_t)(nb - 1));
-  }
-}
 // Stable counting sort of the cells by block, with every (block, combination) bin padded to a multiple of
 // 16 positions (dummy entries = -1) so that a 16-cell MFMA tile never straddles two combinations.
 // Sort chunks are static runs of <= SORT_CHUNK cells of ONE combination (D.schunks, built at setup), so the
 // per-chunk histogram counts[blk][chunk] also yields the per-(block, combination) bin sizes.
-// one wave per sort chunk.  FUSED: the block id is computed here from the Feistel bijection (k_blockid's work: saves a
+// one wave per sort chunk.  FUSED: the block id is computed here from the Feistel bijection (no separate block-id kernel: saves a
 // launch and a write + read of blk); the histogram is one ds_add_u32 per 64 cells instead of a ballot loop over the
 // distinct block values.
 struct BlockIdArgs { FeistelKeys fk; uint64_t Nglob, goff, cpb; };
@@ -2035,13 +2027,7 @@ void l_head(const Launch& L, const Dev& D, int mode) {
   if (mode == 0) HMX_DISPATCH_KD(k_head, HMX_COMMA 0, grid, lds, D);
   else HMX_DISPATCH_KD(k_head, HMX_COMMA 1, grid, lds, D);
 }
-void l_blockid(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
-               uint64_t cells_per_block) {
-  FeistelKeys fk = make_keys(seed, round, Nglob);
-  hipLaunchKernelGGL(k_blockid, dim3(2048), dim3(256), 0, L.stream, D.blk, D.perm, D.n, fk, Nglob, goff,
-                     cells_per_block, D.nb);
-}
-// fused = true: D.blk is produced by the histogram kernel from (seed, round) -- l_blockid is not needed
+// fused = true: D.blk is produced by the histogram kernel from (seed, round); false: the host uploaded D.blk (injected shuffle)
 void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                    uint64_t cells_per_block) {
   const size_t lds = (size_t)D.nb * sizeof(int);
