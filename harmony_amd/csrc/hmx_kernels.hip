@@ -964,12 +964,13 @@ __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const
 // Instantiated cluster-tile counts are {1..8,10,12,14,16} (hmx_setup picks the smallest >= ceil(K/16)): cluster tiles
 // below this index are always completely inside K, only the ones from it on can hold k >= K.
 constexpr int first_partial_ct(int nct) { return nct <= 8 ? nct - 1 : nct - 2; }
-// 256-thread workgroups; register budget <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (3 workgroups per CU)
-// are resident and one launch of ~3 workgroups per CU finishes in a single wave of workgroups.
-constexpr int tile_threads(int nct) { return 256; }  // measured: 768-thread workgroups (one per CU) are 30% slower (tail effect)
-// MODE 0: block update (cells gathered through lorder, penalty, second normalisation)      update_R :318-330
+// Static-tile launches (head / Lloyd / seeding) use 256-thread workgroups, capped at one resident generation
+// (D.static_maxblocks); measured: 768-thread workgroups (one per CU) are 30% slower (tail effect).
+constexpr int tile_threads(int nct) { return 256; }
+// MODE 0: block update (cells gathered through lpair, penalty in the exponent, ONE normalisation)  update_R :318-330
 // MODE 1: head (static 16-cell tiles of the internal order, plain softmax)                 :141-150 / :221-227
-// Register budget: <= 168 VGPR+AGPR for K <= 128 so that 3 waves/SIMD (12 per CU) are resident.
+// Register budget: K > 64 runs 2 waves per SIMD (<= 256 VGPRs: row prefetch + two accumulator sets, K <= 112);
+// K <= 64 with a uniform sigma runs the 128-VGPR variant (WPS = 4).
 // MODE 2: one Lloyd iteration of kmeans_centers (nearest centre, fixed-point sums in LDS)  src/utils.cpp:56-61
 // MODE 3: the seeding race of kmeans_centers: for every anchor k  argmin_n -log(u_kn) / |2(1 - y_k.x_n)|  src/utils.cpp:24-34
 // WPS: waves per SIMD the register budget is cut for (update workgroup = 256*WPS threads).  USIG: one sigma for all clusters
@@ -994,8 +995,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   if constexpr (MODE == 0) { p0 = D.boff[j]; ntiles = (D.boff[j + 1] - p0) >> 4; }  // padded: combination-pure tiles
   else ntiles = D.ntitems;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  // wave index as a SCALAR: tile numbers, the tile's combination and all loop control become SALU / s_load work
-  // (lgkmcnt) -- a vector load here would put a loop-carried vmcnt(0), i.e. a drain of the 28 R stores, into every tile
+  // wave index as a SCALAR: tile numbers and all loop control become SALU work (no exec-mask branches in the tile loop)
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
   auto stamp = [&](int slot) {  // diagnostics build only (-DHMX_TRACE, tools/trace_update.py): per-wave phase stamps
 #ifdef HMX_TRACE
