@@ -86,3 +86,19 @@ def test_prepare_setup_args_mirrors_ui_R():
 def test_no_cpu_fallback():
     with pytest.raises(harmony_amd.HarmonyError, match="no HIP device"):
         harmony_amd.RunHarmony(np.random.randn(300, 20), np.repeat([0, 1, 2], 100), verbose=False)
+
+
+def test_r_glue_type_checks_against_the_c_abi():
+    """r/harmony_mi355x_glue.c (the .Call wrappers INTEGRATION.md describes) cannot be built here -- R is not installed --
+    but it must at least agree with include/harmony_mi355x.h: compile it (syntax + types only) against a minimal stand-in
+    for R's C API (tests/stubs/), with implicit declarations and pointer/int mismatches as errors."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc not found"
+    p = subprocess.run([gcc, "-std=c11", "-fsyntax-only", "-Wall", "-Werror=implicit-function-declaration",
+                        "-Werror=incompatible-pointer-types", "-Werror=int-conversion", "-Wno-cast-function-type",
+                        "-I" + os.path.join(root, "tests", "stubs"), "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "r", "harmony_mi355x_glue.c")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
