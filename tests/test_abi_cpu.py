@@ -102,3 +102,24 @@ def test_r_glue_type_checks_against_the_c_abi():
                         "-I" + os.path.join(root, "tests", "stubs"), "-I" + os.path.join(root, "include"),
                         os.path.join(root, "r", "harmony_mi355x_glue.c")], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-3000:]
+
+
+def test_plain_c_host_links_and_fails_loudly_without_gpu(tmp_path):
+    """examples/host_example.c drives the library from C exactly like R/ui.R drives the Rcpp module.  It must compile and
+    link against the C ABI alone (no Python, no torch); on this GPU-less box hmx_setup must fail with the no-fallback error."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc not found"
+    exe = str(tmp_path / "host_example")
+    libdir = os.path.join(root, "harmony_amd", "lib")
+    p = subprocess.run([gcc, "-std=c11", "-Wall", "-Werror=implicit-function-declaration", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "examples", "host_example.c"), "-L" + libdir, "-lharmony_mi355x",
+                        "-Wl,-rpath," + libdir, "-lm", "-o", exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the example would run to completion (covered by the gpu tests)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, stdin=subprocess.DEVNULL)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr, (r.stdout, r.stderr)

@@ -368,3 +368,19 @@ def test_fallback_paths_parity(cell_lines, monkeypatch, env):
     Z, meta, _ = synth(20000, d=50, levels=(10,), seed=5)
     g, c, ig, ic = run_both(Z, meta, "cov0", max_iter=2, nclust=100, seed=8)
     assert_parity(g, c, ig, ic)
+
+
+def test_plain_c_host_example_runs(tmp_path):
+    """The C ABI driven from a plain C program (examples/host_example.c): no Python in the loop."""
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc on this box")
+    exe = str(tmp_path / "host_example")
+    libdir = os.path.join(root, "harmony_amd", "lib")
+    p = subprocess.run([gcc, "-std=c11", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "host_example.c"),
+                        "-L" + libdir, "-lharmony_mi355x", "-Wl,-rpath," + libdir, "-lm", "-o", exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
+    assert r.returncode == 0 and "converged after" in r.stdout and "nan" not in r.stdout.lower(), (r.stdout, r.stderr[-2000:])
