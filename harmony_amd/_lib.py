@@ -24,6 +24,9 @@ SIGNATURES = {
     "hmx_setup": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32, _ip, _ip, _dp, C.c_int32, _dp, _dp, _dp,
                             C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_double,
                             _ip, C.c_int32, C.c_double, C.c_int32]),
+    "hmx_setup_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _ip, _ip, _dp, C.c_int32, _dp,
+                               _dp, _dp, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_double,
+                               _ip, C.c_int32, C.c_double, C.c_int32]),
     "hmx_restart": (C.c_int, [C.c_void_p]),
     "hmx_init_cluster": (C.c_int, [C.c_void_p, _dp]),
     "hmx_kmeans_centers": (C.c_int, [C.c_void_p, _dp]),
@@ -32,7 +35,12 @@ SIGNATURES = {
     "hmx_check_convergence": (C.c_int, [C.c_void_p, C.c_int32]),
     "hmx_compute_objective": (C.c_int, [C.c_void_p]),
     "hmx_get": (C.c_int64, [C.c_void_p, C.c_char_p, _dp, C.c_int64]),
+    "hmx_get_matrix": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64]),
     "hmx_set_int": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "hmx_set_uniform_source": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hmx_r_runif": (None, [C.c_uint32, C.c_int32, _dp]),
+    "hmx_r_shuffle": (None, [C.c_uint32, C.c_int64, _lp]),
+    "hmx_mt19937_by_array": (None, [C.POINTER(C.c_uint32), C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),
     "hmx_feistel_pos": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "hmx_u01": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "hmx_push_update_order": (C.c_int, [C.c_void_p, _lp]),

@@ -4,6 +4,7 @@
 // kernel (hmx_kernels.hip) and all per-cell state stays in HBM between calls.
 #include "../../include/harmony_mi355x.h"
 #include "hmx_internal.h"
+#include "hmx_rrng.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -109,6 +110,13 @@ struct hmx_ctx {
   std::vector<int> qlev, perm;
   std::deque<std::vector<int64_t>> injected;
   int64_t subset_clusters = 0, skipped_clusters = 0;
+  // objective snapshots are read back asynchronously: one pinned 3-double slot per clustering round, resolved into the
+  // four series when a value is needed (convergence checks, getters) -- no host sync per round
+  double* h_obj = nullptr; int obj_cap = 0, obj_pending = 0; hipEvent_t obj_event = nullptr; bool obj_harmony_pending = false;
+  // randomness: 0 = documented counter-based generator, 1 = R-compatible (MT19937 seeded like set.seed, arma draw order)
+  int rng_mode = 0; hmx::RRng rrng; bool rrng_seeded = false;
+  // ridge statistics arithmetic: 0 = exact (fp64 / fixed order), 1 = the reference's (sequential fp32 over the cells)
+  int ridge_arith = 0;
   std::map<std::string, double> timers;
   // ---- device -------------------------------------------------------------------------
   int device = -1;
@@ -121,7 +129,7 @@ struct hmx_ctx {
   int tun_impl = -1, tun_tpw = -1, tun_cpw = -1, tun_wps = -1;  // tunables set through hmx_set_int before setup
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
   double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0;
-  std::string err, warn;
+  std::string err, warn, warn_ret;
 };
 
 namespace {
@@ -148,6 +156,9 @@ void free_all(hmx_ctx* ctx) {
   ctx->allocs.clear();
   for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   ctx->ev_pool.clear(); ctx->ev_used = 0;
+  if (ctx->h_obj) { (void)hipHostFree(ctx->h_obj); ctx->h_obj = nullptr; ctx->obj_cap = 0; }
+  if (ctx->obj_event) { (void)hipEventDestroy(ctx->obj_event); ctx->obj_event = nullptr; }
+  ctx->obj_pending = 0; ctx->obj_harmony_pending = false;
 }
 template <class T> int h2d(hmx_ctx* ctx, T* dst, const T* src, size_t count) {
   if (count) HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->L.stream));
@@ -205,15 +216,33 @@ int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Yt[j*K+k] and the MFMA 
   return h2d(ctx, D.Yimg, img.data(), img.size());
 }
 
-// objective snapshot obj[2..4] -> the four series (src/harmony.cpp:165-168)
-int push_objective(hmx_ctx* ctx) {
-  double o[3];
-  CHK(d2h(ctx, o, ctx->D.obj + 2, 3));
+// objective snapshot obj[2..4] -> the four series (src/harmony.cpp:165-168).  The copy is enqueued into a pinned slot;
+// flush_objectives() waits for the last copy only (an event, not the stream: later kernels keep running) and appends.
+int flush_objectives(hmx_ctx* ctx) {
+  if (!ctx->obj_pending) return 0;
+  HIPCHK(hipEventSynchronize(ctx->obj_event));
   const float norm_const = 2000 / ((float)ctx->N_global);
-  ctx->obj_kmeans.push_back((float)((o[0] + o[1] + o[2]) * norm_const));
-  ctx->obj_dist.push_back((float)(o[0] * norm_const));
-  ctx->obj_entropy.push_back((float)(o[1] * norm_const));
-  ctx->obj_cross.push_back((float)(o[2] * norm_const));
+  for (int i = 0; i < ctx->obj_pending; i++) {
+    const double* o = ctx->h_obj + 3 * i;
+    ctx->obj_kmeans.push_back((float)((o[0] + o[1] + o[2]) * norm_const));
+    ctx->obj_dist.push_back((float)(o[0] * norm_const));
+    ctx->obj_entropy.push_back((float)(o[1] * norm_const));
+    ctx->obj_cross.push_back((float)(o[2] * norm_const));
+  }
+  ctx->obj_pending = 0;
+  if (ctx->obj_harmony_pending) { ctx->obj_harmony.push_back(ctx->obj_kmeans.back()); ctx->obj_harmony_pending = false; }
+  return 0;
+}
+int push_objective(hmx_ctx* ctx) {
+  if (!ctx->h_obj) {
+    ctx->obj_cap = 64;
+    HIPCHK(hipHostMalloc((void**)&ctx->h_obj, sizeof(double) * 3 * ctx->obj_cap, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&ctx->obj_event, hipEventDisableTiming));
+  }
+  if (ctx->obj_pending == ctx->obj_cap) CHK(flush_objectives(ctx));
+  HIPCHK(hipMemcpyAsync(ctx->h_obj + 3 * ctx->obj_pending, ctx->D.obj + 2, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->L.stream));
+  HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
+  ctx->obj_pending++;
   return 0;
 }
 
@@ -252,6 +281,11 @@ bool check_convergence_impl(hmx_ctx* c, int type) {  // src/harmony.cpp:173-205
   return true;
 }
 
+// R-compatible mode: the generator is seeded like set.seed(seed) once per run (hmx_restart re-arms it)
+void ensure_rrng(hmx_ctx* ctx) {
+  if (!ctx->rrng_seeded) { ctx->rrng.set_seed((uint32_t)ctx->seed); ctx->rrng_seeded = true; }
+}
+
 // ---- kmeans_centers (src/utils.cpp:10-64) ---------------------------------------------------
 int gather_centres(hmx_ctx* ctx, const std::vector<long long>& gcells, long long* d_gcells, double* d_rows) {
   const int K = ctx->K, d = ctx->d;
@@ -268,16 +302,61 @@ int kmeans_centers(hmx_ctx* ctx) {
   const int K = ctx->K, d = ctx->d;
   const Dev& D = ctx->D;
   ctx->Y.assign((size_t)d * K, 0.f);
-  long long* d_gcells; double* d_rows; unsigned* d_excl;
-  CHK(dalloc(ctx, &d_gcells, (size_t)K)); CHK(dalloc(ctx, &d_rows, (size_t)K * d)); CHK(dalloc(ctx, &d_excl, (size_t)K));
+  long long* const d_gcells = D.km_gcells; double* const d_rows = D.km_rows; unsigned* const d_excl = D.km_excl;   // allocated once in hmx_setup
   // random anchors (:12-15): indices = floor(randu * (N-1))
   std::vector<long long> gcells(K);
   const float Nm1 = (float)((uint64_t)ctx->N_global - 1);
-  for (int i = 0; i < K; i++) gcells[i] = (long long)std::floor(hmx_u01(ctx->seed, 0, (uint64_t)i) * Nm1);
+  const bool rmode = ctx->rng_mode == 1;
+  if (rmode) ensure_rrng(ctx);
+  for (int i = 0; i < K; i++) gcells[i] = (long long)std::floor((rmode ? ctx->rrng.arma_randu() : hmx_u01(ctx->seed, 0, (uint64_t)i)) * Nm1);
   CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
   CHK(upload_Y(ctx));
-  // exponential race for every anchor in one pass (:24-34)
   std::vector<unsigned long long> win(K), sentinel(K, SEED_SENTINEL);
+  std::set<unsigned> sup;
+  if (rmode) {
+    // R-compatible stream: anchor i consumes N_global uniforms in cell order (VECTYPE random_numbers(size(distances), randu), :29).
+    // The host draws them (MT19937 or the host's unif_rand callback), a batch of anchors at a time; the race itself
+    // (-log(u) / |2(1 - y_i.x)|, index_min) runs on the device over this shard's cells.
+    const int64_t n = ctx->N;
+    int A = (int)std::max<int64_t>(1, std::min<int64_t>(K, (int64_t)(64ll << 20) / (4 * std::max<int64_t>(n, 1))));
+    A = std::max(1, std::min(A, 12288 / d));   // anchor rows of a batch live in LDS (<= 48 KB)
+    float* d_u; HIPCHK(hipMalloc((void**)&d_u, sizeof(float) * (size_t)A * (size_t)n));
+    std::vector<float> hu((size_t)A * (size_t)n);
+    int st = 0;
+    for (int a0 = 0; a0 < K && !st; a0 += A) {
+      const int na = std::min(A, K - a0);
+      for (int a = 0; a < na; a++)
+        for (int64_t g = 0; g < ctx->N_global; g++) {
+          const float u = ctx->rrng.arma_randu();
+          if (g >= ctx->goff && g < ctx->goff + n) hu[(size_t)a * n + (size_t)(g - ctx->goff)] = u;
+        }
+      st = h2d(ctx, d_u, hu.data(), (size_t)na * (size_t)n);
+      if (!st) st = h2d(ctx, D.seedmin, sentinel.data(), (size_t)K);
+      if (!st) { l_seed_race_u(ctx->L, D, d_u, a0, na, 0, (uint64_t)ctx->goff, nullptr, 0); if (hipGetLastError() != hipSuccess) st = fail(ctx, HMX_ERR_DEVICE, "seed race launch failed"); }
+      if (!st) st = allreduce(ctx, D.seedmin, K, 2);
+      if (!st) st = d2h(ctx, win.data(), D.seedmin, (size_t)K);
+      for (int i = a0; i < a0 + na && !st; i++) {   // duplicates in cluster order (:38-43)
+        if (win[i] == SEED_SENTINEL) { st = fail(ctx, HMX_ERR_STATE, "centroid seeding found no candidate cell"); break; }
+        unsigned g = (unsigned)(win[i] & 0xffffffffu);
+        if (sup.count(g)) {
+          std::vector<unsigned> ex(sup.begin(), sup.end());
+          st = h2d(ctx, d_excl, ex.data(), ex.size());
+          if (!st) st = h2d(ctx, D.seedmin, sentinel.data(), (size_t)K);
+          if (!st) { l_seed_race_u(ctx->L, D, d_u, a0, na, i - a0, (uint64_t)ctx->goff, d_excl, (int)ex.size()); if (hipGetLastError() != hipSuccess) st = fail(ctx, HMX_ERR_DEVICE, "seed race launch failed"); }
+          if (!st) st = allreduce(ctx, D.seedmin, K, 2);
+          std::vector<unsigned long long> w2(K);
+          if (!st) st = d2h(ctx, w2.data(), D.seedmin, (size_t)K);
+          if (!st && w2[i] == SEED_SENTINEL) st = fail(ctx, HMX_ERR_STATE, "centroid seeding ran out of distinct cells");
+          g = (unsigned)(w2[i] & 0xffffffffu);
+        }
+        sup.insert(g);
+        gcells[i] = (long long)g;
+      }
+    }
+    (void)hipFree(d_u);
+    if (st) return st;
+  } else {
+  // exponential race for every anchor in one pass (:24-34)
   CHK(h2d(ctx, D.seedmin, sentinel.data(), (size_t)K));
   // the race on the matrix cores (k_tile mode 3) when the centroid image fits; else the cluster-lane VALU kernel
   const bool seed_tile = D.tile_impl && (size_t)D.NQ * D.NS * 1024 <= 150 * 1024;
@@ -293,7 +372,6 @@ int kmeans_centers(hmx_ctx* ctx) {
   CHK(allreduce(ctx, D.seedmin, K, 2));
   CHK(d2h(ctx, win.data(), D.seedmin, (size_t)K));
   // duplicates are resolved in cluster order (:38-43): re-sample cluster i among cells not yet chosen
-  std::set<unsigned> sup;
   for (int i = 0; i < K; i++) {
     unsigned g = (unsigned)(win[i] & 0xffffffffu);
     if (win[i] == SEED_SENTINEL) return fail(ctx, HMX_ERR_STATE, "centroid seeding found no candidate cell");
@@ -310,6 +388,7 @@ int kmeans_centers(hmx_ctx* ctx) {
     }
     sup.insert(g);
     gcells[i] = (long long)g;
+  }
   }
   CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
   // 10 x one Lloyd iteration (:53-64); the centre update runs on the device, no host round trip per iteration
@@ -337,6 +416,12 @@ int kmeans_centers(hmx_ctx* ctx) {
 int prepare_round(hmx_ctx* ctx, uint64_t round) {
   Dev& D = ctx->D;
   bool gen_blocks = false;
+  if (ctx->injected.empty() && ctx->rng_mode == 1) {   // update_order = shuffle(linspace(0, N-1, N)) from R's stream (:272-273)
+    ensure_rrng(ctx);
+    std::vector<int64_t> order;
+    ctx->rrng.arma_shuffle(ctx->N_global, order);
+    ctx->injected.push_back(std::move(order));
+  }
   if (!ctx->injected.empty()) {  // host-provided shuffle: block(g) from its position
     std::vector<int64_t> order = std::move(ctx->injected.front());
     ctx->injected.pop_front();
@@ -421,8 +506,9 @@ int update_R(hmx_ctx* ctx) {
   l_obj_reduce(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.obj, 2, 1));
   l_objective_tables(ctx->L, D); KCHK();
-  CHK(push_objective(ctx));  // synchronises
+  CHK(push_objective(ctx));  // asynchronous: resolved by flush_objectives when a value is needed
   if (ctx->profile) {
+    HIPCHK(hipStreamSynchronize(ctx->L.stream));
     for (size_t i = 0; i < ctx->ev_used; i++) {
       float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
       ctx->prof_update_ms += ms;
@@ -484,7 +570,7 @@ struct SolveOut { int status = 0; bool skipped = false, subset = false; std::vec
 // O, E: K x B column-major floats; Sq [Q][K][d], nq [Q][K] doubles; Wq [Q][K][d] floats (output)
 void solve_cluster(const hmx_ctx* ctx, int k, const std::vector<float>& O, const std::vector<float>& E,
                    const std::vector<double>& Sq, const std::vector<double>& nq, std::vector<float>& Wq,
-                   std::vector<float>& Ynew, SolveOut& out) {
+                   std::vector<float>& Ynew, SolveOut& out, const double* S0 = nullptr, const double* n0 = nullptr) {
   const int K = ctx->K, B = ctx->B, C = ctx->C, d = ctx->d, Q = ctx->Q;
   std::vector<int> cov_levels(C, 0);
   for (int b = 0, cov = 0; b < B; b++) {  // :368-380
@@ -521,8 +607,11 @@ void solve_cluster(const hmx_ctx* ctx, int k, const std::vector<float>& O, const
       if (!(den > 0.0)) { ok = false; break; }
       coef[b] = n / den;                       // n_b / (n_b + lambda_b)
       N += n; u += n * coef[b];
-      if (q >= 0) { const double* sq = &Sq[((size_t)q * K + k) * d]; for (int j = 0; j < d; j++) w0[j] += (1.0 - coef[b]) * sq[j]; }
+      if (q >= 0) { const double* sq = &Sq[((size_t)q * K + k) * d]; for (int j = 0; j < d; j++) w0[j] += (S0 ? -coef[b] : (1.0 - coef[b])) * sq[j]; }
     }
+    // the arrowhead system's first row: (sum_i R_ki) w0 + sum_b n_b w_b = sum_i R_ki z_i.  Exact statistics: both totals are
+    // the sums of the level rows.  ridge_arith = 1: the reference's OWN sequential fp32 totals (separate chains, :567,:599).
+    if (S0) { N = *n0; for (int j = 0; j < d; j++) w0[j] += S0[j]; }
     u = N - u;
     if (ok && u > 0.0 && std::isfinite(u)) {
       for (int j = 0; j < d; j++) { w0[j] /= u; Ynew[(size_t)k * d + j] = (float)w0[j]; }          // intercept row :610
@@ -606,7 +695,11 @@ void hmx_destroy(hmx_ctx* ctx) {
   delete ctx;
 }
 const char* hmx_last_error(hmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null handle"; }
-const char* hmx_last_warning(hmx_ctx* ctx) { return ctx ? ctx->warn.c_str() : ""; }
+const char* hmx_last_warning(hmx_ctx* ctx) {   // one-shot: a warning is reported once (Rcpp::warning fires once, src/harmony.cpp:87)
+  if (!ctx) return "";
+  ctx->warn_ret.swap(ctx->warn); ctx->warn.clear();
+  return ctx->warn_ret.c_str();
+}
 
 uint64_t hmx_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g) {
   int bits = 2;
@@ -671,8 +764,33 @@ int hmx_set_abort_poll(hmx_ctx* ctx, int (*poll)(void*), void* user) {
   ctx->poll = poll; ctx->poll_user = user;
   return 0;
 }
+// probes of the R-compatible stream (no device needed): n uniforms after set.seed(seed); arma::shuffle(0..N-1) after set.seed(seed)
+void hmx_r_runif(uint32_t seed, int32_t n, double* out) { hmx::RRng r; r.set_seed(seed); for (int i = 0; i < n; i++) out[i] = r.unif_rand(); }
+void hmx_r_shuffle(uint32_t seed, int64_t N, int64_t* out) {
+  hmx::RRng r; r.set_seed(seed);
+  std::vector<int64_t> o; r.arma_shuffle(N, o);
+  std::copy(o.begin(), o.end(), out);
+}
+void hmx_mt19937_by_array(const uint32_t* key, int32_t len, int32_t n, uint32_t* out) {   // MT19937's published known-answer vector
+  hmx::RRng r; r.mt_init_by_array(key, len);
+  for (int i = 0; i < n; i++) out[i] = r.genrand_int32();
+}
+int hmx_set_uniform_source(hmx_ctx* ctx, double (*unif_rand)(void*), void* user) {
+  if (!ctx) return HMX_ERR_ARG;
+  ctx->rrng.set_source(unif_rand, user);
+  return 0;
+}
 int hmx_push_update_order(hmx_ctx* ctx, const int64_t* order) {
   if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
+  if (!order) return fail(ctx, HMX_ERR_ARG, "null update_order");
+  {  // must be a permutation of 0..N_global-1: prepare_round indexes a position table with these values
+    std::vector<bool> seen((size_t)ctx->N_global, false);
+    for (int64_t p = 0; p < ctx->N_global; p++) {
+      const int64_t v = order[p];
+      if (v < 0 || v >= ctx->N_global || seen[(size_t)v]) return fail(ctx, HMX_ERR_ARG, "update_order is not a permutation of 0..N-1");
+      seen[(size_t)v] = true;
+    }
+  }
   ctx->injected.emplace_back(order, order + ctx->N_global);
   return 0;
 }
@@ -681,7 +799,9 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   if (!ctx || !field) return HMX_ERR_ARG;
   const std::string f(field);
   if (f == "max_iter_kmeans") ctx->max_iter_kmeans = (int)v;
-  else if (f == "seed") ctx->seed = (uint64_t)v;
+  else if (f == "seed") { ctx->seed = (uint64_t)v; ctx->rrng_seeded = false; }
+  else if (f == "rng") { if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, "rng: 0 (counter-based) or 1 (R-compatible)"); ctx->rng_mode = (int)v; ctx->rrng_seeded = false; }
+  else if (f == "ridge_arith") { if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, "ridge_arith: 0 (exact) or 1 (reference fp32 order)"); ctx->ridge_arith = (int)v; }
   else if (f == "device") ctx->device = (int)v;
   else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; }
   else if (f == "grid") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "grid must be set before setup"); ctx->L.grid = (int)v; }
@@ -700,7 +820,18 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
               const double* phi_x, int32_t B, const double* sigma, const double* theta, const double* lambda,
               int32_t n_lambda, double alpha, int32_t max_iter_kmeans, double epsilon_kmeans, double epsilon_harmony,
               int32_t K, double block_size, const int32_t* B_vec, int32_t C, double cutoff, int32_t verbose) {
+  return hmx_setup_ex(ctx, Z, HMX_F64, HMX_HOST, N, d, phi_i, phi_p, phi_x, B, sigma, theta, lambda, n_lambda, alpha, max_iter_kmeans,
+                      epsilon_kmeans, epsilon_harmony, K, block_size, B_vec, C, cutoff, verbose);
+}
+
+int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_location, int64_t N, int32_t d, const int32_t* phi_i,
+                 const int32_t* phi_p, const double* phi_x, int32_t B, const double* sigma, const double* theta,
+                 const double* lambda, int32_t n_lambda, double alpha, int32_t max_iter_kmeans, double epsilon_kmeans,
+                 double epsilon_harmony, int32_t K, double block_size, const int32_t* B_vec, int32_t C, double cutoff,
+                 int32_t verbose) {
   if (!ctx) return HMX_ERR_ARG;
+  if ((z_dtype != HMX_F64 && z_dtype != HMX_F32) || (z_location != HMX_HOST && z_location != HMX_DEVICE))
+    return fail(ctx, HMX_ERR_ARG, "bad dtype / location of Z");
   ctx->err.clear(); ctx->warn.clear();
   if (!Z || !phi_i || !phi_p || !sigma || !theta || !lambda || !B_vec) return fail(ctx, HMX_ERR_ARG, "null argument");
   if (N <= 0 || d <= 0 || K <= 0 || B <= 0 || C <= 0) return fail(ctx, HMX_ERR_ARG, "non-positive dimension");
@@ -849,7 +980,9 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   }
   qchunk[Q] = (int)schunks.size();
   D.nchunks = (int)schunks.size();
-  D.npad = (int)std::min<int64_t>((int64_t)N + (int64_t)D.nb * Q * 16, 2147483000ll);
+  if ((int64_t)N + (int64_t)D.nb * Q * 16 > 2147483000ll)
+    return fail(ctx, HMX_ERR_LIMIT, "padded block order (N + n_blocks * combinations * 16) exceeds the int32 index range of one shard");
+  D.npad = (int)((int64_t)N + (int64_t)D.nb * Q * 16);
   D.nitems = (int)items.size(); D.naitems = (int)aitems.size(); D.ntitems = (int)titems.size();
   { const char* e = getenv("HMX_TILE_IMPL"); D.tile_impl = (e && std::string(e) == "v1") ? 0 : 1; }
   CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, ((size_t)N + 1) * K));   // + one dummy row (target of masked stores)
@@ -869,7 +1002,10 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
-  CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d)); CHK(dalloc(ctx, &D.Wimg, D.moe_mfma ? (size_t)Q * D.wNQ * D.wNS * 256 : 1));
+  CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K));
+  CHK(dalloc(ctx, &D.S0, (size_t)K * d)); CHK(dalloc(ctx, &D.n0, (size_t)K)); CHK(dalloc(ctx, &D.qstart, (size_t)Q + 1)); CHK(dalloc(ctx, &D.sizes, (size_t)B));
+  CHK(h2d(ctx, D.qstart, start.data(), (size_t)Q + 1)); CHK(h2d(ctx, D.sizes, ctx->sizes.data(), (size_t)B)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d)); CHK(dalloc(ctx, &D.Wimg, D.moe_mfma ? (size_t)Q * D.wNQ * D.wNS * 256 : 1));
+  CHK(dalloc(ctx, &D.km_gcells, (size_t)K)); CHK(dalloc(ctx, &D.km_rows, (size_t)K * d)); CHK(dalloc(ctx, &D.km_excl, (size_t)K));
   CHK(dalloc(ctx, &D.seedmin, (size_t)K)); CHK(dalloc(ctx, &D.lsum, (size_t)K * d + K)); D.lcnt = reinterpret_cast<unsigned long long*>(D.lsum + (size_t)K * d); CHK(dalloc(ctx, &D.ynorm, (size_t)K));
   CHK(h2d(ctx, D.perm, ctx->perm.data(), (size_t)N)); CHK(h2d(ctx, D.invperm, invperm.data(), (size_t)N));
   CHK(h2d(ctx, D.combo, combo_sorted.data(), (size_t)N)); CHK(h2d(ctx, D.qlev, ctx->qlev.data(), ctx->qlev.size()));
@@ -889,18 +1025,42 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d, const int32_t
   HIPCHK(hipMemsetAsync(D.Zo, 0, sizeof(float) * (size_t)N * D.zs, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Zc, 0, sizeof(float) * (size_t)N * D.zs, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Wq, 0, sizeof(float) * (size_t)Q * K * d, ctx->L.stream));
-  // Z: double d x N (cell-major) -> fp32 rows in internal order, staged through HBM in slabs (conv_to, :41)
+  // Z: d x N (cell-major), double (the R seam, conv_to :41) or float, on the host or already in HBM -> fp32 rows in internal
+  // order.  Host input goes through two HBM staging slabs: the copy of slab s+1 (copy stream) overlaps the conversion of slab s.
   {
-    const int64_t slab = std::max<int64_t>(1, (int64_t)(256ll << 20) / (8ll * d));
-    double* dstage; HIPCHK(hipMalloc((void**)&dstage, (size_t)std::min<int64_t>(slab, N) * d * sizeof(double)));
-    for (int64_t s = 0; s < N; s += slab) {
-      const int64_t cnt = std::min<int64_t>(slab, N - s);
-      hipError_t e = hipMemcpyAsync(dstage, Z + s * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, ctx->L.stream);
-      if (e == hipSuccess) { l_convert_in(ctx->L, dstage, D.Zo, D.invperm + s, (int)cnt, d, D.zs); e = hipGetLastError(); }
+    const double t_in = now_ms();
+    const int f32 = z_dtype == HMX_F32;
+    const size_t esz = f32 ? 4 : 8;
+    if (z_location == HMX_DEVICE) {
+      l_convert_in(ctx->L, Z, f32, D.Zo, D.invperm, (int)N, d, D.zs); KCHK();
+      HIPCHK(hipStreamSynchronize(ctx->L.stream));
+    } else {
+      const int64_t slab = std::max<int64_t>(1, (int64_t)(128ll << 20) / ((int64_t)esz * d));
+      const int64_t scnt = std::min<int64_t>(slab, N);
+      void* stage[2] = {nullptr, nullptr}; hipStream_t cs = nullptr; hipEvent_t copied[2] = {nullptr, nullptr}, used[2] = {nullptr, nullptr};
+      hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+      for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipMalloc(&stage[i], (size_t)scnt * d * esz);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&copied[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&used[i], hipEventDisableTiming);
+      }
+      int it = 0;
+      for (int64_t s0 = 0; s0 < N && e == hipSuccess; s0 += slab, it++) {
+        const int64_t cnt = std::min<int64_t>(slab, N - s0);
+        const int b = it & 1;
+        if (it >= 2) e = hipStreamWaitEvent(cs, used[b], 0);           // the slab's previous conversion has read it
+        if (e == hipSuccess) e = hipMemcpyAsync(stage[b], (const char*)Z + (size_t)s0 * d * esz, (size_t)cnt * d * esz, hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipEventRecord(copied[b], cs);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->L.stream, copied[b], 0);
+        if (e == hipSuccess) { l_convert_in(ctx->L, stage[b], f32, D.Zo, D.invperm + s0, (int)cnt, d, D.zs); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipEventRecord(used[b], ctx->L.stream);
+      }
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
-      if (e != hipSuccess) { (void)hipFree(dstage); return fail(ctx, HMX_ERR_DEVICE, hipGetErrorString(e)); }
+      for (int i = 0; i < 2; i++) { if (stage[i]) (void)hipFree(stage[i]); if (copied[i]) (void)hipEventDestroy(copied[i]); if (used[i]) (void)hipEventDestroy(used[i]); }
+      if (cs) (void)hipStreamDestroy(cs);
+      if (e != hipSuccess) return fail(ctx, HMX_ERR_DEVICE, hipGetErrorString(e));
     }
-    (void)hipFree(dstage);
+    ctx->timers["ingest_Z"] = now_ms() - t_in;
   }
   ctx->W.assign((size_t)(B + 1) * d, 0.f); ctx->W_rows = B + 1;  // allocate_buffers :127
   ctx->Y.assign((size_t)d * K, 0.f);
@@ -918,8 +1078,9 @@ int hmx_restart(hmx_ctx* ctx) {
   l_copy(ctx->L, D.Zo, D.Zc, (size_t)D.n * D.zs); KCHK();
   l_normalize(ctx->L, D.Zc, D.n, D.d, D.zs); KCHK();  // Z_corr = normalise(Z_orig) :42
   HIPCHK(hipStreamSynchronize(ctx->L.stream));
+  ctx->obj_pending = 0; ctx->obj_harmony_pending = false;
   ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();
-  ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear();
+  ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear(); ctx->rrng_seeded = false;
   return 0;
 }
 
@@ -942,6 +1103,7 @@ int hmx_init_cluster(hmx_ctx* ctx, const double* Y0) {  // src/harmony.cpp:131-1
   CHK(head_pass(ctx));
   l_objective_tables(ctx->L, ctx->D); KCHK();
   CHK(push_objective(ctx));
+  CHK(flush_objectives(ctx));
   ctx->obj_harmony.push_back(ctx->obj_kmeans.back());
   ctx->ran_init = true;
   ctx->timers["init_cluster"] += now_ms() - t0;
@@ -956,11 +1118,13 @@ int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the cur
   l_obj_reduce(ctx->L, ctx->D); KCHK();
   CHK(allreduce(ctx, ctx->D.obj, 2, 1));
   l_objective_tables(ctx->L, ctx->D); KCHK();
-  return push_objective(ctx);
+  CHK(push_objective(ctx));
+  return flush_objectives(ctx);
 }
 
 int hmx_check_convergence(hmx_ctx* ctx, int32_t type) {
   if (!ctx) return -HMX_ERR_ARG;
+  if (flush_objectives(ctx)) return -HMX_ERR_DEVICE;
   if ((type == 0 && ctx->obj_kmeans.size() < (size_t)ctx->window_size + 1) || (type == 1 && ctx->obj_harmony.size() < 2)) {
     fail(ctx, HMX_ERR_STATE, "not enough objective values"); return -HMX_ERR_STATE;
   }
@@ -971,6 +1135,7 @@ int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
   if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   const double t0 = now_ms();
+  CHK(flush_objectives(ctx));   // (values of an earlier call that nobody asked for yet)
   if (ctx->obj_harmony.size() != 1) {  // :214-228
     l_normalize(ctx->L, ctx->D.Zc, ctx->D.n, ctx->D.d, ctx->D.zs); KCHK();
     CHK(head_pass(ctx));
@@ -979,12 +1144,14 @@ int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
   for (iter = 0; iter < ctx->max_iter_kmeans; iter++) {
     if (ctx->poll && ctx->poll(ctx->poll_user)) return HMX_ABORTED;  // :233-234
     CHK(update_R(ctx));                                                 // :241 (objective fused, :248)
-    if (iter > ctx->window_size) {                                      // :250-256
+    if (iter > ctx->window_size) {                                      // :250-256 (the only place a round's value is needed at once)
+      CHK(flush_objectives(ctx));
       if (check_convergence_impl(ctx, 0)) { iter++; break; }
     }
   }
   ctx->kmeans_rounds.push_back(iter);
-  ctx->obj_harmony.push_back(ctx->obj_kmeans.back());
+  ctx->obj_harmony_pending = true;   // objective_harmony <- objective_kmeans.back() (:260), resolved with the pending rounds
+  if (ctx->obj_pending == 0) { ctx->obj_harmony.push_back(ctx->obj_kmeans.back()); ctx->obj_harmony_pending = false; }
   ctx->timers["cluster"] += now_ms() - t0;
   return 0;
 }
@@ -996,14 +1163,20 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   const double t0 = now_ms();
   const Dev& D = ctx->D;
   const int K = ctx->K, B = ctx->B, d = ctx->d, Q = ctx->Q;
+  const bool seq = ctx->ridge_arith == 1;
+  if (seq && (ctx->C != 1 || ctx->world > 1 || ctx->comm_force || B > 1024))
+    return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 (reference summation order) supports one covariate on one GPU");
   HIPCHK(hipMemsetAsync(D.Sq, 0, sizeof(double) * (size_t)Q * d * K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.nq, 0, sizeof(double) * (size_t)Q * K, ctx->L.stream));
-  if (D.moe_mfma) { l_moe_stats_mfma(ctx->L, D); KCHK(); } else { l_moe_stats(ctx->L, D); KCHK(); }
+  if (seq) { l_moe_stats_seq(ctx->L, D, ctx->cutoff); KCHK(); }
+  else if (D.moe_mfma) { l_moe_stats_mfma(ctx->L, D); KCHK(); } else { l_moe_stats(ctx->L, D); KCHK(); }
   CHK(allreduce(ctx, D.Sq, (int64_t)Q * d * K, 1));
   CHK(allreduce(ctx, D.nq, (int64_t)Q * K, 1));
   std::vector<double> Sq((size_t)Q * d * K), nq((size_t)Q * K);
   std::vector<long long> ofx((size_t)B * K);
   CHK(d2h(ctx, Sq.data(), D.Sq, Sq.size())); CHK(d2h(ctx, nq.data(), D.nq, nq.size())); CHK(d2h(ctx, ofx.data(), D.O_fx, ofx.size()));
+  std::vector<double> S0, n0;
+  if (seq) { S0.resize((size_t)K * d); n0.resize((size_t)K); CHK(d2h(ctx, S0.data(), D.S0, S0.size())); CHK(d2h(ctx, n0.data(), D.n0, n0.size())); }
   const double t1 = now_ms();
   const std::vector<float> O = table_O(ctx, ofx), E = table_E(ctx, ofx);
   std::vector<float> Wq((size_t)Q * K * d), Ynew = ctx->Y;
@@ -1012,7 +1185,7 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
     unsigned nt = std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16; if ((int)nt > K) nt = K;
     if ((size_t)K * (B + 1) * (B + 1) < 200000) nt = 1;
     std::vector<std::thread> th;
-    auto work = [&](int t) { for (int k = t; k < K; k += (int)nt) solve_cluster(ctx, k, O, E, Sq, nq, Wq, Ynew, outs[k]); };
+    auto work = [&](int t) { for (int k = t; k < K; k += (int)nt) solve_cluster(ctx, k, O, E, Sq, nq, Wq, Ynew, outs[k], seq ? &S0[(size_t)k * d] : nullptr, seq ? &n0[k] : nullptr); };
     if (nt == 1) work(0);
     else { for (unsigned t = 0; t < nt; t++) th.emplace_back(work, (int)t); for (auto& x : th) x.join(); }
   }
@@ -1104,6 +1277,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "prof:update_launches") return scalar((double)ctx->prof_update_launches);
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
   if (f.rfind("timer:", 0) == 0) { auto it = ctx->timers.find(f.substr(6)); return scalar(it == ctx->timers.end() ? 0.0 : it->second); }
+  if (f.rfind("objective_", 0) == 0 || f == "kmeans_rounds") { if (flush_objectives(ctx)) return -1; }
   if (f == "Y") return vec(ctx->Y);
   if (f == "W") return vec(ctx->W);
   if (f == "Pr_b") return vec(ctx->Pr_b);
@@ -1133,22 +1307,61 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
       L[(size_t)(b + 1) * K + k] = ctx->lambda_estimation ? (double)(E[(size_t)b * K + k] * ctx->alpha) : (double)ctx->lambda[b + 1];
     return vec(L);
   }
-  if (f == "Z_corr" || f == "Z_orig" || f == "R") {
-    const int w = (f == "R") ? ctx->K : ctx->d;
-    const int64_t cnt = ctx->N * w;
-    if (!out) return cnt;
-    if (cap < cnt) return cnt;
-    const float* src = (f == "R") ? ctx->D.R : (f == "Z_corr" ? ctx->D.Zc : ctx->D.Zo);
-    double* dfull;
-    if (hipMalloc((void**)&dfull, (size_t)cnt * sizeof(double)) != hipSuccess) { ctx->err = "out of device memory in getter"; return -1; }
-    l_convert_out(ctx->L, src, dfull, ctx->D.perm, ctx->D.n, w, (f == "R") ? w : ctx->D.zs);
-    hipError_t e = hipMemcpyAsync(out, dfull, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->L.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
-    (void)hipFree(dfull);
-    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
-    return cnt;
-  }
+  if (f == "Z_corr" || f == "Z_orig" || f == "R") return hmx_get_matrix(ctx, field, out, HMX_F64, HMX_HOST, cap);
   return -1;
+}
+
+// getZcorr / getZorig / getR (src/harmony.cpp:640-655) with a choice of element type and destination: double on the host is the
+// R seam; float and/or a device pointer avoid the fp64 blow-up and the PCIe trip for hosts that keep working on the GPU.
+// Host destinations are filled slab by slab through two HBM staging buffers (conversion of slab s+1 overlaps the copy of slab s).
+int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype, int32_t location, int64_t cap) {
+  if (!ctx || !field || !ctx->ran_setup) return -1;
+  const std::string f(field);
+  if (f != "Z_corr" && f != "Z_orig" && f != "R") return -1;
+  if ((dtype != HMX_F64 && dtype != HMX_F32) || (location != HMX_HOST && location != HMX_DEVICE)) { ctx->err = "bad dtype / location"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  const int w = (f == "R") ? ctx->K : ctx->d;
+  const int64_t cnt = ctx->N * w;
+  if (!out || cap < cnt) return cnt;
+  const float* src = (f == "R") ? ctx->D.R : (f == "Z_corr" ? ctx->D.Zc : ctx->D.Zo);
+  const int ws = (f == "R") ? w : ctx->D.zs;
+  const int f32 = dtype == HMX_F32;
+  const size_t esz = f32 ? 4 : 8;
+  const double t0 = now_ms();
+  hipError_t e = hipSuccess;
+  if (location == HMX_DEVICE) {
+    l_convert_out(ctx->L, src, out, f32, ctx->D.invperm, ctx->D.n, w, ws);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
+  } else {
+    const int64_t slab = std::max<int64_t>(1, (int64_t)(128ll << 20) / ((int64_t)esz * w));
+    const int64_t scnt = std::min<int64_t>(slab, ctx->N);
+    void* stage[2] = {nullptr, nullptr}; hipStream_t cs = nullptr; hipEvent_t conv[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+      e = hipMalloc(&stage[i], (size_t)scnt * w * esz);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&conv[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&copied[i], hipEventDisableTiming);
+    }
+    int it = 0;
+    for (int64_t s0 = 0; s0 < ctx->N && e == hipSuccess; s0 += slab, it++) {
+      const int64_t c = std::min<int64_t>(slab, ctx->N - s0);
+      const int b = it & 1;
+      if (it >= 2) e = hipStreamWaitEvent(ctx->L.stream, copied[b], 0);   // the slab's previous contents have left for the host
+      if (e == hipSuccess) { l_convert_out(ctx->L, src, stage[b], f32, ctx->D.invperm + s0, (int)c, w, ws); e = hipGetLastError(); }
+      if (e == hipSuccess) e = hipEventRecord(conv[b], ctx->L.stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs, conv[b], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync((char*)out + (size_t)s0 * w * esz, stage[b], (size_t)c * w * esz, hipMemcpyDeviceToHost, cs);
+      if (e == hipSuccess) e = hipEventRecord(copied[b], cs);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(cs);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
+    for (int i = 0; i < 2; i++) { if (stage[i]) (void)hipFree(stage[i]); if (conv[i]) (void)hipEventDestroy(conv[i]); if (copied[i]) (void)hipEventDestroy(copied[i]); }
+    if (cs) (void)hipStreamDestroy(cs);
+  }
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
+  ctx->timers["egress_" + f] = now_ms() - t0;
+  return cnt;
 }
 
 }  // extern "C"

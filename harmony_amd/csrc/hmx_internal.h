@@ -97,11 +97,16 @@ struct Dev {
   // MoE
   double* Sq;       // [Q][K][d]  sum_i R_ki z_ij over cells of combination q
   double* nq;       // [Q][K]     sum_i R_ki
+  double* S0;       // [K][d]     ridge_arith = 1: the intercept row's own sequential sum over all kept cells
+  double* n0;       // [K]
+  int* qstart;      // [Q+1] first internal cell of every combination
+  float* sizes;     // [B] N_b
   float* Wq;        // [Q][K][d]  correction table
   float* Wimg;      // [Q][wNQ][wNS][4][16][4] the same table as MFMA B-operand image (clusters = reduction dim)
   int wNQ, wNT4, wtail, wNS;  // image geometry for k_moe_apply_mfma (valid when moe_mfma)
   int moe_mfma;     // 1: MFMA stats/apply kernels (needs K % 4 == 0, d <= 64, K <= 128)
   // kmeans init
+  long long* km_gcells; double* km_rows; unsigned* km_excl;   // [K] chosen global cells, [K][d] their rows, [K] exclusion list
   unsigned long long* seedmin;  // [K] packed (key bits << 32 | global cell)
   long long* lsum;  // [K][d] 2^30 fixed-point sums of unit-vector components (exact, order-independent)
   int lloyd_lds;    // 1: the Lloyd sums are accumulated in an LDS table per workgroup first
@@ -115,8 +120,8 @@ struct Launch {
 };
 
 // ---- launchers (hmx_kernels.hip) -----------------------------------------------------
-void l_convert_in(const Launch& L, const double* src, float* dst, const int* invperm, int n, int d, int zs);
-void l_convert_out(const Launch& L, const float* src, double* dst, const int* perm, int n, int w, int ws);
+void l_convert_in(const Launch& L, const void* src, int f32, float* dst, const int* invperm, int n, int d, int zs);
+void l_convert_out(const Launch& L, const float* src, void* dst, int f32, const int* invperm, int n, int w, int ws);
 void l_copy(const Launch& L, const float* src, float* dst, size_t count);
 void l_normalize(const Launch& L, float* Z, int n, int d, int zs);
 // mode 0: head (write R, accumulate O_fx, objective partials); mode 1: objective only (read R)
@@ -135,8 +140,11 @@ void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term o
 void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);
 void l_moe_stats_mfma(const Launch& L, const Dev& D);
+void l_moe_stats_seq(const Launch& L, const Dev& D, float cutoff);
 void l_moe_apply_mfma(const Launch& L, const Dev& D);
 void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl);
+void l_seed_race_u(const Launch& L, const Dev& D, const float* u, int a0, int na, int only, uint64_t goff, const unsigned* excl,
+                   int nexcl);
 void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint64_t goff, double* rows);
 void l_lloyd(const Launch& L, const Dev& D);
 void l_lloyd_finish(const Launch& L, const Dev& D);

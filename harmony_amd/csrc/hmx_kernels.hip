@@ -177,8 +177,10 @@ __device__ __forceinline__ void flush_fx(long long* __restrict__ tab, const int*
 // --------------------------------------------------------------------------------------
 // ingest / egress
 // --------------------------------------------------------------------------------------
-// src: [n][d] doubles in local original order -> dst: [n][d] floats in internal order
-__global__ void k_convert_in(const double* __restrict__ src, float* __restrict__ dst, const int* __restrict__ invperm,
+// src: [n][d] doubles or floats in local original order (host slab staged in HBM, or the caller's device buffer)
+// -> dst: [n][zs] floats in internal order
+template <class T>
+__global__ void k_convert_in(const T* __restrict__ src, float* __restrict__ dst, const int* __restrict__ invperm,
                              int n, int d, int zs) {
   const size_t total = (size_t)n * d;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -186,13 +188,15 @@ __global__ void k_convert_in(const double* __restrict__ src, float* __restrict__
     dst[(size_t)invperm[cell] * zs + j] = (float)src[i];
   }
 }
-// src: [n][ws] floats internal order (first w of each row) -> dst: [n][w] doubles original order
-__global__ void k_convert_out(const float* __restrict__ src, double* __restrict__ dst, const int* __restrict__ perm,
+// egress of a slab of cells in ORIGINAL order: dst[i][0..w) = src[invperm[i]][0..w) (rows gathered, output written
+// contiguously -> the slab can be copied to the host while the next one is converted).  T = double (the R seam) or float.
+template <class T>
+__global__ void k_convert_out(const float* __restrict__ src, T* __restrict__ dst, const int* __restrict__ invperm,
                               int n, int w, int ws) {
   const size_t total = (size_t)n * w;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t cell = i / w; const int j = (int)(i - cell * w);
-    dst[(size_t)perm[cell] * w + j] = (double)src[cell * ws + j];
+    dst[i] = (T)src[(size_t)invperm[cell] * ws + j];
   }
 }
 __global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, size_t count) {
@@ -1622,6 +1626,67 @@ __global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
   }
 }
 
+// k_moe_stats_seq ("ridge_arith" = 1, one covariate): the ridge statistics in the REFERENCE'S arithmetic -- every accumulator a
+// sequential fp32 sum over the cells in ascending cell order, products rounded to fp32 first:
+//   Z_tmp = Z_orig % R_k (:592);  W.row(0) <- sum(Z_tmp, 1) (:599: arma::sum adds column after column);  level rows
+//   sum(Z_tmp.cols(index[b]), 1) (:605-608, index[b] ascending);  Phi_Rk * Phi_moe_t (:567) adds R_ki cell after cell.
+// These sums lose the many tiny R_ki z_i of far-away cells once the accumulator has grown (a systematic, N-dependent bias of
+// the reference: DESIGN.md section 2); the default path sums exactly instead.  One wave per (cluster, row): row 0 = the
+// intercept chain over ALL kept cells in original order (gathered through invperm), row 1+q = the cells of level/combination q
+// (contiguous and ascending in the internal order).  lanes = PCs; a chain of N dependent fp32 adds per wave: slow by design.
+__global__ __launch_bounds__(64) void k_moe_stats_seq(Dev D, float cutoff) {
+  __shared__ unsigned char keep[1024];
+  const int k = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
+  const int K = D.K, d = D.d, zs = D.zs, B = D.B;
+  // kept levels of this cluster (:358-402, one covariate): O[k,b] / N_b > cutoff, and at least two such levels
+  int nk = 0;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int b = b0 + lane;
+    bool kp = false;
+    if (b < B) { const float o = (float)((double)D.O_fx[(size_t)b * K + k] * FX_INV); kp = (o / D.sizes[b]) > cutoff; }
+    if (b < B) keep[b] = kp ? 1 : 0;
+    nk += __popcll(__ballot(kp));
+  }
+  __syncthreads();
+  const bool any = nk > 1;
+  float a0 = 0.0f, a1 = 0.0f, an = 0.0f;
+  int lo, hi;
+  if (row == 0) { lo = 0; hi = D.n; } else { lo = D.qstart[row - 1]; hi = D.qstart[row]; }
+  const int j0 = min(lane, zs - 1), j1 = min(lane + 64, zs - 1);
+  for (int base = lo; base < hi; base += 64) {
+    const int i = min(base + lane, hi - 1);
+    const int p = (row == 0) ? D.invperm[i] : i;
+    const float r = D.R[(size_t)p * K + k];
+    bool in = base + lane < hi;
+    if (row == 0) in = in && any && keep[D.qlev[D.combo[p]]];     // cells of dropped levels do not enter (:400,456-460)
+    const int nc = min(64, hi - base);
+    for (int c0 = 0; c0 < nc; c0 += 8) {
+      float z0[8], z1[8], rr[8]; bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int c = min(c0 + u, nc - 1);
+        const int pc = __builtin_amdgcn_readlane(p, c);
+        rr[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), c));
+        ok[u] = (c0 + u < nc) && __builtin_amdgcn_readlane((int)in, c);
+        z0[u] = D.Zo[(size_t)pc * zs + j0];
+        z1[u] = D.Zo[(size_t)pc * zs + j1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (ok[u]) {
+          a0 = __fadd_rn(a0, __fmul_rn(z0[u], rr[u]));
+          a1 = __fadd_rn(a1, __fmul_rn(z1[u], rr[u]));
+          an = __fadd_rn(an, rr[u]);
+        }
+      }
+    }
+  }
+  double* S = (row == 0) ? D.S0 + (size_t)k * d : D.Sq + ((size_t)(row - 1) * K + k) * d;
+  if (lane < d) S[lane] = (double)a0;
+  if (lane + 64 < d) S[lane + 64] = (double)a1;
+  if (lane == 0) { if (row == 0) D.n0[k] = (double)an; else D.nq[(size_t)(row - 1) * K + k] = (double)an; }
+}
+
 // ---- MFMA variants of the two MoE passes (static 16-cell tiles, rows of a tile are contiguous in HBM) ----
 // k_moe_stats_mfma: Sq[q] (K x d) += R_tile^T (K x 16) * Zo_tile (16 x d): the 16 cells are the MFMA reduction dim.
 //   A[i = cluster 16ct+(l&15)][slot l>>4] = R[cell 4s+(l>>4)][cluster],  B[slot][j = PC 16pt+(l&15)] = Zo[cell][PC]
@@ -1828,6 +1893,40 @@ __global__ __launch_bounds__(TPB) void k_seed_probe(Dev D, uint64_t seed, uint64
     if (lane + 64 * q < K && best[q] != ~0ull) atomicMin(&D.seedmin[lane + 64 * q], best[q]);
 }
 
+// R-compatible seeding race (hmx_set_int "rng" = 1): the uniforms come from the HOST's stream (MT19937 seeded like set.seed, or
+// the host's unif_rand), u[a][local original cell] for the anchors a0 .. a0+na-1; per anchor the race of src/utils.cpp:24-34
+// over this shard's cells: key = -log(u) / |2(1 - y_a.x)|, index_min (ties -> the smaller global cell index).
+__global__ __launch_bounds__(256) void k_seed_race_u(Dev D, const float* __restrict__ u, int a0, int na, int a_lo, int a_hi,
+                                                     uint64_t goff, const unsigned* __restrict__ excl, int nexcl) {
+  extern __shared__ float ys_[];   // [na][d] anchor rows
+  const int d = D.d, zs = D.zs, n = D.n;
+  for (int i = threadIdx.x; i < na * d; i += blockDim.x) ys_[i] = D.Ycur[(size_t)a0 * d + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (int a = a_lo; a < a_hi; a++) {
+    unsigned long long best = ~0ull;
+    const float* y = ys_ + a * d;
+    for (size_t p = gt; p < (size_t)n; p += stride) {
+      const float* z = D.Zc + p * zs;
+      float dot = 0.0f;
+      for (int j = 0; j < d; j++) dot = fmaf(y[j], z[j], dot);
+      const int loc = D.perm[p];
+      const uint64_t gg = goff + (uint64_t)loc;
+      bool skip = false;
+      for (int x = 0; x < nexcl; x++) skip |= ((uint64_t)excl[x] == gg);
+      const float dis = fabsf(2.0f * (1.0f - dot));
+      const float key = -logf(u[(size_t)a * n + loc]) / dis;
+      unsigned kb = __float_as_uint(key);
+      if (!(key >= 0.0f)) kb = 0x7f800000u;
+      const unsigned long long pk = ((unsigned long long)kb << 32) | (unsigned long long)(uint32_t)gg;
+      if (!skip && pk < best) best = pk;
+    }
+    best = wmin64(best);
+    if (lane == 0 && best != ~0ull) atomicMin(&D.seedmin[a0 + a], best);
+  }
+}
+
 // rows[k][:] = Z_corr row of global cell gcells[k] if it lives on this shard, else 0 (summed across ranks)
 __global__ void k_gather_rows(Dev D, const long long* __restrict__ gcells, uint64_t goff, double* __restrict__ rows) {
   const int k = blockIdx.x;
@@ -1975,11 +2074,13 @@ static int stream_grid(const Launch& L, long long work_waves) {
   return (int)blocks;
 }
 
-void l_convert_in(const Launch& L, const double* src, float* dst, const int* invperm, int n, int d, int zs) {
-  hipLaunchKernelGGL(k_convert_in, dim3(2048), dim3(256), 0, L.stream, src, dst, invperm, n, d, zs);
+void l_convert_in(const Launch& L, const void* src, int f32, float* dst, const int* invperm, int n, int d, int zs) {
+  if (f32) hipLaunchKernelGGL(k_convert_in<float>, dim3(2048), dim3(256), 0, L.stream, (const float*)src, dst, invperm, n, d, zs);
+  else hipLaunchKernelGGL(k_convert_in<double>, dim3(2048), dim3(256), 0, L.stream, (const double*)src, dst, invperm, n, d, zs);
 }
-void l_convert_out(const Launch& L, const float* src, double* dst, const int* perm, int n, int w, int ws) {
-  hipLaunchKernelGGL(k_convert_out, dim3(2048), dim3(256), 0, L.stream, src, dst, perm, n, w, ws);
+void l_convert_out(const Launch& L, const float* src, void* dst, int f32, const int* invperm, int n, int w, int ws) {
+  if (f32) hipLaunchKernelGGL(k_convert_out<float>, dim3(2048), dim3(256), 0, L.stream, src, (float*)dst, invperm, n, w, ws);
+  else hipLaunchKernelGGL(k_convert_out<double>, dim3(2048), dim3(256), 0, L.stream, src, (double*)dst, invperm, n, w, ws);
 }
 void l_copy(const Launch& L, const float* src, float* dst, size_t count) {
   hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, L.stream, src, dst, count);
@@ -2145,6 +2246,9 @@ void l_moe_apply(const Launch& L, const Dev& D) {
   const dim3 grid(g);
   HMX_DISPATCH_KD(k_moe_apply, , grid, lds, D);
 }
+void l_moe_stats_seq(const Launch& L, const Dev& D, float cutoff) {
+  hipLaunchKernelGGL(k_moe_stats_seq, dim3(D.K, D.Q + 1), dim3(64), 0, L.stream, D, cutoff);
+}
 void l_moe_stats_mfma(const Launch& L, const Dev& D) {
   const int npt = (D.d + 15) / 16;
   int tpw = (D.ntitems + 2 * 256 - 1) / (2 * 256);   // ~2 workgroups per CU
@@ -2176,6 +2280,13 @@ void l_moe_apply_mfma(const Launch& L, const Dev& D) {
 void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl) {
   const dim3 grid(stream_grid(L, D.nitems));
   HMX_DISPATCH_KD(k_seed_probe, , grid, lds_bytes_y(D), D, seed, goff, excl, nexcl);
+}
+void l_seed_race_u(const Launch& L, const Dev& D, const float* u, int a0, int na, int only, uint64_t goff, const unsigned* excl,
+                   int nexcl) {
+  int blocks = (D.n + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  const int lo = excl ? only : 0, hi = excl ? only + 1 : na;
+  hipLaunchKernelGGL(k_seed_race_u, dim3(blocks), dim3(256), (size_t)na * D.d * sizeof(float), L.stream, D, u, a0, na, lo, hi, goff,
+                     excl, nexcl);
 }
 void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint64_t goff, double* rows) {
   hipLaunchKernelGGL(k_gather_rows, dim3(D.K), dim3(64), 0, L.stream, D, gcells, goff, rows);

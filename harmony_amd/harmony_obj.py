@@ -30,7 +30,10 @@ def _iptr(a):
 class Harmony(object):
     """new(harmony)  (R/ui.R:269)."""
 
-    def __init__(self, device=None, seed=None):
+    def __init__(self, device=None, seed=None, rng=None, ridge_arith=None):
+        """rng: None/0 = the library's documented counter-based generator; 1 / "R" = R-compatible stream (MT19937 seeded like
+        set.seed(seed), RcppArmadillo's randu / shuffle draw order).  ridge_arith: 0 exact ridge statistics (default),
+        1 = the reference's sequential fp32 accumulation order (slow; for parity studies against the reference's arithmetic)."""
         self._lib = _lib.load()
         self._h = C.c_void_p(self._lib.hmx_create())
         if not self._h:
@@ -41,6 +44,10 @@ class Harmony(object):
             self._set("device", int(device))
         if seed is not None:
             self._set("seed", int(seed))
+        if rng:
+            self._set("rng", 1)
+        if ridge_arith:
+            self._set("ridge_arith", int(ridge_arith))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -122,8 +129,18 @@ class Harmony(object):
     def setup(self, Z, Phi, sigma, theta, lambda_vec, alpha, max_iter_kmeans, epsilon_kmeans, epsilon_harmony,
               K, block_size, B_vec, batch_proportion_cutoff, verbose):
         """harmony::setup (src/harmony.cpp:29-111).  Z: d x N; Phi: (i, p, x, B) CSC of the B x N design."""
-        Z = np.asfortranarray(Z, dtype=np.float64)
-        d, N = Z.shape
+        # Z: a numpy array (float64 = the R seam, or float32), or a device buffer (d, N, dtype, device_pointer) --
+        # hmx_setup_ex ingests fp32 and/or HBM-resident embeddings without the fp64 host copy (SURVEY 8f-3)
+        z_loc = 0
+        if isinstance(Z, tuple):
+            d, N, zdt, zptr = Z
+            z_dtype = 1 if np.dtype(zdt) == np.float32 else 0
+            z_loc, zarg = 1, C.c_void_p(int(zptr))
+        else:
+            z_dtype = 1 if getattr(Z, "dtype", None) == np.float32 else 0
+            Z = np.asfortranarray(Z, dtype=np.float32 if z_dtype else np.float64)
+            d, N = Z.shape
+            zarg = C.c_void_p(Z.ctypes.data)
         phi_i, phi_p, phi_x, B = Phi
         phi_i = np.ascontiguousarray(phi_i, dtype=np.int32)
         phi_p = np.ascontiguousarray(phi_p, dtype=np.int32)
@@ -136,11 +153,11 @@ class Harmony(object):
             raise HarmonyError("sigma must have one value per cluster")
         if theta.size != B:
             raise HarmonyError("theta must have one value per covariate level")
-        st = self._lib.hmx_setup(self._h, _dptr(Z), N, d, _iptr(phi_i), _iptr(phi_p),
-                                 None if phi_x is None else _dptr(phi_x), int(B), _dptr(sigma), _dptr(theta),
-                                 _dptr(lam), lam.size, float(alpha), int(max_iter_kmeans), float(epsilon_kmeans),
-                                 float(epsilon_harmony), int(K), float(block_size), _iptr(B_vec), B_vec.size,
-                                 float(batch_proportion_cutoff), int(bool(verbose)))
+        st = self._lib.hmx_setup_ex(self._h, zarg, z_dtype, z_loc, N, d, _iptr(phi_i), _iptr(phi_p),
+                                    None if phi_x is None else _dptr(phi_x), int(B), _dptr(sigma), _dptr(theta),
+                                    _dptr(lam), lam.size, float(alpha), int(max_iter_kmeans), float(epsilon_kmeans),
+                                    float(epsilon_harmony), int(K), float(block_size), _iptr(B_vec), B_vec.size,
+                                    float(batch_proportion_cutoff), int(bool(verbose)))
         self._check(st, "setup")
         w = self._lib.hmx_last_warning(self._h).decode()
         if w:
@@ -178,6 +195,23 @@ class Harmony(object):
 
     def getZcorr(self):
         return self._get("Z_corr", (int(self.d), int(self._scalar("N_local"))))
+
+    def get_matrix(self, field, dtype=np.float64, device_ptr=None):
+        """Z_corr / Z_orig / R as float64 or float32, into a new numpy array or (device_ptr given) into the caller's HBM
+        buffer -- hmx_get_matrix."""
+        w = int(self.K) if field == "R" else int(self.d)
+        n = int(self._scalar("N_local"))
+        f32 = 1 if np.dtype(dtype) == np.float32 else 0
+        if device_ptr is not None:
+            got = self._lib.hmx_get_matrix(self._h, field.encode(), C.c_void_p(int(device_ptr)), f32, 1, n * w)
+            if got != n * w:
+                raise HarmonyError("get_matrix(%s) failed: %s" % (field, self._lib.hmx_last_error(self._h).decode()))
+            return None
+        out = np.empty((w, n), dtype=np.float32 if f32 else np.float64, order="F")
+        got = self._lib.hmx_get_matrix(self._h, field.encode(), C.c_void_p(out.ctypes.data), f32, 0, n * w)
+        if got != n * w:
+            raise HarmonyError("get_matrix(%s) failed: %s" % (field, self._lib.hmx_last_error(self._h).decode()))
+        return out
 
     def getZorig(self):
         return self._get("Z_orig", (int(self.d), int(self._scalar("N_local"))))

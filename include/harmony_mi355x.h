@@ -66,6 +66,20 @@ int hmx_setup(hmx_ctx* ctx, const double* Z, int64_t N, int32_t d,
               int32_t K, double block_size, const int32_t* B_vec, int32_t C,
               double batch_proportion_cutoff, int32_t verbose);
 
+/* Device-side / single-precision ingest (the reference's seam is R/ui.R:178-183 -> conv_to<fp32>,
+ * src/harmony.cpp:41).  Same as hmx_setup, but Z may be float (HMX_F32) and/or already live in HBM (HMX_DEVICE: a device
+ * pointer valid on the handle's device; it is read once and may be freed after the call).  hmx_setup(...) ==
+ * hmx_setup_ex(..., HMX_F64, HMX_HOST, ...).  Host input is streamed through two HBM staging slabs (copy of slab s+1
+ * overlaps the conversion of slab s); hmx_get("timer:ingest_Z") reports the time of the last ingest. */
+enum { HMX_F64 = 0, HMX_F32 = 1 };
+enum { HMX_HOST = 0, HMX_DEVICE = 1 };
+int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_location, int64_t N, int32_t d,
+                 const int32_t* phi_i, const int32_t* phi_p, const double* phi_x, int32_t B,
+                 const double* sigma, const double* theta, const double* lambda, int32_t n_lambda,
+                 double alpha, int32_t max_iter_kmeans, double epsilon_kmeans, double epsilon_harmony,
+                 int32_t K, double block_size, const int32_t* B_vec, int32_t C,
+                 double batch_proportion_cutoff, int32_t verbose);
+
 /* Return to the state right after hmx_setup without re-uploading the inputs (Z_corr <-
  * normalise(Z_orig), objective series cleared).  No reference counterpart; used by bench.py
  * so that every timed step starts from HBM-resident inputs. */
@@ -86,7 +100,12 @@ int hmx_cluster(hmx_ctx* ctx);
 int hmx_moe_correct_ridge(hmx_ctx* ctx);
 /* ---- harmony::check_convergence (src/harmony.cpp:173-205): returns 1/0, or <0 on error */
 int hmx_check_convergence(hmx_ctx* ctx, int32_t type);
-/* ---- harmony::compute_objective (src/harmony.cpp:158-170): appends to the 4 series */
+/* ---- harmony::compute_objective (src/harmony.cpp:158-170): appends to the 4 series.
+ * Deviation (documented): the reference evaluates the k-means term on its STORED dist_mat (:160), which
+ * moe_correct_ridge_cpp does not refresh; this library keeps no K x N distance matrix and recomputes the distances from
+ * the current Z_corr and Y.  Inside the reference's own call sequence (init_cluster_cpp / cluster_cpp, where dist_mat is
+ * current) the values agree; a stand-alone call made between a correction and the next cluster_cpp sees the corrected,
+ * un-normalised Z_corr and the new Y instead of the stale distances. */
 int hmx_compute_objective(hmx_ctx* ctx);
 
 /* ---- fields and getters (src/harmony.cpp:675-707, 640-669).
@@ -97,8 +116,16 @@ int hmx_compute_objective(hmx_ctx* ctx);
  * "upd_wps" "comm:calls" "comm:bytes" and "timer:<phase>" in ms).  Returns the number of doubles the field holds (call with
  * out == NULL to size), or -1 for an unknown field.  At most `cap` values are written. */
 int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap);
+/* getZcorr / getZorig / getR (src/harmony.cpp:640-655) with a choice of element type (HMX_F64 = the R seam, HMX_F32) and
+ * destination (HMX_HOST or HMX_DEVICE pointer); `cap` counts elements.  Host destinations are filled slab by slab
+ * through two HBM staging buffers -- no N x w fp64 device copy.  hmx_get(ctx, "Z_corr", ...) is this with (F64, HOST). */
+int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype, int32_t location, int64_t cap);
 /* writable fields: "max_iter_kmeans" (vignettes/detailedWalkthrough.Rmd:364), "seed",
- * "device" (before setup), "profile" (HIP-event timing of the update kernel, see below).
+ * "device" (before setup), "profile" (HIP-event timing of the update kernel, see below),
+ * "rng" (0 counter-based generator | 1 R-compatible stream, see "randomness"),
+ * "ridge_arith" (0 exact ridge statistics: fp64, fixed order | 1 the reference's arithmetic: fp32 sums over the cells in
+ *  ascending cell order as arma::sum / the sparse products do, src/harmony.cpp:561-609 -- one covariate, single GPU;
+ *  slow, for parity studies against the reference's own rounding).
  * Tuning / fallback selectors (tests and measurements; the defaults are the measured best):
  *   fields "grid", "upd_wps" (before setup), "upd_tpw", "upd_cpw", "upd_impl", "comm_force";
  *   environment, read by hmx_setup: HMX_GRID, HMX_NREP, HMX_UPD_WPS (2|4), HMX_USIG=0 (general-sigma kernels),
@@ -115,8 +142,23 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t value);
  * and block(g) = min(pos / cells_per_block, n_blocks-1) exactly as src/harmony.cpp:280-300.
  * A host that owns an RNG stream (e.g. R's) can inject its own shuffles instead:
  * each call queues one update_order (N_global entries, update_order[p] = cell at position p,
- * consumed by the next update_R round). */
+ * consumed by the next update_R round).
+ *
+ * R-compatible mode: hmx_set_int(ctx, "rng", 1) makes the library draw exactly what the reference draws
+ * from R: K anchors `randu`, then N uniforms per anchor in cell order (src/utils.cpp:12,29), then per clustering round N
+ * `randi` values sorted into arma::shuffle's order (src/harmony.cpp:272-273) -- RcppArmadillo maps randu to
+ * Rf_runif(0,1) and randi to int(Rf_runif(0,RAND_MAX)).  The uniforms come either from the built-in MT19937 seeded as
+ * R's set.seed(seed) does (field "seed"; reproduces `set.seed(seed); RunHarmony(...)` of a default R session), or from
+ * the host's own generator through hmx_set_uniform_source (the .Call glue passes R's unif_rand between GetRNGstate /
+ * PutRNGstate).  Verified here against MT19937's published vector and R's documented set.seed(1); runif(3) stream;
+ * equality with a live R run needs R.  The draws are made on the host (N per round): a compatibility mode, not the
+ * fast path. */
 uint64_t hmx_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g);
+int hmx_set_uniform_source(hmx_ctx* ctx, double (*unif_rand)(void* user), void* user);
+/* probes of the R-compatible stream (host only, no device needed; used by the CPU tests) */
+void hmx_r_runif(uint32_t seed, int32_t n, double* out);            /* set.seed(seed); runif(n)                      */
+void hmx_r_shuffle(uint32_t seed, int64_t N, int64_t* out);         /* set.seed(seed); arma::shuffle(0..N-1)         */
+void hmx_mt19937_by_array(const uint32_t* key, int32_t len, int32_t n, uint32_t* out);  /* MT19937 known-answer vector */
 float hmx_u01(uint64_t seed, uint64_t stream, uint64_t idx);
 int hmx_push_update_order(hmx_ctx* ctx, const int64_t* update_order);
 

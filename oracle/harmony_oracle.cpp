@@ -96,6 +96,39 @@ inline uint64_t feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t 
   return x;
 }
 
+// ---- R-compatible stream (optional, set_int("rng", 1)): what the reference really draws from.  RcppArmadillo maps
+// arma's generator to R's (randu -> Rf_runif(0,1), randi -> int(Rf_runif(0, RAND_MAX))); R's default generator is
+// MT19937 seeded by set.seed (initial scrambling with the LCG 69069 x + 1; R: src/main/RNG.c).  Written independently of
+// the product's harmony_amd/csrc/hmx_rrng.h; both are checked against R's documented set.seed(1); runif(3) values.
+struct RStream {
+  uint32_t mt[624]; int mti = 625;
+  void set_seed(uint32_t seed) {
+    for (int j = 0; j < 50; j++) seed = 69069u * seed + 1u;
+    seed = 69069u * seed + 1u;                      // dummy[0] (overwritten with mti = 624 by FixupSeeds)
+    for (int j = 0; j < 624; j++) { seed = 69069u * seed + 1u; mt[j] = seed; }
+    mti = 624;
+  }
+  uint32_t next() {
+    if (mti >= 624) {
+      for (int kk = 0; kk < 624; kk++) {
+        const uint32_t y = (mt[kk] & 0x80000000u) | (mt[(kk + 1) % 624] & 0x7fffffffu);
+        mt[kk] = mt[(kk + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      mti = 0;
+    }
+    uint32_t y = mt[mti++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  }
+  double unif_rand() {
+    const double x = (double)next() * 2.3283064365386963e-10, h = 0.5 * 2.328306437080797e-10;
+    return x <= 0.0 ? h : ((1.0 - x) <= 0.0 ? 1.0 - h : x);
+  }
+  double runif(double a, double b) { if (a == b) return a; double u; do { u = unif_rand(); } while (u <= 0 || u >= 1); return a + (b - a) * u; }
+  float randu() { return (float)runif(0.0, 1.0); }
+  int randi() { return (int)runif(0.0, (double)RAND_MAX); }
+};
+
 inline float trunc_logf(float x) {  // arma::trunc_log
   if (!(x > 0.0f)) return std::log(FLT_MIN);
   if (std::isinf(x)) return std::log(FLT_MAX);
@@ -168,7 +201,13 @@ template <class T> bool lu_solve(std::vector<T>& A, int n, std::vector<T>& Bm, i
   return true;
 }
 
-// ACC = float  -> faithful mode;  ACC = double -> accurate mode
+// Arithmetic mask (one bit per group of accumulators; 0 = the reference's fp32, 1 = fp64):
+//   bit 0 (1)  O / E tables and the row sums that feed them        src/harmony.cpp:149-150,312-313,329-330
+//   bit 1 (2)  objective accumulators (my_accu)                     src/utils.cpp:67-75
+//   bit 2 (4)  ridge statistics  Phi* diag(R_k) Phi*^T,  Phi* diag(R_k) Z^T   src/harmony.cpp:561-609
+//   bit 3 (8)  ridge solve (inverse and the W products)             src/harmony.cpp:571-609
+// MASK = 0 -> faithful mode;  MASK = 15 -> accurate mode;  the single-bit flips attribute the faithful-vs-accurate gap
+// to one group at a time (tools/arith_gap.py).
 struct OracleBase {
   virtual ~OracleBase() {}
   virtual int setup(const double* Z, int64_t N, int d, const int32_t* phi_i, const int32_t* phi_p, int B,
@@ -187,7 +226,11 @@ struct OracleBase {
   Timers timers;
 };
 
-template <class ACC> struct Oracle : OracleBase {
+template <unsigned MASK> struct Oracle : OracleBase {
+  using ACC = typename std::conditional<(MASK & 1u) != 0, double, float>::type;    // O / E tables
+  using AOBJ = typename std::conditional<(MASK & 2u) != 0, double, float>::type;   // objective sums
+  using AST = typename std::conditional<(MASK & 4u) != 0, double, float>::type;    // ridge statistics
+  using ASV = typename std::conditional<(MASK & 8u) != 0, double, float>::type;    // ridge solve
   int64_t N = 0; int d = 0, K = 0, B = 0, C = 0;
   std::vector<float> Z_orig, Z_corr, R, dist, Y, W;  // column-major like the reference
   std::vector<ACC> O, E;                              // K x B, column-major: [b*K + k]
@@ -203,6 +246,8 @@ template <class ACC> struct Oracle : OracleBase {
   int max_iter_kmeans = 4, window_size = 3;
   bool lambda_estimation = false;
   uint64_t seed = 0, round_counter = 0;
+  int rng_mode = 0; RStream rs_; bool rs_seeded = false;   // 1: R-compatible stream (set.seed(seed) at the first draw)
+  void ensure_rs() { if (!rs_seeded) { rs_.set_seed((uint32_t)seed); rs_seeded = true; } }
   std::deque<std::vector<int64_t>> injected;
   int W_rows = 0;
   int64_t subset_clusters = 0, skipped_clusters = 0;
@@ -256,8 +301,9 @@ template <class ACC> struct Oracle : OracleBase {
     Y.assign((size_t)d * K, 0.f);
     // initialize_centroids :10-49
     const uint64_t Nm1 = (uint64_t)N - 1;
+    if (rng_mode == 1) ensure_rs();
     for (int i = 0; i < K; i++) {
-      int64_t idx = (int64_t)std::floor(u01(seed_, 0, (uint64_t)i) * (float)Nm1);
+      int64_t idx = (int64_t)std::floor((rng_mode == 1 ? rs_.randu() : u01(seed_, 0, (uint64_t)i)) * (float)Nm1);
       std::memcpy(&Y[(size_t)i * d], X + idx * d, sizeof(float) * d);
     }
     std::set<int64_t> sup;
@@ -268,7 +314,7 @@ template <class ACC> struct Oracle : OracleBase {
         float dot = 0.f; const float* x = X + n * d;
         for (int j = 0; j < d; j++) dot += y[j] * x[j];
         float dis = std::fabs(2.f * (1.f - dot));
-        prob[n] = -std::log(u01(seed_, 1 + (uint64_t)i, (uint64_t)n)) / dis;
+        prob[n] = -std::log(rng_mode == 1 ? rs_.randu() : u01(seed_, 1 + (uint64_t)i, (uint64_t)n)) / dis;
       }
       int64_t best = std::min_element(prob.begin(), prob.end()) - prob.begin();
       while (sup.count(best)) {                                                    // :38-43
@@ -315,7 +361,7 @@ template <class ACC> struct Oracle : OracleBase {
   }
 
   int init_cluster(const double* Y0, uint64_t seed_) override {  // :131-156
-    seed = seed_;
+    seed = seed_; rs_seeded = false;
     if (Y0) { Y.resize((size_t)d * K); for (size_t i = 0; i < Y.size(); i++) Y[i] = (float)Y0[i]; }
     else kmeans_centers(seed_);
     normalise_cols_l2(Y.data(), d, K);
@@ -327,7 +373,7 @@ template <class ACC> struct Oracle : OracleBase {
 
   void compute_objective() override {  // :158-170
     const float norm_const = 2000 / ((float)N);
-    ACC kmeans_error = 0, entropy = 0, cross = 0;
+    AOBJ kmeans_error = 0, entropy = 0, cross = 0;
     std::vector<float> M((size_t)K * B);  // theta_b * log((O+E+1)/(2E+1))
     for (int b = 0; b < B; b++) for (int k = 0; k < K; k++) {
       float o = (float)O[(size_t)b * K + k], e = (float)E[(size_t)b * K + k];
@@ -383,7 +429,15 @@ template <class ACC> struct Oracle : OracleBase {
   int update_R() {  // :269-342
     std::vector<int64_t> update_order;
     if (!injected.empty()) { update_order = std::move(injected.front()); injected.pop_front(); }
-    else {  // documented generator: cell g sits at position feistel_pos(seed, round, N, g)
+    else if (rng_mode == 1) {  // arma::shuffle on R's stream: one randi per element in order, std::sort of (value, index) packets
+      ensure_rs();
+      struct Pk { int val; int64_t index; };
+      std::vector<Pk> pk((size_t)N);
+      for (int64_t i = 0; i < N; i++) { pk[i].val = rs_.randi(); pk[i].index = i; }
+      std::sort(pk.begin(), pk.end(), [](const Pk& a, const Pk& b) { return a.val < b.val; });
+      update_order.resize(N);
+      for (int64_t i = 0; i < N; i++) update_order[i] = pk[i].index;
+    } else {  // documented generator: cell g sits at position feistel_pos(seed, round, N, g)
       update_order.resize(N);
       for (int64_t g = 0; g < N; g++) update_order[feistel_pos(seed, round_counter, (uint64_t)N, (uint64_t)g)] = g;
     }
@@ -479,45 +533,48 @@ template <class ACC> struct Oracle : OracleBase {
       if (full) std::fill(in_set.begin(), in_set.end(), 1);
       else { std::fill(in_set.begin(), in_set.end(), 0); for (int b : keep) for (int64_t i : index[b]) in_set[i] = 1; }
       // cov = Phi* diag(R_k) Phi*^T + Lambda ; rhs = Phi* diag(R_k) Z_orig^T   :561-568,592-609
-      std::vector<ACC> cov((size_t)m * m, 0), rhs((size_t)m * d, 0);
+      std::vector<AST> cov((size_t)m * m, 0), rhs((size_t)m * d, 0);
       for (int64_t i = 0; i < N; i++) {
         if (!in_set[i]) continue;
-        const ACC r = R[i * K + k];
+        const AST r = R[i * K + k];
         int rows[16]; int nr = 0; rows[nr++] = 0;
         for (int c = 0; c < C; c++) { int ro = row_of[codes[(size_t)c * N + i]]; if (ro >= 0) rows[nr++] = ro; }
         for (int a = 0; a < nr; a++) for (int b2 = 0; b2 < nr; b2++) cov[(size_t)rows[b2] * m + rows[a]] += r;
         const float* z = &Z_orig[i * d];
-        for (int j = 0; j < d; j++) { ACC zt = (ACC)(z[j] * (float)r);  // Z_tmp = Z_orig % R_k (fp32 product :592)
+        for (int j = 0; j < d; j++) { AST zt = (AST)(z[j] * (float)r);  // Z_tmp = Z_orig % R_k (fp32 product :592)
           for (int a = 0; a < nr; a++) rhs[(size_t)j * m + rows[a]] += zt; }
       }
       for (int a = 1; a < m; a++) {
         float lam = lambda_estimation ? (float)E[(size_t)keep[a - 1] * K + k] * alpha : lambda[keep[a - 1] + 1];  // :434-439,533-544
-        cov[(size_t)a * m + a] += (ACC)lam;
+        cov[(size_t)a * m + a] += (AST)lam;
       }
       // W = inv(cov) * rhs  (:571-609).  Faithful: explicit fp32 inverse (arrowhead closed form for C==1,
       // LU otherwise) then fp32 products; accurate: fp64 LU solve.
-      std::vector<ACC> Wk((size_t)m * d);
+      std::vector<ASV> Wk((size_t)m * d);
       bool ok = true;
-      if (std::is_same<ACC, float>::value && C == 1) {
+      if (std::is_same<ASV, float>::value && C == 1) {
         std::vector<float> ac(m), bb(m), acb(m);
         for (int a = 0; a < m; a++) { ac[a] = -(float)cov[(size_t)a * m + 0]; bb[a] = 1.f / (float)cov[(size_t)a * m + a]; }
         ac[0] = 1.f; float b0 = (float)cov[0]; bb[0] = 0.f;
-        float u = 0.f; for (int a = 0; a < m; a++) u += (ac[a] * ac[a]) * bb[a]; u = b0 - u;
-        for (int a = 0; a < m; a++) acb[a] = ac[a] * bb[a]; acb[0] = 1.f;
+        float u = 0.f; for (int a = 0; a < m; a++) u += (ac[a] * ac[a]) * bb[a];
+        u = b0 - u;
+        for (int a = 0; a < m; a++) acb[a] = ac[a] * bb[a];
+        acb[0] = 1.f;
         std::vector<float> inv((size_t)m * m);
         for (int c2 = 0; c2 < m; c2++) for (int r2 = 0; r2 < m; r2++) inv[(size_t)c2 * m + r2] = (1.f / u) * (acb[r2] * acb[c2]);
         for (int a = 0; a < m; a++) inv[(size_t)a * m + a] += bb[a];
         for (int j = 0; j < d; j++) for (int r2 = 0; r2 < m; r2++) {
           float s = 0.f; for (int c2 = 0; c2 < m; c2++) s += inv[(size_t)c2 * m + r2] * (float)rhs[(size_t)j * m + c2];
           Wk[(size_t)j * m + r2] = s; }
-      } else if (std::is_same<ACC, float>::value) {
-        std::vector<ACC> A = cov, I((size_t)m * m, 0); for (int a = 0; a < m; a++) I[(size_t)a * m + a] = 1;
+      } else if (std::is_same<ASV, float>::value) {
+        std::vector<float> A(cov.begin(), cov.end()), I((size_t)m * m, 0); for (int a = 0; a < m; a++) I[(size_t)a * m + a] = 1;
         ok = lu_solve(A, m, I, m);
         for (int j = 0; j < d; j++) for (int r2 = 0; r2 < m; r2++) {
-          ACC s = 0; for (int c2 = 0; c2 < m; c2++) s += I[(size_t)c2 * m + r2] * rhs[(size_t)j * m + c2];
+          float s = 0; for (int c2 = 0; c2 < m; c2++) s += I[(size_t)c2 * m + r2] * (float)rhs[(size_t)j * m + c2];
           Wk[(size_t)j * m + r2] = s; }
       } else {
-        std::vector<ACC> A = cov; Wk = rhs; ok = lu_solve(A, m, Wk, d);
+        std::vector<double> A(cov.begin(), cov.end()), X(rhs.begin(), rhs.end()); ok = lu_solve(A, m, X, d);
+        for (size_t i = 0; i < Wk.size(); i++) Wk[i] = (ASV)X[i];
       }
       if (!ok) { err = "singular ridge system"; return 4; }
       for (int j = 0; j < d; j++) { Y[(size_t)k * d + j] = (float)Wk[(size_t)j * m]; Wk[(size_t)j * m] = 0; }  // :610-611
@@ -539,7 +596,8 @@ template <class ACC> struct Oracle : OracleBase {
   void set_int(const char* what, int64_t v) override {
     std::string w(what);
     if (w == "max_iter_kmeans") max_iter_kmeans = (int)v;
-    else if (w == "seed") seed = (uint64_t)v;
+    else if (w == "seed") { seed = (uint64_t)v; rs_seeded = false; }
+    else if (w == "rng") { rng_mode = (int)v; rs_seeded = false; }
   }
 
   template <class T> static int64_t copy_out(const std::vector<T>& v, double* out) {
@@ -582,7 +640,16 @@ template <class ACC> struct Oracle : OracleBase {
 }  // namespace
 
 extern "C" {
-void* orc_create(int accurate) { return accurate ? (OracleBase*)new Oracle<double>() : (OracleBase*)new Oracle<float>(); }
+void* orc_create_mask(unsigned mask) {
+  switch (mask & 15u) {
+#define ORC_CASE(M) case M: return (OracleBase*)new Oracle<M>();
+    ORC_CASE(0) ORC_CASE(1) ORC_CASE(2) ORC_CASE(3) ORC_CASE(4) ORC_CASE(5) ORC_CASE(6) ORC_CASE(7)
+    ORC_CASE(8) ORC_CASE(9) ORC_CASE(10) ORC_CASE(11) ORC_CASE(12) ORC_CASE(13) ORC_CASE(14) ORC_CASE(15)
+#undef ORC_CASE
+  }
+  return nullptr;
+}
+void* orc_create(int accurate) { return orc_create_mask(accurate ? 15u : 0u); }
 void orc_destroy(void* h) { delete (OracleBase*)h; }
 void orc_set_sgemm(void* fn) { g_sgemm = (sgemm_fn)fn; }
 int orc_setup(void* h, const double* Z, int64_t N, int d, const int32_t* phi_i, const int32_t* phi_p, int B,
@@ -604,4 +671,14 @@ const char* orc_last_error(void* h) { return ((OracleBase*)h)->err.c_str(); }
 // generator spec probes (used by tests to check the product's implementation of the same spec)
 uint64_t orc_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g) { return feistel_pos(seed, round, N, g); }
 float orc_u01(uint64_t seed, uint64_t stream, uint64_t idx) { return u01(seed, stream, idx); }
+// R-compatible stream probes: n uniforms after set.seed(seed); the first n entries of arma::shuffle(0..N-1)
+void orc_r_runif(uint32_t seed, int n, double* out) { RStream r; r.set_seed(seed); for (int i = 0; i < n; i++) out[i] = r.unif_rand(); }
+void orc_r_shuffle(uint32_t seed, int64_t N, int64_t* out) {
+  RStream r; r.set_seed(seed);
+  struct Pk { int val; int64_t index; };
+  std::vector<Pk> pk((size_t)N);
+  for (int64_t i = 0; i < N; i++) { pk[i].val = r.randi(); pk[i].index = i; }
+  std::sort(pk.begin(), pk.end(), [](const Pk& a, const Pk& b) { return a.val < b.val; });
+  for (int64_t i = 0; i < N; i++) out[i] = pk[i].index;
+}
 }

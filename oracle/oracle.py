@@ -35,6 +35,8 @@ def load():
         dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         lib.orc_create.restype = C.c_void_p
         lib.orc_create.argtypes = [C.c_int]
+        lib.orc_create_mask.restype = C.c_void_p
+        lib.orc_create_mask.argtypes = [C.c_uint]
         lib.orc_destroy.argtypes = [C.c_void_p]
         lib.orc_set_sgemm.argtypes = [C.c_void_p]
         lib.orc_setup.argtypes = [C.c_void_p, dp, C.c_int64, C.c_int, ip, ip, C.c_int, dp, dp, dp, C.c_int, C.c_double,
@@ -55,6 +57,10 @@ def load():
         lib.orc_feistel_pos.argtypes = [C.c_uint64] * 4
         lib.orc_u01.restype = C.c_float
         lib.orc_u01.argtypes = [C.c_uint64] * 3
+        lib.orc_r_runif.restype = None
+        lib.orc_r_runif.argtypes = [C.c_uint32, C.c_int, dp]
+        lib.orc_r_shuffle.restype = None
+        lib.orc_r_shuffle.argtypes = [C.c_uint32, C.c_int64, lp]
         _lib = lib
     return _lib
 
@@ -81,9 +87,14 @@ def _dp(a):
 
 
 class OracleHarmony(object):
-    def __init__(self, accurate=True, seed=0):
+    def __init__(self, accurate=True, seed=0, mask=None, rng=0):
+        """mask: per-group arithmetic (bit 0 O/E tables, 1 objective sums, 2 ridge statistics, 3 ridge solve; bit set =
+        fp64, clear = the reference's fp32).  accurate=True is mask 15, accurate=False (faithful) is mask 0."""
         self._lib = load()
-        self._h = C.c_void_p(self._lib.orc_create(1 if accurate else 0))
+        self.mask = (15 if accurate else 0) if mask is None else int(mask)
+        self._h = C.c_void_p(self._lib.orc_create_mask(self.mask))
+        if rng:   # 1: R-compatible stream (MT19937 seeded like set.seed(seed), RcppArmadillo draw order)
+            self._lib.orc_set_int(self._h, b"rng", int(rng))
         self.seed = int(seed)
         self._dims = None
 
@@ -205,3 +216,17 @@ def feistel_order(seed, rnd, N):
     for g in range(N):
         order[lib.orc_feistel_pos(seed, rnd, N, g)] = g
     return order
+
+
+def r_runif(seed, n):
+    """n uniforms of R's default generator after set.seed(seed) (oracle's own MT19937 restatement)."""
+    out = np.empty(n, dtype=np.float64)
+    load().orc_r_runif(int(seed), int(n), _dp(out))
+    return out
+
+
+def r_shuffle(seed, N):
+    """arma::shuffle(0..N-1) on R's stream after set.seed(seed)."""
+    out = np.empty(N, dtype=np.int64)
+    load().orc_r_shuffle(int(seed), int(N), out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out

@@ -24,7 +24,8 @@ static hmx_ctx* handle(SEXP ptr) {
 }
 static void check(hmx_ctx* h, int status, const char* what) {
   if (status > 0) Rf_error("%s: %s", what, hmx_last_error(h));          /* Rcpp::stop equivalent */
-  const char* w = hmx_last_warning(h);
+  if (status < 0) Rf_error("%s: terminated by user", what);              /* HMX_ABORTED from a method that returns void in the module */
+  const char* w = hmx_last_warning(h);                                   /* one-shot: cleared by the read */
   if (w && w[0]) Rf_warning("%s", w);                                    /* Rcpp::warning equivalent */
 }
 static int poll_interrupt(void* unused) {                                 /* Progress::check_abort() */

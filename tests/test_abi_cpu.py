@@ -36,6 +36,30 @@ def test_generators_match_oracle_spec():
         assert 0.0 < lib.hmx_u01(*args) < 1.0
 
 
+def test_r_compatible_stream_known_answers():
+    """the R-compatible generator (product: harmony_amd/csrc/hmx_rrng.h; oracle: its own restatement) against
+    MT19937's published known-answer vector and R's documented `set.seed(s); runif(n)` streams; the two independent
+    implementations must also produce the same arma::shuffle order (ties included: same std::sort)."""
+    import ctypes as C
+    from oracle import oracle as orc
+    lib = _lib.load()
+    key = (C.c_uint32 * 4)(0x123, 0x234, 0x345, 0x456)
+    out = (C.c_uint32 * 5)()
+    lib.hmx_mt19937_by_array(key, 4, 5, out)                       # mt19937ar.c's test output (Matsumoto & Nishimura)
+    assert list(out) == [1067595299, 955945823, 477289528, 4107218783, 4228976476]
+    known = {1: [0.2655087, 0.3721239, 0.5728534], 42: [0.9148060, 0.9370754, 0.2861395], 123: [0.2875775, 0.7883051, 0.4089769]}
+    for seed, vals in known.items():
+        u = np.empty(3)
+        lib.hmx_r_runif(seed, 3, u.ctypes.data_as(C.POINTER(C.c_double)))
+        np.testing.assert_allclose(u, vals, atol=5e-8)
+        np.testing.assert_array_equal(u, orc.r_runif(seed, 3))     # bit-identical across the two implementations
+    for seed, N in [(1, 10), (7, 2370), (99, 200003)]:
+        a = np.empty(N, dtype=np.int64)
+        lib.hmx_r_shuffle(seed, N, a.ctypes.data_as(C.POINTER(C.c_int64)))
+        assert np.array_equal(np.sort(a), np.arange(N))
+        assert np.array_equal(a, orc.r_shuffle(seed, N))
+
+
 def test_feistel_is_a_permutation():
     lib = _lib.load()
     for N in (6, 40, 300, 1000, 4097):
