@@ -1,10 +1,16 @@
 #!/usr/bin/env python
 """bench.py -- cells/s to convergence of the Harmony clustering+correction loop on MI355X.
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on and that fits one GPU): synthetic
+Default workload (BASELINE.json configs[2], the one the metric is quoted on and that fits one GPU): synthetic
 1M cells x 50 PCs, K=100, 10 batches, reference defaults (sigma 0.1, theta 2, lambda auto, block.size 0.05,
-max.iter.cluster 4, epsilon 1e-3 / 1e-2, max_iter 10).  With --gpus N every rank holds 1M cells (weak
-scaling; 8 ranks ~ configs[3] at 8M cells) and the accumulators are all-reduced over RCCL.
+max.iter.cluster 4, epsilon 1e-3 / 1e-2, max_iter 10).  With --gpus N every rank holds --cells-per-gpu cells (weak
+scaling; 8 ranks ~ configs[3]) and the accumulators are all-reduced over RCCL.  `--gpus N` without a launcher
+(WORLD_SIZE unset) re-launches itself under torch.distributed.run with N ranks; the line's n_gpus always equals --gpus
+or the run exits non-zero.
+
+Other driver-reproducible modes:
+    --cells-per-gpu 10000000 --batches 20          north_star target: 10M x 50 x K=100 on ONE GPU (configs[3]'s size)
+    --workload c5 [--cells-per-gpu N]              configs[4] shape: K=200, 3 nested covariates 8 > 64 > 128 (200 levels)
 
 A "step" = one full run from HBM-resident inputs: hmx_restart -> init_cluster_cpp (k-means seeding + 10 Lloyd)
 -> {cluster_cpp, moe_correct_ridge_cpp, check_convergence}* until converged.  Prints ONE JSON line (rank 0).
@@ -12,6 +18,8 @@ A "step" = one full run from HBM-resident inputs: hmx_restart -> init_cluster_cp
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,29 +45,49 @@ def run_to_convergence(obj, max_iter=10):
     return it
 
 
-def cpu_baseline(cells, d, K, levels, seed):
-    """The oracle (a port: the reference itself cannot be built here) in faithful fp32 mode, GEMM through
-    OpenBLAS with 1 thread (the reference's default ncores=1), timed on a bounded sample of the same workload."""
-    from harmony_amd import harmony_options, prepare_setup_args
+def cpu_baseline(cells, d, K, levels, nested, seed):
+    """The oracle (a port: the reference itself cannot be built here) in faithful fp32 mode on a bounded sample of the same
+    workload, GEMM through OpenBLAS: 1 thread (the reference's default ncores = 1, R/ui.R:101) = `value`; and all host cores
+    (`all_cores`; like the reference's ncores > 1, only the BLAS calls are threaded)."""
+    from harmony_amd import prepare_setup_args
     from oracle.oracle import OracleHarmony, use_openblas
-    blas = use_openblas(1)
-    Z, meta, _ = synth(cells, d=d, levels=levels, seed=seed)
+    Z, meta, _ = synth(cells, d=d, levels=levels, seed=seed, nested=nested)
     skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
-    o = OracleHarmony(accurate=False, seed=1)
-    o.setup(**skw)
-    t0 = time.time()
-    o.init_cluster_cpp()
-    it = 0
-    for it in range(1, 11):
-        o.cluster_cpp()
-        o.moe_correct_ridge_cpp()
-        if o.check_convergence(1):
+    out = {}
+    ncpu = os.cpu_count() or 1
+    for tag, threads in (("one", 1), ("all", ncpu)):
+        blas = use_openblas(threads)
+        o = OracleHarmony(accurate=False, seed=1)
+        o.setup(**skw)
+        t0 = time.time()
+        o.init_cluster_cpp()
+        it = 0
+        for it in range(1, 11):
+            o.cluster_cpp()
+            o.moe_correct_ridge_cpp()
+            if o.check_convergence(1):
+                break
+        dt = time.time() - t0
+        out[tag] = (cells / dt, it, dt, blas)
+        if ncpu == 1:
+            out["all"] = out["one"]
             break
-    dt = time.time() - t0
-    return {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "oracle (faithful fp32%s), %d cells x %d PCs, K=%d, %d batches, to convergence (%d iterations, %.1f s)"
-                      % (", OpenBLAS sgemm 1 thread" if blas else "", cells, d, K, levels[0], it, dt),
-            "host_cores_available": os.cpu_count()}
+    v1, it, dt, blas = out["one"]
+    va, _, dta, _ = out["all"]
+    return {"value": v1, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "oracle (faithful fp32%s), %d cells x %d PCs, K=%d, levels %s, to convergence (%d iterations, %.1f s); the "
+                      "algorithm is O(N) per iteration, so cells/s at the full size is the same figure up to the iteration count"
+                      % (", OpenBLAS sgemm" if blas else "", cells, d, K, "x".join(map(str, levels)), it, dt),
+            "all_cores": {"value": va, "cores": ncpu, "seconds": dta},
+            "host_cores_available": ncpu}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -67,14 +95,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"], help="c3: one covariate (--batches levels), K=--clusters; "
+                    "c5: configs[4] shape, K=200, nested covariates 8 > 64 > 128")
     ap.add_argument("--cells-per-gpu", type=int, default=1000000)
     ap.add_argument("--pcs", type=int, default=50)
-    ap.add_argument("--clusters", type=int, default=100)
+    ap.add_argument("--clusters", type=int, default=None)
     ap.add_argument("--batches", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=100000, help="cells for the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the T_e2e measurement (ingest + egress over PCIe)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for smoke tests on one GPU)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one (one process per GPU over RCCL), and make sure the line really is an N-GPU line
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     from harmony_amd import Harmony, prepare_setup_args
@@ -82,8 +119,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to print a line whose n_gpus differs from --gpus" % (a.gpus, world))
     local_rank = local_rank % max(torch.cuda.device_count(), 1)   # (smoke tests may oversubscribe one GPU with gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -96,9 +133,14 @@ def main():
             dist.init_process_group(a.backend)
             os.environ["HMX_BENCH_COMM"] = "torch"     # no RCCL communicator without nccl: use the all-reduce hook
 
-    n, d, K, B = a.cells_per_gpu, a.pcs, a.clusters, a.batches
+    if a.workload == "c5":
+        levels, nested, K = (8, 64, 128), True, (a.clusters or 200)
+    else:
+        levels, nested, K = (a.batches,), False, (a.clusters or 100)
+    n, d = a.cells_per_gpu, a.pcs
     N = n * world
-    Z, meta, _ = synth(n, d=d, levels=(B,), seed=a.seed, shard=rank)
+    Z, meta, _ = synth(n, d=d, levels=levels, seed=a.seed, shard=rank, nested=nested)
+    vars_use = list(meta)
     # harmony_amd is loaded AFTER torch initialised its HIP runtime: both then share ONE runtime in the process,
     # so torch streams, zero-copy tensor views of the library's buffers and RCCL all interoperate.
     obj = Harmony(device=local_rank, seed=1)
@@ -145,11 +187,17 @@ def main():
             obj.set_stream(torch.cuda.current_stream().cuda_stream)
             obj.set_shard(rank, world, rank * n, N, TorchAllReduce(device=dev))
             comm_kind = "torch.distributed %s all_reduce hook%s" % (a.backend, " (RCCL over xGMI)" if a.backend == "nccl" else "")
-        cnt = torch.from_numpy(np.bincount(meta["cov0"], minlength=B).astype(np.int64)).to(dev)
-        dist.all_reduce(cnt)
-        N_b = cnt.cpu().numpy().astype(float)
-    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K, N_b=N_b, levels={"cov0": np.arange(B)})
+        N_b = []
+        for v, L in zip(vars_use, levels):
+            cnt = torch.from_numpy(np.bincount(meta[v], minlength=L).astype(np.int64)).to(dev)
+            dist.all_reduce(cnt)
+            N_b.append(cnt.cpu().numpy().astype(float))
+        N_b = np.concatenate(N_b)
+    skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=K, N_b=N_b, levels={v: np.arange(L) for v, L in zip(vars_use, levels)})
+    t_setup = time.perf_counter()
     obj.setup(**skw)
+    t_setup = time.perf_counter() - t_setup
+    ingest_ms = obj.timer("ingest_Z")     # H2D of Z (N*d*8 B from pageable host memory) + fp32 conversion, inside setup
     del Z
 
     def sync():
@@ -173,42 +221,69 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / a.steps
-    rounds = int(np.sum(obj.kmeans_rounds))
+    kr = np.asarray(obj.kmeans_rounds, dtype=np.int64)      # rounds of every harmony iteration of the LAST step
+    rounds = int(kr.sum())
 
-    # roofline of the dominant kernel (k_update: E-step of one block of cells).  Algorithmic bytes per cell
+    # roofline of the dominant kernel (k_tile<NCT,0>: E-step of one block of cells).  Algorithmic bytes per cell
     # per launch: read the cell's normalised embedding row (4d) + write its R row (4K)  [DESIGN.md]
     upd_ms = obj._scalar("prof:update_ms")
     upd_launches = obj._scalar("prof:update_launches")
     upd_cells = obj._scalar("prof:update_cells")  # cells summed over rounds (every round touches every cell once)
     alg_bytes = upd_cells * (4.0 * d + 4.0 * K)
     achieved = alg_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
-    traffic = None  # HBM bytes per launch from the PMC passes (collected separately, see profiles/r1_pmc_summary.json)
+    traffic = mfma_util = None  # HBM bytes / MFMA busy per launch from the PMC passes (collected separately, profiles/)
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_update_kernel.json")))
-        if pm["workload"] == {"cells_per_gpu": n, "pcs": d, "clusters": K, "batches": B}:
+        if pm["workload"] == {"cells_per_gpu": n, "pcs": d, "clusters": K, "batches": levels[0]} and len(levels) == 1:
             traffic = pm["hbm_bytes_per_launch"]
+            mfma_util = pm.get("mfma_busy_frac")
     except Exception:
         pass
+    # SURVEY 8(d) whole-run figure: compulsory bytes per cell per harmony iteration = 4d(4 + I_k) + 4K(3 + 2 I_k)
+    run_bytes = float(n) * float(np.sum(4.0 * d * (4 + kr) + 4.0 * K * (3 + 2 * kr)))
+    run_gbs = run_bytes / (ms_per_step * 1e-3) / 1e9
     roofline = {"kernel": "k_tile<NCT,0> (block update of update_R)", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
-                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "mfma_busy_frac": mfma_util,
                 "avg_launch_us": 1e3 * upd_ms / max(upd_launches, 1), "launches": int(upd_launches),
                 "alg_bytes_per_launch": alg_bytes / max(upd_launches, 1),
-                "kernel_time_share": upd_ms / (1e3 * dt) if dt > 0 else None}
+                "kernel_time_share": upd_ms / (1e3 * dt) if dt > 0 else None,
+                "run": {"alg_bytes_per_step_per_gpu": run_bytes, "achieved": run_gbs, "frac": run_gbs / 8000.0,
+                        "note": "SURVEY 8(d): N * sum_iters(4d(4+I_k) + 4K(3+2 I_k)) / T_conv, per GPU, vs 8 TB/s"}}
+    gpu_phase = {k: round(obj._scalar("gputimer:" + k) / a.steps, 3) for k in
+                 ("kmeans_centers", "cluster_head", "randomize", "EO_update", "Rcells_update", "correct_ridge_loop",
+                  "ridge_statistics", "arma_inv", "update_Zcorr")}
+    # T_e2e: T_conv + H2D of Z (double, the R seam) + D2H of Z_corr (double); PCIe-inclusive, never `value`
+    e2e = None
+    if not a.no_e2e:
+        sync()
+        t1 = time.perf_counter()
+        zc = obj.getZcorr()
+        egress_ms = 1e3 * (time.perf_counter() - t1)
+        zc32 = None
+        t1 = time.perf_counter()
+        zc32 = obj.get_matrix("Z_corr", np.float32)
+        egress32_ms = 1e3 * (time.perf_counter() - t1)
+        del zc, zc32
+        e2e = {"T_conv_ms": ms_per_step, "ingest_Z_f64_ms": ingest_ms, "egress_Zcorr_f64_ms": egress_ms,
+               "egress_Zcorr_f32_ms": egress32_ms, "T_e2e_ms": ms_per_step + ingest_ms + egress_ms,
+               "cells_per_sec_e2e": n / ((ms_per_step + ingest_ms + egress_ms) * 1e-3), "setup_total_ms": 1e3 * t_setup,
+               "note": "pageable host buffers, per GPU; setup_total also holds Phi -> level codes and the combination sort on the host"}
     out = {
         "metric": "cells_per_sec_to_convergence", "value": N / (ms_per_step * 1e-3), "unit": "cells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "synthetic %d cells x %d PCs, K=%d, %d batches%s (BASELINE configs[2] per GPU)"
-                               % (N, d, K, B, "" if world == 1 else ", %d cells/GPU cell-sharded" % n),
+        "config": {"workload": "synthetic %d cells x %d PCs, K=%d, levels %s%s%s (BASELINE %s per GPU)"
+                               % (N, d, K, "x".join(map(str, levels)), " nested" if nested else "",
+                                  "" if world == 1 else ", %d cells/GPU cell-sharded" % n,
+                                  "configs[4] shape" if a.workload == "c5" else ("configs[2]" if n == 1000000 and levels == (10,) else "configs[2]/[3] family")),
                    "parallelism": ("cells sharded x%d, all-reduce of O/E/statistics: %s" % (world, comm_kind)) if world > 1 else "single GPU",
                    "harmony_iterations": iters, "kmeans_rounds_last_step": rounds,
                    "s_per_iter": 1e-3 * ms_per_step / max(float(np.mean(iters)), 1.0),
-                   "host_phase_ms_per_step": {k: round(obj.timer(k) / (a.steps + a.warmup), 3) for k in
-                                              ("init_cluster", "cluster", "update_R", "moe_correct_ridge", "moe_solve_host")}},
+                   "gpu_phase_ms_per_step": gpu_phase, "e2e": e2e},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and a.cpu_sample > 0:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, d, K, (B,), a.seed)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, d, K, levels, nested, a.seed)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

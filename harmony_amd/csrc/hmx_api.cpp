@@ -115,6 +115,10 @@ struct hmx_ctx {
   double* h_obj = nullptr; int obj_cap = 0, obj_pending = 0; hipEvent_t obj_event = nullptr; bool obj_harmony_pending = false;
   // randomness: 0 = documented counter-based generator, 1 = R-compatible (MT19937 seeded like set.seed, arma draw order)
   int rng_mode = 0; hmx::RRng rrng; bool rrng_seeded = false;
+  // device-side ridge solve (default; HMX_MOE_SOLVE=host selects the synchronous host path): scratch and result buffers
+  bool solve_on_device = true, y_on_device = false, solve_pending = false;
+  double* sv_cov = nullptr; double* sv_rhs = nullptr; float* sv_Wall = nullptr; int* sv_mrows = nullptr; int* sv_flags = nullptr;
+  float* sv_lambda = nullptr; int* sv_cov_bounds = nullptr;
   // ridge statistics arithmetic: 0 = exact (fp64 / fixed order), 1 = the reference's (sequential fp32 over the cells)
   int ridge_arith = 0;
   std::map<std::string, double> timers;
@@ -128,6 +132,10 @@ struct hmx_ctx {
   bool fused_ok = false;       // k_tile prologue fold usable (LDS budget) and not disabled
   int tun_impl = -1, tun_tpw = -1, tun_cpw = -1, tun_wps = -1;  // tunables set through hmx_set_int before setup
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
+  // GPU phase timers (profile mode): event pairs tagged with a phase name, named after the reference's Timer phases
+  // (src/harmony.cpp:302-335,557-615) where a phase has a counterpart; resolved lazily into gpu_timers
+  struct PhaseEv { hipEvent_t a, b; int name; };
+  std::vector<PhaseEv> ph_pool; size_t ph_used = 0; std::vector<std::string> ph_names; std::map<std::string, double> gpu_timers;
   double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0;
   std::string err, warn, warn_ret;
 };
@@ -156,6 +164,8 @@ void free_all(hmx_ctx* ctx) {
   ctx->allocs.clear();
   for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   ctx->ev_pool.clear(); ctx->ev_used = 0;
+  for (auto& e : ctx->ph_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  ctx->ph_pool.clear(); ctx->ph_used = 0;
   if (ctx->h_obj) { (void)hipHostFree(ctx->h_obj); ctx->h_obj = nullptr; ctx->obj_cap = 0; }
   if (ctx->obj_event) { (void)hipEventDestroy(ctx->obj_event); ctx->obj_event = nullptr; }
   ctx->obj_pending = 0; ctx->obj_harmony_pending = false;
@@ -187,6 +197,35 @@ int allreduce(hmx_ctx* ctx, void* buf, int64_t count, int dtype) {
 }
 #define CHK(expr) do { int s_ = (expr); if (s_) return s_; } while (0)
 #define KCHK() HIPCHK(hipGetLastError())
+
+// profile mode only: bracket a group of launches with an event pair tagged `name`
+struct PhaseScope {
+  hmx_ctx* c; int idx = -1;
+  PhaseScope(hmx_ctx* ctx, const char* name) : c(ctx) {
+    if (!c->profile) return;
+    int id = -1;
+    for (size_t i = 0; i < c->ph_names.size(); i++) if (c->ph_names[i] == name) { id = (int)i; break; }
+    if (id < 0) { id = (int)c->ph_names.size(); c->ph_names.push_back(name); }
+    if (c->ph_used == c->ph_pool.size()) {
+      hmx_ctx::PhaseEv e; e.name = id;
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+      c->ph_pool.push_back(e);
+    }
+    idx = (int)c->ph_used++;
+    c->ph_pool[idx].name = id;
+    (void)hipEventRecord(c->ph_pool[idx].a, c->L.stream);
+  }
+  ~PhaseScope() { if (idx >= 0) (void)hipEventRecord(c->ph_pool[idx].b, c->L.stream); }
+};
+void resolve_phases(hmx_ctx* c) {
+  if (!c->ph_used) return;
+  (void)hipStreamSynchronize(c->L.stream);
+  for (size_t i = 0; i < c->ph_used; i++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ph_pool[i].a, c->ph_pool[i].b) == hipSuccess) c->gpu_timers[c->ph_names[c->ph_pool[i].name]] += ms;
+  }
+  c->ph_used = 0;
+}
 
 void normalise_cols(std::vector<float>& Y, int d, int K) {  // arma::normalise(Y, 2, 0)
   for (int k = 0; k < K; k++) {
@@ -279,6 +318,31 @@ bool check_convergence_impl(hmx_ctx* c, int type) {  // src/harmony.cpp:173-205
     return (obj_old - obj_new) / std::fabs(obj_old) < c->eps_h;
   }
   return true;
+}
+
+// Results of the last device-side correction that live on the host only on demand: flags (singular system -> error; subset /
+// skipped counts), W of the last solved cluster, the centroids.
+int sync_solve_results(hmx_ctx* ctx) {
+  if (ctx->solve_pending) {
+    ctx->solve_pending = false;
+    const int K = ctx->K, d = ctx->d;
+    std::vector<int> flags(K), mrows(K);
+    CHK(d2h(ctx, flags.data(), ctx->sv_flags, (size_t)K)); CHK(d2h(ctx, mrows.data(), ctx->sv_mrows, (size_t)K));
+    ctx->subset_clusters = ctx->skipped_clusters = 0;
+    int last = -1;
+    for (int k = 0; k < K; k++) {
+      if (flags[k] & 4) return fail(ctx, HMX_ERR_SOLVE, "singular ridge system");
+      if (flags[k] & 1) ctx->subset_clusters++;
+      if (flags[k] & 2) ctx->skipped_clusters++; else last = k;
+    }
+    if (last >= 0) {   // the reference's W field holds the last cluster's coefficients (:592-611)
+      const int m = mrows[last];
+      ctx->W.resize((size_t)m * d); ctx->W_rows = m;
+      CHK(d2h(ctx, ctx->W.data(), ctx->sv_Wall + (size_t)last * d * ((size_t)ctx->B + 1), (size_t)m * d));
+    }
+  }
+  if (ctx->y_on_device) { ctx->y_on_device = false; CHK(d2h(ctx, ctx->Y.data(), ctx->D.Ycur, ctx->Y.size())); }
+  return 0;
 }
 
 // R-compatible mode: the generator is seeded like set.seed(seed) once per run (hmx_restart re-arms it)
@@ -445,11 +509,13 @@ int update_R(hmx_ctx* ctx) {
   const char* fold_env = getenv("HMX_FOLD_IMPL");   // "split": force the two-kernel fold + penalty fallback (tests)
   const bool merged = (size_t)D.B * 128 <= 64 * 1024 && !(fold_env && std::string(fold_env) == "split");   // LDS budget of k_foldpen
   const double t0 = now_ms();
-  CHK(prepare_round(ctx, ctx->round_counter));
+  { PhaseScope ph(ctx, "randomize");      // the round's shuffle (:272-291, timers "randomize")
+    CHK(prepare_round(ctx, ctx->round_counter)); }
   ctx->round_counter++;
-  HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
-  l_oldsum(ctx->L, D); KCHK();
-  CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0));
+  { PhaseScope ph(ctx, "EO_update");      // removal of every block's old contribution (:312-313), all blocks in one pass
+    HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
+    l_oldsum(ctx->L, D); KCHK();
+    CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0)); }
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
   const bool fused = merged && ctx->fused_ok;
@@ -507,14 +573,7 @@ int update_R(hmx_ctx* ctx) {
   CHK(allreduce(ctx, D.obj, 2, 1));
   l_objective_tables(ctx->L, D); KCHK();
   CHK(push_objective(ctx));  // asynchronous: resolved by flush_objectives when a value is needed
-  if (ctx->profile) {
-    HIPCHK(hipStreamSynchronize(ctx->L.stream));
-    for (size_t i = 0; i < ctx->ev_used; i++) {
-      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
-      ctx->prof_update_ms += ms;
-    }
-    ctx->prof_update_launches += (int64_t)ctx->ev_used; ctx->prof_update_cells += ctx->N; ctx->ev_used = 0;
-  }
+  if (ctx->profile) { ctx->prof_update_cells += ctx->N; }   // the event pairs are resolved when a "prof:*" field is read
   ctx->timers["update_R"] += now_ms() - t0;
   return 0;
 }
@@ -803,7 +862,8 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "rng") { if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, "rng: 0 (counter-based) or 1 (R-compatible)"); ctx->rng_mode = (int)v; ctx->rrng_seeded = false; }
   else if (f == "ridge_arith") { if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, "ridge_arith: 0 (exact) or 1 (reference fp32 order)"); ctx->ridge_arith = (int)v; }
   else if (f == "device") ctx->device = (int)v;
-  else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; }
+  else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->ev_used = 0;
+                             ctx->ph_used = 0; ctx->gpu_timers.clear(); }
   else if (f == "grid") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "grid must be set before setup"); ctx->L.grid = (int)v; }
   else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
   else if (f == "comm_force") ctx->comm_force = v != 0;
@@ -1003,6 +1063,17 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K));
+  { const char* e = getenv("HMX_MOE_SOLVE"); ctx->solve_on_device = !(e && std::string(e) == "host"); }
+  ctx->y_on_device = false; ctx->solve_pending = false;
+  if (ctx->solve_on_device) {
+    const size_t M = (size_t)B + 1;
+    CHK(dalloc(ctx, &ctx->sv_cov, (size_t)K * M * M)); CHK(dalloc(ctx, &ctx->sv_rhs, (size_t)K * d * M)); CHK(dalloc(ctx, &ctx->sv_Wall, (size_t)K * d * M));
+    CHK(dalloc(ctx, &ctx->sv_mrows, (size_t)K)); CHK(dalloc(ctx, &ctx->sv_flags, (size_t)K)); CHK(dalloc(ctx, &ctx->sv_lambda, M)); CHK(dalloc(ctx, &ctx->sv_cov_bounds, (size_t)C));
+    if (!ctx->lambda_estimation) CHK(h2d(ctx, ctx->sv_lambda, ctx->lambda.data(), M));
+    CHK(h2d(ctx, ctx->sv_cov_bounds, ctx->cov_bounds.data(), (size_t)C));
+    HIPCHK(hipMemsetAsync(ctx->sv_flags, 0, sizeof(int) * (size_t)K, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(ctx->sv_mrows, 0, sizeof(int) * (size_t)K, ctx->L.stream));
+  }
   CHK(dalloc(ctx, &D.S0, (size_t)K * d)); CHK(dalloc(ctx, &D.n0, (size_t)K)); CHK(dalloc(ctx, &D.qstart, (size_t)Q + 1)); CHK(dalloc(ctx, &D.sizes, (size_t)B));
   CHK(h2d(ctx, D.qstart, start.data(), (size_t)Q + 1)); CHK(h2d(ctx, D.sizes, ctx->sizes.data(), (size_t)B)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d)); CHK(dalloc(ctx, &D.Wimg, D.moe_mfma ? (size_t)Q * D.wNQ * D.wNS * 256 : 1));
   CHK(dalloc(ctx, &D.km_gcells, (size_t)K)); CHK(dalloc(ctx, &D.km_rows, (size_t)K * d)); CHK(dalloc(ctx, &D.km_excl, (size_t)K));
@@ -1081,6 +1152,7 @@ int hmx_restart(hmx_ctx* ctx) {
   ctx->obj_pending = 0; ctx->obj_harmony_pending = false;
   ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();
   ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear(); ctx->rrng_seeded = false;
+  ctx->y_on_device = false; ctx->solve_pending = false;
   return 0;
 }
 
@@ -1096,8 +1168,9 @@ int hmx_init_cluster(hmx_ctx* ctx, const double* Y0) {  // src/harmony.cpp:131-1
   if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   const double t0 = now_ms();
+  ctx->y_on_device = false;
   if (Y0) { ctx->Y.resize((size_t)ctx->d * ctx->K); for (size_t i = 0; i < ctx->Y.size(); i++) ctx->Y[i] = (float)Y0[i]; }
-  else CHK(kmeans_centers(ctx));
+  else { PhaseScope ph(ctx, "kmeans_centers"); CHK(kmeans_centers(ctx)); }
   normalise_cols(ctx->Y, ctx->d, ctx->K);  // :136
   CHK(upload_Y(ctx));
   CHK(head_pass(ctx));
@@ -1125,6 +1198,7 @@ int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the cur
 int hmx_check_convergence(hmx_ctx* ctx, int32_t type) {
   if (!ctx) return -HMX_ERR_ARG;
   if (flush_objectives(ctx)) return -HMX_ERR_DEVICE;
+  { const int st = sync_solve_results(ctx); if (st) return -st; }   // a singular system of the last correction surfaces here
   if ((type == 0 && ctx->obj_kmeans.size() < (size_t)ctx->window_size + 1) || (type == 1 && ctx->obj_harmony.size() < 2)) {
     fail(ctx, HMX_ERR_STATE, "not enough objective values"); return -HMX_ERR_STATE;
   }
@@ -1137,6 +1211,7 @@ int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
   const double t0 = now_ms();
   CHK(flush_objectives(ctx));   // (values of an earlier call that nobody asked for yet)
   if (ctx->obj_harmony.size() != 1) {  // :214-228
+    PhaseScope ph(ctx, "cluster_head");
     l_normalize(ctx->L, ctx->D.Zc, ctx->D.n, ctx->D.d, ctx->D.zs); KCHK();
     CHK(head_pass(ctx));
   }
@@ -1166,12 +1241,29 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   const bool seq = ctx->ridge_arith == 1;
   if (seq && (ctx->C != 1 || ctx->world > 1 || ctx->comm_force || B > 1024))
     return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 (reference summation order) supports one covariate on one GPU");
-  HIPCHK(hipMemsetAsync(D.Sq, 0, sizeof(double) * (size_t)Q * d * K, ctx->L.stream));
-  HIPCHK(hipMemsetAsync(D.nq, 0, sizeof(double) * (size_t)Q * K, ctx->L.stream));
-  if (seq) { l_moe_stats_seq(ctx->L, D, ctx->cutoff); KCHK(); }
-  else if (D.moe_mfma) { l_moe_stats_mfma(ctx->L, D); KCHK(); } else { l_moe_stats(ctx->L, D); KCHK(); }
-  CHK(allreduce(ctx, D.Sq, (int64_t)Q * d * K, 1));
-  CHK(allreduce(ctx, D.nq, (int64_t)Q * K, 1));
+  { PhaseScope pall(ctx, "correct_ridge_loop");
+  { PhaseScope ph(ctx, "ridge_statistics");   // reference timers Phi_Rk + Phi_cov + Z_tmp + Z_intercept + batch_exprod: ONE pass here
+    HIPCHK(hipMemsetAsync(D.Sq, 0, sizeof(double) * (size_t)Q * d * K, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.nq, 0, sizeof(double) * (size_t)Q * K, ctx->L.stream));
+    if (seq) { l_moe_stats_seq(ctx->L, D, ctx->cutoff); KCHK(); }
+    else if (D.moe_mfma) { l_moe_stats_mfma(ctx->L, D); KCHK(); } else { l_moe_stats(ctx->L, D); KCHK(); }
+    CHK(allreduce(ctx, D.Sq, (int64_t)Q * d * K, 1));
+    CHK(allreduce(ctx, D.nq, (int64_t)Q * K, 1)); }
+  if (ctx->solve_on_device) {
+    // the whole correction stays on the device: statistics -> K fp64 solves (one workgroup per cluster) -> apply -> Y;
+    // no host synchronisation (a singular system is reported by the next call that waits for the device)
+    SolveArgs A;
+    A.cov = ctx->sv_cov; A.rhs = ctx->sv_rhs; A.Wall = ctx->sv_Wall; A.mrows = ctx->sv_mrows; A.flags = ctx->sv_flags;
+    A.lambda = ctx->lambda_estimation ? nullptr : ctx->sv_lambda; A.cov_bounds = ctx->sv_cov_bounds;
+    A.alpha = ctx->alpha; A.cutoff = ctx->cutoff; A.use_s0 = seq ? 1 : 0;
+    { PhaseScope ph(ctx, "arma_inv"); l_moe_solve(ctx->L, D, A); KCHK(); }
+    { PhaseScope ph(ctx, "update_Zcorr");
+      if (D.moe_mfma) { l_moe_apply_mfma(ctx->L, D); KCHK(); } else { l_moe_apply(ctx->L, D); KCHK(); } }
+    ctx->y_on_device = true; ctx->solve_pending = true;
+    ctx->timers["moe_correct_ridge"] += now_ms() - t0;
+    return 0;
+  }
+  }
   std::vector<double> Sq((size_t)Q * d * K), nq((size_t)Q * K);
   std::vector<long long> ofx((size_t)B * K);
   CHK(d2h(ctx, Sq.data(), D.Sq, Sq.size())); CHK(d2h(ctx, nq.data(), D.nq, nq.size())); CHK(d2h(ctx, ofx.data(), D.O_fx, ofx.size()));
@@ -1239,6 +1331,8 @@ double hmx_debug_solve_bench(int K, int B, int d, int reps) {
 int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (!ctx || !field) return -1;
   const std::string f(field);
+  if (f.rfind("objective_", 0) == 0 || f == "kmeans_rounds") { if (flush_objectives(ctx)) return -1; }
+  if (f == "Y" || f == "W" || f == "W_rows" || f == "subset_clusters" || f == "skipped_clusters") { if (sync_solve_results(ctx)) return -1; }
   auto scalar = [&](double v) -> int64_t { if (out && cap >= 1) out[0] = v; return 1; };
   auto vec = [&](const auto& v) -> int64_t {
     if (out) for (size_t i = 0; i < v.size() && (int64_t)i < cap; i++) out[i] = (double)v[i];
@@ -1273,11 +1367,24 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   }
   if (f == "usig") return scalar((double)ctx->D.usig);
   if (f == "upd_wps") return scalar((double)ctx->D.upd_wps);
+  if (f.rfind("prof:", 0) == 0 && ctx->ev_used) {   // resolve the pending event pairs (one sync, outside any timed region)
+    (void)hipStreamSynchronize(ctx->L.stream);
+    for (size_t i = 0; i < ctx->ev_used; i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second) == hipSuccess) ctx->prof_update_ms += ms;
+    }
+    ctx->prof_update_launches += (int64_t)ctx->ev_used; ctx->ev_used = 0;
+  }
   if (f == "prof:update_ms") return scalar(ctx->prof_update_ms);
   if (f == "prof:update_launches") return scalar((double)ctx->prof_update_launches);
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
+  if (f.rfind("gputimer:", 0) == 0) {   // GPU time of a phase (profile mode), ms; "gputimer:Rcells_update" == "prof:update_ms"
+    resolve_phases(ctx);
+    const std::string nm = f.substr(9);
+    if (nm == "Rcells_update") return hmx_get(ctx, "prof:update_ms", out, cap);
+    auto it = ctx->gpu_timers.find(nm); return scalar(it == ctx->gpu_timers.end() ? 0.0 : it->second);
+  }
   if (f.rfind("timer:", 0) == 0) { auto it = ctx->timers.find(f.substr(6)); return scalar(it == ctx->timers.end() ? 0.0 : it->second); }
-  if (f.rfind("objective_", 0) == 0 || f == "kmeans_rounds") { if (flush_objectives(ctx)) return -1; }
   if (f == "Y") return vec(ctx->Y);
   if (f == "W") return vec(ctx->W);
   if (f == "Pr_b") return vec(ctx->Pr_b);

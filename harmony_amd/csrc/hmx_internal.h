@@ -114,6 +114,15 @@ struct Dev {
   float* ynorm;     // [K]
 };
 
+// arguments of the device-side ridge solve (k_moe_solve)
+struct SolveArgs {
+  double* cov; double* rhs;        // scratch: [K][M*M], [K][d*M]   (M = B + 1)
+  float* Wall; int* mrows; int* flags;   // [K][d*M] W of every cluster (column-major m x d), its rows m, flags
+  const float* lambda;             // [B+1] fixed lambda or nullptr (estimation: alpha * E)
+  const int* cov_bounds;           // [C] cumulative level counts
+  float alpha, cutoff; int use_s0;
+};
+
 struct Launch {
   hipStream_t stream;
   int grid;  // workgroups for streaming kernels
@@ -141,6 +150,7 @@ void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);
 void l_moe_stats_mfma(const Launch& L, const Dev& D);
 void l_moe_stats_seq(const Launch& L, const Dev& D, float cutoff);
+void l_moe_solve(const Launch& L, const Dev& D, const SolveArgs& A);
 void l_moe_apply_mfma(const Launch& L, const Dev& D);
 void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl);
 void l_seed_race_u(const Launch& L, const Dev& D, const float* u, int a0, int na, int only, uint64_t goff, const unsigned* excl,

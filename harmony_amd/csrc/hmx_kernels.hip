@@ -1687,6 +1687,153 @@ __global__ __launch_bounds__(64) void k_moe_stats_seq(Dev D, float cutoff) {
   if (lane == 0) { if (row == 0) D.n0[k] = (double)an; else D.nq[(size_t)(row - 1) * K + k] = (double)an; }
 }
 
+// index of centroid entry (PC j, cluster k) in the MFMA B-operand image (inverse of the host builder in upload_Y)
+__device__ __forceinline__ size_t yimg_index(const Dev& D, int j, int k) {
+  int s_, p_;
+  if (j < 16 * D.NT4) { const int t = j >> 4, r = j & 15; p_ = r >> 2; s_ = 4 * t + (r & 3); }
+  else { const int r = j - 16 * D.NT4; s_ = 4 * D.NT4 + (r >> 2); p_ = r & 3; }
+  const int qd = k >> 6, i = (k & 63) >> 4, c = k & 15;
+  return ((((size_t)qd * D.NS + s_) * 4 + p_) * 16 + c) * 4 + i;
+}
+// k_moe_solve: the K ridge systems of moe_correct_ridge_cpp ON THE DEVICE (src/harmony.cpp:358-611), fp64, one workgroup
+// per cluster -- no D2H of the statistics, no host solve, no H2D of the correction table: the whole correction is a
+// chain of kernels with no host synchronisation.  Per cluster k:
+//   kept levels (O[k,b] / N_b > cutoff and >= 2 such levels in the covariate, :368-402), lambda_k (fixed or alpha * E, :434-439),
+//   cov = Phi* diag(R_k) Phi*^T + Lambda and rhs = Phi* diag(R_k) Z^T assembled from the per-combination statistics
+//   (subset path = masks, :440-547), Cholesky (LU with partial pivoting if a pivot is not positive -- what arma::inv falls
+//   back to), W = cov^-1 rhs, Y[:,k] = W[0,:], W[0,:] = 0 (:610-611), correction table Wq[q][k][:] = sum of the kept
+//   levels' rows of combination q (+ its MFMA image), Y <- normalise (:633).
+// flags[k]: bit 0 subset path, bit 1 skipped (no covariate with two kept levels), bit 2 singular system.
+__global__ __launch_bounds__(256) void k_moe_solve(Dev D, SolveArgs A) {
+  extern __shared__ int sm_[];
+  const int K = D.K, B = D.B, C = D.C, d = D.d, Q = D.Q, M = B + 1;
+  const int k = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  int* row_of = sm_;                 // [B]
+  int* keepl = sm_ + B;              // [B] kept levels in order
+  int* okb = sm_ + 2 * B;            // [B]
+  int* misc = sm_ + 3 * B;           // [0] m, [1] active, [2] full, [3] fail, [4..4+C) cov_levels
+  double* cov = A.cov + (size_t)k * M * M;
+  double* rhs = A.rhs + (size_t)k * d * M;
+  for (int b = tid; b < B; b += nt) {
+    const float o = (float)((double)D.O_fx[(size_t)b * K + k] * FX_INV);
+    okb[b] = (o / D.sizes[b]) > A.cutoff ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int c = 0; c < C; c++) misc[4 + c] = 0;
+    for (int b = 0, cv = 0; b < B; b++) { if (!(b < A.cov_bounds[cv])) cv++; if (okb[b]) misc[4 + cv]++; }
+    int nk = 0;
+    for (int b = 0, cv = 0; b < B; b++) {
+      if (cv < C && !(b < A.cov_bounds[cv])) cv++;
+      if (okb[b] && misc[4 + cv] > 1) { keepl[nk] = b; row_of[b] = nk + 1; nk++; } else row_of[b] = -1;
+    }
+    int act = 0; for (int c = 0; c < C; c++) if (misc[4 + c] > 1) act++;
+    misc[0] = nk + 1; misc[1] = act; misc[2] = (nk == B) ? 1 : 0; misc[3] = 0;
+  }
+  __syncthreads();
+  const int m = misc[0];
+  const bool full = misc[2] != 0, skipped = !full && misc[1] == 0;
+  // correction rows of this cluster start from zero (also the result for a skipped cluster, :449-452)
+  for (int i = tid; i < Q * d; i += nt) { const int q = i / d, j = i - q * d; D.Wq[((size_t)q * K + k) * d + j] = 0.0f; }
+  if (!skipped) {
+    for (int i = tid; i < m * m; i += nt) cov[i] = 0.0;
+    for (int i = tid; i < m * d; i += nt) rhs[i] = 0.0;
+    __syncthreads();
+    for (int q = 0; q < Q; q++) {   // sequential over combinations (fixed order), parallel inside
+      int rows[17]; int nr = 1; rows[0] = 0;
+      for (int c = 0; c < C; c++) { const int ro = row_of[D.qlev[q * C + c]]; if (ro >= 0) rows[nr++] = ro; }
+      if (nr > 1) {   // (none of its levels kept: the combination's cells do not enter, :400,456-460)
+        const double n = D.nq[(size_t)q * K + k];
+        for (int i = tid; i < nr * nr; i += nt) { const int a = i / nr, b2 = i - a * nr; cov[(size_t)rows[b2] * m + rows[a]] += n; }
+        const double* sq = D.Sq + ((size_t)q * K + k) * d;
+        for (int i = tid; i < nr * d; i += nt) { const int j = i / nr, a = i - j * nr; rhs[(size_t)j * m + rows[a]] += sq[j]; }
+      }
+      __syncthreads();
+    }
+    if (A.use_s0) {   // ridge_arith = 1: the intercept row's own sequential fp32 totals (k_moe_stats_seq)
+      if (tid == 0) cov[0] = D.n0[k];
+      for (int j = tid; j < d; j += nt) rhs[(size_t)j * m] = D.S0[(size_t)k * d + j];
+    }
+    // lambda on the diagonal (intercept 0): estimation lambda = alpha * E[k,b]
+    long long rs = 0;
+    for (int b0 = 0; b0 < D.B0; b0++) rs += D.O_fx[(size_t)b0 * K + k];
+    const double rsd = (double)rs * FX_INV;
+    for (int a = 1 + tid; a < m; a += nt) {
+      const int b = keepl[a - 1];
+      const float lam = A.lambda ? A.lambda[b + 1] : (float)(rsd * (double)D.Pr_b[b]) * A.alpha;
+      cov[(size_t)a * m + a] += (double)lam;
+    }
+    __syncthreads();
+    // ---- Cholesky (lower, column-major, in place), right-looking
+    for (int c = 0; c < m; c++) {
+      if (tid == 0) { const double sdiag = cov[(size_t)c * m + c]; if (!(sdiag > 0.0)) misc[3] = 1; else cov[(size_t)c * m + c] = sqrt(sdiag); }
+      __syncthreads();
+      if (misc[3]) break;
+      const double l = cov[(size_t)c * m + c];
+      for (int r = c + 1 + tid; r < m; r += nt) cov[(size_t)c * m + r] /= l;
+      __syncthreads();
+      const int w = m - c - 1;
+      for (int i = tid; i < w * w; i += nt) {
+        const int c2 = c + 1 + i / w, r = c + 1 + i % w;
+        if (r >= c2) cov[(size_t)c2 * m + r] -= cov[(size_t)c * m + r] * cov[(size_t)c * m + c2];
+      }
+      __syncthreads();
+    }
+    if (!misc[3]) {
+      for (int j = tid; j < d; j += nt) {   // forward / back substitution, one right-hand side per thread
+        double* b = rhs + (size_t)j * m;
+        for (int r = 0; r < m; r++) { double t = b[r]; for (int kk = 0; kk < r; kk++) t -= cov[(size_t)kk * m + r] * b[kk]; b[r] = t / cov[(size_t)r * m + r]; }
+        for (int r = m - 1; r >= 0; r--) { double t = b[r]; for (int kk = r + 1; kk < m; kk++) t -= cov[(size_t)r * m + kk] * b[kk]; b[r] = t / cov[(size_t)r * m + r]; }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    A.flags[k] = (full ? 0 : 1) | (skipped ? 2 : 0) | (misc[3] ? 4 : 0);
+    A.mrows[k] = skipped ? 0 : m;
+  }
+  const bool solved = !skipped && !misc[3];
+  float* Wk = A.Wall + (size_t)k * d * M;
+  __shared__ float ynew[128];
+  for (int j = tid; j < d; j += nt) {
+    float y = D.Ycur[(size_t)k * d + j];                      // a skipped cluster keeps its centroid
+    if (solved) { y = (float)rhs[(size_t)j * m]; rhs[(size_t)j * m] = 0.0; }   // :610-611
+    ynew[j] = y;
+  }
+  __syncthreads();
+  if (solved) {
+    for (int i = tid; i < m * d; i += nt) Wk[i] = (float)rhs[i];
+    __syncthreads();
+    for (int i = tid; i < Q * d; i += nt) {
+      const int q = i / d, j = i - q * d;
+      float w = 0.0f;
+      for (int c = 0; c < C; c++) { const int ro = row_of[D.qlev[q * C + c]]; if (ro >= 0) w += Wk[(size_t)j * m + ro]; }
+      D.Wq[((size_t)q * K + k) * d + j] = w;
+    }
+  }
+  if (D.moe_mfma) {   // MFMA B-operand image of the correction table (clusters = reduction dim), as the host builder lays it out
+    int s_, p_;
+    if (k < 16 * D.wNT4) { const int t = k >> 4, r = k & 15; p_ = r >> 2; s_ = 4 * t + (r & 3); }
+    else { const int r = k - 16 * D.wNT4; s_ = 4 * D.wNT4 + (r >> 2); p_ = r & 3; }
+    __syncthreads();
+    for (int i = tid; i < Q * d; i += nt) {
+      const int q = i / d, j = i - q * d;
+      const int qd = j >> 6, ii = (j & 63) >> 4, cc = j & 15;
+      D.Wimg[((((size_t)q * D.wNQ + qd) * D.wNS + s_) * 4 + p_) * 64 + cc * 4 + ii] = D.Wq[((size_t)q * K + k) * d + j];
+    }
+  }
+  // Y[:,k] <- normalise (:633): sequential fp32 sum of squares, as the host-side normalise does
+  __shared__ float nrm_;
+  if (tid == 0) { float sacc = 0.0f; for (int j = 0; j < d; j++) sacc += ynew[j] * ynew[j]; float nn = sqrtf(sacc); if (nn == 0.0f) nn = 1.0f; nrm_ = nn; }
+  __syncthreads();
+  for (int j = tid; j < d; j += nt) {
+    const float y = ynew[j] / nrm_;
+    D.Ycur[(size_t)k * d + j] = y;
+    D.Yt[(size_t)j * K + k] = y;
+    D.Yimg[yimg_index(D, j, k)] = y;
+  }
+}
+
 // ---- MFMA variants of the two MoE passes (static 16-cell tiles, rows of a tile are contiguous in HBM) ----
 // k_moe_stats_mfma: Sq[q] (K x d) += R_tile^T (K x 16) * Zo_tile (16 x d): the 16 cells are the MFMA reduction dim.
 //   A[i = cluster 16ct+(l&15)][slot l>>4] = R[cell 4s+(l>>4)][cluster],  B[slot][j = PC 16pt+(l&15)] = Zo[cell][PC]
@@ -2011,14 +2158,6 @@ __global__ __launch_bounds__(TPB) void k_lloyd(Dev D) {
   }
 }
 
-// index of centroid entry (PC j, cluster k) in the MFMA B-operand image (inverse of the host builder in upload_Y)
-__device__ __forceinline__ size_t yimg_index(const Dev& D, int j, int k) {
-  int s_, p_;
-  if (j < 16 * D.NT4) { const int t = j >> 4, r = j & 15; p_ = r >> 2; s_ = 4 * t + (r & 3); }
-  else { const int r = j - 16 * D.NT4; s_ = 4 * D.NT4 + (r >> 2); p_ = r & 3; }
-  const int qd = k >> 6, i = (k & 63) >> 4, c = k & 15;
-  return ((((size_t)qd * D.NS + s_) * 4 + p_) * 16 + c) * 4 + i;
-}
 // Lloyd centre update on the device (src/utils.cpp:56-61): mean of the members (2^30 fixed-point sums / counts), an
 // empty cluster keeps its centre; refreshes Ycur [K][d], Yt [d][K], the MFMA image and ||y||^2.  One workgroup per cluster.
 __global__ __launch_bounds__(64) void k_lloyd_finish(Dev D) {
@@ -2245,6 +2384,10 @@ void l_moe_apply(const Launch& L, const Dev& D) {
   if (g < 1) g = 1;
   const dim3 grid(g);
   HMX_DISPATCH_KD(k_moe_apply, , grid, lds, D);
+}
+void l_moe_solve(const Launch& L, const Dev& D, const SolveArgs& A) {
+  const size_t lds = ((size_t)3 * D.B + 4 + D.C) * sizeof(int);
+  hipLaunchKernelGGL(k_moe_solve, dim3(D.K), dim3(256), lds, L.stream, D, A);
 }
 void l_moe_stats_seq(const Launch& L, const Dev& D, float cutoff) {
   hipLaunchKernelGGL(k_moe_stats_seq, dim3(D.K, D.Q + 1), dim3(64), 0, L.stream, D, cutoff);

@@ -138,20 +138,22 @@ def prepare_setup_args(data_mat, meta_data, vars_use, theta=None, sigma=0.1, lam
 
 def RunHarmony(data_mat, meta_data, vars_use=None, theta=None, sigma=0.1, lambda_=None, nclust=None, max_iter=10,
                early_stop=True, ncores=1, plot_convergence=False, return_object=False, verbose=True,
-               options=None, seed=None, device=None, **kwargs):
+               options=None, seed=None, device=None, rng=None, **kwargs):
     """RunHarmony.default (R/ui.R:91-309).
 
     `lambda` is a Python keyword, so the ridge penalty is `lambda_` (``**{"lambda": x}`` also works);
     `.options` is `options`.  `ncores` is accepted and ignored (the reference uses it for BLAS threads,
     R/ui.R:114-128).  Returns the corrected embedding with the orientation of the input (cells x PCs if
     the input was cells x PCs -- the reference returns t(Z_corr)), or the Harmony object.
+    `seed` + `rng="R"`: draw the centroid seeds and the per-round shuffles as `set.seed(seed); RunHarmony(...)` does in R
+    (MT19937, RcppArmadillo's draw order); default: the library's counter-based generator keyed by `seed`.
     """
     if "lambda" in kwargs:
         lambda_ = kwargs.pop("lambda")
     check_legacy_args(**kwargs)
     skw, _ = prepare_setup_args(data_mat, meta_data, vars_use, theta=theta, sigma=sigma, lambda_=lambda_,
                                 nclust=nclust, early_stop=early_stop, verbose=verbose, options=options)
-    harmonyObj = Harmony(device=device, seed=seed)
+    harmonyObj = Harmony(device=device, seed=seed, rng=rng)
     harmonyObj.setup(**skw)
     if verbose:
         _message("Initializing state using k-means centroids initialization")

@@ -1,0 +1,248 @@
+"""Round-2 GPU parity tests (-m gpu): the arithmetic-gap table (GPU vs the oracle in BOTH arithmetic modes at 20k / 100k /
+1M cells, incl. BASELINE configs[2] exactly), the configs[4] shape at 200k cells, k-means initialisation at the headline
+shape and on the fallback kernels, the R-compatible random stream end to end, reference-arithmetic ridge statistics,
+single-precision / device-pointer ingest and egress."""
+import json
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from harmony_amd import Harmony, prepare_setup_args
+from helpers import synth
+from oracle import oracle as orc
+from oracle.oracle import OracleHarmony
+from parity import assert_parity, compare_state, relfro, run_both
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def _iterate(obj, max_iter=10):
+    it = 0
+    for it in range(1, max_iter + 1):
+        assert obj.cluster_cpp() == 0
+        obj.moe_correct_ridge_cpp()
+        if obj.check_convergence(1):
+            break
+    return it
+
+
+def _flips(Ra, Rb, margin):
+    aa, ab = Ra.argmax(axis=0), Rb.argmax(axis=0)
+    bad = np.where(aa != ab)[0]
+    if bad.size == 0:
+        return 0, 0
+    srt = np.sort(Rb[:, bad], axis=0)
+    return int(bad.size), int(((srt[-1] - srt[-2]) >= margin).sum())
+
+
+# ---------------------------------------------------------------- VERDICT r1 item 1 + 2a: the arithmetic-gap table
+@pytest.mark.timeout(1500, method="thread")
+@pytest.mark.parametrize("N", [20000, 100000, 1000000])
+def test_arithmetic_gap_table(N):
+    """GPU (default: exact ridge statistics) and GPU (ridge_arith = 1: the reference's sequential fp32 statistics) against the
+    oracle in accurate (fp64 accumulators) AND faithful (the reference's fp32 arithmetic) mode: N x 50, K = 100, 10 batches,
+    reference defaults, to convergence -- N = 1M is BASELINE configs[2] exactly.  Shared random choices: the GPU's k-means
+    centres, the documented Feistel block partitions (same seed).  The numbers go to gpurun_out/r2_parity_table_<N>.json
+    (copied to profiles/ and quoted in DESIGN.md section 2)."""
+    K, B, seed = 100, 10, 3
+    Z, meta, _ = synth(N, d=50, levels=(B,), seed=7)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
+    g = Harmony(seed=seed)
+    g.setup(**skw)
+    Y0 = g.kmeans_centers()
+    res, timing = {}, {}
+
+    def gpu(name, ridge_arith):
+        o = g if ridge_arith == 0 else Harmony(seed=seed, ridge_arith=1)
+        if ridge_arith:
+            o.setup(**skw)
+        t0 = time.time()
+        o.init_cluster_cpp(Y0)
+        it = _iterate(o)
+        timing[name] = time.time() - t0
+        res[name] = dict(Z=o.getZcorr(), R=o.R, it=it, obj=o.objective_kmeans.copy(), rounds=o.kmeans_rounds.copy())
+
+    def cpu(name, mask):
+        o = OracleHarmony(mask=mask, seed=seed)
+        o.setup(**skw)
+        t0 = time.time()
+        o.init_cluster_cpp(Y0)
+        it = _iterate(o)
+        timing[name] = time.time() - t0
+        res[name] = dict(Z=o.getZcorr(), R=o.R, it=it, obj=o.objective_kmeans.copy(), rounds=o.kmeans_rounds.copy())
+
+    orc.use_openblas(4)
+    th = [threading.Thread(target=cpu, args=("oracle_accurate", 15)), threading.Thread(target=cpu, args=("oracle_faithful", 0))]
+    [t.start() for t in th]
+    gpu("gpu", 0)
+    gpu("gpu_ref_arith", 1)
+    [t.join() for t in th]
+    assert set(res) == {"gpu", "gpu_ref_arith", "oracle_accurate", "oracle_faithful"}
+    rows = {}
+    for a, b in [("gpu", "oracle_accurate"), ("gpu", "oracle_faithful"), ("gpu_ref_arith", "oracle_faithful"),
+                 ("gpu_ref_arith", "oracle_accurate"), ("oracle_faithful", "oracle_accurate")]:
+        ra, rb = res[a], res[b]
+        n = min(len(ra["obj"]), len(rb["obj"]))
+        f, f5 = _flips(ra["R"], rb["R"], 1e-5)
+        rows["%s_vs_%s" % (a, b)] = {
+            "Z_rel": relfro(ra["Z"], rb["Z"]), "R_maxabs": float(np.abs(ra["R"] - rb["R"]).max()),
+            "argmax_diff": f, "argmax_diff_margin_ge_1e-5": f5, "iterations": [int(ra["it"]), int(rb["it"])],
+            "objective_rel_max": float(np.max(np.abs(ra["obj"][:n] - rb["obj"][:n]) / np.abs(rb["obj"][:n]))),
+            "final_objective": [float(ra["obj"][-1]), float(rb["obj"][-1])]}
+    out = {"workload": {"cells": N, "pcs": 50, "clusters": K, "batches": B}, "seconds": timing, "pairs": rows}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "r2_parity_table_%d.json" % N), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+    ga, gf, rf = rows["gpu_vs_oracle_accurate"], rows["gpu_vs_oracle_faithful"], rows["gpu_ref_arith_vs_oracle_faithful"]
+    # the parity target proper: same algorithm, exact accumulators -> tight bar, SURVEY's 1e-5 assignment margin
+    assert ga["Z_rel"] <= 2e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1], ga
+    assert ga["objective_rel_max"] <= 1e-4, ga
+    # the reference's own arithmetic: with its summation order reproduced the GPU is inside north_star's 1e-4
+    assert rf["Z_rel"] <= 1e-4 and rf["iterations"][0] == rf["iterations"][1], rf
+    # (gf -- default GPU vs the reference's fp32 drift -- is REPORTED, not asserted: it is the reference's N-dependent bias)
+    assert gf["iterations"][0] == gf["iterations"][1], gf
+
+
+# ---------------------------------------------------------------- configs[4] shape at 200k cells
+@pytest.mark.timeout(1500, method="thread")
+def test_config5_shape_200k():
+    """BASELINE configs[4] scaled to one test: 200k x 50, K = 200, three nested covariates 8 > 64 > 128 = 200 levels;
+    batch-subset ridge path asserted (src/harmony.cpp:440-547)."""
+    Z, meta, _ = synth(200000, d=50, levels=(8, 64, 128), seed=11, nested=True)
+    orc.use_openblas(4)
+    g, c, ig, ic = run_both(Z, meta, list(meta), max_iter=2, nclust=200, seed=5)
+    s = assert_parity(g, c, ig, ic)
+    assert c.subset_clusters > 0 and int(g._scalar("subset_clusters")) == c.subset_clusters
+    print("config5 200k:", s, "subset clusters", c.subset_clusters)
+
+
+# ---------------------------------------------------------------- k-means initialisation
+@pytest.mark.parametrize("env", [{}, {"HMX_TILE_IMPL": "v1"}])
+def test_kmeans_centers_headline_shape(monkeypatch, env):
+    """kmeans_centers (src/utils.cpp:10-64: seeding race + 10 Lloyd iterations) at d = 50, K = 100, 100k cells against the
+    oracle, on the MFMA tile kernels and on the cluster-lane fallbacks (k_seed_probe, k_lloyd)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    Z, meta, _ = synth(100000, d=50, levels=(10,), seed=9)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
+    g = Harmony(seed=17)
+    g.setup(**skw)
+    Yg = g.kmeans_centers()
+    c = OracleHarmony(accurate=True, seed=17)
+    c.setup(**skw)
+    c.init_cluster_cpp()                     # kmeans_centers + normalise
+    Yg_n = Yg / np.linalg.norm(Yg, axis=0, keepdims=True)
+    assert relfro(Yg_n, c.Y) < 1e-4, relfro(Yg_n, c.Y)
+
+
+def test_kmeans_duplicate_winner_resample():
+    """More anchors than the data can serve distinctly: several anchors win the same cell and must be re-sampled among the
+    cells not yet chosen, in cluster order (src/utils.cpp:38-43)."""
+    rng = np.random.default_rng(5)
+    base = rng.normal(size=(6, 5))
+    Z = np.repeat(base, 10, axis=0) + 1e-3 * rng.normal(size=(60, 5))      # 6 tight groups of 10 cells
+    meta = {"b": np.arange(60) % 2}
+    skw, _ = prepare_setup_args(Z, meta, "b", nclust=40)
+    for seed in (1, 2, 3):
+        g = Harmony(seed=seed)
+        g.setup(**skw)
+        Yg = g.kmeans_centers()
+        c = OracleHarmony(accurate=True, seed=seed)
+        c.setup(**skw)
+        c.init_cluster_cpp()
+        Yg_n = Yg / np.linalg.norm(Yg, axis=0, keepdims=True)
+        assert relfro(Yg_n, c.Y) < 1e-4, (seed, relfro(Yg_n, c.Y))
+
+
+# ---------------------------------------------------------------- R-compatible randomness, end to end
+@pytest.mark.parametrize("case", ["cell_lines", "synth20k"])
+def test_r_compatible_stream_end_to_end(case, cell_lines):
+    """rng = R on both sides, NO shared random choices: seeds (K + K*N uniforms) and every round's arma::shuffle come from
+    MT19937 seeded like set.seed(seed) -- two independent implementations (product / oracle) must walk the same stream and
+    reach the same corrected embedding."""
+    if case == "cell_lines":
+        Z = cell_lines["pcs"]
+        meta = {"dataset": cell_lines["dataset_levels"][cell_lines["dataset"]]}
+        K, vu = 20, "dataset"
+    else:
+        Z, meta, _ = synth(20000, d=50, levels=(5,), seed=3)
+        K, vu = 50, "cov0"
+    skw, _ = prepare_setup_args(Z, meta, vu, nclust=K)
+    g = Harmony(seed=42, rng="R")
+    g.setup(**skw)
+    c = OracleHarmony(accurate=True, seed=42, rng=1)
+    c.setup(**skw)
+    g.init_cluster_cpp()
+    c.init_cluster_cpp()
+    assert relfro(g.Y, c.Y) < 1e-4, relfro(g.Y, c.Y)
+    ig, ic = _iterate(g, 4), _iterate(c, 4)
+    s = assert_parity(g, c, ig, ic)
+    print("R-stream parity:", s)
+    # and the stream matters: another seed gives another partition history
+    g2 = Harmony(seed=43, rng="R")
+    g2.setup(**skw)
+    g2.init_cluster_cpp()
+    assert relfro(g2.Y, g.Y) > 1e-3
+
+
+# ---------------------------------------------------------------- single precision / device pointers
+def test_f32_and_device_pointer_ingest_egress():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    N, d, K = 30011, 50, 40
+    Z, meta, _ = synth(N, d=d, levels=(4,), seed=2)
+    skw, dm = prepare_setup_args(Z, meta, "cov0", nclust=K)
+    ref = Harmony(seed=1)
+    ref.setup(**skw)                                        # float64 host = the R seam
+    Z32 = np.asfortranarray(skw["Z"], dtype=np.float32)
+    a = Harmony(seed=1)
+    a.setup(**dict(skw, Z=Z32))                             # float32 host
+    np.testing.assert_array_equal(a.getZorig(), ref.getZorig())
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), Z32.nbytes) == 0
+    assert hip.hipMemcpy(dptr, Z32.ctypes.data, Z32.nbytes, 1) == 0
+    b = Harmony(seed=1)
+    b.setup(**dict(skw, Z=(d, N, np.float32, dptr.value)))  # float32 already in HBM
+    hip.hipFree(dptr)
+    np.testing.assert_array_equal(b.getZorig(), ref.getZorig())
+    for o in (ref, b):
+        o.init_cluster_cpp(np.asfortranarray(skw["Z"][:, :K]))
+        assert o.cluster_cpp() == 0
+        o.moe_correct_ridge_cpp()
+    Zc = ref.getZcorr()
+    np.testing.assert_array_equal(b.getZcorr(), Zc)
+    np.testing.assert_array_equal(b.get_matrix("Z_corr", np.float32), Zc.astype(np.float32))
+    np.testing.assert_array_equal(b.get_matrix("R", np.float64), ref.R)
+    out = C.c_void_p()
+    assert hip.hipMalloc(C.byref(out), N * d * 4) == 0
+    b.get_matrix("Z_corr", np.float32, device_ptr=out.value)
+    back = np.empty((d, N), dtype=np.float32, order="F")
+    assert hip.hipMemcpy(back.ctypes.data, out, back.nbytes, 2) == 0
+    hip.hipFree(out)
+    np.testing.assert_array_equal(back, Zc.astype(np.float32))
+    assert ref.timer("ingest_Z") > 0 and ref.timer("egress_Z_corr") > 0
+
+
+def test_update_order_must_be_a_permutation(cell_lines_small):
+    from harmony_amd import HarmonyError
+    meta = {"dataset": cell_lines_small["dataset_levels"][cell_lines_small["dataset"]]}
+    skw, _ = prepare_setup_args(cell_lines_small["pcs"], meta, "dataset", nclust=5)
+    g = Harmony(seed=1)
+    g.setup(**skw)
+    bad = np.arange(300)
+    bad[7] = 8
+    with pytest.raises(HarmonyError, match="permutation"):
+        g.push_update_order(bad)
+    bad[7] = 300
+    with pytest.raises(HarmonyError, match="permutation"):
+        g.push_update_order(bad)
+    g.push_update_order(np.arange(300)[::-1].copy())
