@@ -108,6 +108,7 @@ struct hmx_ctx {
   std::vector<float> obj_kmeans, obj_dist, obj_entropy, obj_cross, obj_harmony;
   std::vector<int> kmeans_rounds;
   std::vector<int> qlev, perm;
+  std::vector<long long> seed_cells;
   std::deque<std::vector<int64_t>> injected;
   int64_t subset_clusters = 0, skipped_clusters = 0;
   // objective snapshots are read back asynchronously: one pinned 3-double slot per clustering round, resolved into the
@@ -454,6 +455,7 @@ int kmeans_centers(hmx_ctx* ctx) {
     gcells[i] = (long long)g;
   }
   }
+  ctx->seed_cells.assign(gcells.begin(), gcells.end());   // diagnostics: hmx_get("seed_cells")
   CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
   // 10 x one Lloyd iteration (:53-64); the centre update runs on the device, no host round trip per iteration
   {
@@ -1385,6 +1387,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
     auto it = ctx->gpu_timers.find(nm); return scalar(it == ctx->gpu_timers.end() ? 0.0 : it->second);
   }
   if (f.rfind("timer:", 0) == 0) { auto it = ctx->timers.find(f.substr(6)); return scalar(it == ctx->timers.end() ? 0.0 : it->second); }
+  if (f == "seed_cells") return vec(ctx->seed_cells);
   if (f == "Y") return vec(ctx->Y);
   if (f == "W") return vec(ctx->W);
   if (f == "Pr_b") return vec(ctx->Pr_b);

@@ -1353,7 +1353,8 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
           const float key = -logf(u) / dis;  // >= 0 (or +inf / nan when dis == 0)
           unsigned kb = __float_as_uint(key);
-          if (!(key >= 0.0f)) kb = 0x7f800000u;  // nan -> +inf: never the minimum
+          if (!(key >= 0.0f)) kb = 0x7f800000u;
+          kb &= 0x7fffffffu;   // -0.0 (u == 1: -log(u) = -0) must order as zero, not as the largest unsigned pattern  // nan -> +inf: never the minimum
           const unsigned long long pk = ((unsigned long long)kb << 32) | (unsigned long long)(uint32_t)gg;
           const bool take = !skip && (ct < first_partial_ct(NCT) || 16 * ct + c < K) && pk < best[ct];
           best[ct] = take ? pk : best[ct];
@@ -2025,7 +2026,8 @@ __global__ __launch_bounds__(TPB) void k_seed_probe(Dev D, uint64_t seed, uint64
                 const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
                 const float key = -logf(u) / dis;  // >= 0 (or +inf / nan when dis == 0)
                 unsigned kb = __float_as_uint(key);
-                if (!(key >= 0.0f)) kb = 0x7f800000u;  // nan -> +inf: never the minimum
+                if (!(key >= 0.0f)) kb = 0x7f800000u;
+          kb &= 0x7fffffffu;   // -0.0 (u == 1: -log(u) = -0) must order as zero, not as the largest unsigned pattern  // nan -> +inf: never the minimum
                 const unsigned long long pk = ((unsigned long long)kb << 32) | (unsigned long long)(uint32_t)g;
                 best[q] = pk < best[q] ? pk : best[q];
               }
@@ -2066,6 +2068,7 @@ __global__ __launch_bounds__(256) void k_seed_race_u(Dev D, const float* __restr
       const float key = -logf(u[(size_t)a * n + loc]) / dis;
       unsigned kb = __float_as_uint(key);
       if (!(key >= 0.0f)) kb = 0x7f800000u;
+          kb &= 0x7fffffffu;   // -0.0 (u == 1: -log(u) = -0) must order as zero, not as the largest unsigned pattern
       const unsigned long long pk = ((unsigned long long)kb << 32) | (unsigned long long)(uint32_t)gg;
       if (!skip && pk < best) best = pk;
     }

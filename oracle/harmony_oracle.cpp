@@ -241,6 +241,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
   std::vector<float> objective_kmeans, objective_kmeans_dist, objective_kmeans_entropy,
       objective_kmeans_cross, objective_harmony;
   std::vector<int> kmeans_rounds;
+  std::vector<int64_t> seed_cells;   // diagnostics: the cells initialize_centroids chose
   float block_size = 0.05f, epsilon_kmeans = 1e-3f, epsilon_harmony = 1e-2f, alpha = 0.2f,
         batch_proportion_cutoff = 1e-5f;
   int max_iter_kmeans = 4, window_size = 3;
@@ -307,6 +308,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
       std::memcpy(&Y[(size_t)i * d], X + idx * d, sizeof(float) * d);
     }
     std::set<int64_t> sup;
+    seed_cells.clear();
     std::vector<float> prob(N);
     for (int i = 0; i < K; i++) {
       const float* y = &Y[(size_t)i * d];
@@ -322,6 +324,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
         best = std::min_element(prob.begin(), prob.end()) - prob.begin();
       }
       sup.insert(best);
+      seed_cells.push_back(best);
       std::memcpy(&Y[(size_t)i * d], X + best * d, sizeof(float) * d);
     }
     // 10 x one Lloyd iteration :53-64 (arma::kmeans semantics: see header)
@@ -625,6 +628,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
     if (w == "objective_kmeans_cross") return copy_out(objective_kmeans_cross, out);
     if (w == "objective_harmony") return copy_out(objective_harmony, out);
     if (w == "kmeans_rounds") return copy_out(kmeans_rounds, out);
+    if (w == "seed_cells") return copy_out(seed_cells, out);
     if (w == "subset_clusters") { if (out) out[0] = (double)subset_clusters; return 1; }
     if (w == "skipped_clusters") { if (out) out[0] = (double)skipped_clusters; return 1; }
     if (w == "Lambda") {  // getLambda :657-669  (K x (B+1), column-major)

@@ -137,6 +137,8 @@ def test_kmeans_centers_headline_shape(monkeypatch, env):
     c = OracleHarmony(accurate=True, seed=17)
     c.setup(**skw)
     c.init_cluster_cpp()                     # kmeans_centers + normalise
+    sg, sc = g._get("seed_cells").astype(np.int64), c._get("seed_cells").astype(np.int64)
+    assert np.array_equal(sg, sc), np.where(sg != sc)[0]
     Yg_n = Yg / np.linalg.norm(Yg, axis=0, keepdims=True)
     assert relfro(Yg_n, c.Y) < 1e-4, relfro(Yg_n, c.Y)
 
@@ -156,8 +158,12 @@ def test_kmeans_duplicate_winner_resample():
         c = OracleHarmony(accurate=True, seed=seed)
         c.setup(**skw)
         c.init_cluster_cpp()
+        sg, sc = g._get("seed_cells").astype(np.int64), c._get("seed_cells").astype(np.int64)
+        assert np.array_equal(sg, sc), (seed, np.where(sg != sc)[0])       # the race and the re-sampling pick the same cells
+        assert len(set(sg.tolist())) == 40
+        # the centres themselves are tie-sensitive here BY CONSTRUCTION (40 centres in 6 tight groups): loose bar
         Yg_n = Yg / np.linalg.norm(Yg, axis=0, keepdims=True)
-        assert relfro(Yg_n, c.Y) < 1e-4, (seed, relfro(Yg_n, c.Y))
+        assert relfro(Yg_n, c.Y) < 2e-3, (seed, relfro(Yg_n, c.Y))
 
 
 # ---------------------------------------------------------------- R-compatible randomness, end to end
