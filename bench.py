@@ -245,6 +245,7 @@ def main():
     roofline = {"kernel": "k_tile<NCT,0> (block update of update_R)", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "mfma_busy_frac": mfma_util,
                 "avg_launch_us": 1e3 * upd_ms / max(upd_launches, 1), "launches": int(upd_launches),
+                "avg_block_step_us": 1e3 * upd_ms / max(obj._scalar("prof:update_steps"), 1),
                 "alg_bytes_per_launch": alg_bytes / max(upd_launches, 1),
                 "kernel_time_share": upd_ms / (1e3 * dt) if dt > 0 else None,
                 "run": {"alg_bytes_per_step_per_gpu": run_bytes, "achieved": run_gbs, "frac": run_gbs / 8000.0,
@@ -252,6 +253,14 @@ def main():
     gpu_phase = {k: round(obj._scalar("gputimer:" + k) / a.steps, 3) for k in
                  ("kmeans_centers", "cluster_head", "randomize", "EO_update", "Rcells_update", "correct_ridge_loop",
                   "ridge_statistics", "arma_inv", "update_Zcorr")}
+    chain = None
+    if obj._scalar("chain"):   # persistent block chain: where its workgroups spent their time (100 MHz ticks -> us per block step)
+        dbg = obj._get("chain_dbg")
+        steps_ = max(float(dbg[3]) * 20.0, 1.0)
+        names = ["folder_wait_arrivals", "folder_fold", "folder_publish", None, "worker_wait_flag", "worker_copy_table",
+                 "worker_wait_stores_issued_to_retired", "worker_barrier_arrive", "worker_next_mfma", "worker_tiles_but_last",
+                 "worker_last_epilogue", "worker_flush_and_store_issue", "worker_next_mfma_cyclecounter_x100"]
+        chain = {nm: round(float(dbg[i]) / 100.0 / steps_, 3) for i, nm in enumerate(names) if nm}
     # T_e2e: T_conv + H2D of Z (double, the R seam) + D2H of Z_corr (double); PCIe-inclusive, never `value`
     e2e = None
     if not a.no_e2e:
@@ -279,7 +288,7 @@ def main():
                    "parallelism": ("cells sharded x%d, all-reduce of O/E/statistics: %s" % (world, comm_kind)) if world > 1 else "single GPU",
                    "harmony_iterations": iters, "kmeans_rounds_last_step": rounds,
                    "s_per_iter": 1e-3 * ms_per_step / max(float(np.mean(iters)), 1.0),
-                   "gpu_phase_ms_per_step": gpu_phase, "e2e": e2e},
+                   "gpu_phase_ms_per_step": gpu_phase, "chain_us_per_block_step": chain, "e2e": e2e},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and a.cpu_sample > 0:

@@ -131,13 +131,15 @@ struct hmx_ctx {
   // profiling of the dominant kernel
   bool profile = false;
   bool fused_ok = false;       // k_tile prologue fold usable (LDS budget) and not disabled
+  bool chain_ok = false; int chain_wgs = 0; uint64_t chain_rounds = 0;   // persistent block chain (one launch per round)
   int tun_impl = -1, tun_tpw = -1, tun_cpw = -1, tun_wps = -1;  // tunables set through hmx_set_int before setup
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
   // GPU phase timers (profile mode): event pairs tagged with a phase name, named after the reference's Timer phases
   // (src/harmony.cpp:302-335,557-615) where a phase has a counterpart; resolved lazily into gpu_timers
   struct PhaseEv { hipEvent_t a, b; int name; };
   std::vector<PhaseEv> ph_pool; size_t ph_used = 0; std::vector<std::string> ph_names; std::map<std::string, double> gpu_timers;
-  double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0;
+  double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0, prof_update_steps = 0;
+  bool chain_check = false;    // a persistent-chain launch has run since the error word was last read
   std::string err, warn, warn_ret;
 };
 
@@ -263,7 +265,9 @@ int flush_objectives(hmx_ctx* ctx) {
   HIPCHK(hipEventSynchronize(ctx->obj_event));
   const float norm_const = 2000 / ((float)ctx->N_global);
   for (int i = 0; i < ctx->obj_pending; i++) {
-    const double* o = ctx->h_obj + 3 * i;
+    const double* o = ctx->h_obj + 4 * i;
+    int chain_err = 0; std::memcpy(&chain_err, o + 3, sizeof(int));
+    if (chain_err) { ctx->obj_pending = 0; return fail(ctx, HMX_ERR_DEVICE, "persistent block chain: a workgroup timed out waiting for its peers (code " + std::to_string(chain_err) + ")"); }
     ctx->obj_kmeans.push_back((float)((o[0] + o[1] + o[2]) * norm_const));
     ctx->obj_dist.push_back((float)(o[0] * norm_const));
     ctx->obj_entropy.push_back((float)(o[1] * norm_const));
@@ -276,11 +280,16 @@ int flush_objectives(hmx_ctx* ctx) {
 int push_objective(hmx_ctx* ctx) {
   if (!ctx->h_obj) {
     ctx->obj_cap = 64;
-    HIPCHK(hipHostMalloc((void**)&ctx->h_obj, sizeof(double) * 3 * ctx->obj_cap, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_obj, sizeof(double) * 4 * ctx->obj_cap, hipHostMallocDefault));
+    std::memset(ctx->h_obj, 0, sizeof(double) * 4 * ctx->obj_cap);
     HIPCHK(hipEventCreateWithFlags(&ctx->obj_event, hipEventDisableTiming));
   }
   if (ctx->obj_pending == ctx->obj_cap) CHK(flush_objectives(ctx));
-  HIPCHK(hipMemcpyAsync(ctx->h_obj + 3 * ctx->obj_pending, ctx->D.obj + 2, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->L.stream));
+  HIPCHK(hipMemcpyAsync(ctx->h_obj + 4 * ctx->obj_pending, ctx->D.obj + 2, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->L.stream));
+  if (ctx->chain_check) {   // error word of the persistent chain rides along (slot's 4th double)
+    HIPCHK(hipMemcpyAsync(ctx->h_obj + 4 * ctx->obj_pending + 3, ctx->D.chain_ctl + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->L.stream));
+    ctx->chain_check = false;
+  } else std::memset(ctx->h_obj + 4 * ctx->obj_pending + 3, 0, sizeof(double));
   HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
   ctx->obj_pending++;
   return 0;
@@ -521,7 +530,22 @@ int update_R(hmx_ctx* ctx) {
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
   const bool fused = merged && ctx->fused_ok;
-  if (fused) {
+  if (fused && ctx->chain_ok && !sharded) {
+    // default on one GPU: the whole block chain in ONE persistent launch (k_tile MODE 4)
+    HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 16), ctx->L.stream));
+    D.chain_tag = (unsigned)(1 + (ctx->chain_rounds++ % (1u << 24)) * 64);
+    long long* const keep_snew = D.Snew_fx;
+    D.Snew_fx = D.Snew_set[0];     // one replica set: the folder resets it by exchange (zeroed by the round's memset)
+    if (ctx->profile) {
+      if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t x, y; HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y)); ctx->ev_pool.emplace_back(x, y); }
+      HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
+    }
+    l_chain(ctx->L, D, ctx->chain_wgs); KCHK();
+    if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps += D.nb; }
+    D.Snew_fx = keep_snew;
+    ctx->chain_check = true;
+    round_done = true;
+  } else if (fused) {
     // default: the fold + penalty of step j happens in the prologue of its own update launch.  Sharded: the replica set a
     // launch has filled is all-reduced IN PLACE (nrep*B*K int64, 64 KB at C4: latency-bound like the 8 KB of one table), so
     // the next launch's prologue sums global replicas exactly as it sums local ones -- one kernel + one collective per block
@@ -536,6 +560,7 @@ int update_R(hmx_ctx* ctx) {
       }
       l_update(ctx->L, D, j); KCHK();
       if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; }
+      if (ctx->profile) ctx->prof_update_steps++;
       if (sharded) CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.nrep * D.B * D.K, 0));   // this block's new contribution, all ranks
       std::swap(D.O_fx, D.O_alt);   // workgroup 0 published O' into O_alt
     }
@@ -569,7 +594,7 @@ int update_R(hmx_ctx* ctx) {
       HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
     }
     l_update(ctx->L, D, j); KCHK();
-    if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; }
+    if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
   }
   l_obj_reduce(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.obj, 2, 1));
@@ -864,7 +889,7 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "rng") { if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, "rng: 0 (counter-based) or 1 (R-compatible)"); ctx->rng_mode = (int)v; ctx->rrng_seeded = false; }
   else if (f == "ridge_arith") { if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, "ridge_arith: 0 (exact) or 1 (reference fp32 order)"); ctx->ridge_arith = (int)v; }
   else if (f == "device") ctx->device = (int)v;
-  else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->ev_used = 0;
+  else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->prof_update_steps = 0; ctx->ev_used = 0;
                              ctx->ph_used = 0; ctx->gpu_timers.clear(); }
   else if (f == "grid") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "grid must be set before setup"); ctx->L.grid = (int)v; }
   else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
@@ -1140,6 +1165,20 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   { const char* e = getenv("HMX_FUSED_FOLD");
     ctx->fused_ok = !(e && std::string(e) == "0") && D.upd_impl == 0 &&
                     (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024; }
+  { // persistent block chain: one workgroup per CU must be resident at once (they synchronise inside the launch)
+    const char* e = getenv("HMX_CHAIN");
+    int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    ctx->chain_wgs = cus;
+    ctx->chain_ok = !(e && std::string(e) == "0") && ctx->fused_ok && cus >= 8 && D.NCT <= 7 && D.NT4 <= 4 && D.nb <= 64 &&
+                    (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024;
+    CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 16)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)16));
+    HIPCHK(hipMemsetAsync(D.chain_dbg, 0, sizeof(unsigned long long) * 16, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.pen_g, 0, sizeof(unsigned long long) * (size_t)B * K, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 16), ctx->L.stream));
+    { const char* w = getenv("HMX_CHAIN_WPS"); D.chain_wps = (w && (atoi(w) == 4 || atoi(w) == 3) && D.usig) ? atoi(w) : 2;
+      // the 4-waves-per-SIMD variant keeps one LDS-DMA row image per wave: 16 KB per 16-byte group of a row
+      if (D.chain_wps >= 3 && (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 + (size_t)16 * (D.NT4 + D.tail + 1) * 1024 > 158 * 1024) D.chain_wps = 2; }
+    ctx->chain_rounds = 0; }
   ctx->ran_setup = true;
   return hmx_restart(ctx);
 }
@@ -1380,6 +1419,16 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "prof:update_ms") return scalar(ctx->prof_update_ms);
   if (f == "prof:update_launches") return scalar((double)ctx->prof_update_launches);
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
+  if (f == "prof:update_steps") return scalar((double)ctx->prof_update_steps);
+  if (f == "chain") return scalar(ctx->chain_ok ? 1.0 : 0.0);
+  if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them
+    if (!ctx->ran_setup) return -1;
+    if (!out) return 16;
+    std::vector<unsigned long long> h(16);
+    if (d2h(ctx, h.data(), ctx->D.chain_dbg, 16)) return -1;
+    (void)hipMemsetAsync(ctx->D.chain_dbg, 0, sizeof(unsigned long long) * 16, ctx->L.stream);
+    return vec(h);
+  }
   if (f.rfind("gputimer:", 0) == 0) {   // GPU time of a phase (profile mode), ms; "gputimer:Rcells_update" == "prof:update_ms"
     resolve_phases(ctx);
     const std::string nm = f.substr(9);

@@ -67,6 +67,13 @@ struct Dev {
   long long* Snew_set[3];      // the three rotating replica sets of the fused path
   long long* O_alt;   // ping-pong partners of O_fx / Snew_fx for the single-launch fold+penalty (host swaps)
   long long* Snew_alt;
+  // persistent block chain (k_tile MODE 4): penalty granules, control block, tag of the round's first block
+  unsigned long long* pen_g;   // [B][K] { tag << 32 | penalty bits }
+  int* chain_ctl;              // [0] block flag (tag), [1] error, [2 + j] arrivals of block j
+  unsigned chain_tag;
+  int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)
+  unsigned long long* chain_dbg;   // diagnostics: accumulated 100 MHz ticks [0..2] folder wait / fold / publish, [3] launches,
+                                   //              [4..8] worker (workgroup 0) flag wait / table copy / tiles / drain+arrive / next block's MFMAs
   float* pen;         // [B][K] ((2E+1)/(O+E+1))^theta
   double* obj;        // [0..1] reduced sums: sum R*dist, sum sigma*R*log R ; [2..4] snapshot incl. cross term
   double* objpart;    // [objslots][nwmax][2] per-(block,wave) partial sums: private slots, no atomics
@@ -145,6 +152,7 @@ void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long 
                long long* Szero);
 void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
+void l_chain(const Launch& L, const Dev& D, int workgroups);   // the whole block chain of a round: one persistent launch
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
 void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);

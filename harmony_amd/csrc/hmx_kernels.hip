@@ -16,6 +16,9 @@
 #ifndef HMX_USE_DPP
 #define HMX_USE_DPP 1
 #endif
+#ifndef HMX_CHAIN_BALANCE
+#define HMX_CHAIN_BALANCE 1
+#endif
 #ifndef HMX_TILE_LB
 #define HMX_TILE_LB(NCT) 1   // waves/SIMD the tile kernel is register-budgeted for; 3 measured slower than unconstrained
 #endif
@@ -879,6 +882,63 @@ __device__ __forceinline__ void tile_dots(const f32x4* __restrict__ ldsY4, const
   }
 }
 
+// LDS-DMA: every lane copies 16 bytes from its own global address to  lds_base + lane * 16  (wave-uniform base) without
+// touching a VGPR; completion is counted by vmcnt like an ordinary load.
+__device__ __forceinline__ void glds16(const float* gsrc, f32x4* lds_base) {
+  // inline asm on purpose: with the builtin hipcc treats the DMA as a store to LDS and drains it (vmcnt(0)) in front of the next
+  // LDS read -- the epilogue's penalty-table reads -- which exposes the whole copy latency.  The asm statement is invisible
+  // to the wait-count pass; the caller waits with a counted s_waitcnt (the copies are older than everything it leaves in flight).
+  // M0 = wave-uniform LDS byte address of the destination; written and restored inside the statement (compiler-reserved).
+  const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)(uintptr_t)lds_base));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const int* gsrc, int* lds_base) {   // 4 bytes per lane, same contract as glds16
+  const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)(uintptr_t)lds_base));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// the MFMA chain of one tile with the A operands in an LDS image filled by glds16: group t < NT4 holds each lane's PCs
+// 16t+4g..+3, group NT4+u the 16 bytes at PC 16*NT4+4u (the same for the four k-slot lanes of a cell: lane g uses component g)
+template <int NCT>
+__device__ __forceinline__ void tile_dots_lds(const f32x4* __restrict__ ldsY4, const f32x4* __restrict__ rows, bool valid, int g,
+                                              int lane, int NS, int NT4, int tail, f32x4 (&acc)[NCT]) {
+  constexpr int NQ = (NCT + 3) / 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) acc[ct] = zero4;
+  for (int t = 0; t < NT4; ++t) {
+    const f32x4 zl = rows[t * 64 + lane];
+    const f32x4 zc = valid ? zl : zero4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int s = 4 * t + e;
+#pragma unroll
+      for (int qd = 0; qd < NQ; ++qd) {
+        const f32x4 y = ldsY4[(qd * NS + s) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * qd + i < NCT) acc[4 * qd + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc[e], y[i], acc[4 * qd + i], 0, 0, 0);
+      }
+    }
+  }
+  for (int u = 0; u < tail; ++u) {
+    const int s = 4 * NT4 + u;
+    const f32x4 zl = rows[(NT4 + u) * 64 + lane];
+    const float zg = (g == 0) ? zl[0] : (g == 1) ? zl[1] : (g == 2) ? zl[2] : zl[3];
+    const float zv = valid ? zg : 0.0f;
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) {
+      const f32x4 y = ldsY4[(qd * NS + s) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * qd + i < NCT) acc[4 * qd + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv, y[i], acc[4 * qd + i], 0, 0, 0);
+    }
+  }
+}
+
 // A-operand rows of one tile held in registers (d <= 76: at most 4 float4 groups + 3 single steps), so that the rows of
 // tile i+1 can be requested while tile i is computed.  Loads are unconditional with clamped offsets (see ld_or).
 struct RowRegs { f32x4 v[4]; float t[3]; };
@@ -977,6 +1037,11 @@ constexpr int tile_threads(int nct) { return 256; }
 // K <= 64 with a uniform sigma runs the 128-VGPR variant (WPS = 4).
 // MODE 2: one Lloyd iteration of kmeans_centers (nearest centre, fixed-point sums in LDS)  src/utils.cpp:56-61
 // MODE 3: the seeding race of kmeans_centers: for every anchor k  argmin_n -log(u_kn) / |2(1 - y_k.x_n)|  src/utils.cpp:24-34
+// MODE 4: the WHOLE block chain of one update_R round in ONE persistent launch (one workgroup per CU): the workers run MODE 0's
+//         tile pipeline for block j, arrive on a counter, and -- while a dedicated folder workgroup folds the block's
+//         contribution into O and publishes the next penalty table -- already gather the rows and run the MFMAs of their
+//         first tile of block j+1.  Only  + log2 pen -> exp2 -> normalise -> store -> flush  stays on the chain's critical
+//         path; the centroid image is staged once per round instead of once per block step.
 // WPS: waves per SIMD the register budget is cut for (update workgroup = 256*WPS threads).  USIG: one sigma for all clusters
 // (the reference's default, R/ui.R:219-221): ce / cl become scalars, 2-3 register arrays of NCT floats disappear.
 template <int NCT, int MODE, int WPS = 2, bool USIG = false>
@@ -992,15 +1057,27 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // publishes O' and zeroes the replica set of the NEXT launch (three sets rotate, so nobody reads what is zeroed).
   const int nBK = D.B * K;
   long long* ldsO = reinterpret_cast<long long*>(lds4 + nY4);
-  float* ldsPen = (MODE == 0 && D.fused_fold) ? reinterpret_cast<float*>(ldsO + nBK) : reinterpret_cast<float*>(lds4 + nY4);
+  float* ldsPen = ((MODE == 0 && D.fused_fold) || MODE == 4) ? reinterpret_cast<float*>(ldsO + nBK) : reinterpret_cast<float*>(lds4 + nY4);
   int* ldsQlev = reinterpret_cast<int*>(ldsPen + ((nBK + 3) & ~3));
   long long* ltab = reinterpret_cast<long long*>(lds4 + nY4);
+  constexpr bool UPD = (MODE == 0 || MODE == 4);   // block update modes (gathered cells, penalty, O contributions)
   int p0 = 0, ntiles;
   if constexpr (MODE == 0) { p0 = D.boff[j]; ntiles = (D.boff[j + 1] - p0) >> 4; }  // padded: combination-pure tiles
+  else if constexpr (MODE == 4) { p0 = D.boff[0]; ntiles = (D.boff[1] - p0) >> 4; }
   else ntiles = D.ntitems;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   // wave index as a SCALAR: tile numbers and all loop control become SALU work (no exec-mask branches in the tile loop)
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
+  // (MODE 4: the last workgroup is the folder, the others are the workers)
+  const int nw = ((gridDim.x - (MODE == 4 ? 1 : 0)) * blockDim.x) >> 6;
+  int wave_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if constexpr (MODE == 4) {
+    // tiles are dealt t = wave + i * nw, so the waves with the low indices get the extra tile of a block: number the first
+    // wave of every SIMD (all workgroups) before the second ones, and each SIMD hosts one heavy and one light wave -- the
+    // same tile count on every SIMD instead of 4 tiles on half the CUs and 2 on the others
+    const int wpg = (int)blockDim.x >> 6, wib = (int)threadIdx.x >> 6, half = wpg >> 1, nwg = (int)gridDim.x - 1;
+    if (HMX_CHAIN_BALANCE && half >= 1) wave_ = (wib < half) ? (int)blockIdx.x * half + wib : nwg * half + (int)blockIdx.x * (wpg - half) + (wib - half);
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(wave_);
   auto stamp = [&](int slot) {  // diagnostics build only (-DHMX_TRACE, tools/trace_update.py): per-wave phase stamps
 #ifdef HMX_TRACE
     if constexpr (MODE == 0) {
@@ -1014,9 +1091,10 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // (dealing tiles workgroup-major instead -- equal tiles per CU -- measured 25% SLOWER: the 8 consecutive tiles of a
   //  workgroup share lorder/lcombo cache lines and the lighter half of the CUs finishing early helps the tail)
   const int per = (ntiles + nw - 1) / nw;
-  const int ts = (MODE == 0) ? wave : wave * per;
-  const int te = (MODE == 0) ? ntiles : min(ntiles, ts + per);
-  const int tstep = (MODE == 0) ? nw : 1;
+  const int ts = UPD ? wave : wave * per;
+  int te = UPD ? ntiles : min(ntiles, ts + per);     // (MODE 4 re-derives it for every block)
+  if (MODE == 4 && blockIdx.x == gridDim.x - 1) te = ts;   // the folder owns no tiles
+  const int tstep = UPD ? nw : 1;
   // MODE 0: the first tile's cell ids and the first 16 bytes of their embedding rows are requested BEFORE the
   // LDS staging below, so the two dependent HBM round trips overlap with it
   // Software pipeline over tiles (when the rows fit in registers, D.NT4 <= 4): cell ids two tiles ahead, embedding rows
@@ -1029,7 +1107,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   RowRegs rowsN;
   auto tile_cell = [&](int tile) -> int2 {     // (-1, .): padding slot / beyond the end
     if (tile >= te) return make_int2(-1, -1);
-    if constexpr (MODE == 0) return D.lpair[p0 + 16 * tile + c];
+    if constexpr (UPD) return D.lpair[p0 + 16 * tile + c];
     else {
       // keep this a per-lane (vector) load: with the uniform tile index hipcc would emit load + readfirstlane, i.e. a
       // vmcnt(0) -- a full memory latency per tile that also drains the prefetched rows
@@ -1127,12 +1205,13 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
       }
     }
+    if constexpr (MODE == 4) for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
     if constexpr (MODE == 2) for (int i = threadIdx.x; i < K * D.d + K; i += blockDim.x) ltab[i] = 0;
     __syncthreads();
   }
   stamp(2);
-  const float* penT = (MODE == 0 && (D.pen_lds || D.fused_fold)) ? ldsPen : D.pen;
-  const int* qlevT = (MODE == 0 && (D.pen_lds || D.fused_fold)) ? ldsQlev : D.qlev;
+  const float* penT = ((MODE == 0 && (D.pen_lds || D.fused_fold)) || MODE == 4) ? ldsPen : D.pen;
+  const int* qlevT = ((MODE == 0 && (D.pen_lds || D.fused_fold)) || MODE == 4) ? ldsQlev : D.qlev;
   long long* snew = D.Snew_fx + (size_t)(wave & (D.nrep - 1)) * D.B * K;  // this wave's table replica
   // per-lane cluster constants: exp(-dist/sigma) = exp2(dist * ce), ce = -log2(e)/sigma;  sigma r ln r = cl r log2 r,
   // cl = sigma ln 2;  lpen = log2(penalty of the current combination), clp = cl * lpen (general sigma only).
@@ -1173,7 +1252,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     if (q0 != curq) {
       if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
       curq = q0;
-      if constexpr (MODE == 0) {
+      if constexpr (UPD) {
         float penv[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
@@ -1198,7 +1277,11 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   //        uniform sigma:  = inv cl (ce sum e_k x_k + sum e_k lpen_k + log2(inv) sum e_k)
   //        general sigma:  = inv (sum e_k clp_k - sum e_k x_k + log2(inv) sum e_k cl_k)     (cl_k ce_k = -1)
   //   -- no logarithm per value, one per row
-  auto epi_rows = [&](const int cellA, f32x4 (&acc)[NCT]) __attribute__((always_inline)) {
+  // DEFER (std::true_type, MODE 4's last tile of a block): the normalised values replace `acc` instead of being stored, so that the
+  // O contributions can be flushed BEFORE the tile's 28 stores are issued (store_rows) -- the arrival then waits for the
+  // atomics only, not for the block's R rows to reach HBM (vector memory operations retire in issue order on gfx9).
+  auto epi_rows = [&](const int cellA, f32x4 (&acc)[NCT], auto defer_tag) __attribute__((always_inline)) {
+    constexpr bool DEFER = decltype(defer_tag)::value;
     constexpr int RB = (NCT <= 7 && !LEAN) ? 4 : 2;   // rows per batch: all four while the registers last
 #pragma unroll
     for (int r0 = 0; r0 < 4; r0 += RB) {
@@ -1217,12 +1300,12 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #pragma unroll
         for (int i = 0; i < RB; i++) {
           const float x = fmaf(acc[ct][r0 + i], -2.0f, 2.0f);
-          float e = __builtin_amdgcn_exp2f((MODE == 0) ? fmaf(x, CE(ct), lpen[ct]) : x * CE(ct));
+          float e = __builtin_amdgcn_exp2f(UPD ? fmaf(x, CE(ct), lpen[ct]) : x * CE(ct));
           if (ct >= first_partial_ct(NCT)) e = (16 * ct + c < K) ? e : 0.0f;
           acc[ct][r0 + i] = e;
           se[i] += e;
           sx[i] = fmaf(e, x, sx[i]);
-          if constexpr (MODE == 0) sp[i] = fmaf(e, USIG ? lpen[ct] : clp[USIG ? 0 : ct], sp[i]);
+          if constexpr (UPD) sp[i] = fmaf(e, USIG ? lpen[ct] : clp[USIG ? 0 : ct], sp[i]);
           if constexpr (!USIG) sc[i] = fmaf(e, CL(ct), sc[i]);
         }
       }
@@ -1250,13 +1333,27 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #pragma unroll
         for (int i = 0; i < RB; i++) {
           const float rn = acc[ct][r0 + i] * inv[i];
+          if constexpr (DEFER) acc[ct][r0 + i] = rn;
+          else {
 #ifdef HMX_TRACE
-          if (!(D.upd_debug & 4))   // timing experiment: no R stores
+            if (!(D.upd_debug & 4))   // timing experiment: no R stores
 #endif
-          if (ct < first_partial_ct(NCT) || 16 * ct + c < K) Rrow[i][16 * ct] = rn;
+            if (ct < first_partial_ct(NCT) || 16 * ct + c < K) Rrow[i][16 * ct] = rn;
+          }
           oacc[ct] += fx_of(rn);
         }
       }
+    }
+  };
+  // the deferred stores of epi_rows<DEFER>: `acc` holds the normalised rows
+  auto store_rows = [&](const int cellA, const f32x4 (&acc)[NCT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int cell = __shfl(cellA, 4 * g + i, 64);
+      float* Rrow = D.R + (size_t)(cell >= 0 ? cell : D.n) * K + c;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++)
+        if (ct < first_partial_ct(NCT) || 16 * ct + c < K) Rrow[16 * ct] = acc[ct][i];
     }
   };
   // epilogue of a tile whose distances are in `acc`
@@ -1362,13 +1459,304 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       }
     } else {
       epi_begin(q0);
-      epi_rows(cellA, acc);
+      epi_rows(cellA, acc, std::false_type{});
     }
   };
   constexpr bool DUAL = !LEAN && NCT <= 7;  // two accumulator sets fit the 256-VGPR budget (2 waves/SIMD) only up to K = 112
   auto next_rows = [&](const int2 nxt, const int2 cur) {  // row address of the NEXT tile's lane (any valid row if padding)
     return D.Zc + (size_t)(nxt.x >= 0 ? nxt.x : (cur.x >= 0 ? cur.x : 0)) * zs;
   };
+  if constexpr (MODE == 4) {
+    // ======================= persistent block chain of one round =======================
+    // Cross-workgroup traffic (L2s of different XCDs are not coherent, so nothing here relies on plain loads of data another
+    // workgroup wrote during this launch):
+    //   Snew replicas   workers: device-scope atomic adds;  folder: atomic exchange with 0 (read + reset in one RMW)
+    //   ctl[2 + j]      arrivals of block j (atomic add, after the wave's vmcnt(0) drained its contribution atomics)
+    //   pen_g[i]        8-byte granules { tag << 32 | penalty bits } written through with ONE sc1 store each and read
+    //                   with sc1 loads until the tag is this block's (self-validating: no ordering assumed)
+    //   ctl[0]          block flag (tag), stored after the granules drained; one lane per workgroup polls it
+    // Every spin is bounded: on a timeout ctl[1] is raised and the launch runs out with garbage instead of hanging the GPU.
+    int* const ctl = D.chain_ctl;
+    unsigned long long* const peng = D.pen_g;
+    const unsigned tag0 = D.chain_tag;
+    const int nbk = D.nb, nworkWG = (int)gridDim.x - 1, bd = blockDim.x, tid = threadIdx.x;
+    constexpr int SPIN_LIMIT = 1 << 20;     // ~1 s of polling; once ANY spin has timed out (ctl[1] != 0) the others give up at once
+    auto dead = [&](int spins) -> bool { return (spins & 255) == 255 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; };
+    if ((int)blockIdx.x == nworkWG) {
+      // ---------------- the folder: O' = O + new(block j-1) - old(block j), E, penalty table of block j (:312-322,:329-330)
+      for (int i = tid; i < nBK; i += bd) ldsO[i] = D.O_fx[i];
+      __syncthreads();
+      constexpr int FE = 4;
+      unsigned long long tw = 0, tf = 0, tp = 0, t_prev = wall_clock64();   // diagnostics: wait / fold / publish time of the folder
+      for (int jj = 0; jj <= nbk; jj++) {
+        long long sv[FE];
+#pragma unroll
+        for (int e = 0; e < FE; e++) sv[e] = (jj < nbk) ? D.Sold_fx[(size_t)jj * nBK + min(tid + e * bd, nBK - 1)] : 0;   // before the wait
+        if (jj > 0) {
+          if (tid == 0) {
+            int spins = 0;
+            // arrivals are sharded over 8 counters (workgroup b -> counter b & 7: one per XCD under the observed placement);
+            // 255 increments of ONE word serialise at ~12 ns each
+            const int* arr = &ctl[8 + 8 * (jj - 1)];
+            auto arrived = [&]() { int t = 0; for (int x = 0; x < 8; x++) t += __hip_atomic_load(&arr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return t; };
+            while (arrived() < nworkWG) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 1); break; }
+              if (dead(spins)) break;
+            }
+          }
+          __syncthreads();
+        }
+        { const unsigned long long t = wall_clock64(); tw += t - t_prev; t_prev = t; }
+        auto fold_entry = [&](int i, long long soldv) {
+          long long o = ldsO[i];
+          if (jj > 0) {     // all replicas' exchanges in flight together (a runtime-bounded loop would wait for each in turn)
+            unsigned long long a[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) a[r] = (r < D.nrep) ? atomicExch((unsigned long long*)&D.Snew_fx[(size_t)r * nBK + i], 0ull) : 0ull;
+#pragma unroll
+            for (int r = 0; r < 8; r++) o += (long long)a[r];
+          }
+          if (jj < nbk) o -= soldv;
+          ldsO[i] = o;
+          if (jj == nbk) D.O_fx[i] = o;      // the round's final O (read by the kernels that follow this launch)
+        };
+#pragma unroll
+        for (int e = 0; e < FE; e++) { const int i = tid + e * bd; if (i < nBK) fold_entry(i, sv[e]); }
+        for (int i = tid + FE * bd; i < nBK; i += bd) fold_entry(i, jj < nbk ? D.Sold_fx[(size_t)jj * nBK + i] : 0);
+        if (jj == nbk) break;
+        __syncthreads();
+        { const unsigned long long t = wall_clock64(); tf += t - t_prev; t_prev = t; }
+        const unsigned long long tagbits = (unsigned long long)(tag0 + (unsigned)jj) << 32;
+        for (int i = tid; i < nBK; i += bd) {      // same arithmetic as k_foldpen / the fused prologue: identical tables
+          const int b = i / K, k = i - b * K;
+          long long rs = 0;
+          for (int b0 = 0; b0 < D.B0; b0++) rs += ldsO[b0 * K + k];
+          const float of = (float)((double)ldsO[i] * FX_INV);
+          const float ef = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
+          const float pv = pen_pow((2.0f * ef) + 1.0f, of + ef + 1.0f, D.theta[b]);
+          __hip_atomic_store(&peng[i], tagbits | (unsigned long long)__float_as_uint(pv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the flag needs no ordering against the granules (they validate themselves by tag): raise it at once
+        if (tid == 0) __hip_atomic_store(&ctl[0], (int)(tag0 + (unsigned)jj), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        { const unsigned long long t = wall_clock64(); tp += t - t_prev; t_prev = t; }
+      }
+      if (tid == 0 && D.chain_dbg) { atomicAdd(&D.chain_dbg[0], tw); atomicAdd(&D.chain_dbg[1], tf); atomicAdd(&D.chain_dbg[2], tp); atomicAdd(&D.chain_dbg[3], 1ull); }
+      return;
+    }
+    // ---------------- the workers
+    if constexpr (LEAN) {
+      // 4 waves per SIMD (1024-thread workgroups, <= 128 VGPRs): one accumulator set, rows streamed inside the MFMA loop.  With
+      // ~4000 resident waves a block's ~3100 tiles are ONE tile per wave: after the flag only a single epilogue remains.
+      f32x4 accC[NCT];
+      int2 cellC = make_int2(-1, -1);
+      bool have = ts < te;
+      auto mfma_tile = [&](const int2 cq) __attribute__((always_inline)) {
+        cellC = cq;
+        // all of the row's operand loads in flight at once (tile_dots streams them one group ahead: three exposed latencies)
+        if (D.NT4 <= 4) {
+          RowRegs rr;
+          load_rows(D.Zc + (size_t)(cq.x >= 0 ? cq.x : 0) * zs, g, D.NT4, D.tail, rr);
+          tile_dots_regs<NCT>(lds4, rr, cq.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
+        } else tile_dots<NCT>(lds4, D.Zc + (size_t)(cq.x >= 0 ? cq.x : 0) * zs, cq.x >= 0, g, lane, D.NS, D.NT4, D.tail, accC);
+      };
+      if (have) mfma_tile(cellN);
+      // rows of the NEXT block's first tile travel global -> LDS by LDS-DMA while this block's epilogue runs (no registers, no
+      // exposed latency in the MFMA phase); the (cell, combination) pairs are fetched two blocks ahead.
+      const int NG = D.NT4 + D.tail;                                    // 16-byte groups per row (<= 7)
+      // per wave: [NG][64] float4 row image + [2 parities][2][64] ints (cell, combination) of the first tile of a block
+      f32x4* const rowimg = lds4 + nY4 + ((nBK * 8 + ((nBK + 3) & ~3) * 4 + D.Q * C * 4 + 15) >> 4) + (size_t)(tid >> 6) * (NG * 64 + 64);
+      int* const pimg = reinterpret_cast<int*>(rowimg + NG * 64);
+      auto geom = [&](int jb, int& p0b, int& teb) { p0b = 0; teb = 0; if (jb < nbk) { p0b = D.boff[jb]; teb = (D.boff[jb + 1] - p0b) >> 4; } };
+      auto pair_fetch = [&](int jb, int p0b, int teb) {     // LDS-DMA of block jb's first-tile pairs into parity jb & 1 (no registers held)
+        if (ts < teb) {
+          const int* src = reinterpret_cast<const int*>(D.lpair + p0b + 16 * ts + c);
+          glds4(src, pimg + (jb & 1) * 128);
+          glds4(src + 1, pimg + (jb & 1) * 128 + 64);
+        }
+      };
+      int p0n, ten, p0nn, tenn;
+      geom(1, p0n, ten); geom(2, p0nn, tenn);
+      pair_fetch(1, p0n, ten);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long wq = 0, wg = 0, ww = 0, wd = 0, wm = 0, w1 = 0, w2 = 0, w3 = 0, wcyc = 0, w_prev = wall_clock64();
+      auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - w_prev; w_prev = t; };
+      for (int jj = 0; jj < nbk; jj++) {
+        const unsigned tag = tag0 + (unsigned)jj;
+        if (tid == 0) {
+          int spins = 0;
+          while ((int)((unsigned)__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tag) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 2); break; }
+            if (dead(spins)) break;
+          }
+        }
+        __syncthreads();
+        lap(wq);
+        for (int i = tid; i < nBK; i += bd) {
+          unsigned long long gv = __hip_atomic_load(&peng[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while ((unsigned)(gv >> 32) != tag && ++spins < SPIN_LIMIT && !dead(spins)) { __builtin_amdgcn_s_sleep(1); gv = __hip_atomic_load(&peng[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          if ((unsigned)(gv >> 32) != tag) atomicExch(&ctl[1], 3);
+          ldsPen[i] = __uint_as_float((unsigned)(gv & 0xffffffffu));
+        }
+        __syncthreads();
+        lap(wg);
+        curq = -1;
+        od = 0.0; oe = 0.0;
+        const bool haveN = ts < ten;
+        if (haveN) {       // next block's first tile: its rows -> this wave's LDS image
+          const int cx = pimg[((jj + 1) & 1) * 128 + lane];
+          const float* zr = D.Zc + (size_t)(cx >= 0 ? cx : 0) * zs;
+          for (int t = 0; t < D.NT4; t++) glds16(zr + 16 * t + 4 * g, rowimg + t * 64);
+          for (int u = 0; u < D.tail; u++) glds16(zr + 16 * D.NT4 + 4 * u, rowimg + (D.NT4 + u) * 64);
+        }
+        pair_fetch(jj + 2, p0nn, tenn);                                                     // two blocks ahead
+        if (have) {
+          for (int tile = ts; tile + tstep < te; tile += tstep) {     // all but the last tile of this wave in the block
+            epilogue(cellC.x, tile_q(cellC), accC);
+            mfma_tile(tile_cell(tile + tstep));
+          }
+          lap(w1);
+          epi_begin(tile_q(cellC));
+          epi_rows(cellC.x, accC, std::true_type{});
+          lap(w2);
+          od = wsumd(od); oe = wsumd(oe);
+          if (lane == 0) {
+            double* slot = D.objpart + ((size_t)(jj % D.objslots) * D.nwmax + wave) * 2;
+            if (D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; } else { slot[0] += od; slot[1] += oe; }
+          }
+          if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+          store_rows(cellC.x, accC);
+          lap(w3);
+          __builtin_amdgcn_s_waitcnt(0x0F70 | ((NCT * 4 - 4) & 15) | ((((NCT * 4 - 4) >> 4) & 3) << 14));
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lap(ww);
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) atomicAdd(&ctl[8 + 8 * jj + ((int)blockIdx.x & 7)], 1);
+        p0 = p0n; te = ten;
+        lap(wd);
+        have = haveN;
+        const unsigned long long cyc0 = __builtin_readcyclecounter();
+        if (have) {                         // the next block's first tile, operands from the LDS image: off the critical path
+          cellC = make_int2(pimg[((jj + 1) & 1) * 128 + lane], pimg[((jj + 1) & 1) * 128 + 64 + lane]);
+          tile_dots_lds<NCT>(lds4, rowimg, cellC.x >= 0, g, lane, D.NS, D.NT4, D.tail, accC);
+        }
+        wcyc += __builtin_readcyclecounter() - cyc0;
+        p0n = p0nn; ten = tenn; geom(jj + 3, p0nn, tenn);
+        lap(wm);
+      }
+      if (blockIdx.x == 0 && tid == 0 && D.chain_dbg) {
+        atomicAdd(&D.chain_dbg[4], wq); atomicAdd(&D.chain_dbg[5], wg); atomicAdd(&D.chain_dbg[6], ww); atomicAdd(&D.chain_dbg[7], wd); atomicAdd(&D.chain_dbg[8], wm);
+        atomicAdd(&D.chain_dbg[9], w1); atomicAdd(&D.chain_dbg[10], w2); atomicAdd(&D.chain_dbg[11], w3); atomicAdd(&D.chain_dbg[12], wcyc);
+      }
+      return;
+    } else {
+    f32x4 accC[NCT];
+    int2 cellC = make_int2(-1, -1);
+    bool have = ts < te;
+    // MFMAs of this wave's first tile of the current block (rows were requested earlier); requests the second tile's rows
+    auto first_tile = [&]() __attribute__((always_inline)) {
+      cellC = cellN;
+      const RowRegs rowsA = rowsN;
+      cellN = cellNN;
+      cellNN = tile_cell(ts + 2 * tstep);
+      load_rows(next_rows(cellN, cellC), g, D.NT4, D.tail, rowsN);
+      tile_dots_regs<NCT>(lds4, rowsA, cellC.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
+    };
+    if (have) first_tile();
+    unsigned long long wq = 0, wg = 0, ww = 0, wd = 0, wm = 0, w1 = 0, w2 = 0, w3 = 0, w_prev = wall_clock64();   // diagnostics (workgroup 0, wave 0)
+    auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - w_prev; w_prev = t; };
+    for (int jj = 0; jj < nbk; jj++) {
+      const unsigned tag = tag0 + (unsigned)jj;
+      if (tid == 0) {                       // one lane per workgroup polls the block flag
+        int spins = 0;
+        while ((int)((unsigned)__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tag) < 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 2); break; }
+          if (dead(spins)) break;
+        }
+      }
+      __syncthreads();
+      lap(wq);
+      for (int i = tid; i < nBK; i += bd) {   // the block's penalty table -> LDS (granules validate themselves)
+        unsigned long long gv = __hip_atomic_load(&peng[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while ((unsigned)(gv >> 32) != tag && ++spins < SPIN_LIMIT && !dead(spins)) { __builtin_amdgcn_s_sleep(1); gv = __hip_atomic_load(&peng[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if ((unsigned)(gv >> 32) != tag) atomicExch(&ctl[1], 3);
+        ldsPen[i] = __uint_as_float((unsigned)(gv & 0xffffffffu));
+      }
+      __syncthreads();
+      lap(wg);
+      curq = -1;                            // the table changed: the penalty row of the first tile must be re-read
+      od = 0.0; oe = 0.0;
+      // geometry of the next block and the (cell, combination) pairs of this wave's first two tiles in it, requested now
+      const bool more = jj + 1 < nbk;
+      int p0n = 0, ten = 0; bool haveN = false;
+      int2 cN1 = make_int2(-1, -1), cNN1 = make_int2(-1, -1);
+      if (more) {
+        p0n = D.boff[jj + 1];
+        ten = (D.boff[jj + 2] - p0n) >> 4;
+        haveN = ts < ten;
+        if (haveN) { cN1 = D.lpair[p0n + 16 * ts + c]; if (ts + tstep < ten) cNN1 = D.lpair[p0n + 16 * (ts + tstep) + c]; }
+      }
+      if (have) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the two-accumulator loop below
+        for (int tile = ts + tstep; tile < te; tile += tstep) {
+          const int2 cellT = cellN;
+          const RowRegs rowsA = rowsN;
+          cellN = cellNN;
+          cellNN = tile_cell(tile + 2 * tstep);
+          load_rows(next_rows(cellN, cellT), g, D.NT4, D.tail, rowsN);
+          f32x4 accT[NCT];
+          tile_dots_regs<NCT>(lds4, rowsA, cellT.x >= 0, lane, D.NS, D.NT4, D.tail, accT);   // MFMA pipe: tile i+1
+          epilogue(cellC.x, tile_q(cellC), accC);                                           // VALU pipe: tile i
+#pragma unroll
+          for (int ct = 0; ct < NCT; ct++) accC[ct] = accT[ct];
+          cellC = cellT;
+        }
+        // last tile of the block: next block's first rows requested first (older than everything below), then the
+        // epilogue with DEFERRED stores, the objective slot, the contribution atomics, and only then the tile's R stores
+        lap(w1);
+        if (haveN) load_rows(D.Zc + (size_t)(cN1.x >= 0 ? cN1.x : 0) * zs, g, D.NT4, D.tail, rowsN);
+        epi_begin(tile_q(cellC));
+        epi_rows(cellC.x, accC, std::true_type{});
+        lap(w2);
+        od = wsumd(od); oe = wsumd(oe);
+        if (lane == 0) {
+          double* slot = D.objpart + ((size_t)(jj % D.objslots) * D.nwmax + wave) * 2;
+          if (D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; } else { slot[0] += od; slot[1] += oe; }
+        }
+        if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+        store_rows(cellC.x, accC);
+        lap(w3);
+        // in-order retirement: at most the youngest NCT*4 - 4 operations (all of them R stores) may still be in flight
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((NCT * 4 - 4) & 15) | ((((NCT * 4 - 4) >> 4) & 3) << 14));
+      } else {
+        if (haveN) load_rows(D.Zc + (size_t)(cN1.x >= 0 ? cN1.x : 0) * zs, g, D.NT4, D.tail, rowsN);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      lap(ww);
+      // a BARE s_barrier: __syncthreads() is also a workgroup-scope fence, i.e. an s_waitcnt vmcnt(0) that would wait for the
+      // R stores after all.  Nothing another wave of this workgroup reads is published here -- the barrier only says "every
+      // wave's contribution atomics have been performed" (each wave waited for its own above).
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) atomicAdd(&ctl[8 + 8 * jj + ((int)blockIdx.x & 7)], 1);          // arrival of this workgroup
+      if (more) { p0 = p0n; te = ten; cellN = cN1; cellNN = cNN1; }
+      lap(wd);
+      have = haveN;
+      if (have) first_tile();                           // off the critical path: overlaps the folder's work
+      lap(wm);
+    }
+    if (blockIdx.x == 0 && tid == 0 && D.chain_dbg) {
+      atomicAdd(&D.chain_dbg[4], wq); atomicAdd(&D.chain_dbg[5], wg); atomicAdd(&D.chain_dbg[6], ww); atomicAdd(&D.chain_dbg[7], wd); atomicAdd(&D.chain_dbg[8], wm);
+      atomicAdd(&D.chain_dbg[9], w1); atomicAdd(&D.chain_dbg[10], w2); atomicAdd(&D.chain_dbg[11], w3);
+    }
+    return;
+    }
+  }
   if (pre && !DUAL) {
     for (int tile = ts; tile < te; tile += tstep) {
       const int2 cellA = cellN;
@@ -2360,6 +2748,21 @@ void l_update(const Launch& L, const Dev& D, int j) {
     default: break;
   }
 #undef HMX_UPD
+}
+void l_chain(const Launch& L, const Dev& D, int workgroups) {
+  size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + (size_t)D.B * D.K * 8 +
+               ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4;
+  if (D.chain_wps >= 3) lds = ((lds + 15) & ~(size_t)15) + (size_t)(4 * D.chain_wps) * ((D.NT4 + D.tail) * 1024 + 1024);   // per wave: glds row image + pair images
+  const dim3 grid((unsigned)workgroups);
+#define HMX_CH(N) case N: if (D.chain_wps == 4 && D.usig) hipLaunchKernelGGL((k_tile<N, 4, 4, true>), grid, dim3(1024), lds, L.stream, D, 0); \
+                          else if (D.chain_wps == 3 && D.usig) hipLaunchKernelGGL((k_tile<N, 4, 3, true>), grid, dim3(768), lds, L.stream, D, 0); \
+                          else if (D.usig) hipLaunchKernelGGL((k_tile<N, 4, 2, true>), grid, dim3(512), lds, L.stream, D, 0); \
+                          else hipLaunchKernelGGL((k_tile<N, 4>), grid, dim3(512), lds, L.stream, D, 0); break;
+  switch (D.NCT) {
+    HMX_CH(1) HMX_CH(2) HMX_CH(3) HMX_CH(4) HMX_CH(5) HMX_CH(6) HMX_CH(7)
+    default: break;
+  }
+#undef HMX_CH
 }
 void l_objective_tables(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);
