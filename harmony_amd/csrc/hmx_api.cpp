@@ -1103,6 +1103,31 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   }
   CHK(dalloc(ctx, &D.S0, (size_t)K * d)); CHK(dalloc(ctx, &D.n0, (size_t)K)); CHK(dalloc(ctx, &D.qstart, (size_t)Q + 1)); CHK(dalloc(ctx, &D.sizes, (size_t)B));
   CHK(h2d(ctx, D.qstart, start.data(), (size_t)Q + 1)); CHK(h2d(ctx, D.sizes, ctx->sizes.data(), (size_t)B)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d)); CHK(dalloc(ctx, &D.Wimg, D.moe_mfma ? (size_t)Q * D.wNQ * D.wNS * 256 : 1));
+  { // deterministic statistics pass (k_moe_stats_q): static split of the 16-cell tiles over ~2 workgroups per CU; one partial
+    // slot per (workgroup, combination met) -- known here because the tiles are listed by combination
+    const char* e = getenv("HMX_MOE_STATS");
+    D.st_dma = (D.moe_mfma && D.NCT <= 8 && !(e && std::string(e) == "atomic")) ? 1 : 0;
+    if (D.st_dma) {
+      const int nt = (int)titems.size();
+      int tpw = (nt + 2 * 256 - 1) / (2 * 256); if (tpw < 16) tpw = 16;
+      D.st_cpw = tpw; D.st_nwg = (nt + tpw - 1) / tpw;
+      std::vector<int> slot0((size_t)D.st_nwg), qptr((size_t)Q + 1, 0);
+      std::vector<std::vector<int>> byq((size_t)Q);
+      int nslots = 0;
+      for (int w = 0; w < D.st_nwg; w++) {
+        slot0[w] = nslots;
+        int last = -1;
+        for (int t = w * tpw; t < std::min(nt, (w + 1) * tpw); t++) if (titems[t].q != last) { last = titems[t].q; byq[(size_t)last].push_back(nslots++); }
+      }
+      std::vector<int> qslots; qslots.reserve((size_t)nslots);
+      for (int q = 0; q < Q; q++) { qptr[q] = (int)qslots.size(); qslots.insert(qslots.end(), byq[q].begin(), byq[q].end()); }
+      qptr[Q] = (int)qslots.size();
+      CHK(dalloc(ctx, &D.st_part, (size_t)std::max(nslots, 1) * ((size_t)K * d + K))); CHK(dalloc(ctx, &D.st_slot0, slot0.size()));
+      CHK(dalloc(ctx, &D.st_qptr, qptr.size())); CHK(dalloc(ctx, &D.st_qslots, std::max<size_t>(qslots.size(), 1)));
+      CHK(h2d(ctx, D.st_slot0, slot0.data(), slot0.size())); CHK(h2d(ctx, D.st_qptr, qptr.data(), qptr.size()));
+      if (!qslots.empty()) CHK(h2d(ctx, D.st_qslots, qslots.data(), qslots.size()));
+    }
+  }
   CHK(dalloc(ctx, &D.km_gcells, (size_t)K)); CHK(dalloc(ctx, &D.km_rows, (size_t)K * d)); CHK(dalloc(ctx, &D.km_excl, (size_t)K));
   CHK(dalloc(ctx, &D.seedmin, (size_t)K)); CHK(dalloc(ctx, &D.lsum, (size_t)K * d + K)); D.lcnt = reinterpret_cast<unsigned long long*>(D.lsum + (size_t)K * d); CHK(dalloc(ctx, &D.ynorm, (size_t)K));
   CHK(h2d(ctx, D.perm, ctx->perm.data(), (size_t)N)); CHK(h2d(ctx, D.invperm, invperm.data(), (size_t)N));

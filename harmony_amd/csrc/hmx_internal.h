@@ -104,6 +104,11 @@ struct Dev {
   // MoE
   double* Sq;       // [Q][K][d]  sum_i R_ki z_ij over cells of combination q
   double* nq;       // [Q][K]     sum_i R_ki
+  // deterministic statistics pass (k_moe_stats_q): per-(workgroup, combination run) partial slots, reduced in fixed order
+  int st_dma, st_nwg, st_cpw;       // enabled, workgroups, 16-cell tiles per workgroup
+  double* st_part;                  // [slots][K*d + K]
+  int* st_slot0;                    // [st_nwg] first slot of every workgroup
+  int* st_qptr; int* st_qslots;     // CSR: slots of every combination in ascending (= cell) order
   double* S0;       // [K][d]     ridge_arith = 1: the intercept row's own sequential sum over all kept cells
   double* n0;       // [K]
   int* qstart;      // [Q+1] first internal cell of every combination

@@ -2316,6 +2316,149 @@ __global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg,
   fold(); flush(curq);
 }
 
+// k_moe_stats_q: k_moe_stats_mfma with (a) 16-byte operand loads and (b) a bit-reproducible reduction (K <= 128).
+//  (a) Which cluster an MFMA row stands for is free: inside a quad of cluster tiles (64 clusters) row m of tile i stands for
+//      cluster 64 qd + nt m + i (nt = tiles of the quad: 4, or what is left in the last quad), so the nt A operands a lane
+//      needs for one cell are CONSECUTIVE floats of its R row -- one dwordx4 (x3 / x2 / x1) load instead of nt dword gathers:
+//      9 load instructions per tile and lane at K = 100 instead of 32.  Only the flush has to know the mapping.
+//  (b) no floating-point atomics: every workgroup writes the K x (d+1) partial of each combination run it meets to its own slot
+//      (slot order = workgroup order = cell order); k_moe_stats_reduce adds a combination's slots in ascending order -> Sq, nq
+//      (and with them Z_corr) are identical from run to run.
+template <int NCT>
+__global__ __launch_bounds__(256) void k_moe_stats_q(Dev D, int tiles_per_wg) {
+  constexpr int NQD = (NCT + 3) / 4, NTL = NCT - 4 * (NQD - 1);     // quads; tiles in the last quad
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int pt = threadIdx.x >> 6;
+  const int K = D.K, d = D.d, zs = D.zs;
+  const int ts = (int)blockIdx.x * tiles_per_wg, te = min(D.ntitems, ts + tiles_per_wg);
+  if (ts >= te) return;
+  const int jj = 16 * pt + c;           // this lane's PC
+  const bool jv = jj < d;
+  f32x4 acc[NCT];
+  double sh[NCT][4], nsh[NCT];
+  float nacc[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) {
+    acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; nacc[ct] = 0.0f; nsh[ct] = 0.0;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) sh[ct][reg] = 0.0;
+  }
+  auto kmap = [&](int ct, int m) -> int { const int qd = ct >> 2, nt = (qd == NQD - 1) ? NTL : 4; return 64 * qd + nt * m + (ct & 3); };
+  auto fold = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) sh[ct][reg] += (double)acc[ct][reg];
+      acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      nsh[ct] += (double)nacc[ct]; nacc[ct] = 0.0f;
+    }
+  };
+  int slot = D.st_slot0[blockIdx.x];
+  auto flush = [&]() {
+    double* S = D.st_part + (size_t)slot * ((size_t)K * d + K);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int k = kmap(ct, 4 * g + reg);
+        if (jv && k < K) S[(size_t)k * d + jj] = sh[ct][reg];
+        sh[ct][reg] = 0.0;
+      }
+      if (pt == 0) {                            // sum_i R_ki of this lane's cluster: add the four cell slots
+        double v = nsh[ct];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        const int k = kmap(ct, c);
+        if (g == 0 && k < K) S[(size_t)K * d + k] = v;
+      }
+      nsh[ct] = 0.0;
+    }
+    slot++;
+  };
+  auto item_at = [&](int tile) -> Item {       // per-lane load (a uniform one costs a vmcnt(0) per tile, see k_tile)
+    const Item* tp = D.titems + min(tile, te - 1);
+    asm volatile("" : "+v"(tp));
+    return *tp;
+  };
+  // this lane's first cluster in every quad (clamped so that the whole load stays inside the row) and which of them exist
+  int koff[NQD]; bool kval[NCT];
+#pragma unroll
+  for (int qd = 0; qd < NQD; qd++) {
+    const int nt = (qd == NQD - 1) ? NTL : 4;
+    // (a lane whose first cluster exists loads at its exact offset: the tail of a partially valid load runs into the next row --
+    //  R has a dummy row behind the last cell -- and is masked by kval; only fully invalid lanes are clamped)
+    koff[qd] = (64 * qd + nt * c < K) ? 64 * qd + nt * c : K - nt;
+  }
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) kval[ct] = kmap(ct, c) < K;
+  // (a software pipeline over tiles -- operands of tile t+1 requested before tile t's MFMAs -- was measured SLOWER, 413 vs 388 us:
+  //  290 VGPRs leave one wave per SIMD; the pass is not bound by the loads' latency)
+  Item itN = item_at(ts);
+  int curq = __builtin_amdgcn_readfirstlane(itN.q);
+  for (int tile = ts; tile < te; ++tile) {
+    const Item it = itN;
+    itN = item_at(tile + 1);
+    const int tq = __builtin_amdgcn_readfirstlane(it.q);
+    if (tq != curq) { fold(); flush(); curq = tq; }
+    const size_t c0 = (size_t)it.start;
+    float a[4][NCT], b[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {           // all of the tile's operand loads first
+      const int cell = 4 * st + g;
+      const size_t row = c0 + (cell < it.cnt ? cell : 0);
+      const float* rr = D.R + row * K;
+#pragma unroll
+      for (int qd = 0; qd < NQD; qd++) {
+        if (qd < NQD - 1 || NTL == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(rr + koff[qd]);
+#pragma unroll
+          for (int i = 0; i < 4; i++) if (4 * qd + i < NCT) a[st][4 * qd + i] = v[i];
+        } else if (NTL == 3) {
+          struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+          const F3 v = *reinterpret_cast<const F3*>(rr + koff[qd]);
+          a[st][4 * qd] = v.x; a[st][4 * qd + 1] = v.y; a[st][4 * qd + 2] = v.z;
+        } else if (NTL == 2) {
+          const float2 v = *reinterpret_cast<const float2*>(rr + koff[qd]);
+          a[st][4 * qd] = v.x; a[st][4 * qd + 1] = v.y;
+        } else a[st][4 * qd] = rr[koff[qd]];
+      }
+      b[st] = D.Zo[row * zs + min(jj, zs - 1)];
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const bool cv = 4 * st + g < it.cnt;
+      const float bb = (cv && jv) ? b[st] : 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+        const float av = (cv && kval[ct]) ? a[st][ct] : 0.0f;
+        nacc[ct] += av;
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bb, acc[ct], 0, 0, 0);
+      }
+    }
+    if (((tile - ts) & 3) == 3) fold();
+  }
+  fold(); flush();
+}
+// Sq[q], nq[q] = sum of the combination's partial slots in ascending slot (= cell) order: fixed order, no atomics
+__global__ __launch_bounds__(256) void k_moe_stats_reduce(Dev D) {
+  const int q = blockIdx.x;
+  const size_t per = (size_t)D.K * D.d + D.K;
+  const int s0 = D.st_qptr[q], s1 = D.st_qptr[q + 1];
+  const size_t e = (size_t)blockIdx.y * blockDim.x + threadIdx.x;    // one entry per thread, eight slots in flight
+  if (e >= per) return;
+  double v = 0.0;
+  int sidx = s0;
+  for (; sidx + 8 <= s1; sidx += 8) {
+    double t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = D.st_part[(size_t)D.st_qslots[sidx + i] * per + e];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v += t[i];                            // ascending slot order: the sum is reproducible
+  }
+  for (; sidx < s1; sidx++) v += D.st_part[(size_t)D.st_qslots[sidx] * per + e];
+  if (e < (size_t)D.K * D.d) D.Sq[(size_t)q * D.K * D.d + e] = v;
+  else D.nq[(size_t)q * D.K + (e - (size_t)D.K * D.d)] = v;
+}
+
 // k_moe_apply_mfma: Z_corr tile (16 x d) = Z_orig tile - R tile (16 x K) * Wq[q] (K x d); clusters are the MFMA reduction
 // dim, so this is tile_dots with (rows = R rows, "centroid image" = Wimg[q] staged in LDS).  One workgroup per apply item.
 template <int NPT>
@@ -2800,6 +2943,15 @@ void l_moe_stats_seq(const Launch& L, const Dev& D, float cutoff) {
 }
 void l_moe_stats_mfma(const Launch& L, const Dev& D) {
   const int npt = (D.d + 15) / 16;
+  if (D.st_dma) {   // 16-byte operand loads + deterministic slot reduction (K <= 128)
+    const dim3 grid((unsigned)D.st_nwg), block(64 * npt);
+#define HMX_MSQ(N) case N: hipLaunchKernelGGL((k_moe_stats_q<N>), grid, block, 0, L.stream, D, D.st_cpw); break;
+    switch (D.NCT) { HMX_MSQ(1) HMX_MSQ(2) HMX_MSQ(3) HMX_MSQ(4) HMX_MSQ(5) HMX_MSQ(6) HMX_MSQ(7) HMX_MSQ(8) default: break; }
+#undef HMX_MSQ
+    const size_t per = (size_t)D.K * D.d + D.K;
+    hipLaunchKernelGGL(k_moe_stats_reduce, dim3((unsigned)D.Q, (unsigned)((per + 255) / 256)), dim3(256), 0, L.stream, D);
+    return;
+  }
   int tpw = (D.ntitems + 2 * 256 - 1) / (2 * 256);   // ~2 workgroups per CU
   if (tpw < 16) tpw = 16;
   const bool split = D.NCT > 8;                       // K > 128: two workgroups (cluster-tile halves) per tile range
