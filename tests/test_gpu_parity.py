@@ -198,7 +198,7 @@ def test_full_size_properties():
     obj1 = g.objective_kmeans.copy()
     g.restart(); g.init_cluster_cpp(); assert g.cluster_cpp() == 0; g.moe_correct_ridge_cpp()
     np.testing.assert_array_equal(g.objective_kmeans, obj1)
-    assert relfro(g.getZcorr(), Zc) < 1e-6
+    np.testing.assert_array_equal(g.getZcorr(), Zc)     # ridge statistics are reduced in a fixed order: no fp atomics anywhere
 
 
 # ---------------------------------------------------------------- multi-GPU path on one GPU: virtual shards

@@ -252,3 +252,39 @@ def test_update_order_must_be_a_permutation(cell_lines_small):
     with pytest.raises(HarmonyError, match="permutation"):
         g.push_update_order(bad)
     g.push_update_order(np.arange(300)[::-1].copy())
+
+
+# ---------------------------------------------------------------- the sharded path through two PROCESSES
+@pytest.mark.timeout(600, method="thread")
+def test_two_processes_sharded_run():
+    """Two processes (torch.distributed.run, world 2), one shard each, the whole RunHarmony with every accumulator all-reduced
+    through the hook; both ranks share the box's single GPU, so the transport is gloo (RCCL refuses two ranks per device) --
+    the same script runs with --backend nccl on a multi-GPU node.  Rank 0 checks against the unsharded run."""
+    import subprocess
+    import sys
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dist_two_proc.py")],
+                       capture_output=True, text=True, timeout=500, stdin=subprocess.DEVNULL)
+    assert "DIST2_OK world=2" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_torch_free_c_host_with_builtin_rccl(tmp_path):
+    """examples/comm_example.c: a process WITHOUT torch (the R / plain-C host) brings up the built-in RCCL communicator from the
+    system librccl with the unique id shipped through a file, and runs the sharded code path with forced collectives
+    (world 1 on this single-GPU box; `comm_example <rank> <world> <file>` per GPU on a node).  Round 1 reported a hang here:
+    ncclCommInitRank simply takes ~5 s in a fresh process (kernel loading)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc on this box")
+    exe = str(tmp_path / "comm_example")
+    libdir = os.path.join(ROOT, "harmony_amd", "lib")
+    p = subprocess.run([gcc, "-std=c11", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "comm_example.c"),
+                        "-L" + libdir, "-lharmony_mi355x", "-Wl,-rpath," + libdir, "-lm", "-o", exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = subprocess.run([exe, "0", "1", str(tmp_path / "uid")], capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
+    assert r.returncode == 0 and "COMM_EXAMPLE_OK rank 0/1" in r.stdout, (r.stdout, r.stderr[-2000:])
+    assert int(r.stdout.split("collectives")[1].split()[0]) > 100
