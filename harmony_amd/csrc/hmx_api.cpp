@@ -523,16 +523,22 @@ int update_R(hmx_ctx* ctx) {
   { PhaseScope ph(ctx, "randomize");      // the round's shuffle (:272-291, timers "randomize")
     CHK(prepare_round(ctx, ctx->round_counter)); }
   ctx->round_counter++;
-  { PhaseScope ph(ctx, "EO_update");      // removal of every block's old contribution (:312-313), all blocks in one pass
-    HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
-    l_oldsum(ctx->L, D); KCHK();
-    CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0)); }
+  const bool chain_path = merged && ctx->fused_ok && ctx->chain_ok && !sharded;
+  const bool chain_old = chain_path && D.chain_old && D.chain_wps == 2 && D.K % 4 == 0;   // (16-byte row loads)
+  { PhaseScope ph(ctx, "EO_update");      // removal of every block's old contribution (:312-313)
+    if (chain_old) {   // gathered inside the persistent chain, two blocks ahead of their use: only the replica tables are reset here
+      HIPCHK(hipMemsetAsync(D.Sold_rep, 0, sizeof(long long) * (size_t)D.nrep * D.nb * D.B * D.K, ctx->L.stream));
+      HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
+    } else {           // all blocks in one pass over R
+      HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
+      l_oldsum(ctx->L, D); KCHK();
+      CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0)); } }
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
   const bool fused = merged && ctx->fused_ok;
   if (fused && ctx->chain_ok && !sharded) {
     // default on one GPU: the whole block chain in ONE persistent launch (k_tile MODE 4)
-    HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 16), ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 24), ctx->L.stream));
     D.chain_tag = (unsigned)(1 + (ctx->chain_rounds++ % (1u << 24)) * 64);
     long long* const keep_snew = D.Snew_fx;
     D.Snew_fx = D.Snew_set[0];     // one replica set: the folder resets it by exchange (zeroed by the round's memset)
@@ -540,7 +546,9 @@ int update_R(hmx_ctx* ctx) {
       if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t x, y; HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y)); ctx->ev_pool.emplace_back(x, y); }
       HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
     }
+    const int keep_old = D.chain_old; D.chain_old = chain_old ? 1 : 0;
     l_chain(ctx->L, D, ctx->chain_wgs); KCHK();
+    D.chain_old = keep_old;
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps += D.nb; }
     D.Snew_fx = keep_snew;
     ctx->chain_check = true;
@@ -1196,10 +1204,14 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     ctx->chain_wgs = cus;
     ctx->chain_ok = !(e && std::string(e) == "0") && ctx->fused_ok && cus >= 8 && D.NCT <= 7 && D.NT4 <= 4 && D.nb <= 64 &&
                     (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024;
-    CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 16)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)16));
+    CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)16));
+    CHK(dalloc(ctx, &D.Sold_rep, (size_t)D.nrep * D.nb * B * K));
     HIPCHK(hipMemsetAsync(D.chain_dbg, 0, sizeof(unsigned long long) * 16, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.pen_g, 0, sizeof(unsigned long long) * (size_t)B * K, ctx->L.stream));
-    HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 16), ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 24), ctx->L.stream));
+    // in-chain old sums (opt-in): measured 25.8 us per block step against 20.4 us + the 100 us k_oldsum pass per round -- a wash at
+    // 1M cells (the extra device-scope atomics and the folder's extra loads land on the chain's critical path)
+    { const char* o = getenv("HMX_CHAIN_OLD"); D.chain_old = (o && atoi(o) == 1) ? 1 : 0; }
     { const char* w = getenv("HMX_CHAIN_WPS"); D.chain_wps = (w && (atoi(w) == 4 || atoi(w) == 3) && D.usig) ? atoi(w) : 2;
       // the 4-waves-per-SIMD variant keeps one LDS-DMA row image per wave: 16 KB per 16-byte group of a row
       if (D.chain_wps >= 3 && (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 + (size_t)16 * (D.NT4 + D.tail + 1) * 1024 > 158 * 1024) D.chain_wps = 2; }

@@ -71,6 +71,8 @@ struct Dev {
   unsigned long long* pen_g;   // [B][K] { tag << 32 | penalty bits }
   int* chain_ctl;              // [0] block flag (tag), [1] error, [2 + j] arrivals of block j
   unsigned chain_tag;
+  int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
+  long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)
   unsigned long long* chain_dbg;   // diagnostics: accumulated 100 MHz ticks [0..2] folder wait / fold / publish, [3] launches,
                                    //              [4..8] worker (workgroup 0) flag wait / table copy / tiles / drain+arrive / next block's MFMAs

@@ -1491,7 +1491,20 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       for (int jj = 0; jj <= nbk; jj++) {
         long long sv[FE];
 #pragma unroll
-        for (int e = 0; e < FE; e++) sv[e] = (jj < nbk) ? D.Sold_fx[(size_t)jj * nBK + min(tid + e * bd, nBK - 1)] : 0;   // before the wait
+        for (int e = 0; e < FE; e++) sv[e] = (jj < nbk && !D.chain_old) ? D.Sold_fx[(size_t)jj * nBK + min(tid + e * bd, nBK - 1)] : 0;   // before the wait
+        if (jj == 0 && D.chain_old) {     // the old sums of blocks 0 and 1 come from the workers' prologue: wait for it
+          if (tid == 0) {
+            int spins = 0;
+            const int* arr = &ctl[8 + 8 * nbk];
+            auto arrived = [&]() { int t = 0; for (int x = 0; x < 8; x++) t += __hip_atomic_load(&arr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return t; };
+            while (arrived() < nworkWG) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 4); break; }
+              if (dead(spins)) break;
+            }
+          }
+          __syncthreads();
+        }
         if (jj > 0) {
           if (tid == 0) {
             int spins = 0;
@@ -1510,14 +1523,16 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         { const unsigned long long t = wall_clock64(); tw += t - t_prev; t_prev = t; }
         auto fold_entry = [&](int i, long long soldv) {
           long long o = ldsO[i];
-          if (jj > 0) {     // all replicas' exchanges in flight together (a runtime-bounded loop would wait for each in turn)
-            unsigned long long a[8];
+          // every memory operation of the entry in flight before the first is consumed: the new contributions (exchange = read +
+          // reset) and, with in-chain old sums, block jj's old contributions (filled two blocks ago by the workers)
+          unsigned long long a[8]; long long b8[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) a[r] = (r < D.nrep) ? atomicExch((unsigned long long*)&D.Snew_fx[(size_t)r * nBK + i], 0ull) : 0ull;
+          for (int r = 0; r < 8; r++) a[r] = (jj > 0 && r < D.nrep) ? atomicExch((unsigned long long*)&D.Snew_fx[(size_t)r * nBK + i], 0ull) : 0ull;
 #pragma unroll
-            for (int r = 0; r < 8; r++) o += (long long)a[r];
-          }
-          if (jj < nbk) o -= soldv;
+          for (int r = 0; r < 8; r++) b8[r] = (D.chain_old && jj < nbk && r < D.nrep) ? (long long)__hip_atomic_load((unsigned long long*)&D.Sold_rep[((size_t)r * nbk + jj) * nBK + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ll;
+#pragma unroll
+          for (int r = 0; r < 8; r++) o += (long long)a[r] - b8[r];
+          if (jj < nbk && !D.chain_old) o -= soldv;
           ldsO[i] = o;
           if (jj == nbk) D.O_fx[i] = o;      // the round's final O (read by the kernels that follow this launch)
         };
@@ -1667,6 +1682,48 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       tile_dots_regs<NCT>(lds4, rowsA, cellC.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
     };
     if (have) first_tile();
+    // Old contributions inside the chain (D.chain_old): the sums "remove block b's cells from O" (:312-313) of block b are
+    // gathered by the waves that will update it, TWO blocks ahead, in the slack between their arrival and the next flag --
+    // one pass over R per round disappears (k_oldsum).  Same fixed-point sums, same replica scheme as the new contributions.
+    auto old_block = [&](int blk) __attribute__((always_inline)) {
+      const int pb = D.boff[blk], nt = (D.boff[blk + 1] - pb) >> 4;
+      long long* tab = D.Sold_rep + ((size_t)(wave & (D.nrep - 1)) * nbk + blk) * nBK;
+      // lane -> four consecutive clusters (K % 4 == 0), lane half -> eight of the tile's sixteen rows: every load instruction
+      // reads two whole R rows (16 bytes per lane); the per-cluster sums need one cross-half add and no 16-lane reduction
+      const int kq = 4 * (lane & 31), half = lane >> 5;
+      const bool kv = kq < K;
+      for (int tile = ts; tile < nt; tile += tstep) {
+        const int2 cq = D.lpair[pb + 16 * tile + c];
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int cell = __shfl(cq.x, 8 * half + i, 64);
+          v[i] = *reinterpret_cast<const f32x4*>(D.R + (size_t)(cell >= 0 ? cell : D.n) * K + (kv ? kq : 0));   // padding: the dummy row
+        }
+        unsigned long long oa[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) oa[e] += fx_of(v[i][e]);
+        const int q0 = __builtin_amdgcn_readfirstlane(cq.y);
+#pragma unroll
+        for (int e = 0; e < 4; e++) oa[e] += shfl_xor_u64(oa[e], 32);
+        if (half == 0 && kv) {
+          for (int cc = 0; cc < C; cc++) {
+            const int b = qlevT[q0 * C + cc];
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (oa[e]) atomicAdd((unsigned long long*)&tab[(size_t)b * K + kq + e], oa[e]);
+          }
+        }
+      }
+    };
+    if (D.chain_old) {
+      old_block(0);
+      if (nbk > 1) old_block(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) atomicAdd(&ctl[8 + 8 * nbk + ((int)blockIdx.x & 7)], 1);
+    }
     unsigned long long wq = 0, wg = 0, ww = 0, wd = 0, wm = 0, w1 = 0, w2 = 0, w3 = 0, w_prev = wall_clock64();   // diagnostics (workgroup 0, wave 0)
     auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - w_prev; w_prev = t; };
     for (int jj = 0; jj < nbk; jj++) {
@@ -1748,6 +1805,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       lap(wd);
       have = haveN;
       if (have) first_tile();                           // off the critical path: overlaps the folder's work
+      if (D.chain_old && jj + 2 < nbk) old_block(jj + 2);
       lap(wm);
     }
     if (blockIdx.x == 0 && tid == 0 && D.chain_dbg) {
