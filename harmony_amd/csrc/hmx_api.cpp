@@ -1098,7 +1098,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K));
-  { const char* e = getenv("HMX_MOE_SOLVE"); ctx->solve_on_device = !(e && std::string(e) == "host"); }
+  { const char* e = getenv("HMX_MOE_SOLVE"); ctx->solve_on_device = !(e && std::string(e) == "host") && (size_t)(B + 1) * 16 * 8 + (size_t)(3 * B + 8 + C) * 4 <= 158 * 1024; }   // (LDS panel of the device Cholesky)
   ctx->y_on_device = false; ctx->solve_pending = false;
   if (ctx->solve_on_device) {
     const size_t M = (size_t)B + 1;
@@ -1202,7 +1202,12 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     const char* e = getenv("HMX_CHAIN");
     int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     ctx->chain_wgs = cus;
-    ctx->chain_ok = !(e && std::string(e) == "0") && ctx->fused_ok && cus >= 8 && D.NCT <= 7 && D.NT4 <= 4 && D.nb <= 64 &&
+    // The chain pays off while a block step is latency-bound: a few 16-cell tiles per resident wave (1.5 at 1M cells, where a
+    // step takes 21 us against 27.5 + 3 us of launch gap).  At 10M cells per GPU (15 tiles per wave) the per-step launches
+    // stream just as well and were measured 6 % faster (142 vs 151 us per step): HMX_CHAIN=1 forces the chain there.
+    const double tiles_per_wave = (double)N / std::max(D.nb, 1) / 16.0 / (8.0 * std::max(cus - 1, 1));
+    const bool chain_fits = (e && std::string(e) == "1") || tiles_per_wave <= 6.0;
+    ctx->chain_ok = !(e && std::string(e) == "0") && chain_fits && ctx->fused_ok && cus >= 8 && D.NCT <= 7 && D.NT4 <= 4 && D.nb <= 64 &&
                     (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024;
     CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)16));
     CHK(dalloc(ctx, &D.Sold_rep, (size_t)D.nrep * D.nb * B * K));

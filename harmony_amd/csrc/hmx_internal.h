@@ -135,6 +135,7 @@ struct SolveArgs {
   const float* lambda;             // [B+1] fixed lambda or nullptr (estimation: alpha * E)
   const int* cov_bounds;           // [C] cumulative level counts
   float alpha, cutoff; int use_s0;
+  size_t lds_b_bytes;              // LDS bytes available for the right-hand sides during the substitution (0: leave them in HBM)
 };
 
 struct Launch {

@@ -6,10 +6,16 @@
 ## (R/utils.R:50-81), the Seurat / SingleCellExperiment methods (R/RunHarmony.R) -- runs unchanged, because the
 ## returned environment exposes the same `$` names as class_<harmony> (src/harmony.cpp:675-707).
 
-new_harmony_mi355x <- function(seed = NULL) {
+new_harmony_mi355x <- function(seed = NULL, r_rng = FALSE) {
     ptr <- .Call("C_hmx_new")
-    if (is.null(seed)) seed <- sample.int(.Machine$integer.max, 1)   # one draw from R's RNG => set.seed() still governs the run
-    .Call("C_hmx_set_seed", ptr, as.numeric(seed))
+    if (r_rng) {
+        ## exact reference randomness: the library consumes R's own stream (unif_rand) in RcppArmadillo's draw order --
+        ## `set.seed(x); RunHarmony(...)` then walks the same seeds and shuffles as the reference package (slower: N draws per round)
+        .Call("C_hmx_use_r_rng", ptr)
+    } else {
+        if (is.null(seed)) seed <- sample.int(.Machine$integer.max, 1)   # one draw from R's RNG => set.seed() still governs the run
+        .Call("C_hmx_set_seed", ptr, as.numeric(seed))
+    }
     get <- function(field) .Call("C_hmx_get", ptr, field)
     mat <- function(field, nr, nc) matrix(get(field), nrow = nr, ncol = nc)
     obj <- new.env()

@@ -60,10 +60,29 @@ SEXP C_hmx_setup(SEXP ptr, SEXP Z, SEXP phi_i, SEXP phi_p, SEXP phi_x, SEXP B, S
   return R_NilValue;
 }
 SEXP C_hmx_set_seed(SEXP ptr, SEXP seed) { hmx_set_int(handle(ptr), "seed", (int64_t)Rf_asReal(seed)); return R_NilValue; }
-SEXP C_hmx_init_cluster(SEXP ptr) { hmx_ctx* h = handle(ptr); check(h, hmx_init_cluster(h, NULL), "init_cluster_cpp"); return R_NilValue; }
+/* R-compatible randomness (hmx_set_int "rng" = 1): the library draws what the reference draws through RcppArmadillo --
+ * randu = Rf_runif(0, 1), randi = int(Rf_runif(0, RAND_MAX)) -- but from R's OWN generator: unif_rand() between
+ * GetRNGstate() / PutRNGstate(), so set.seed(), RNGkind() and the position of the stream are all R's. */
+static double r_unif(void* unused) { (void)unused; return unif_rand(); }
+SEXP C_hmx_use_r_rng(SEXP ptr) {
+  hmx_ctx* h = handle(ptr);
+  hmx_set_uniform_source(h, r_unif, NULL);
+  check(h, hmx_set_int(h, "rng", 1), "rng");
+  return R_NilValue;
+}
+SEXP C_hmx_init_cluster(SEXP ptr) {
+  hmx_ctx* h = handle(ptr);
+  GetRNGstate();                                                          /* centroid seeds may come from R's stream */
+  int st = hmx_init_cluster(h, NULL);
+  PutRNGstate();
+  check(h, st, "init_cluster_cpp");
+  return R_NilValue;
+}
 SEXP C_hmx_cluster(SEXP ptr) {
   hmx_ctx* h = handle(ptr);
+  GetRNGstate();                                                          /* the rounds' shuffles may come from R's stream */
   int st = hmx_cluster(h);
+  PutRNGstate();
   if (st > 0) check(h, st, "cluster_cpp");
   return Rf_ScalarInteger(st);                                            /* 0 ok, -1 user interrupt (R/utils.R:26-32) */
 }
@@ -96,6 +115,7 @@ static const R_CallMethodDef CallEntries[] = {
   {"C_hmx_new", (DL_FUNC)&C_hmx_new, 0},
   {"C_hmx_setup", (DL_FUNC)&C_hmx_setup, 18},
   {"C_hmx_set_seed", (DL_FUNC)&C_hmx_set_seed, 2},
+  {"C_hmx_use_r_rng", (DL_FUNC)&C_hmx_use_r_rng, 1},
   {"C_hmx_init_cluster", (DL_FUNC)&C_hmx_init_cluster, 1},
   {"C_hmx_cluster", (DL_FUNC)&C_hmx_cluster, 1},
   {"C_hmx_moe_correct_ridge", (DL_FUNC)&C_hmx_moe_correct_ridge, 1},

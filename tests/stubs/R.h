@@ -37,4 +37,8 @@ typedef void (*R_CFinalizer_t)(SEXP);
 void R_RegisterCFinalizerEx(SEXP, R_CFinalizer_t, Rboolean);
 Rboolean R_ToplevelExec(void (*fun)(void*), void* data);
 void R_CheckUserInterrupt(void);
+/* R_ext/Random.h */
+void GetRNGstate(void);
+void PutRNGstate(void);
+double unif_rand(void);
 #endif

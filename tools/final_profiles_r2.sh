@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round-2 evidence for profiles/: default bench (plain and under rocprofv3 kernel stats), PMC passes (separate, --kernel-trace only),
+# the 10M-cells-on-one-GPU and configs[4]-shape bench modes.  Writes gpurun_out/r2/.
+exec </dev/null
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 300 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --cpu-sample 0 --no-e2e > $O/bench_rocprof.json 2> $O/bench_rocprof.err
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/tools/prof_update.py 1000000 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/tools/prof_update.py 1000000 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python $R/tools/prof_update.py 1000000 > $O/pmc_sq.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- python $R/tools/prof_update.py 1000000 > $O/pmc_sq2.log 2>&1
+cd $R
+for p in fetch write sq sq2; do f=$O/pmc_$p/p_counter_collection.csv; test -f $f && python tools/pmc_report.py $f "k_tile" "k_copy" "k_oldsum" "k_moe" > $O/pmc_$p.txt; rm -f $O/pmc_$p/p_kernel_trace.csv; rm -f $O/pmc_$p/*.db; done
+cp $O/stats/b_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null; rm -rf $O/stats
+cd /tmp
+timeout 400 python $R/bench.py --cpu-sample 0 --cells-per-gpu 10000000 --batches 20 --steps 3 > $O/bench_10M.json 2> $O/bench_10M.err
+timeout 400 python $R/bench.py --cpu-sample 0 --workload c5 --cells-per-gpu 1000000 --steps 3 > $O/bench_c5_1M.json 2> $O/bench_c5_1M.err
+cd $R
+tail -1 $O/bench_default.json | cut -c1-300; tail -1 $O/bench_10M.json | cut -c1-200; tail -1 $O/bench_c5_1M.json | cut -c1-200; head -12 $O/kernel_stats.csv | cut -c1-120; cat $O/pmc_fetch.txt $O/pmc_write.txt $O/pmc_sq.txt $O/pmc_sq2.txt | cut -c1-600; tail -3 $O/bench_c5_1M.err $O/bench_10M.err
