@@ -16,6 +16,9 @@
 #ifndef HMX_USE_DPP
 #define HMX_USE_DPP 1
 #endif
+#ifndef HMX_CHAIN_PRE2
+#define HMX_CHAIN_PRE2 1      // the chain runs the MFMAs of a wave's second tile of a block ahead of the flag too
+#endif
 #ifndef HMX_CHAIN_BALANCE
 #define HMX_CHAIN_BALANCE 1
 #endif
@@ -1669,10 +1672,11 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       }
       return;
     } else {
-    f32x4 accC[NCT];
-    int2 cellC = make_int2(-1, -1);
-    bool have = ts < te;
-    // MFMAs of this wave's first tile of the current block (rows were requested earlier); requests the second tile's rows
+    f32x4 accC[NCT], accS[NCT];
+    int2 cellC = make_int2(-1, -1), cellS = make_int2(-1, -1);
+    bool have = ts < te, have2 = false;
+    // BOTH accumulator sets are filled ahead of the flag: the MFMAs of this wave's first tile of the current block (rows were
+    // requested earlier) and, if it owns a second one, of that too -- after the flag only epilogues remain for up to two tiles
     auto first_tile = [&]() __attribute__((always_inline)) {
       cellC = cellN;
       const RowRegs rowsA = rowsN;
@@ -1680,6 +1684,15 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       cellNN = tile_cell(ts + 2 * tstep);
       load_rows(next_rows(cellN, cellC), g, D.NT4, D.tail, rowsN);
       tile_dots_regs<NCT>(lds4, rowsA, cellC.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
+      have2 = HMX_CHAIN_PRE2 && USIG && ts + tstep < te;    // (the general-sigma variant has no registers to spare: 95 spills)
+      if (have2) {
+        cellS = cellN;
+        const RowRegs rowsB = rowsN;
+        cellN = cellNN;
+        cellNN = tile_cell(ts + 3 * tstep);
+        load_rows(next_rows(cellN, cellS), g, D.NT4, D.tail, rowsN);
+        tile_dots_regs<NCT>(lds4, rowsB, cellS.x >= 0, lane, D.NS, D.NT4, D.tail, accS);
+      }
     };
     if (have) first_tile();
     // Old contributions inside the chain (D.chain_old): the sums "remove block b's cells from O" (:312-313) of block b are
@@ -1761,7 +1774,15 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       }
       if (have) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the two-accumulator loop below
-        for (int tile = ts + tstep; tile < te; tile += tstep) {
+        int tile0 = ts + tstep;
+        if (have2) {                          // second hoisted tile: the first one's epilogue, then it becomes the pending tile
+          epilogue(cellC.x, tile_q(cellC), accC);
+#pragma unroll
+          for (int ct = 0; ct < NCT; ct++) accC[ct] = accS[ct];
+          cellC = cellS;
+          tile0 = ts + 2 * tstep;
+        }
+        for (int tile = tile0; tile < te; tile += tstep) {
           const int2 cellT = cellN;
           const RowRegs rowsA = rowsN;
           cellN = cellNN;
