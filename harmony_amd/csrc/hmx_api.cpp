@@ -266,7 +266,7 @@ int flush_objectives(hmx_ctx* ctx) {
   const float norm_const = 2000 / ((float)ctx->N_global);
   for (int i = 0; i < ctx->obj_pending; i++) {
     const double* o = ctx->h_obj + 4 * i;
-    int chain_err = 0; std::memcpy(&chain_err, o + 3, sizeof(int));
+    const int chain_err = (int)o[3];
     if (chain_err) { ctx->obj_pending = 0; return fail(ctx, HMX_ERR_DEVICE, "persistent block chain: a workgroup timed out waiting for its peers (code " + std::to_string(chain_err) + ")"); }
     ctx->obj_kmeans.push_back((float)((o[0] + o[1] + o[2]) * norm_const));
     ctx->obj_dist.push_back((float)(o[0] * norm_const));
@@ -285,11 +285,7 @@ int push_objective(hmx_ctx* ctx) {
     HIPCHK(hipEventCreateWithFlags(&ctx->obj_event, hipEventDisableTiming));
   }
   if (ctx->obj_pending == ctx->obj_cap) CHK(flush_objectives(ctx));
-  HIPCHK(hipMemcpyAsync(ctx->h_obj + 4 * ctx->obj_pending, ctx->D.obj + 2, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->L.stream));
-  if (ctx->chain_check) {   // error word of the persistent chain rides along (slot's 4th double)
-    HIPCHK(hipMemcpyAsync(ctx->h_obj + 4 * ctx->obj_pending + 3, ctx->D.chain_ctl + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->L.stream));
-    ctx->chain_check = false;
-  } else std::memset(ctx->h_obj + 4 * ctx->obj_pending + 3, 0, sizeof(double));
+  HIPCHK(hipMemcpyAsync(ctx->h_obj + 4 * ctx->obj_pending, ctx->D.obj + 2, sizeof(double) * 4, hipMemcpyDeviceToHost, ctx->L.stream));   // dist, entropy, cross, chain error word
   HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
   ctx->obj_pending++;
   return 0;
@@ -538,7 +534,7 @@ int update_R(hmx_ctx* ctx) {
   const bool fused = merged && ctx->fused_ok;
   if (fused && ctx->chain_ok && !sharded) {
     // default on one GPU: the whole block chain in ONE persistent launch (k_tile MODE 4)
-    HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 24), ctx->L.stream));
+    // (chain_ctl was reset by k_sort_binoff of this round's shuffle)
     D.chain_tag = (unsigned)(1 + (ctx->chain_rounds++ % (1u << 24)) * 64);
     long long* const keep_snew = D.Snew_fx;
     D.Snew_fx = D.Snew_set[0];     // one replica set: the folder resets it by exchange (zeroed by the round's memset)

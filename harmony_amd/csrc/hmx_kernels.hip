@@ -381,6 +381,9 @@ __global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
   if (t == 1023) bins[nbins] = part[1023];
   __syncthreads();
   for (int v = t; v <= nb; v += 1024) D.boff[v] = bins[v < nb ? v * Q : nbins];
+  // (this single-workgroup kernel runs once per round ahead of the block chain: it also resets the chain's control block,
+  //  which saves a memset launch per round)
+  if (D.chain_ctl) for (int i = t; i < 8 * nb + 24; i += 1024) D.chain_ctl[i] = 0;
 }
 __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   extern __shared__ int base_[];
@@ -1969,6 +1972,7 @@ __global__ __launch_bounds__(TPB) void k_objective_tables(Dev D) {
   }
   if (threadIdx.x == 0) {
     D.obj[2] = D.obj[0]; D.obj[3] = D.obj[1]; D.obj[4] = red[0];
+    D.obj[5] = D.chain_ctl ? (double)D.chain_ctl[1] : 0.0;      // the chain's error word rides along with the objective snapshot
   }
 }
 
@@ -2454,7 +2458,7 @@ __global__ __launch_bounds__(256) void k_moe_stats_mfma(Dev D, int tiles_per_wg,
 //      (slot order = workgroup order = cell order); k_moe_stats_reduce adds a combination's slots in ascending order -> Sq, nq
 //      (and with them Z_corr) are identical from run to run.
 template <int NCT>
-__global__ __launch_bounds__(256) void k_moe_stats_q(Dev D, int tiles_per_wg) {
+__global__ __launch_bounds__(320) void k_moe_stats_q(Dev D, int tiles_per_wg) {
   constexpr int NQD = (NCT + 3) / 4, NTL = NCT - 4 * (NQD - 1);     // quads; tiles in the last quad
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int pt = threadIdx.x >> 6;
@@ -2463,12 +2467,13 @@ __global__ __launch_bounds__(256) void k_moe_stats_q(Dev D, int tiles_per_wg) {
   if (ts >= te) return;
   const int jj = 16 * pt + c;           // this lane's PC
   const bool jv = jj < d;
+  const bool bcol1 = jj == d;           // column d of the B operand is all ones: its output column is sum_i R_ki (the launcher
+                                        // adds a wave when d is a multiple of 16)
   f32x4 acc[NCT];
-  double sh[NCT][4], nsh[NCT];
-  float nacc[NCT];
+  double sh[NCT][4];
 #pragma unroll
   for (int ct = 0; ct < NCT; ct++) {
-    acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; nacc[ct] = 0.0f; nsh[ct] = 0.0;
+    acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) sh[ct][reg] = 0.0;
   }
@@ -2479,7 +2484,6 @@ __global__ __launch_bounds__(256) void k_moe_stats_q(Dev D, int tiles_per_wg) {
 #pragma unroll
       for (int reg = 0; reg < 4; reg++) sh[ct][reg] += (double)acc[ct][reg];
       acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-      nsh[ct] += (double)nacc[ct]; nacc[ct] = 0.0f;
     }
   };
   int slot = D.st_slot0[blockIdx.x];
@@ -2491,15 +2495,9 @@ __global__ __launch_bounds__(256) void k_moe_stats_q(Dev D, int tiles_per_wg) {
       for (int reg = 0; reg < 4; reg++) {
         const int k = kmap(ct, 4 * g + reg);
         if (jv && k < K) S[(size_t)k * d + jj] = sh[ct][reg];
+        if (bcol1 && k < K) S[(size_t)K * d + k] = sh[ct][reg];       // the ones column: sum_i R_ki
         sh[ct][reg] = 0.0;
       }
-      if (pt == 0) {                            // sum_i R_ki of this lane's cluster: add the four cell slots
-        double v = nsh[ct];
-        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        const int k = kmap(ct, c);
-        if (g == 0 && k < K) S[(size_t)K * d + k] = v;
-      }
-      nsh[ct] = 0.0;
     }
     slot++;
   };
@@ -2509,7 +2507,7 @@ __global__ __launch_bounds__(256) void k_moe_stats_q(Dev D, int tiles_per_wg) {
     return *tp;
   };
   // this lane's first cluster in every quad (clamped so that the whole load stays inside the row) and which of them exist
-  int koff[NQD]; bool kval[NCT];
+  int koff[NQD];
 #pragma unroll
   for (int qd = 0; qd < NQD; qd++) {
     const int nt = (qd == NQD - 1) ? NTL : 4;
@@ -2517,8 +2515,6 @@ __global__ __launch_bounds__(256) void k_moe_stats_q(Dev D, int tiles_per_wg) {
     //  R has a dummy row behind the last cell -- and is masked by kval; only fully invalid lanes are clamped)
     koff[qd] = (64 * qd + nt * c < K) ? 64 * qd + nt * c : K - nt;
   }
-#pragma unroll
-  for (int ct = 0; ct < NCT; ct++) kval[ct] = kmap(ct, c) < K;
   // (a software pipeline over tiles -- operands of tile t+1 requested before tile t's MFMAs -- was measured SLOWER, 413 vs 388 us:
   //  290 VGPRs leave one wave per SIMD; the pass is not bound by the loads' latency)
   Item itN = item_at(ts);
@@ -2552,15 +2548,23 @@ __global__ __launch_bounds__(256) void k_moe_stats_q(Dev D, int tiles_per_wg) {
       }
       b[st] = D.Zo[row * zs + min(jj, zs - 1)];
     }
+    if (it.cnt == 16) {
+      // full tile (all but the last tile of a combination): NO masking at all.  Rows of the result that stand for clusters >= K
+      // and columns that stand for PCs >= d hold finite garbage (clamped loads) and are never flushed.  sum_i R_ki comes out of
+      // the same MFMAs: the PC tile that has room for it feeds a column of ones (bcol1).
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const bool cv = 4 * st + g < it.cnt;
-      const float bb = (cv && jv) ? b[st] : 0.0f;
+      for (int st = 0; st < 4; ++st) {
+        const float bb = bcol1 ? 1.0f : b[st];
 #pragma unroll
-      for (int ct = 0; ct < NCT; ct++) {
-        const float av = (cv && kval[ct]) ? a[st][ct] : 0.0f;
-        nacc[ct] += av;
-        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bb, acc[ct], 0, 0, 0);
+        for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st][ct], bb, acc[ct], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const bool cv = 4 * st + g < it.cnt;
+        const float bb = cv ? (bcol1 ? 1.0f : b[st]) : 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv ? a[st][ct] : 0.0f, bb, acc[ct], 0, 0, 0);
       }
     }
     if (((tile - ts) & 3) == 3) fold();
@@ -3081,7 +3085,7 @@ void l_moe_stats_seq(const Launch& L, const Dev& D, float cutoff) {
 void l_moe_stats_mfma(const Launch& L, const Dev& D) {
   const int npt = (D.d + 15) / 16;
   if (D.st_dma) {   // 16-byte operand loads + deterministic slot reduction (K <= 128)
-    const dim3 grid((unsigned)D.st_nwg), block(64 * npt);
+    const dim3 grid((unsigned)D.st_nwg), block(64 * ((D.d + 16) / 16));   // PC tiles incl. the ones column at index d
 #define HMX_MSQ(N) case N: hipLaunchKernelGGL((k_moe_stats_q<N>), grid, block, 0, L.stream, D, D.st_cpw); break;
     switch (D.NCT) { HMX_MSQ(1) HMX_MSQ(2) HMX_MSQ(3) HMX_MSQ(4) HMX_MSQ(5) HMX_MSQ(6) HMX_MSQ(7) HMX_MSQ(8) default: break; }
 #undef HMX_MSQ
