@@ -140,6 +140,12 @@ struct hmx_ctx {
   std::vector<PhaseEv> ph_pool; size_t ph_used = 0; std::vector<std::string> ph_names; std::map<std::string, double> gpu_timers;
   double prof_update_ms = 0; int64_t prof_update_launches = 0, prof_update_cells = 0, prof_update_steps = 0;
   bool chain_check = false;    // a persistent-chain launch has run since the error word was last read
+  // The round's shuffle (counting sort by block) touches no algorithmic state, and with the counter-based generator it depends
+  // on (seed, round) only: the sort of round r+1 runs on a SIDE stream while round r's old-sum pass streams on the main one,
+  // into the second of two buffer sets.
+  struct SortSet { int* blk; int* lorder; int2* lpair; int* lcombo; int* boff; int* binoff; int* counts; int* offs; };
+  SortSet sets[2] = {}; hipStream_t side = nullptr; hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  int64_t sorted_round[2] = {-1, -1}; uint64_t sorted_seed[2] = {0, 0}; bool sorted_on_side[2] = {false, false}; bool sort_overlap = true;
   std::string err, warn, warn_ret;
 };
 
@@ -169,6 +175,12 @@ void free_all(hmx_ctx* ctx) {
   ctx->ev_pool.clear(); ctx->ev_used = 0;
   for (auto& e : ctx->ph_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   ctx->ph_pool.clear(); ctx->ph_used = 0;
+  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); ctx->side = nullptr; }
+  for (int i = 0; i < 2; i++) {
+    if (ctx->ev_sorted[i]) { (void)hipEventDestroy(ctx->ev_sorted[i]); ctx->ev_sorted[i] = nullptr; }
+    if (ctx->ev_free[i]) { (void)hipEventDestroy(ctx->ev_free[i]); ctx->ev_free[i] = nullptr; }
+    ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false;
+  }
   if (ctx->h_obj) { (void)hipHostFree(ctx->h_obj); ctx->h_obj = nullptr; ctx->obj_cap = 0; }
   if (ctx->obj_event) { (void)hipEventDestroy(ctx->obj_event); ctx->obj_event = nullptr; }
   ctx->obj_pending = 0; ctx->obj_harmony_pending = false;
@@ -484,8 +496,33 @@ int kmeans_centers(hmx_ctx* ctx) {
 // The round's block order: block id per cell (Feistel bijection of (seed, round), or a host-injected shuffle) + the padded
 // counting sort.  Touches no algorithmic state (only blk / lorder / lcombo / lpair / boff).  (Enqueuing it speculatively
 // for the NEXT round before the host waits for this round's objective was measured: no gain, 26.1 vs 25.9 ms per step.)
+void apply_set(Dev& D, const hmx_ctx::SortSet& s) {
+  D.blk = s.blk; D.lorder = s.lorder; D.lpair = s.lpair; D.lcombo = s.lcombo; D.boff = s.boff; D.binoff = s.binoff; D.counts = s.counts; D.offs = s.offs;
+}
 int prepare_round(hmx_ctx* ctx, uint64_t round) {
   Dev& D = ctx->D;
+  const int sset = (int)(round & 1);
+  const bool host_order = !ctx->injected.empty() || ctx->rng_mode == 1;
+  if (ctx->sorted_on_side[sset]) {   // a prefetch into this set is (or was) in flight on the side stream: order the main stream behind it
+    HIPCHK(hipStreamWaitEvent(ctx->L.stream, ctx->ev_sorted[sset], 0));
+    ctx->sorted_on_side[sset] = false;
+  }
+  apply_set(D, ctx->sets[sset]);
+  const bool have = !host_order && ctx->sorted_round[sset] == (int64_t)round && ctx->sorted_seed[sset] == ctx->seed;
+  auto prefetch_next = [&]() -> int {   // round + 1 into the other set, on the side stream, behind everything that still reads that set
+    if (!ctx->sort_overlap || host_order || !ctx->side) return 0;
+    const int t = sset ^ 1;
+    HIPCHK(hipEventRecord(ctx->ev_free[t], ctx->L.stream));
+    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_free[t], 0));
+    Dev Dt = D; apply_set(Dt, ctx->sets[t]);
+    Launch L2 = ctx->L; L2.stream = ctx->side;
+    l_sort_blocks(L2, Dt, true, ctx->seed, round + 1, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
+    HIPCHK(hipEventRecord(ctx->ev_sorted[t], ctx->side));
+    ctx->sorted_round[t] = (int64_t)round + 1; ctx->sorted_seed[t] = ctx->seed; ctx->sorted_on_side[t] = true;
+    return 0;
+  };
+  if (have) return prefetch_next();
+  ctx->sorted_round[sset] = -1;
   bool gen_blocks = false;
   if (ctx->injected.empty() && ctx->rng_mode == 1) {   // update_order = shuffle(linspace(0, N-1, N)) from R's stream (:272-273)
     ensure_rrng(ctx);
@@ -506,7 +543,8 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
     CHK(h2d(ctx, D.blk, pos_blk.data(), pos_blk.size()));
   } else gen_blocks = true;   // block ids from the Feistel bijection, computed inside the sort's histogram kernel
   l_sort_blocks(ctx->L, D, gen_blocks, ctx->seed, round, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
-  return 0;
+  if (gen_blocks) { ctx->sorted_round[sset] = (int64_t)round; ctx->sorted_seed[sset] = ctx->seed; }
+  return prefetch_next();
 }
 
 // ---- update_R (src/harmony.cpp:269-342) ---------------------------------------------------------
@@ -1092,6 +1130,16 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   CHK(dalloc(ctx, &D.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));
+  { // second buffer set + side stream for the overlapped shuffle of the next round (HMX_SORT_OVERLAP=0: always sort in line)
+    ctx->sets[0] = {D.blk, D.lorder, D.lpair, D.lcombo, D.boff, D.binoff, D.counts, D.offs};
+    hmx_ctx::SortSet& t = ctx->sets[1];
+    CHK(dalloc(ctx, &t.blk, (size_t)N)); CHK(dalloc(ctx, &t.lorder, (size_t)3 * D.npad + 2)); t.lpair = reinterpret_cast<int2*>(t.lorder + (((size_t)D.npad + 1) & ~(size_t)1));
+    CHK(dalloc(ctx, &t.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &t.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &t.boff, (size_t)D.nb + 1));
+    CHK(dalloc(ctx, &t.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &t.offs, (size_t)D.nb * D.nchunks));
+    const char* e = getenv("HMX_SORT_OVERLAP"); ctx->sort_overlap = !(e && atoi(e) == 0);
+    { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lowest priority: the shuffle only fills gaps
+      HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, lo)); }
+    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); } }
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K));
   { const char* e = getenv("HMX_MOE_SOLVE"); ctx->solve_on_device = !(e && std::string(e) == "host") && (size_t)(B + 1) * 16 * 8 + (size_t)(3 * B + 8 + C) * 4 <= 158 * 1024; }   // (LDS panel of the device Cholesky)
@@ -1232,6 +1280,8 @@ int hmx_restart(hmx_ctx* ctx) {
   ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();
   ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear(); ctx->rrng_seeded = false;
   ctx->y_on_device = false; ctx->solve_pending = false;
+  if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
+  for (int i = 0; i < 2; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
   return 0;
 }
 

@@ -381,9 +381,6 @@ __global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
   if (t == 1023) bins[nbins] = part[1023];
   __syncthreads();
   for (int v = t; v <= nb; v += 1024) D.boff[v] = bins[v < nb ? v * Q : nbins];
-  // (this single-workgroup kernel runs once per round ahead of the block chain: it also resets the chain's control block,
-  //  which saves a memset launch per round)
-  if (D.chain_ctl) for (int i = t; i < 8 * nb + 24; i += 1024) D.chain_ctl[i] = 0;
 }
 __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   extern __shared__ int base_[];
@@ -1978,6 +1975,10 @@ __global__ __launch_bounds__(TPB) void k_objective_tables(Dev D) {
     D.obj[2] = D.obj[0]; D.obj[3] = D.obj[1]; D.obj[4] = red[0];
     D.obj[5] = D.chain_ctl ? (double)D.chain_ctl[1] : 0.0;      // the chain's error word rides along with the objective snapshot
   }
+  // (this single-workgroup kernel closes every round: it also resets the chain's control block for the next one -- one memset
+  //  launch less per round; the shuffle kernels cannot do it, they may run on the side stream while a chain is in flight)
+  __syncthreads();
+  if (D.chain_ctl) for (int i = threadIdx.x; i < 8 * D.nb + 24; i += blockDim.x) D.chain_ctl[i] = 0;
 }
 
 // --------------------------------------------------------------------------------------

@@ -1,9 +1,9 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "not rccl and not nccl and not host_example" 2>&1 | tail -6 ) > gpurun_out/c11_tests.log 2>&1
-tail -3 gpurun_out/c11_tests.log
-timeout 300 python tools/stats_time.py 2>&1 | grep dbg
+
+
+
 ( timeout 200 python bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-e2e ) > gpurun_out/c11_bench.json 2> gpurun_out/c11_bench.err
 python - <<PY
 import json
