@@ -1253,6 +1253,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // ---- per-tile stages ------------------------------------------------------------------------------------------
   // the tile's combination: slot 0 of a tile is always a real cell (static tiles: every lane holds it)
   auto tile_q = [&](const int2 cq) -> int { return __builtin_amdgcn_readfirstlane(cq.y); };
+  const RowRegs* erows = nullptr;   // MODE 2: the A-operand registers of the tile whose epilogue runs (single-accumulator loop)
   // MODE 0/1 epilogue, split so that the fused loop below can interleave it with the next tile's MFMAs:
   // epi_begin: run change -> flush the O contributions of the finished combination, fetch the new penalty row
   auto epi_begin = [&](const int q0) __attribute__((always_inline)) {
@@ -1409,6 +1410,34 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       // tile are issued before the first is used (they hit L1/L2 -- the rows were just read as MFMA operands)
       const int dd = D.d;          // locals: after the first LDS atomic hipcc would re-read D's fields from a spilled copy
       const float* const Zcp = D.Zc;
+      if (erows) {
+        // the rows are still in the A-operand registers (lane = cell l & 15, k-slot l >> 4): no second read of the tile.  The
+        // centre of THIS lane's cell sits in the row group (l & 15) >> 2, register (l & 15) & 3.
+        int t4[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) t4[reg] = __shfl(kb[reg], 16 * (c >> 2), 64);
+        const int kc = ((c & 3) == 0) ? t4[0] : ((c & 3) == 1) ? t4[1] : ((c & 3) == 2) ? t4[2] : t4[3];
+        if (cellA >= 0) {
+          long long* row = ltab + (size_t)kc * dd;
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            if (t < D.NT4) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const int jj = 16 * t + 4 * g + e;
+                if (jj < dd) atomicAdd((unsigned long long*)&row[jj], (unsigned long long)(long long)__float2int_rn(erows->v[t][e] * 1073741824.0f));
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            const int jj = 16 * D.NT4 + 4 * u + g;
+            if (u < D.tail && jj < dd) atomicAdd((unsigned long long*)&row[jj], (unsigned long long)(long long)__float2int_rn(erows->t[u] * 1073741824.0f));
+          }
+          if (g == 0) atomicAdd((unsigned long long*)&ltab[K * dd + kc], 1ull);
+        }
+        return;
+      }
       int cellr[4];
 #pragma unroll
       for (int reg = 0; reg < 4; reg++) cellr[reg] = __shfl(cellA, 4 * g + reg, 64);
@@ -1840,7 +1869,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     return;
     }
   }
-  if (pre && !DUAL) {
+  if (pre && (!DUAL || MODE == 2)) {   // (Lloyd: one accumulator set, its epilogue wants the tile's rows still in registers)
     for (int tile = ts; tile < te; tile += tstep) {
       const int2 cellA = cellN;
       const RowRegs rowsA = rowsN;
@@ -1849,6 +1878,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       load_rows(next_rows(cellN, cellA), g, D.NT4, D.tail, rowsN);
       f32x4 acc[NCT];
       tile_dots_regs<NCT>(lds4, rowsA, cellA.x >= 0, lane, D.NS, D.NT4, D.tail, acc);
+      if constexpr (MODE == 2) erows = &rowsA;
       epilogue(cellA.x, tile_q(cellA), acc);
     }
   } else if (pre) {
