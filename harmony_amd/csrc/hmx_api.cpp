@@ -16,6 +16,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <set>
 #include <string>
@@ -76,6 +77,13 @@ RcclApi* rccl_api(std::string* err) {
   }
   return &api;
 }
+
+// Two persistent block chains must never be resident at once: each needs one workgroup on EVERY CU and spins on its peers, so
+// two of them sharing the CUs would starve each other (bounded spins turn that into an error, not a hang -- but the round is
+// lost).  Handles of one process are therefore chained through an event per device: a chain launch waits for the previous
+// chain launch of any handle on that device.  (Two PROCESSES running unsharded chains on one GPU are not protected; HMX_CHAIN=0.)
+struct ChainGate { std::mutex mu; std::map<int, hipEvent_t> last; };
+ChainGate& chain_gate() { static ChainGate g; return g; }
 
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -581,7 +589,15 @@ int update_R(hmx_ctx* ctx) {
       HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
     }
     const int keep_old = D.chain_old; D.chain_old = chain_old ? 1 : 0;
-    l_chain(ctx->L, D, ctx->chain_wgs); KCHK();
+    {
+      ChainGate& gate = chain_gate();
+      std::lock_guard<std::mutex> lk(gate.mu);
+      hipEvent_t& ev = gate.last[ctx->device];
+      if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      else HIPCHK(hipStreamWaitEvent(ctx->L.stream, ev, 0));
+      l_chain(ctx->L, D, ctx->chain_wgs); KCHK();
+      HIPCHK(hipEventRecord(ev, ctx->L.stream));
+    }
     D.chain_old = keep_old;
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps += D.nb; }
     D.Snew_fx = keep_snew;
