@@ -51,6 +51,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;   // optional (P2P bootstrap)
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -70,6 +71,7 @@ RcclApi* rccl_api(std::string* err) {
   api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
   api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
+  api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
   api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
   if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) {
@@ -99,6 +101,9 @@ struct hmx_ctx {
   ncclComm_t comm = nullptr;   // built-in all-reduce: RCCL over xGMI (hmx_comm_init)
   int64_t comm_calls = 0, comm_bytes = 0;
   bool comm_force = false;     // test hook: issue the collectives even when world == 1
+  // peer-to-peer block chain (hmx_p2p_*): inboxes shared through HIP IPC; on only after the connection self-test passed everywhere
+  unsigned long long* p2p_self = nullptr; unsigned long long* p2p_peer[8] = {}; int p2p_rank = 0, p2p_world = 0; bool p2p_on = false;
+  unsigned p2p_tests = 0; int* p2p_result = nullptr; std::string p2p_note = "not connected";
   int (*poll)(void*) = nullptr; void* poll_user = nullptr;
   // ---- problem --------------------------------------------------------------------
   int64_t N = 0;  // local cells
@@ -565,8 +570,12 @@ int update_R(hmx_ctx* ctx) {
   { PhaseScope ph(ctx, "randomize");      // the round's shuffle (:272-291, timers "randomize")
     CHK(prepare_round(ctx, ctx->round_counter)); }
   ctx->round_counter++;
-  const bool chain_path = merged && ctx->fused_ok && ctx->chain_ok && !sharded;
-  const bool chain_old = chain_path && D.chain_old && D.chain_wps == 2 && D.K % 4 == 0;   // (16-byte row loads)
+  // sharded: the chain needs the in-launch exchange over the peers' inboxes (hmx_p2p_*); without it, one launch + one collective per block
+  const bool p2p = sharded && ctx->p2p_on && ctx->p2p_world == ctx->world && !ctx->comm_force && (size_t)D.B * D.K <= (size_t)P2P_CAP;
+  const bool chain_path = merged && ctx->fused_ok && ctx->chain_ok && (!sharded || p2p);
+  D.p2p_world = p2p ? ctx->p2p_world : 0; D.p2p_rank = ctx->p2p_rank;
+  for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g];
+  const bool chain_old = chain_path && !p2p && D.chain_old && D.chain_wps == 2 && D.K % 4 == 0;   // (16-byte row loads)
   { PhaseScope ph(ctx, "EO_update");      // removal of every block's old contribution (:312-313)
     if (chain_old) {   // gathered inside the persistent chain, two blocks ahead of their use: only the replica tables are reset here
       HIPCHK(hipMemsetAsync(D.Sold_rep, 0, sizeof(long long) * (size_t)D.nrep * D.nb * D.B * D.K, ctx->L.stream));
@@ -578,7 +587,7 @@ int update_R(hmx_ctx* ctx) {
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
   const bool fused = merged && ctx->fused_ok;
-  if (fused && ctx->chain_ok && !sharded) {
+  if (chain_path) {
     // default on one GPU: the whole block chain in ONE persistent launch (k_tile MODE 4)
     // (chain_ctl was reset by k_sort_binoff of this round's shuffle)
     D.chain_tag = (unsigned)(1 + (ctx->chain_rounds++ % (1u << 24)) * 64);
@@ -834,11 +843,15 @@ void hmx_destroy(hmx_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   if (ctx->comm) { RcclApi* api = rccl_api(nullptr); if (api) (void)api->CommDestroy(ctx->comm); ctx->comm = nullptr; }
+  for (int g = 0; g < 8; g++) if (ctx->p2p_peer[g] && ctx->p2p_peer[g] != ctx->p2p_self) (void)hipIpcCloseMemHandle(ctx->p2p_peer[g]);
+  if (ctx->p2p_self) (void)hipFree(ctx->p2p_self);
+  if (ctx->p2p_result) (void)hipFree(ctx->p2p_result);
   free_all(ctx);
   if (ctx->own_stream && ctx->L.stream) (void)hipStreamDestroy(ctx->L.stream);
   delete ctx;
 }
 const char* hmx_last_error(hmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null handle"; }
+const char* hmx_p2p_status(hmx_ctx* ctx) { return ctx ? ctx->p2p_note.c_str() : "null handle"; }
 const char* hmx_last_warning(hmx_ctx* ctx) {   // one-shot: a warning is reported once (Rcpp::warning fires once, src/harmony.cpp:87)
   if (!ctx) return "";
   ctx->warn_ret.swap(ctx->warn); ctx->warn.clear();
@@ -884,6 +897,7 @@ int hmx_comm_unique_id(uint8_t* out) {
   std::memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
   return 0;
 }
+static void p2p_auto(hmx_ctx* ctx, RcclApi* api, int rank, int world);
 int hmx_comm_init(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* unique_id) {
   if (!ctx || !unique_id || world < 1 || rank < 0 || rank >= world) return ctx ? fail(ctx, HMX_ERR_ARG, "bad communicator description") : HMX_ERR_ARG;
   if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "hmx_comm_init must precede hmx_setup");
@@ -895,7 +909,103 @@ int hmx_comm_init(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* uniq
   ncclUniqueId id; std::memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
   ncclResult_t r = api->CommInitRank(&ctx->comm, world, id, rank);
   if (r != ncclSuccess) { ctx->comm = nullptr; return fail(ctx, HMX_ERR_COMM, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "error")); }
+  p2p_auto(ctx, api, rank, world);     // in-launch exchange of the block chain over the peers' inboxes, if the node allows it
   return 0;
+}
+// ---- peer-to-peer block chain ------------------------------------------------------------------------------------------
+int hmx_p2p_export(hmx_ctx* ctx, uint8_t* handle_out) {
+  if (!ctx || !handle_out) return ctx ? fail(ctx, HMX_ERR_ARG, "null handle buffer") : HMX_ERR_ARG;
+  static_assert(sizeof(hipIpcMemHandle_t) == HMX_P2P_HANDLE_BYTES, "HIP IPC handle size");
+  if (ctx->device < 0) { int cur = 0; (void)hipGetDevice(&cur); ctx->device = cur; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->p2p_self) {
+    // fine-grained device memory: peers write it over xGMI while this GPU's folder polls it (coarse-grained memory is only
+    // coherent at kernel boundaries).  HMX_P2P_MEM=uncached selects hipDeviceMallocUncached instead.
+    const char* m = getenv("HMX_P2P_MEM");
+    const unsigned flags = (m && std::string(m) == "uncached") ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+    void* p = nullptr;
+    HIPCHK(hipExtMallocWithFlags(&p, P2P_INBOX_GRANULES * sizeof(unsigned long long), flags));
+    HIPCHK(hipMemset(p, 0, P2P_INBOX_GRANULES * sizeof(unsigned long long)));
+    HIPCHK(hipDeviceSynchronize());
+    ctx->p2p_self = (unsigned long long*)p;
+  }
+  hipIpcMemHandle_t h;
+  HIPCHK(hipIpcGetMemHandle(&h, ctx->p2p_self));
+  std::memcpy(handle_out, &h, sizeof(h));
+  return 0;
+}
+int hmx_p2p_connect(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* handles) {
+  if (!ctx || !handles) return ctx ? fail(ctx, HMX_ERR_ARG, "null handle table") : HMX_ERR_ARG;
+  if (world < 2 || world > 8 || rank < 0 || rank >= world) return fail(ctx, HMX_ERR_ARG, "the peer-to-peer chain takes 2..8 ranks");
+  if (!ctx->p2p_self) return fail(ctx, HMX_ERR_STATE, "hmx_p2p_export first");
+  HIPCHK(hipSetDevice(ctx->device));
+  for (int g = 0; g < world; g++) {
+    if (g == rank) { ctx->p2p_peer[g] = ctx->p2p_self; continue; }
+    if (ctx->p2p_peer[g]) continue;
+    hipIpcMemHandle_t h; std::memcpy(&h, handles + (size_t)g * HMX_P2P_HANDLE_BYTES, sizeof(h));
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); ctx->p2p_note = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e); return fail(ctx, HMX_ERR_COMM, ctx->p2p_note); }
+    ctx->p2p_peer[g] = (unsigned long long*)p;
+  }
+  ctx->p2p_rank = rank; ctx->p2p_world = world; ctx->p2p_note = "connected, not tested";
+  return 0;
+}
+int hmx_p2p_selftest(hmx_ctx* ctx) {
+  if (!ctx || ctx->p2p_world < 2) return ctx ? fail(ctx, HMX_ERR_STATE, "hmx_p2p_connect first") : HMX_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->L.stream) { HIPCHK(hipStreamCreateWithFlags(&ctx->L.stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+  if (!ctx->p2p_result) HIPCHK(hipMalloc((void**)&ctx->p2p_result, sizeof(int)));
+  Dev T{};
+  T.p2p_world = ctx->p2p_world; T.p2p_rank = ctx->p2p_rank;
+  for (int g = 0; g < 8; g++) T.p2p_inbox[g] = ctx->p2p_peer[g];
+  l_p2p_selftest(ctx->L, T, 0xC0DE0000u + (++ctx->p2p_tests), ctx->p2p_result); KCHK();
+  int heard = 0;
+  HIPCHK(hipMemcpyAsync(&heard, ctx->p2p_result, sizeof(int), hipMemcpyDeviceToHost, ctx->L.stream));
+  HIPCHK(hipStreamSynchronize(ctx->L.stream));
+  if (heard != ctx->p2p_world - 1) {
+    ctx->p2p_note = "self-test: heard " + std::to_string(heard) + " of " + std::to_string(ctx->p2p_world - 1) + " peers";
+    return fail(ctx, HMX_ERR_COMM, "peer-to-peer " + ctx->p2p_note);
+  }
+  ctx->p2p_note = "self-test passed";
+  return 0;
+}
+int hmx_p2p_enable(hmx_ctx* ctx, int32_t on) {
+  if (!ctx) return HMX_ERR_ARG;
+  if (on && ctx->p2p_world < 2) return fail(ctx, HMX_ERR_STATE, "hmx_p2p_connect first");
+  ctx->p2p_on = on != 0;
+  if (on) ctx->p2p_note = "on";
+  return 0;
+}
+// with the built-in communicator the whole bootstrap is automatic; every failure just leaves the per-block collectives in place
+static void p2p_auto(hmx_ctx* ctx, RcclApi* api, int rank, int world) {
+  const char* e = getenv("HMX_P2P");
+  if ((e && std::string(e) == "0") || world < 2 || world > 8 || !api->AllGather) { ctx->p2p_note = "off"; return; }
+  auto give_up = [&](const std::string& why) { ctx->p2p_note = why; ctx->p2p_on = false; ctx->err.clear(); };
+  if (!ctx->L.stream) { if (hipStreamCreateWithFlags(&ctx->L.stream, hipStreamNonBlocking) != hipSuccess) return give_up("no stream"); ctx->own_stream = true; }
+  uint8_t mine[HMX_P2P_HANDLE_BYTES] = {};
+  long long ok = hmx_p2p_export(ctx, mine) == 0 ? 1 : 0;    // (a rank that cannot export still takes part in the collectives)
+  uint8_t* dev = nullptr; long long* flag = nullptr;
+  std::vector<uint8_t> all((size_t)world * HMX_P2P_HANDLE_BYTES);
+  if (hipMalloc((void**)&dev, all.size()) != hipSuccess || hipMalloc((void**)&flag, 8) != hipSuccess) return give_up("hipMalloc");
+  bool comm_ok = hipMemcpyAsync(dev + (size_t)rank * HMX_P2P_HANDLE_BYTES, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->L.stream) == hipSuccess &&
+                 api->AllGather(dev + (size_t)rank * HMX_P2P_HANDLE_BYTES, dev, HMX_P2P_HANDLE_BYTES, ncclInt8, ctx->comm, ctx->L.stream) == ncclSuccess &&
+                 hipMemcpyAsync(all.data(), dev, all.size(), hipMemcpyDeviceToHost, ctx->L.stream) == hipSuccess &&
+                 hipStreamSynchronize(ctx->L.stream) == hipSuccess;
+  auto agree = [&]() {     // min over the ranks of `ok`
+    if (!comm_ok) return;
+    comm_ok = hipMemcpyAsync(flag, &ok, 8, hipMemcpyHostToDevice, ctx->L.stream) == hipSuccess &&
+              api->AllReduce(flag, flag, 1, ncclInt64, ncclMin, ctx->comm, ctx->L.stream) == ncclSuccess &&
+              hipMemcpyAsync(&ok, flag, 8, hipMemcpyDeviceToHost, ctx->L.stream) == hipSuccess &&
+              hipStreamSynchronize(ctx->L.stream) == hipSuccess;
+  };
+  agree();                                                                       // everyone exported (also a barrier)
+  if (comm_ok && ok) { ok = hmx_p2p_connect(ctx, rank, world, all.data()) == 0 ? 1 : 0; agree(); }     // everyone connected
+  if (comm_ok && ok) { ok = hmx_p2p_selftest(ctx) == 0 ? 1 : 0; agree(); }                             // everyone heard everyone
+  (void)hipFree(dev); (void)hipFree(flag);
+  if (!comm_ok) return give_up("bootstrap collectives failed");
+  if (!ok) return give_up(ctx->p2p_note.empty() ? "a rank failed" : ctx->p2p_note + " (on some rank)");
+  (void)hmx_p2p_enable(ctx, 1);
 }
 int hmx_set_stream(hmx_ctx* ctx, void* s) {
   if (!ctx) return HMX_ERR_ARG;
@@ -1262,6 +1372,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     const char* e = getenv("HMX_CHAIN");
     int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     ctx->chain_wgs = cus;
+    if (const char* w = getenv("HMX_CHAIN_WGS")) ctx->chain_wgs = std::max(8, std::min(cus, atoi(w)));   // (tests: two ranks sharing one GPU)
     // The chain pays off while a block step is latency-bound: a few 16-cell tiles per resident wave (1.5 at 1M cells, where a
     // step takes 21 us against 27.5 + 3 us of launch gap).  At 10M cells per GPU (15 tiles per wave) the per-step launches
     // stream just as well and were measured 6 % faster (142 vs 151 us per step): HMX_CHAIN=1 forces the chain there.
@@ -1280,7 +1391,9 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     { const char* w = getenv("HMX_CHAIN_WPS"); D.chain_wps = (w && (atoi(w) == 4 || atoi(w) == 3) && D.usig) ? atoi(w) : 2;
       // the 4-waves-per-SIMD variant keeps one LDS-DMA row image per wave: 16 KB per 16-byte group of a row
       if (D.chain_wps >= 3 && (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 + (size_t)16 * (D.NT4 + D.tail + 1) * 1024 > 158 * 1024) D.chain_wps = 2; }
-    ctx->chain_rounds = 0; }
+    ctx->chain_rounds = 0;
+    D.p2p_world = 0; D.p2p_rank = ctx->p2p_rank;
+    for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g]; }
   ctx->ran_setup = true;
   return hmx_restart(ctx);
 }
@@ -1525,6 +1638,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
   if (f == "prof:update_steps") return scalar((double)ctx->prof_update_steps);
   if (f == "chain") return scalar(ctx->chain_ok ? 1.0 : 0.0);
+  if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);
   if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them
     if (!ctx->ran_setup) return -1;
     if (!out) return 16;

@@ -74,6 +74,16 @@ struct Dev {
   int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
   long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)
+  // peer-to-peer block chain (sharded runs, one process per GPU on a node): p2p_inbox[g] = rank g's inbox as mapped into THIS
+  // process (fine-grained device memory shared through HIP IPC), [2 parities][8 sources][P2P_CAP entries][2 granules]
+  int p2p_world, p2p_rank;
+  unsigned long long* p2p_inbox[8];
+  __host__ __device__ unsigned long long* p2p_inbox_self() const {   // (static indices only: a dynamic one would spill the kernarg copy)
+    unsigned long long* p = p2p_inbox[0];
+#pragma unroll
+    for (int q = 1; q < 8; q++) if (q == p2p_rank) p = p2p_inbox[q];
+    return p;
+  }
   unsigned long long* chain_dbg;   // diagnostics: accumulated 100 MHz ticks [0..2] folder wait / fold / publish, [3] launches,
                                    //              [4..8] worker (workgroup 0) flag wait / table copy / tiles / drain+arrive / next block's MFMAs
   float* pen;         // [B][K] ((2E+1)/(O+E+1))^theta
@@ -160,7 +170,11 @@ void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long 
                long long* Szero);
 void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
-void l_chain(const Launch& L, const Dev& D, int workgroups);   // the whole block chain of a round: one persistent launch
+void l_chain(const Launch& L, const Dev& D, int workgroups);
+constexpr int P2P_CAP = 16384;                       // K x B entries an inbox holds per (parity, source)
+constexpr size_t P2P_TEST_BASE = (size_t)2 * 8 * P2P_CAP * 2;   // 64 granules behind the tables: the connection self-test
+constexpr size_t P2P_INBOX_GRANULES = P2P_TEST_BASE + 64;
+void l_p2p_selftest(const Launch& L, const Dev& D, unsigned tag, int* result);   // the whole block chain of a round: one persistent launch
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
 void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);

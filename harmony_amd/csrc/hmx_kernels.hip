@@ -1557,6 +1557,73 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           __syncthreads();
         }
         { const unsigned long long t = wall_clock64(); tw += t - t_prev; t_prev = t; }
+        if (D.p2p_world > 1) {
+          // Sharded run: the new contributions of block jj-1 are summed over the GPUs INSIDE the launch.  One-shot exchange over
+          // xGMI: every folder writes its local sums straight into every peer's inbox (two self-validating 8-byte granules
+          // {tag, half of the int64} per entry, system-scope write-through stores), then sums what the peers wrote into its own.
+          // Integer sums: every rank folds exactly the same O.  Two parities suffice: a rank can run at most one exchange ahead
+          // of a peer (it needs that peer's contribution of step jj to finish step jj).
+          const int G = D.p2p_world, me = D.p2p_rank;
+          const unsigned tagx = tag0 + (unsigned)jj;
+          const unsigned long long tb = (unsigned long long)tagx << 32;
+          const size_t par = (size_t)(jj & 1) * 8;
+          for (int base = 0; base < nBK; base += FE * bd) {
+            long long dl[FE], so[FE];
+#pragma unroll
+            for (int e = 0; e < FE; e++) {
+              const int i = base + tid + e * bd;
+              dl[e] = 0; so[e] = 0;
+              if (i < nBK) {
+                if (jj < nbk) so[e] = D.Sold_fx[(size_t)jj * nBK + i];
+                if (jj > 0) {
+                  unsigned long long a[8];
+#pragma unroll
+                  for (int r = 0; r < 8; r++) a[r] = (r < D.nrep) ? atomicExch((unsigned long long*)&D.Snew_fx[(size_t)r * nBK + i], 0ull) : 0ull;
+#pragma unroll
+                  for (int r = 0; r < 8; r++) dl[e] += (long long)a[r];
+                  const unsigned long long lo = tb | ((unsigned long long)dl[e] & 0xffffffffull), hi = tb | ((unsigned long long)dl[e] >> 32);
+#pragma unroll
+                  for (int gq = 0; gq < 8; gq++) if (gq < G && gq != me) {
+                    unsigned long long* dst = D.p2p_inbox[gq] + ((par + me) * P2P_CAP + i) * 2;
+                    __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < FE; e++) {
+              const int i = base + tid + e * bd;
+              if (i < nBK) {
+                long long o = ldsO[i] + dl[e] - so[e];
+                if (jj > 0) {
+                  unsigned long long lo[8], hi[8];
+#pragma unroll
+                  for (int gq = 0; gq < 8; gq++) if (gq < G && gq != me) {
+                    const unsigned long long* src = D.p2p_inbox_self() + ((par + gq) * P2P_CAP + i) * 2;
+                    lo[gq] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    hi[gq] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  }
+#pragma unroll
+                  for (int gq = 0; gq < 8; gq++) if (gq < G && gq != me) {
+                    const unsigned long long* src = D.p2p_inbox_self() + ((par + gq) * P2P_CAP + i) * 2;
+                    int spins = 0;
+                    while ((unsigned)(lo[gq] >> 32) != tagx || (unsigned)(hi[gq] >> 32) != tagx) {
+                      __builtin_amdgcn_s_sleep(1);
+                      if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 5); break; }
+                      if (dead(spins)) break;
+                      lo[gq] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                      hi[gq] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    o += (long long)((hi[gq] << 32) | (lo[gq] & 0xffffffffull));
+                  }
+                }
+                ldsO[i] = o;
+                if (jj == nbk) D.O_fx[i] = o;
+              }
+            }
+          }
+        }
         auto fold_entry = [&](int i, long long soldv) {
           long long o = ldsO[i];
           // every memory operation of the entry in flight before the first is consumed: the new contributions (exchange = read +
@@ -1572,9 +1639,11 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           ldsO[i] = o;
           if (jj == nbk) D.O_fx[i] = o;      // the round's final O (read by the kernels that follow this launch)
         };
+        if (D.p2p_world <= 1) {
 #pragma unroll
-        for (int e = 0; e < FE; e++) { const int i = tid + e * bd; if (i < nBK) fold_entry(i, sv[e]); }
-        for (int i = tid + FE * bd; i < nBK; i += bd) fold_entry(i, jj < nbk ? D.Sold_fx[(size_t)jj * nBK + i] : 0);
+          for (int e = 0; e < FE; e++) { const int i = tid + e * bd; if (i < nBK) fold_entry(i, sv[e]); }
+          for (int i = tid + FE * bd; i < nBK; i += bd) fold_entry(i, jj < nbk ? D.Sold_fx[(size_t)jj * nBK + i] : 0);
+        }
         if (jj == nbk) break;
         __syncthreads();
         { const unsigned long long t = wall_clock64(); tf += t - t_prev; t_prev = t; }
@@ -3074,6 +3143,30 @@ void l_chain(const Launch& L, const Dev& D, int workgroups) {
     default: break;
   }
 #undef HMX_CH
+}
+// Connection self-test of the peer-to-peer inboxes (run by every rank at the same time): each rank writes one granule into every
+// peer's inbox and waits (bounded, ~4 s) for every peer's granule in its own.  result[0] = number of peers heard.
+__global__ void k_p2p_selftest(Dev D, unsigned tag, int* result) {
+  const int g = threadIdx.x, G = D.p2p_world, me = D.p2p_rank;
+  int heard = 0;
+  if (g < G && g != me) {
+    const unsigned long long v = ((unsigned long long)tag << 32) | (unsigned)(me + 1);
+    unsigned long long* dst = nullptr;
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q == g) dst = D.p2p_inbox[q];
+    __hip_atomic_store(dst + P2P_TEST_BASE + me, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* src = D.p2p_inbox_self() + P2P_TEST_BASE + g;
+    for (int spins = 0; spins < (1 << 20); spins++) {
+      const unsigned long long r = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((unsigned)(r >> 32) == tag && (unsigned)r == (unsigned)(g + 1)) { heard = 1; break; }
+      __builtin_amdgcn_s_sleep(100);
+    }
+  }
+  const unsigned long long m = __ballot(heard);
+  if (threadIdx.x == 0) result[0] = __popcll(m);
+}
+void l_p2p_selftest(const Launch& L, const Dev& D, unsigned tag, int* result) {
+  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(64), 0, L.stream, D, tag, result);
 }
 void l_objective_tables(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);

@@ -95,6 +95,28 @@ class Harmony(object):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._lib.hmx_comm_init(self._h, int(rank), int(world), buf), "comm_init")
 
+    # peer-to-peer block chain for hosts that bring their own all-reduce hook (comm_init does all of this by itself)
+    def p2p_export(self):
+        buf = (C.c_uint8 * 64)()
+        self._check(self._lib.hmx_p2p_export(self._h, buf), "p2p_export")
+        return bytes(buf)
+
+    def p2p_connect(self, rank, world, handles):
+        """handles: the ranks' exported handles in rank order (list of 64-byte strings)."""
+        buf = (C.c_uint8 * (64 * int(world))).from_buffer_copy(b"".join(handles))
+        self._check(self._lib.hmx_p2p_connect(self._h, int(rank), int(world), buf), "p2p_connect")
+
+    def p2p_selftest(self):
+        """collective: every rank at the same time; True if this rank heard every peer"""
+        return self._lib.hmx_p2p_selftest(self._h) == 0
+
+    def p2p_enable(self, on=True):
+        self._check(self._lib.hmx_p2p_enable(self._h, int(bool(on))), "p2p_enable")
+
+    @property
+    def p2p_status(self):
+        return self._lib.hmx_p2p_status(self._h).decode()
+
     def set_shard(self, rank, world, global_offset, N_global, allreduce_cb=None):
         """allreduce_cb None: use the built-in RCCL communicator (comm_init first)."""
         cb = None

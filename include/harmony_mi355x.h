@@ -173,6 +173,21 @@ typedef int (*hmx_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dt
  * communicator, hmx_set_shard may pass fn == NULL. */
 int hmx_comm_unique_id(uint8_t* out128);
 int hmx_comm_init(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* unique_id128);
+/* Peer-to-peer block chain (sharded runs, up to 8 ranks of one node).  The update_R block chain (src/harmony.cpp:296-331) needs
+ * the K x B contribution table of every block summed over all ranks before the next block starts: 20 dependent all-reduces per
+ * round.  With the peers' inboxes connected, the persistent chain kernel does that sum INSIDE the launch (each GPU writes its
+ * table straight into every peer's inbox over xGMI and adds up what arrived in its own): no collective call, no launch per block.
+ * hmx_comm_init sets all of this up by itself (HMX_P2P=0 disables it).  A host that brings its own all-reduce hook can do it by
+ * hand: every rank exports a handle (a hipIpcMemHandle_t, HMX_P2P_HANDLE_BYTES bytes), the host all-gathers them (rank order),
+ * every rank connects, then -- after a host barrier -- every rank runs the self-test AT THE SAME TIME, and only if it passed on
+ * EVERY rank (the host ANDs the results) every rank enables it.  Until then, and whenever it is off, sharded runs use one launch +
+ * one all-reduce per block.  Ranks must be separate processes.  hmx_get "p2p" = 1 when on; hmx_p2p_status = why not. */
+#define HMX_P2P_HANDLE_BYTES 64
+int hmx_p2p_export(hmx_ctx* ctx, uint8_t* handle_out);
+int hmx_p2p_connect(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* handles /* world x HMX_P2P_HANDLE_BYTES */);
+int hmx_p2p_selftest(hmx_ctx* ctx);
+int hmx_p2p_enable(hmx_ctx* ctx, int32_t on);
+const char* hmx_p2p_status(hmx_ctx* ctx);
 /* must be called before hmx_setup; global_offset = index of this rank's first cell.  fn != NULL overrides the
  * built-in RCCL all-reduce with a host-provided hook (tests: thread rendezvous, gloo). */
 int hmx_set_shard(hmx_ctx* ctx, int32_t rank, int32_t world, int64_t global_offset,
