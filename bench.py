@@ -160,6 +160,7 @@ def main():
             # node, every rank falls back to the torch.distributed hook instead of hanging the whole job
             import threading
             res = {}
+            os.environ["HMX_P2P"] = "0"              # (the peer-to-peer chain is bootstrapped below through torch.distributed)
 
             def _init():
                 try:
@@ -187,6 +188,40 @@ def main():
             obj.set_stream(torch.cuda.current_stream().cuda_stream)
             obj.set_shard(rank, world, rank * n, N, TorchAllReduce(device=dev))
             comm_kind = "torch.distributed %s all_reduce hook%s" % (a.backend, " (RCCL over xGMI)" if a.backend == "nccl" else "")
+        # Peer-to-peer block chain: the 20 dependent K x B sums of a clustering round happen INSIDE the persistent launch (every
+        # GPU writes its table into every peer's inbox over xGMI) instead of 20 launches + 20 all-reduces.  The inbox handles
+        # travel through torch.distributed; it is switched on only if the transport self-test passed on EVERY rank.
+        p2p_note = "off"
+        if world <= 8 and os.environ.get("HMX_BENCH_P2P", "1") != "0":
+            def agree(flag):
+                t = torch.tensor([1 if flag else 0], device=dev if a.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
+            if torch.cuda.device_count() < world:
+                os.environ["HMX_CHAIN_WGS"] = str(max(8, 240 // world))    # smoke tests: the ranks' chains share one GPU
+            try:
+                handle = obj.p2p_export()
+            except Exception as e:                    # pragma: no cover
+                handle, p2p_note = None, "export failed: %s" % e
+            handles = [None] * world
+            dist.all_gather_object(handles, handle)
+            good = all(h is not None for h in handles)
+            if good:
+                try:
+                    obj.p2p_connect(rank, world, handles)
+                except Exception as e:                # pragma: no cover
+                    good, p2p_note = False, "connect failed: %s" % e
+            good = agree(good)
+            if good:
+                dist.barrier()
+                good = agree(obj.p2p_selftest())
+                p2p_note = obj.p2p_status
+            if good:
+                obj.p2p_enable(True)
+            elif rank == 0:                           # pragma: no cover
+                print("peer-to-peer chain not available (%s): one launch + one all-reduce per block" % p2p_note, file=sys.stderr)
+        comm_kind += "; block chain: " + ("peer-to-peer inboxes inside the persistent launch (%s)" % p2p_note
+                                          if obj._scalar("p2p") else "one launch + one all-reduce per block (%s)" % p2p_note)
         N_b = []
         for v, L in zip(vars_use, levels):
             cnt = torch.from_numpy(np.bincount(meta[v], minlength=L).astype(np.int64)).to(dev)
@@ -221,6 +256,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / a.steps
+    shard_check = None
+    if world > 1:
+        # sharded sanity: every rank holds the same global O (integer sums) and it accounts for every cell
+        O = torch.from_numpy(np.ascontiguousarray(obj.O, dtype=np.float64)).to(dev if a.backend == "nccl" else "cpu")
+        lo_, hi_ = O.clone(), O.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN); dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        shard_check = {"O_identical_on_all_ranks": bool((lo_ == hi_).all().item()),
+                       "sum_O_over_N": float(O.sum().item()) / float(N)}
+        if not shard_check["O_identical_on_all_ranks"] or abs(shard_check["sum_O_over_N"] - 1.0) > 1e-4:
+            raise SystemExit("sharded run inconsistent: %r" % (shard_check,))
     kr = np.asarray(obj.kmeans_rounds, dtype=np.int64)      # rounds of every harmony iteration of the LAST step
     rounds = int(kr.sum())
 
@@ -286,7 +331,7 @@ def main():
                                   "" if world == 1 else ", %d cells/GPU cell-sharded" % n,
                                   "configs[4] shape" if a.workload == "c5" else ("configs[2]" if n == 1000000 and levels == (10,) else "configs[2]/[3] family")),
                    "parallelism": ("cells sharded x%d, all-reduce of O/E/statistics: %s" % (world, comm_kind)) if world > 1 else "single GPU",
-                   "harmony_iterations": iters, "kmeans_rounds_last_step": rounds,
+                   "shard_check": shard_check, "harmony_iterations": iters, "kmeans_rounds_last_step": rounds,
                    "s_per_iter": 1e-3 * ms_per_step / max(float(np.mean(iters)), 1.0),
                    "gpu_phase_ms_per_step": gpu_phase, "chain_us_per_block_step": chain, "e2e": e2e},
         "roofline": roofline,

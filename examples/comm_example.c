@@ -82,6 +82,7 @@ int main(int argc, char** argv) {
   double calls = 0; hmx_get(h, "comm:calls", &calls, 1);
   printf("COMM_EXAMPLE_OK rank %d/%d iterations %d objective %.4f O-checksum %.6f collectives %.0f\n", rank, world, iter,
          no > 0 ? obj[no - 1] : 0.0, chk, calls);
+  printf("block chain over the peers' inboxes: %s\n", hmx_p2p_status(h));   /* set up by hmx_comm_init when world > 1 */
   hmx_destroy(h);
   free(Z); free(lev); free(phi_i); free(phi_p);
   return 0;

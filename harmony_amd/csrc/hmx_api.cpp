@@ -103,7 +103,7 @@ struct hmx_ctx {
   bool comm_force = false;     // test hook: issue the collectives even when world == 1
   // peer-to-peer block chain (hmx_p2p_*): inboxes shared through HIP IPC; on only after the connection self-test passed everywhere
   unsigned long long* p2p_self = nullptr; unsigned long long* p2p_peer[8] = {}; int p2p_rank = 0, p2p_world = 0; bool p2p_on = false;
-  unsigned p2p_tests = 0; int* p2p_result = nullptr; std::string p2p_note = "not connected";
+  unsigned p2p_tests = 0; int* p2p_result = nullptr; double p2p_exchange_us = 0.0; std::string p2p_note = "not connected";
   int (*poll)(void*) = nullptr; void* poll_user = nullptr;
   // ---- problem --------------------------------------------------------------------
   int64_t N = 0;  // local cells
@@ -955,26 +955,29 @@ int hmx_p2p_selftest(hmx_ctx* ctx) {
   if (!ctx || ctx->p2p_world < 2) return ctx ? fail(ctx, HMX_ERR_STATE, "hmx_p2p_connect first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->L.stream) { HIPCHK(hipStreamCreateWithFlags(&ctx->L.stream, hipStreamNonBlocking)); ctx->own_stream = true; }
-  if (!ctx->p2p_result) HIPCHK(hipMalloc((void**)&ctx->p2p_result, sizeof(int)));
+  if (!ctx->p2p_result) HIPCHK(hipMalloc((void**)&ctx->p2p_result, 2 * sizeof(int)));
   Dev T{};
   T.p2p_world = ctx->p2p_world; T.p2p_rank = ctx->p2p_rank;
   for (int g = 0; g < 8; g++) T.p2p_inbox[g] = ctx->p2p_peer[g];
-  l_p2p_selftest(ctx->L, T, 0xC0DE0000u + (++ctx->p2p_tests), ctx->p2p_result); KCHK();
-  int heard = 0;
-  HIPCHK(hipMemcpyAsync(&heard, ctx->p2p_result, sizeof(int), hipMemcpyDeviceToHost, ctx->L.stream));
+  // tags of the test live above 2^31 (the chain's stay below 2^30 + 64), 128 per test
+  l_p2p_selftest(ctx->L, T, 0x80000000u + ((++ctx->p2p_tests) & 0xffffffu) * 128u, ctx->p2p_result); KCHK();
+  int res[2] = {-1, 0};
+  HIPCHK(hipMemcpyAsync(res, ctx->p2p_result, sizeof(res), hipMemcpyDeviceToHost, ctx->L.stream));
   HIPCHK(hipStreamSynchronize(ctx->L.stream));
-  if (heard != ctx->p2p_world - 1) {
-    ctx->p2p_note = "self-test: heard " + std::to_string(heard) + " of " + std::to_string(ctx->p2p_world - 1) + " peers";
+  if (res[0] != 0) {
+    ctx->p2p_note = "self-test: " + std::to_string(res[0]) + " wrong or missing values";
     return fail(ctx, HMX_ERR_COMM, "peer-to-peer " + ctx->p2p_note);
   }
-  ctx->p2p_note = "self-test passed";
+  ctx->p2p_exchange_us = (double)res[1] / 100.0 / 63.0;    // 100 MHz ticks over the 63 steps after the first
+  char buf[96]; snprintf(buf, sizeof(buf), "self-test passed (%.2f us per exchange step)", ctx->p2p_exchange_us);
+  ctx->p2p_note = buf;
   return 0;
 }
 int hmx_p2p_enable(hmx_ctx* ctx, int32_t on) {
   if (!ctx) return HMX_ERR_ARG;
   if (on && ctx->p2p_world < 2) return fail(ctx, HMX_ERR_STATE, "hmx_p2p_connect first");
   ctx->p2p_on = on != 0;
-  if (on) ctx->p2p_note = "on";
+  if (on && ctx->p2p_note.find("passed") == std::string::npos) ctx->p2p_note = "on (self-test not run)";
   return 0;
 }
 // with the built-in communicator the whole bootstrap is automatic; every failure just leaves the per-block collectives in place
@@ -1638,6 +1641,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
   if (f == "prof:update_steps") return scalar((double)ctx->prof_update_steps);
   if (f == "chain") return scalar(ctx->chain_ok ? 1.0 : 0.0);
+  if (f == "p2p:exchange_us") return scalar(ctx->p2p_exchange_us);
   if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);
   if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them
     if (!ctx->ran_setup) return -1;

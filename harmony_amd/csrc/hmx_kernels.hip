@@ -72,6 +72,17 @@ __device__ __forceinline__ unsigned long long fx_of(float r) {  // R in [0,1] ->
 // (~2e-7 relative; powf's ~100 dependent instructions cost >1 us in the serial prologue of every block step at gfx950's
 // 26-cycle dependent-issue latency).  ONE definition for the fused and the stand-alone fold kernels: the sharded and the
 // single-GPU paths must produce bit-identical penalty tables.
+// one int64 of a K x B table into every peer's inbox: two self-validating granules {tag, half}, written through at system scope
+__device__ __forceinline__ void p2p_send(const Dev& D, size_t par, int i, unsigned tag, long long v) {
+  const unsigned long long tb = (unsigned long long)tag << 32;
+  const unsigned long long lo = tb | ((unsigned long long)v & 0xffffffffull), hi = tb | ((unsigned long long)v >> 32);
+#pragma unroll
+  for (int gq = 0; gq < 8; gq++) if (gq < D.p2p_world && gq != D.p2p_rank) {
+    unsigned long long* dst = D.p2p_inbox[gq] + ((par + D.p2p_rank) * P2P_CAP + i) * 2;
+    __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 __device__ __forceinline__ float pen_pow(float num, float den, float theta) {
   const float x = num * __builtin_amdgcn_rcpf(den);
   return __builtin_amdgcn_exp2f(theta * __builtin_amdgcn_logf(x));
@@ -1565,7 +1576,6 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           // of a peer (it needs that peer's contribution of step jj to finish step jj).
           const int G = D.p2p_world, me = D.p2p_rank;
           const unsigned tagx = tag0 + (unsigned)jj;
-          const unsigned long long tb = (unsigned long long)tagx << 32;
           const size_t par = (size_t)(jj & 1) * 8;
           for (int base = 0; base < nBK; base += FE * bd) {
             long long dl[FE], so[FE];
@@ -1581,13 +1591,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
                   for (int r = 0; r < 8; r++) a[r] = (r < D.nrep) ? atomicExch((unsigned long long*)&D.Snew_fx[(size_t)r * nBK + i], 0ull) : 0ull;
 #pragma unroll
                   for (int r = 0; r < 8; r++) dl[e] += (long long)a[r];
-                  const unsigned long long lo = tb | ((unsigned long long)dl[e] & 0xffffffffull), hi = tb | ((unsigned long long)dl[e] >> 32);
-#pragma unroll
-                  for (int gq = 0; gq < 8; gq++) if (gq < G && gq != me) {
-                    unsigned long long* dst = D.p2p_inbox[gq] + ((par + me) * P2P_CAP + i) * 2;
-                    __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                  }
+                  p2p_send(D, par, i, tagx, dl[e]);
                 }
               }
             }
@@ -3144,29 +3148,55 @@ void l_chain(const Launch& L, const Dev& D, int workgroups) {
   }
 #undef HMX_CH
 }
-// Connection self-test of the peer-to-peer inboxes (run by every rank at the same time): each rank writes one granule into every
-// peer's inbox and waits (bounded, ~4 s) for every peer's granule in its own.  result[0] = number of peers heard.
-__global__ void k_p2p_selftest(Dev D, unsigned tag, int* result) {
-  const int g = threadIdx.x, G = D.p2p_world, me = D.p2p_rank;
-  int heard = 0;
-  if (g < G && g != me) {
-    const unsigned long long v = ((unsigned long long)tag << 32) | (unsigned)(me + 1);
-    unsigned long long* dst = nullptr;
+// Self-test of the peer-to-peer inboxes, run by every rank at the same time before the chain may use them: P2P_TEST_STEPS exchanges of
+// a 2048-entry table with known contents through exactly the chain's code path (p2p_send, the same slots, parities and polls),
+// every received value checked.  result[0] = wrong or missing values (0 = pass), result[1] = 100 MHz ticks of the steps after the
+// first (the first absorbs the launch skew between the ranks; bounded at ~3 s).
+constexpr int P2P_TEST_STEPS = 64;
+__device__ __forceinline__ long long p2p_test_value(int rank, int step, int i) {
+  const long long v = (long long)(rank + 1) * 0x100000001ll * (long long)(i + 1) + (long long)step * 7919;
+  return ((i + step) & 1) ? -v : v;
+}
+__global__ void __launch_bounds__(512) k_p2p_selftest(Dev D, unsigned tag, int* result) {
+  const int tid = threadIdx.x, G = D.p2p_world, me = D.p2p_rank;
+  __shared__ int gave_up, bad;
+  if (tid == 0) { gave_up = 0; bad = 0; }
+  __syncthreads();
+  int wrong = 0;
+  unsigned long long t1 = 0;
+  for (int step = 0; step < P2P_TEST_STEPS; step++) {
+    if (step == 1) t1 = wall_clock64();
+    const unsigned tagx = tag + (unsigned)step;
+    const size_t par = (size_t)(step & 1) * 8;
 #pragma unroll
-    for (int q = 0; q < 8; q++) if (q == g) dst = D.p2p_inbox[q];
-    __hip_atomic_store(dst + P2P_TEST_BASE + me, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long* src = D.p2p_inbox_self() + P2P_TEST_BASE + g;
-    for (int spins = 0; spins < (1 << 20); spins++) {
-      const unsigned long long r = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((unsigned)(r >> 32) == tag && (unsigned)r == (unsigned)(g + 1)) { heard = 1; break; }
-      __builtin_amdgcn_s_sleep(100);
+    for (int e = 0; e < 4; e++) p2p_send(D, par, tid + e * 512, tagx, p2p_test_value(me, step, tid + e * 512));
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = tid + e * 512;
+#pragma unroll
+      for (int gq = 0; gq < 8; gq++) if (gq < G && gq != me) {
+        const unsigned long long* src = D.p2p_inbox_self() + ((par + gq) * P2P_CAP + i) * 2;
+        unsigned long long lo = 0, hi = 0;
+        bool got = false;
+        for (int spins = 0; spins < (1 << 20); spins++) {
+          lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if ((unsigned)(lo >> 32) == tagx && (unsigned)(hi >> 32) == tagx) { got = true; break; }
+          if ((spins & 63) == 63 && __hip_atomic_load(&gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+          if (step == 0) __builtin_amdgcn_s_sleep(100); else __builtin_amdgcn_s_sleep(2);
+        }
+        if (!got) { __hip_atomic_store(&gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); wrong++; }
+        else if ((long long)((hi << 32) | (lo & 0xffffffffull)) != p2p_test_value(gq, step, i)) wrong++;
+      }
     }
   }
-  const unsigned long long m = __ballot(heard);
-  if (threadIdx.x == 0) result[0] = __popcll(m);
+  const unsigned long long t2 = wall_clock64();
+  if (wrong) atomicAdd(&bad, wrong);
+  __syncthreads();
+  if (tid == 0) { result[0] = bad; result[1] = (int)(t2 - t1); }
 }
 void l_p2p_selftest(const Launch& L, const Dev& D, unsigned tag, int* result) {
-  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(64), 0, L.stream, D, tag, result);
+  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(512), 0, L.stream, D, tag, result);
 }
 void l_objective_tables(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);
