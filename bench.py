@@ -306,6 +306,10 @@ def main():
                  "worker_wait_stores_issued_to_retired", "worker_barrier_arrive", "worker_next_mfma", "worker_tiles_but_last",
                  "worker_last_epilogue", "worker_flush_and_store_issue", "worker_next_mfma_cyclecounter_x100"]
         chain = {nm: round(float(dbg[i]) / 100.0 / steps_, 3) for i, nm in enumerate(names) if nm}
+        if len(dbg) >= 48:   # per wave of workgroups 0 and 100: us from "table in LDS" to "own work done" per block step, tiles per step
+            for nm, o in (("wg0", 16), ("wg100", 32)):
+                chain[nm + "_wave_busy_us"] = [round(float(dbg[o + w]) / 100.0 / steps_, 2) for w in range(8)]
+                chain[nm + "_wave_tiles"] = [round(float(dbg[o + 8 + w]) / steps_, 2) for w in range(8)]
     # T_e2e: T_conv + H2D of Z (double, the R seam) + D2H of Z_corr (double); PCIe-inclusive, never `value`
     e2e = None
     if not a.no_e2e:

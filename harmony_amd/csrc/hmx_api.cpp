@@ -270,13 +270,14 @@ int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Yt[j*K+k] and the MFMA 
   for (int k = 0; k < K; k++) for (int j = 0; j < d; j++) yt[(size_t)j * K + k] = ctx->Y[(size_t)k * d + j];
   CHK(h2d(ctx, D.Yt, yt.data(), yt.size()));
   CHK(h2d(ctx, D.Ycur, ctx->Y.data(), ctx->Y.size()));
-  // image[qd][s][p][c][i] = Y[pc(s,p)][16*(4qd+i)+c]; pc(s,p) as the tile kernels assign PCs to MFMA k-slots
+  // image[qd][s][p][c][i] = Y[pc(s,p)][kcol(4qd+i, c)]; pc(s,p) as the tile kernels assign PCs to MFMA k-slots
   std::vector<float> img((size_t)D.NQ * D.NS * 256, 0.f);
   for (int qd = 0; qd < D.NQ; qd++) for (int s = 0; s < D.NS; s++) for (int p = 0; p < 4; p++) {
     const int j = (s < 4 * D.NT4) ? 16 * (s / 4) + 4 * p + (s % 4) : 16 * D.NT4 + 4 * (s - 4 * D.NT4) + p;
     if (j >= d) continue;
     for (int c = 0; c < 16; c++) for (int i = 0; i < 4; i++) {
-      const int k = 16 * (4 * qd + i) + c;
+      if (4 * qd + i >= D.NCT) continue;
+      const int k = kcol(D.NCT, 4 * qd + i, c);
       if (k < K) img[((((size_t)qd * D.NS + s) * 4 + p) * 16 + c) * 4 + i] = ctx->Y[(size_t)k * d + j];
     }
   }
@@ -1210,6 +1211,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     D.wNT4 = K / 16; D.wtail = (K - 16 * D.wNT4) / 4; D.wNS = 4 * D.wNT4 + D.wtail; D.wNQ = ((d + 15) / 16 + 3) / 4; }
   D.nwmax = 4 * ctx->L.grid; D.objslots = std::min(D.nb, 64);
   D.pen_lds = ((size_t)D.NQ * 0 + (size_t)B * K * 4 + (size_t)Q * C * 4 <= 24576) ? 1 : 0;
+  D.rvec = (K % 4 == 0) ? 1 : 0;
   D.NQ = (D.NCT + 3) / 4; D.NT4 = D.zs / 16; D.tail = (D.zs - 16 * D.NT4) / 4; D.NS = 4 * D.NT4 + D.tail;
   { const char* e = getenv("HMX_UPDATE_IMPL"); D.upd_impl = ctx->tun_impl >= 0 ? ctx->tun_impl : ((e && std::string(e) == "v1") ? 1 : 0); }
   { const char* e = getenv("HMX_UPD_THREADS"); D.upd_threads = (e && atoi(e) == 256) ? 256 : 512; }
@@ -1383,9 +1385,9 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     const bool chain_fits = (e && std::string(e) == "1") || tiles_per_wave <= 6.0;
     ctx->chain_ok = !(e && std::string(e) == "0") && chain_fits && ctx->fused_ok && cus >= 8 && D.NCT <= 7 && D.NT4 <= 4 && D.nb <= 64 &&
                     (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024;
-    CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)16));
+    CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)48));
     CHK(dalloc(ctx, &D.Sold_rep, (size_t)D.nrep * D.nb * B * K));
-    HIPCHK(hipMemsetAsync(D.chain_dbg, 0, sizeof(unsigned long long) * 16, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.chain_dbg, 0, sizeof(unsigned long long) * 48, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.pen_g, 0, sizeof(unsigned long long) * (size_t)B * K, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 24), ctx->L.stream));
     // in-chain old sums (opt-in): measured 25.8 us per block step against 20.4 us + the 100 us k_oldsum pass per round -- a wash at
@@ -1645,10 +1647,10 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);
   if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them
     if (!ctx->ran_setup) return -1;
-    if (!out) return 16;
-    std::vector<unsigned long long> h(16);
-    if (d2h(ctx, h.data(), ctx->D.chain_dbg, 16)) return -1;
-    (void)hipMemsetAsync(ctx->D.chain_dbg, 0, sizeof(unsigned long long) * 16, ctx->L.stream);
+    if (!out) return 48;      // [0..12] folder / workgroup 0 wave 0 phases, [16..31] workgroup 0 and [32..47] workgroup 100: per wave busy ticks, tiles
+    std::vector<unsigned long long> h(48);
+    if (d2h(ctx, h.data(), ctx->D.chain_dbg, 48)) return -1;
+    (void)hipMemsetAsync(ctx->D.chain_dbg, 0, sizeof(unsigned long long) * 48, ctx->L.stream);
     return vec(h);
   }
   if (f.rfind("gputimer:", 0) == 0) {   // GPU time of a phase (profile mode), ms; "gputimer:Rcells_update" == "prof:update_ms"

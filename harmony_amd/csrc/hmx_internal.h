@@ -73,6 +73,7 @@ struct Dev {
   unsigned chain_tag;
   int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
   long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
+  int rvec;                    // K % 4 == 0: R rows are 16-byte aligned, the tile kernels store them with vector stores
   int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)
   // peer-to-peer block chain (sharded runs, one process per GPU on a node): p2p_inbox[g] = rank g's inbox as mapped into THIS
   // process (fine-grained device memory shared through HIP IPC), [2 parities][8 sources][P2P_CAP entries][2 granules]
@@ -171,6 +172,19 @@ void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long 
 void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
 void l_chain(const Launch& L, const Dev& D, int workgroups);
+// Cluster <-> MFMA column mapping of the tile kernels.  Lane (g, c) of a wave holds column c of every 16-wide cluster tile ct.
+// Clusters are dealt so that a lane's columns are CONSECUTIVE clusters: within a full quad of cluster tiles (4q..4q+3) the lane
+// holds clusters 64q + 4c + {0,1,2,3} (one 16-byte store per R row instead of four 4-byte ones), within the remaining r = nct % 4
+// tiles clusters 64 nfull + r c + {0..r-1} (one 12/8/4-byte store).  Ascending in ct for a fixed lane.
+__host__ __device__ constexpr int kcol(int nct, int ct, int c) {
+  return ct < 4 * (nct >> 2) ? 64 * (ct >> 2) + 4 * c + (ct & 3) : 64 * (nct >> 2) + (nct & 3) * c + (ct - 4 * (nct >> 2));
+}
+// inverse: cluster k -> (quad qd, component i of the quad's float4, column c) of the B-operand image
+__host__ __device__ inline void kcol_inv(int nct, int k, int& qd, int& i, int& c) {
+  const int nfull = nct >> 2, r = nct & 3;
+  if (k < 64 * nfull) { qd = k >> 6; c = (k & 63) >> 2; i = k & 3; }
+  else { qd = nfull; const int kk = k - 64 * nfull; c = kk / r; i = kk - c * r; }
+}
 constexpr int P2P_CAP = 16384;                       // K x B entries an inbox holds per (parity, source)
 constexpr size_t P2P_TEST_BASE = (size_t)2 * 8 * P2P_CAP * 2;   // 64 granules behind the tables: the connection self-test
 constexpr size_t P2P_INBOX_GRANULES = P2P_TEST_BASE + 64;

@@ -28,6 +28,8 @@
 
 namespace hmx {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };     // 12-byte row segment (global_store_dwordx3)
+struct __attribute__((aligned(8))) F2 { float x, y; };
 
 // --------------------------------------------------------------------------------------
 // device helpers
@@ -1011,6 +1013,10 @@ __device__ __forceinline__ void tile_dots_regs(const f32x4* __restrict__ ldsY4, 
   }
 }
 
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int srclane) {
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)v, srclane, 64), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), srclane, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
   const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), m, 64);
   const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
@@ -1022,6 +1028,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 template <int NCT>
 __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const int* __restrict__ qlev, int q, int C,
                                               int K, int c, int g, unsigned long long (&oacc)[NCT]) {
+  constexpr int NFULL = NCT >> 2, RT = NCT & 3, NG = NFULL + (RT ? 1 : 0);
 #pragma unroll
   for (int ct = 0; ct < NCT; ct++) {
     unsigned long long v = oacc[ct];
@@ -1029,14 +1036,29 @@ __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const
     v += shfl_xor_u64(v, 32);
     oacc[ct] = v;
   }
-  if (g == 0) {
-    for (int cc = 0; cc < C; cc++) {
-      const int b = qlev[q * C + cc];
+  // Every lane now holds the sums of its clusters (kcol: 4c+{0..3} of a quad).  Redistribute so that lane (g, c) owns cluster
+  // 64 G + 16 g + c of group G: ONE atomic instruction per group and level with all 64 lanes on consecutive addresses, instead of
+  // one per cluster tile with 16 lanes.
+  const int kk = 16 * g + c;
+  unsigned long long mine[NG];
 #pragma unroll
-      for (int ct = 0; ct < NCT; ct++) {
-        const int k = 16 * ct + c;
-        if (k < K && oacc[ct]) atomicAdd((unsigned long long*)&tab[(size_t)b * K + k], oacc[ct]);
-      }
+  for (int G = 0; G < NG; G++) {
+    const int RG = (G < NFULL) ? 4 : RT;
+    const int src = min(kk / RG, 15), jsel = kk - (kk / RG) * RG;
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int jj = 0; jj < RG; jj++) {
+      const unsigned long long t = shfl_u64(oacc[4 * G + jj], 16 * g + src);
+      v = (jsel == jj) ? t : v;
+    }
+    mine[G] = (kk < 16 * RG) ? v : 0ull;
+  }
+  for (int cc = 0; cc < C; cc++) {
+    const int b = qlev[q * C + cc];
+#pragma unroll
+    for (int G = 0; G < NG; G++) {
+      const int k = 64 * G + kk;
+      if (k < K && mine[G]) atomicAdd((unsigned long long*)&tab[(size_t)b * K + k], mine[G]);
     }
   }
 #pragma unroll
@@ -1045,7 +1067,8 @@ __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const
 
 // Instantiated cluster-tile counts are {1..8,10,12,14,16} (hmx_setup picks the smallest >= ceil(K/16)): cluster tiles
 // below this index are always completely inside K, only the ones from it on can hold k >= K.
-constexpr int first_partial_ct(int nct) { return nct <= 8 ? nct - 1 : nct - 2; }
+// (cluster tiles are grouped in quads by kcol: the tiles of the last group can hold k >= K)
+constexpr int first_partial_ct(int nct) { return (nct & 3) ? 4 * (nct >> 2) : 4 * ((nct >> 2) - 1); }
 // Static-tile launches (head / Lloyd / seeding) use 256-thread workgroups, capped at one resident generation
 // (D.static_maxblocks); measured: 768-thread workgroups (one per CU) are 30% slower (tail effect).
 constexpr int tile_threads(int nct) { return 256; }
@@ -1238,8 +1261,8 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   unsigned long long oacc[NCT];
 #pragma unroll
   for (int ct = 0; ct < NCT; ct++) {
-    const bool kv = 16 * ct + c < K;
-    const size_t ks = (size_t)min(16 * ct + c, K - 1);
+    const bool kv = kcol(NCT, ct, c) < K;
+    const size_t ks = (size_t)min(kcol(NCT, ct, c), K - 1);
     if (ct < NSIG) {
       if constexpr (MODE == 2) { ce[ct] = ld_or(D.ynorm, ks, kv, 0.0f); cl[ct] = 0.0f; }
       else if constexpr (USIG) { ce[ct] = D.ce[0]; cl[ct] = D.cl[0]; }
@@ -1254,7 +1277,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) {
       best[ct] = ~0ull;
-      sk[ct] = splitmix64(D.seed_key ^ ((uint64_t)(1 + 16 * ct + c) * 0xD1342543DE82EF95ull));
+      sk[ct] = splitmix64(D.seed_key ^ ((uint64_t)(1 + kcol(NCT, ct, c)) * 0xD1342543DE82EF95ull));
     }
   }
   auto CE = [&](int ct) -> float { return ce[USIG ? 0 : ct]; };
@@ -1278,11 +1301,42 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
           const int b = qlevT[q0 * C + cc];
 #pragma unroll
-          for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(penT, (size_t)b * K + min(16 * ct + c, K - 1), 16 * ct + c < K, 0.0f);
+          for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(penT, (size_t)b * K + min(kcol(NCT, ct, c), K - 1), kcol(NCT, ct, c) < K, 0.0f);
         }
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) { lpen[ct] = __builtin_amdgcn_logf(fmaxf(penv[ct], FLT_MIN)); if constexpr (!USIG) clp[ct] = cl[ct] * lpen[ct]; }
       }
+    }
+  };
+  // put_row: one R row (register `reg` of every cluster tile) -> memory.  A lane's columns are consecutive clusters (kcol): one
+  // 16-byte store per quad of cluster tiles and one 12/8/4-byte store for the rest -- 2 store instructions per row at K = 100
+  // instead of 7 (the epilogue is store-ISSUE-bound).  Rows are 16-byte aligned when K % 4 == 0 (D.rvec).
+  auto put_row = [&](float* __restrict__ row, const f32x4 (&acc)[NCT], const int reg) __attribute__((always_inline)) {
+    constexpr int NFULL = NCT >> 2, RT = NCT & 3;
+    if (D.rvec) {
+#pragma unroll
+      for (int q = 0; q < NFULL; q++) {
+        const int k0 = 64 * q + 4 * c;
+        if (4 * q < first_partial_ct(NCT) || k0 < K) {      // (K % 4 == 0: a lane's four clusters are all inside K or all outside)
+          f32x4 v; v[0] = acc[4 * q][reg]; v[1] = acc[4 * q + 1][reg]; v[2] = acc[4 * q + 2][reg]; v[3] = acc[4 * q + 3][reg];
+          *reinterpret_cast<f32x4*>(row + k0) = v;
+        }
+      }
+      if constexpr (RT > 0) {
+        const int k0 = 64 * NFULL + RT * c;
+        if (k0 + RT <= K) {
+          if constexpr (RT == 3) { F3 v; v.x = acc[4 * NFULL][reg]; v.y = acc[4 * NFULL + 1][reg]; v.z = acc[4 * NFULL + 2][reg]; *reinterpret_cast<F3*>(row + k0) = v; }
+          else if constexpr (RT == 2) { F2 v; v.x = acc[4 * NFULL][reg]; v.y = acc[4 * NFULL + 1][reg]; *reinterpret_cast<F2*>(row + k0) = v; }
+          else row[k0] = acc[4 * NFULL][reg];
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < RT; jj++) if (k0 + jj < K) row[k0 + jj] = acc[4 * NFULL + jj][reg];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++)
+        if (ct < first_partial_ct(NCT) || kcol(NCT, ct, c) < K) row[kcol(NCT, ct, c)] = acc[ct][reg];
     }
   };
   // epi_rows: the four accumulator registers (rows 4g..4g+3 of the tile; their cell ids live in lanes 4g+reg of cellA)
@@ -1311,7 +1365,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       for (int i = 0; i < RB; i++) {
         const int cell = __shfl(cellA, 4 * g + r0 + i, 64);
         cv[i] = cell >= 0;
-        Rrow[i] = D.R + (size_t)(cv[i] ? cell : D.n) * K + c;   // invalid rows: the dummy row behind R (zeros)
+        Rrow[i] = D.R + (size_t)(cv[i] ? cell : D.n) * K;       // invalid rows: the dummy row behind R (zeros)
         se[i] = 0.0f; sx[i] = 0.0f; sp[i] = 0.0f; sc[i] = 0.0f;
       }
 #pragma unroll
@@ -1320,7 +1374,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         for (int i = 0; i < RB; i++) {
           const float x = fmaf(acc[ct][r0 + i], -2.0f, 2.0f);
           float e = __builtin_amdgcn_exp2f(UPD ? fmaf(x, CE(ct), lpen[ct]) : x * CE(ct));
-          if (ct >= first_partial_ct(NCT)) e = (16 * ct + c < K) ? e : 0.0f;
+          if (ct >= first_partial_ct(NCT)) e = (kcol(NCT, ct, c) < K) ? e : 0.0f;
           acc[ct][r0 + i] = e;
           se[i] += e;
           sx[i] = fmaf(e, x, sx[i]);
@@ -1352,15 +1406,16 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #pragma unroll
         for (int i = 0; i < RB; i++) {
           const float rn = acc[ct][r0 + i] * inv[i];
-          if constexpr (DEFER) acc[ct][r0 + i] = rn;
-          else {
-#ifdef HMX_TRACE
-            if (!(D.upd_debug & 4))   // timing experiment: no R stores
-#endif
-            if (ct < first_partial_ct(NCT) || 16 * ct + c < K) Rrow[i][16 * ct] = rn;
-          }
+          acc[ct][r0 + i] = rn;            // the normalised value replaces the distance (stored below, or later by store_rows)
           oacc[ct] += fx_of(rn);
         }
+      }
+      if constexpr (!DEFER) {
+#ifdef HMX_TRACE
+        if (!(D.upd_debug & 4))   // timing experiment: no R stores
+#endif
+#pragma unroll
+        for (int i = 0; i < RB; i++) put_row(Rrow[i], acc, r0 + i);
       }
     }
   };
@@ -1369,10 +1424,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int cell = __shfl(cellA, 4 * g + i, 64);
-      float* Rrow = D.R + (size_t)(cell >= 0 ? cell : D.n) * K + c;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ct++)
-        if (ct < first_partial_ct(NCT) || 16 * ct + c < K) Rrow[16 * ct] = acc[ct][i];
+      put_row(D.R + (size_t)(cell >= 0 ? cell : D.n) * K, acc, i);
     }
   };
   // epilogue of a tile whose distances are in `acc`
@@ -1386,10 +1438,10 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         bs[reg] = INFINITY; bk[reg] = 0x7fffffff;
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) {
-          const float sc = (ct < first_partial_ct(NCT) || 16 * ct + c < K) ? fmaf(acc[ct][reg], -2.0f, ce[ct]) : INFINITY;
+          const float sc = (ct < first_partial_ct(NCT) || kcol(NCT, ct, c) < K) ? fmaf(acc[ct][reg], -2.0f, ce[ct]) : INFINITY;
           const bool lt = sc < bs[reg];               // strict: the smaller k (ct ascending) wins a tie
           bs[reg] = lt ? sc : bs[reg];
-          bk[reg] = lt ? 16 * ct + c : bk[reg];
+          bk[reg] = lt ? kcol(NCT, ct, c) : bk[reg];
         }
       }
       float m[4];
@@ -1500,7 +1552,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           if (!(key >= 0.0f)) kb = 0x7f800000u;
           kb &= 0x7fffffffu;   // -0.0 (u == 1: -log(u) = -0) must order as zero, not as the largest unsigned pattern  // nan -> +inf: never the minimum
           const unsigned long long pk = ((unsigned long long)kb << 32) | (unsigned long long)(uint32_t)gg;
-          const bool take = !skip && (ct < first_partial_ct(NCT) || 16 * ct + c < K) && pk < best[ct];
+          const bool take = !skip && (ct < first_partial_ct(NCT) || kcol(NCT, ct, c) < K) && pk < best[ct];
           best[ct] = take ? pk : best[ct];
         }
       }
@@ -1844,6 +1896,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       if (tid == 0) atomicAdd(&ctl[8 + 8 * nbk + ((int)blockIdx.x & 7)], 1);
     }
     unsigned long long wq = 0, wg = 0, ww = 0, wd = 0, wm = 0, w1 = 0, w2 = 0, w3 = 0, w_prev = wall_clock64();   // diagnostics (workgroup 0, wave 0)
+    unsigned long long wv_busy = 0, wv_tiles = 0;    // per wave: table in LDS -> own work done (before the barrier), tiles owned
     auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - w_prev; w_prev = t; };
     for (int jj = 0; jj < nbk; jj++) {
       const unsigned tag = tag0 + (unsigned)jj;
@@ -1866,6 +1919,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       }
       __syncthreads();
       lap(wg);
+      const unsigned long long t_tab = w_prev;
       curq = -1;                            // the table changed: the penalty row of the first tile must be re-read
       od = 0.0; oe = 0.0;
       // geometry of the next block and the (cell, combination) pairs of this wave's first two tiles in it, requested now
@@ -1923,6 +1977,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       lap(ww);
+      wv_busy += w_prev - t_tab; wv_tiles += have ? (unsigned long long)((te - ts + tstep - 1) / tstep) : 0ull;
       // a BARE s_barrier: __syncthreads() is also a workgroup-scope fence, i.e. an s_waitcnt vmcnt(0) that would wait for the
       // R stores after all.  Nothing another wave of this workgroup reads is published here -- the barrier only says "every
       // wave's contribution atomics have been performed" (each wave waited for its own above).
@@ -1938,6 +1993,10 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     if (blockIdx.x == 0 && tid == 0 && D.chain_dbg) {
       atomicAdd(&D.chain_dbg[4], wq); atomicAdd(&D.chain_dbg[5], wg); atomicAdd(&D.chain_dbg[6], ww); atomicAdd(&D.chain_dbg[7], wd); atomicAdd(&D.chain_dbg[8], wm);
       atomicAdd(&D.chain_dbg[9], w1); atomicAdd(&D.chain_dbg[10], w2); atomicAdd(&D.chain_dbg[11], w3);
+    }
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && D.chain_dbg) {
+      const int o = (blockIdx.x == 0 ? 16 : 32) + (tid >> 6);
+      atomicAdd(&D.chain_dbg[o], wv_busy); atomicAdd(&D.chain_dbg[o + 8], wv_tiles);
     }
     return;
     }
@@ -2027,7 +2086,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       unsigned long long v = best[ct];
       unsigned long long o = shfl_xor_u64(v, 16); v = o < v ? o : v;
       o = shfl_xor_u64(v, 32); v = o < v ? o : v;
-      if (g == 0 && 16 * ct + c < K && v != ~0ull) atomicMin(&D.seedmin[16 * ct + c], v);
+      if (g == 0 && kcol(NCT, ct, c) < K && v != ~0ull) atomicMin(&D.seedmin[kcol(NCT, ct, c)], v);
     }
   } else {
     if (ts >= te) return;
@@ -2272,7 +2331,8 @@ __device__ __forceinline__ size_t yimg_index(const Dev& D, int j, int k) {
   int s_, p_;
   if (j < 16 * D.NT4) { const int t = j >> 4, r = j & 15; p_ = r >> 2; s_ = 4 * t + (r & 3); }
   else { const int r = j - 16 * D.NT4; s_ = 4 * D.NT4 + (r >> 2); p_ = r & 3; }
-  const int qd = k >> 6, i = (k & 63) >> 4, c = k & 15;
+  int qd, i, c;
+  kcol_inv(D.NCT, k, qd, i, c);
   return ((((size_t)qd * D.NS + s_) * 4 + p_) * 16 + c) * 4 + i;
 }
 // k_moe_solve: the K ridge systems of moe_correct_ridge_cpp ON THE DEVICE (src/harmony.cpp:358-611), fp64, one workgroup

@@ -256,6 +256,58 @@ def test_update_order_must_be_a_permutation(cell_lines_small):
 
 # ---------------------------------------------------------------- the sharded path through two PROCESSES
 @pytest.mark.timeout(600, method="thread")
+@pytest.mark.parametrize("cfg", ["C4", "C5"])
+def test_full_size_named_configs(cfg):
+    """BASELINE configs[3] (10M x 50, K=100, 20 batches) and configs[4] (5M x 50, K=200, 8/64/128 nested levels) at FULL size on one
+    GPU, to convergence, through the size-independent properties of the path (the oracle needs ~10 min per run there):
+    R columns are distributions; O is exactly the per-level sum of R (fixed-point accumulation carried through every block
+    update of every round == a direct sum over the final R); sum_k O[k,b] = N_b; E = rowsum(R) Pr_b^T; the objective went down;
+    Z_corr finite and moved."""
+    if cfg == "C4":
+        N, K, levels, nested = 10_000_000, 100, (20,), False
+    else:
+        N, K, levels, nested = 5_000_000, 200, (8, 64, 128), True
+    Z, meta, _ = synth(N, d=50, levels=levels, seed=5, nested=nested)
+    vars_use = list(meta)
+    skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=K)
+    g = Harmony(seed=2)
+    g.setup(**skw)
+    znorm = float(np.linalg.norm(Z[::1000]))
+    g.init_cluster_cpp()
+    it = 0
+    for it in range(1, 11):
+        assert g.cluster_cpp() == 0
+        g.moe_correct_ridge_cpp()
+        if g.check_convergence(1):
+            break
+    assert 2 <= it <= 10
+    assert g.cluster_cpp() == 0              # O, E and R of one more clustering pass: consistent with each other
+    oh = np.asarray(g.objective_harmony)
+    assert np.all(np.isfinite(oh)) and oh[-1] < oh[0]
+    R = g.get_matrix("R", np.float32)         # [K, N] column-major == cells x K row-major
+    assert R.shape == (K, N)
+    Rc = R.T                                  # contiguous rows, one per cell
+    assert Rc.flags["C_CONTIGUOUS"] and float(Rc.min()) >= 0.0
+    assert np.abs(Rc.sum(axis=1, dtype=np.float64) - 1).max() < 1e-5
+    O, E = g.O, g.E
+    off = 0
+    for v, L in zip(vars_use, levels):
+        lab = meta[v]
+        N_b = np.bincount(lab, minlength=L).astype(np.float64)
+        Ob = O[:, off:off + L]
+        np.testing.assert_allclose(Ob.sum(axis=0), N_b, rtol=1e-6, atol=1e-2)
+        if v == vars_use[0] or cfg == "C4":
+            Odirect = np.stack([Rc[lab == b].sum(axis=0, dtype=np.float64) for b in range(L)], axis=1)
+            np.testing.assert_allclose(Ob, Odirect, rtol=5e-6, atol=5e-3)
+        np.testing.assert_allclose(E[:, off:off + L], O[:, :levels[0]].sum(axis=1, keepdims=True) * (N_b / N)[None, :], rtol=2e-5, atol=1e-3)
+        off += L
+    del R, Rc
+    Zc = g.get_matrix("Z_corr", np.float32)
+    assert Zc.shape == (50, N) and np.all(np.isfinite(Zc))
+    moved = float(np.linalg.norm(Zc[:, ::1000].T.astype(np.float64) - Z[::1000])) / znorm
+    assert 0.01 < moved < 1.0, moved
+
+
 def test_two_processes_sharded_run():
     """Two processes (torch.distributed.run, world 2), one shard each, the whole RunHarmony with every accumulator all-reduced
     through the hook; both ranks share the box's single GPU, so the transport is gloo (RCCL refuses two ranks per device) --

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 | tee gpurun_out/c16_tests.log
+timeout 600 python bench.py --steps 5 --warmup 2 --cpu-sample 0 > gpurun_out/c16_bench.json 2> gpurun_out/c16_bench.err; echo rc=$?
+python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/c16_bench.json").read().strip().splitlines()[-1])
+print(j["ms_per_step"], j["config"]["harmony_iterations"], j["roofline"]["avg_block_step_us"])
+print(j["config"]["gpu_phase_ms_per_step"])
+print(j["config"]["chain_us_per_block_step"])
+PY
