@@ -1116,7 +1116,9 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     // wave of every SIMD (all workgroups) before the second ones, and each SIMD hosts one heavy and one light wave -- the
     // same tile count on every SIMD instead of 4 tiles on half the CUs and 2 on the others
     const int wpg = (int)blockDim.x >> 6, wib = (int)threadIdx.x >> 6, half = wpg >> 1, nwg = (int)gridDim.x - 1;
-    if (HMX_CHAIN_BALANCE && half >= 1) wave_ = (wib < half) ? (int)blockIdx.x * half + wib : nwg * half + (int)blockIdx.x * (wpg - half) + (wib - half);
+    // (second waves numbered workgroup-minor: the few SIMDs that must take a fourth tile are spread one per workgroup instead of
+    //  filling whole CUs -- a CU's store / atomic queues are shared by its SIMDs)
+    if (HMX_CHAIN_BALANCE && half >= 1) wave_ = (wib < half) ? (int)blockIdx.x * half + wib : nwg * half + (wib - half) * nwg + (int)blockIdx.x;
   }
   const int wave = __builtin_amdgcn_readfirstlane(wave_);
   auto stamp = [&](int slot) {  // diagnostics build only (-DHMX_TRACE, tools/trace_update.py): per-wave phase stamps
@@ -1300,8 +1302,29 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
         for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
           const int b = qlevT[q0 * C + cc];
+          const float* __restrict__ pr = penT + (size_t)b * K;
+          if (D.rvec) {
+            // a lane's clusters are consecutive (kcol): one 16-byte read per quad of cluster tiles, ALL reads of the level in
+            // flight before the first is used (one latency per level instead of one per cluster tile)
+            constexpr int NFULL = NCT >> 2, RT = NCT & 3;
+            f32x4 vq[NFULL > 0 ? NFULL : 1];
+            float vt[RT > 0 ? RT : 1];
 #pragma unroll
-          for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(penT, (size_t)b * K + min(kcol(NCT, ct, c), K - 1), kcol(NCT, ct, c) < K, 0.0f);
+            for (int q = 0; q < NFULL; q++) vq[q] = *reinterpret_cast<const f32x4*>(pr + min(64 * q + 4 * c, K - 4));
+#pragma unroll
+            for (int jj = 0; jj < RT; jj++) vt[jj] = pr[min(64 * NFULL + RT * c + jj, K - 1)];
+#pragma unroll
+            for (int q = 0; q < NFULL; q++) {
+              const bool ok = 4 * q < first_partial_ct(NCT) || 64 * q + 4 * c < K;
+#pragma unroll
+              for (int jj = 0; jj < 4; jj++) penv[4 * q + jj] += ok ? vq[q][jj] : 0.0f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < RT; jj++) penv[4 * NFULL + jj] += (64 * NFULL + RT * c + jj < K) ? vt[jj] : 0.0f;
+          } else {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) penv[ct] += ld_or(penT, (size_t)b * K + min(kcol(NCT, ct, c), K - 1), kcol(NCT, ct, c) < K, 0.0f);
+          }
         }
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) { lpen[ct] = __builtin_amdgcn_logf(fmaxf(penv[ct], FLT_MIN)); if constexpr (!USIG) clp[ct] = cl[ct] * lpen[ct]; }
@@ -1585,6 +1608,17 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       // ---------------- the folder: O' = O + new(block j-1) - old(block j), E, penalty table of block j (:312-322,:329-330)
       for (int i = tid; i < nBK; i += bd) ldsO[i] = D.O_fx[i];
       __syncthreads();
+      // cluster masses rs[k] = sum over the first covariate's levels of O[.,k] (E = rs Pr_b^T), kept up to date entry by entry in
+      // the fold instead of re-summed B0 times per entry in the publish step.  (The folder never reads the centroid image: its
+      // LDS region holds the masses.)
+      long long* const ldsRS = reinterpret_cast<long long*>(lds4);
+      for (int k = tid; k < K; k += bd) {
+        long long rs = 0;
+        for (int b0 = 0; b0 < D.B0; b0++) rs += ldsO[b0 * K + k];
+        ldsRS[k] = rs;
+      }
+      __syncthreads();
+      const int nRS = D.B0 * K;
       constexpr int FE = 4;
       unsigned long long tw = 0, tf = 0, tp = 0, t_prev = wall_clock64();   // diagnostics: wait / fold / publish time of the folder
       for (int jj = 0; jj <= nbk; jj++) {
@@ -1674,6 +1708,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
                     o += (long long)((hi[gq] << 32) | (lo[gq] & 0xffffffffull));
                   }
                 }
+                if (i < nRS && o != ldsO[i]) atomicAdd((unsigned long long*)&ldsRS[i % K], (unsigned long long)(o - ldsO[i]));
                 ldsO[i] = o;
                 if (jj == nbk) D.O_fx[i] = o;
               }
@@ -1692,6 +1727,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #pragma unroll
           for (int r = 0; r < 8; r++) o += (long long)a[r] - b8[r];
           if (jj < nbk && !D.chain_old) o -= soldv;
+          if (i < nRS && o != ldsO[i]) atomicAdd((unsigned long long*)&ldsRS[i % K], (unsigned long long)(o - ldsO[i]));
           ldsO[i] = o;
           if (jj == nbk) D.O_fx[i] = o;      // the round's final O (read by the kernels that follow this launch)
         };
@@ -1706,8 +1742,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         const unsigned long long tagbits = (unsigned long long)(tag0 + (unsigned)jj) << 32;
         for (int i = tid; i < nBK; i += bd) {      // same arithmetic as k_foldpen / the fused prologue: identical tables
           const int b = i / K, k = i - b * K;
-          long long rs = 0;
-          for (int b0 = 0; b0 < D.B0; b0++) rs += ldsO[b0 * K + k];
+          const long long rs = ldsRS[k];
           const float of = (float)((double)ldsO[i] * FX_INV);
           const float ef = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
           const float pv = pen_pow((2.0f * ef) + 1.0f, of + ef + 1.0f, D.theta[b]);
