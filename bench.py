@@ -197,10 +197,17 @@ def main():
                 t = torch.tensor([1 if flag else 0], device=dev if a.backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 return bool(t.item())
+            peers_ok = True
             if torch.cuda.device_count() < world:
                 os.environ["HMX_CHAIN_WGS"] = str(max(8, 240 // world))    # smoke tests: the ranks' chains share one GPU
+            else:                                     # every GPU of the job must be able to map every other's memory
+                peers_ok = all(g == local_rank or torch.cuda.can_device_access_peer(local_rank, g) for g in range(world))
+            handle = None
             try:
-                handle = obj.p2p_export()
+                if peers_ok:
+                    handle = obj.p2p_export()
+                else:
+                    p2p_note = "no peer access between the GPUs of this job"
             except Exception as e:                    # pragma: no cover
                 handle, p2p_note = None, "export failed: %s" % e
             handles = [None] * world
@@ -241,6 +248,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1 and obj._scalar("p2p"):
+        # one untimed run with the in-launch exchange before anything is measured: if any rank's chain timed out on its peers
+        # (every spin is bounded; the error surfaces at the objective read), EVERY rank goes back to per-block collectives
+        try:
+            run_to_convergence(obj)
+            fine = True
+        except Exception as e:                        # pragma: no cover
+            fine = False
+            print("rank %d: peer-to-peer chain failed (%s)" % (rank, e), file=sys.stderr)
+        t = torch.tensor([1 if fine else 0], device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if not bool(t.item()):                        # pragma: no cover
+            obj.p2p_enable(False)
+            comm_kind += " -- SWITCHED OFF after a failed trial run: one launch + one all-reduce per block"
     for _ in range(a.warmup):
         run_to_convergence(obj)
     obj.set_profile(True)  # HIP events around every launch of the dominant kernel, on the library's stream
