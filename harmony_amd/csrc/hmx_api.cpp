@@ -303,6 +303,17 @@ int flush_objectives(hmx_ctx* ctx) {
   if (ctx->obj_harmony_pending) { ctx->obj_harmony.push_back(ctx->obj_kmeans.back()); ctx->obj_harmony_pending = false; }
   return 0;
 }
+int objective_slot(hmx_ctx* ctx, double** slot) {     // next pinned host slot of the objective series (4 doubles)
+  if (!ctx->h_obj) {
+    ctx->obj_cap = 64;
+    HIPCHK(hipHostMalloc((void**)&ctx->h_obj, sizeof(double) * 4 * ctx->obj_cap, hipHostMallocDefault));
+    std::memset(ctx->h_obj, 0, sizeof(double) * 4 * ctx->obj_cap);
+    HIPCHK(hipEventCreateWithFlags(&ctx->obj_event, hipEventDisableTiming));
+  }
+  if (ctx->obj_pending == ctx->obj_cap) CHK(flush_objectives(ctx));
+  *slot = ctx->h_obj + 4 * ctx->obj_pending;
+  return 0;
+}
 int push_objective(hmx_ctx* ctx) {
   if (!ctx->h_obj) {
     ctx->obj_cap = 64;
@@ -664,10 +675,20 @@ int update_R(hmx_ctx* ctx) {
     l_update(ctx->L, D, j); KCHK();
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
   }
-  l_obj_reduce(ctx->L, D); KCHK();
-  CHK(allreduce(ctx, D.obj, 2, 1));
-  l_objective_tables(ctx->L, D); KCHK();
-  CHK(push_objective(ctx));  // asynchronous: resolved by flush_objectives when a value is needed
+  if (!sharded) {
+    // one launch: slot rows -> objective terms -> snapshot written STRAIGHT into the pinned host slot (no copy engine, no
+    // second launch), chain control reset.  Resolved by flush_objectives (event) when a value is needed.
+    double* slot = nullptr;
+    CHK(objective_slot(ctx, &slot));
+    l_round_tail(ctx->L, D, slot); KCHK();
+    HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
+    ctx->obj_pending++;
+  } else {
+    l_obj_reduce(ctx->L, D); KCHK();
+    CHK(allreduce(ctx, D.obj, 2, 1));
+    l_objective_tables(ctx->L, D); KCHK();
+    CHK(push_objective(ctx));  // asynchronous: resolved by flush_objectives when a value is needed
+  }
   if (ctx->profile) { ctx->prof_update_cells += ctx->N; }   // the event pairs are resolved when a "prof:*" field is read
   ctx->timers["update_R"] += now_ms() - t0;
   return 0;
@@ -1385,6 +1406,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     const bool chain_fits = (e && std::string(e) == "1") || tiles_per_wave <= 6.0;
     ctx->chain_ok = !(e && std::string(e) == "0") && chain_fits && ctx->fused_ok && cus >= 8 && D.NCT <= 7 && D.NT4 <= 4 && D.nb <= 64 &&
                     (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024;
+    CHK(dalloc(ctx, &D.tail_ticket, (size_t)1)); HIPCHK(hipMemsetAsync(D.tail_ticket, 0, sizeof(int), ctx->L.stream));
     CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)48));
     CHK(dalloc(ctx, &D.Sold_rep, (size_t)D.nrep * D.nb * B * K));
     HIPCHK(hipMemsetAsync(D.chain_dbg, 0, sizeof(unsigned long long) * 48, ctx->L.stream));

@@ -3189,6 +3189,74 @@ void l_penalty(const Launch& L, const Dev& D) {
   const int n = D.B * D.K;
   hipLaunchKernelGGL(k_penalty, dim3((n + 255) / 256), dim3(256), 0, L.stream, D);
 }
+// One GPU: the three kernels that close a clustering round (slot rows -> obj[0..1] -> cross-entropy term, snapshot, chain control
+// reset) as ONE launch: every workgroup reduces its slot row, the last one to finish (ticket) does the rest.  Same fixed-order sums.
+__global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__ host_slot) {
+  __shared__ double ra[1024], rb[1024];
+  __shared__ int last;
+  const int tid = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  double* row = D.objpart + (size_t)blockIdx.x * D.nwmax * 2;
+  for (int i = tid; i < D.nwmax; i += 1024) { a += row[2 * i]; b += row[2 * i + 1]; row[2 * i] = 0.0; row[2 * i + 1] = 0.0; }
+  ra[tid] = a; rb[tid] = b;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (tid < off) { ra[tid] += ra[tid + off]; rb[tid] += rb[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    D.objrow[2 * blockIdx.x] = ra[0]; D.objrow[2 * blockIdx.x + 1] = rb[0];
+    __threadfence();
+    last = (atomicAdd(D.tail_ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int K = D.K, B = D.B;
+  double cross = 0.0;
+  for (int k = tid; k < K; k += 1024) {      // (same arithmetic as k_objective_tables)
+    long long rs = 0;
+    for (int b0 = 0; b0 < D.B0; b0++) rs += D.O_fx[(size_t)b0 * K + k];
+    const double rsd = (double)rs * FX_INV;
+    double ck = 0.0;
+    for (int bb = 0; bb < B; bb++) {
+      const double od = (double)D.O_fx[(size_t)bb * K + k] * FX_INV;
+      const float o = (float)od, e = (float)(rsd * (double)D.Pr_b[bb]);
+      const float m = D.theta[bb] * logf((o + e + 1.0f) / ((2.0f * e) + 1.0f));
+      ck += od * (double)m;
+    }
+    cross += ck * (double)D.sigma[k];
+  }
+  __syncthreads();
+  ra[tid] = cross;
+  __syncthreads();
+  // (K <= 256: every thread holds at most one cluster, the entries from 256 on are zero -- the same pairwise tree as
+  //  k_objective_tables' 256-entry one, preceded by two levels that add zeros: identical bits)
+  for (int off = 512; off > 0; off >>= 1) {
+    if (tid < off) ra[tid] += ra[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int sl = 0; sl < D.objslots; sl++) { sa += D.objrow[2 * sl]; sb += D.objrow[2 * sl + 1]; }
+    D.obj[0] = sa; D.obj[1] = sb;
+    D.obj[2] = sa; D.obj[3] = sb; D.obj[4] = ra[0];
+    const double err = D.chain_ctl ? (double)D.chain_ctl[1] : 0.0;
+    D.obj[5] = err;
+    if (host_slot) {     // pinned host memory, mapped into the device: visible to the host once the event behind this launch completed
+      __hip_atomic_store(&host_slot[0], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&host_slot[1], sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&host_slot[2], ra[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&host_slot[3], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    *D.tail_ticket = 0;
+  }
+  __syncthreads();
+  if (D.chain_ctl) for (int i = tid; i < 8 * D.nb + 24; i += 1024) D.chain_ctl[i] = 0;
+}
+void l_round_tail(const Launch& L, const Dev& D, double* host_slot) {
+  hipLaunchKernelGGL(k_round_tail, dim3(D.objslots), dim3(1024), 0, L.stream, D, host_slot);
+}
 void l_obj_reduce(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_obj_reduce, dim3(D.objslots), dim3(1024), 0, L.stream, D);
   hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(1), 0, L.stream, D);
