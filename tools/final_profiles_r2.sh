@@ -16,5 +16,9 @@ cp $O/stats/b_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null; rm -rf $O/stats
 cd /tmp
 timeout 400 python $R/bench.py --cpu-sample 0 --cells-per-gpu 10000000 --batches 20 --steps 3 > $O/bench_10M.json 2> $O/bench_10M.err
 timeout 400 python $R/bench.py --cpu-sample 0 --workload c5 --cells-per-gpu 1000000 --steps 3 > $O/bench_c5_1M.json 2> $O/bench_c5_1M.err
+timeout 600 python $R/bench.py --cpu-sample 0 --workload c5 --cells-per-gpu 5000000 --steps 2 --warmup 1 --no-e2e > $O/bench_c5_5M.json 2> $O/bench_c5_5M.err
+# two ranks sharing this box's one GPU (gloo for the remaining collectives): the in-launch exchange of the block chain vs one all-reduce per block
+timeout 600 python $R/bench.py --gpus 2 --backend gloo --cells-per-gpu 500000 --steps 3 --warmup 1 --no-e2e > $O/bench_2ranks_p2p.json 2> $O/bench_2ranks_p2p.err
+HMX_BENCH_P2P=0 timeout 600 python $R/bench.py --gpus 2 --backend gloo --cells-per-gpu 500000 --steps 3 --warmup 1 --no-e2e > $O/bench_2ranks_allreduce.json 2> $O/bench_2ranks_allreduce.err
 cd $R
 tail -1 $O/bench_default.json | cut -c1-300; tail -1 $O/bench_10M.json | cut -c1-200; tail -1 $O/bench_c5_1M.json | cut -c1-200; head -12 $O/kernel_stats.csv | cut -c1-120; cat $O/pmc_fetch.txt $O/pmc_write.txt $O/pmc_sq.txt $O/pmc_sq2.txt | cut -c1-600; tail -3 $O/bench_c5_1M.err $O/bench_10M.err

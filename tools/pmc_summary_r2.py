@@ -37,7 +37,8 @@ json.dump({"workload": {"cells_per_gpu": 1000000, "pcs": 50, "clusters": 100, "b
            "source": "profiles/r2_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs); separate --pmc passes)"},
           open(os.path.join(P, "pmc_traffic_update_kernel.json"), "w"), indent=1)
 for src, dst in [("kernel_stats.csv", "r2_kernel_stats.csv"), ("bench_rocprof.json", "r2_bench_rocprof.json"), ("bench_default.json", "r2_bench_default.json"),
-                 ("bench_10M.json", "r2_bench_10M_one_gpu.json"), ("bench_c5_1M.json", "r2_bench_c5_1M.json")]:
+                 ("bench_10M.json", "r2_bench_10M_one_gpu.json"), ("bench_c5_1M.json", "r2_bench_c5_1M.json"), ("bench_c5_5M.json", "r2_bench_c5_5M.json"),
+                 ("bench_2ranks_p2p.json", "r2_bench_2ranks_one_gpu_p2p_chain.json"), ("bench_2ranks_allreduce.json", "r2_bench_2ranks_one_gpu_allreduce_per_block.json")]:
     if os.path.exists(os.path.join(R, src)): shutil.copy(os.path.join(R, src), os.path.join(P, dst))
 for k, v in summ["kernels"].items():
     print(k, {x: (round(y, 3) if isinstance(y, float) else y) for x, y in v.items() if x in ("avg_duration_us", "hbm_GBps", "mfma_busy_frac", "hbm_total_bytes")})
