@@ -329,8 +329,13 @@ int push_objective(hmx_ctx* ctx) {
 }
 
 // R, O, E from scratch (src/harmony.cpp:141-150, :221-227); leaves objective partials in obj[0..1]
-int head_pass(hmx_ctx* ctx) {
-  const Dev& D = ctx->D;
+int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- normalise(Z_corr) first (:220)
+  Dev D = ctx->D;
+  const bool tiles = D.tile_impl && (size_t)D.NQ * D.NS * 1024 <= 160 * 1024;
+  // the register-pipelined head (two accumulator sets, rows of a tile in registers) normalises the rows it has loaded anyway
+  const bool fused_norm = normalise && tiles && D.NT4 <= 4 && D.NCT <= 7 && D.upd_wps != 4 && !getenv("HMX_HEAD_NORM_SPLIT");
+  if (normalise && !fused_norm) { l_normalize(ctx->L, D.Zc, D.n, D.d, D.zs); KCHK(); }
+  D.head_norm = fused_norm ? 1 : 0;
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
@@ -1500,8 +1505,7 @@ int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
   CHK(flush_objectives(ctx));   // (values of an earlier call that nobody asked for yet)
   if (ctx->obj_harmony.size() != 1) {  // :214-228
     PhaseScope ph(ctx, "cluster_head");
-    l_normalize(ctx->L, ctx->D.Zc, ctx->D.n, ctx->D.d, ctx->D.zs); KCHK();
-    CHK(head_pass(ctx));
+    CHK(head_pass(ctx, true));
   }
   int iter;
   for (iter = 0; iter < ctx->max_iter_kmeans; iter++) {

@@ -74,6 +74,7 @@ struct Dev {
   int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
   long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int* tail_ticket;            // k_round_tail: workgroups done (the last one finishes the round's objective)
+  int head_norm;               // k_tile MODE 1: normalise the tile's Z_corr rows in registers and write them back (fused head of cluster_cpp)
   int rvec;                    // K % 4 == 0: R rows are 16-byte aligned, the tile kernels store them with vector stores
   int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)
   // peer-to-peer block chain (sharded runs, one process per GPU on a node): p2p_inbox[g] = rank g's inbox as mapped into THIS

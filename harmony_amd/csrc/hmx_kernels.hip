@@ -2050,14 +2050,41 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     }
   } else if (pre) {
     // two accumulator sets: the MFMAs of tile i+1 are issued before the (VALU / transcendental / store) epilogue of tile i
+    // Head of cluster_cpp (MODE 1, D.head_norm): Z_corr <- normalise(Z_corr) (src/harmony.cpp:220) happens HERE, on the A-operand
+    // registers of the tile -- the four lanes that hold a cell's row (k-slots 0..3) add up their squares, scale, and write the
+    // normalised pieces back where they came from: no separate pass over Z_corr (it was 67 us of 256 per head at 1M cells).
+    auto norm_rows = [&](RowRegs& r, const int cell) __attribute__((always_inline)) {
+      float ss = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; t++) if (t < D.NT4) ss += r.v[t][0] * r.v[t][0] + r.v[t][1] * r.v[t][1] + r.v[t][2] * r.v[t][2] + r.v[t][3] * r.v[t][3];
+#pragma unroll
+      for (int u = 0; u < 3; u++) if (u < D.tail) ss += r.t[u] * r.t[u];
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      float nrm = sqrtf(ss);
+      nrm = (nrm == 0.0f) ? 1.0f : nrm;            // arma::normalise leaves a zero column alone
+      const float inv = 1.0f / nrm;
+      float* zrow = D.Zc + (size_t)(cell >= 0 ? cell : 0) * zs;
+#pragma unroll
+      for (int t = 0; t < 4; t++) if (t < D.NT4) {
+        r.v[t] = r.v[t] * inv;
+        if (cell >= 0) *reinterpret_cast<f32x4*>(zrow + 16 * t + 4 * g) = r.v[t];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++) if (u < D.tail) {
+        r.t[u] *= inv;
+        if (cell >= 0) zrow[16 * D.NT4 + 4 * u + g] = r.t[u];
+      }
+    };
     if (ts < te) {
       f32x4 accC[NCT];
       int2 cellC = cellN;
       {
-        const RowRegs rowsA = rowsN;
+        RowRegs rowsA = rowsN;
         cellN = cellNN;
         cellNN = tile_cell(ts + 2 * tstep);
         load_rows(next_rows(cellN, cellC), g, D.NT4, D.tail, rowsN);
+        if constexpr (MODE == 1) { if (D.head_norm) norm_rows(rowsA, cellC.x); }
         tile_dots_regs<NCT>(lds4, rowsA, cellC.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
       }
       stamp(3);
@@ -2068,10 +2095,11 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       for (int tile = ts + tstep; tile < te; tile += tstep) {
         stamp(8);
         const int2 cellT = cellN;
-        const RowRegs rowsA = rowsN;
+        RowRegs rowsA = rowsN;
         cellN = cellNN;
         cellNN = tile_cell(tile + 2 * tstep);
         load_rows(next_rows(cellN, cellT), g, D.NT4, D.tail, rowsN);
+        if constexpr (MODE == 1) { if (D.head_norm) norm_rows(rowsA, cellT.x); }
         stamp(9);
         f32x4 accT[NCT];
 #ifdef HMX_TRACE
@@ -3205,13 +3233,16 @@ __global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__
     __syncthreads();
   }
   if (tid == 0) {
-    D.objrow[2 * blockIdx.x] = ra[0]; D.objrow[2 * blockIdx.x + 1] = rb[0];
-    __threadfence();
+    // No fences: an agent-scope release here would write back everything the round left dirty in this XCD's L2 (tens of MB of R
+    // rows).  The two sums go out as write-through device-scope stores, the ticket follows once they are acknowledged, and the
+    // last workgroup reads them with device-scope loads (the scheme of the block chain).
+    __hip_atomic_store(&D.objrow[2 * blockIdx.x], ra[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&D.objrow[2 * blockIdx.x + 1], rb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     last = (atomicAdd(D.tail_ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();
   const int K = D.K, B = D.B;
   double cross = 0.0;
   for (int k = tid; k < K; k += 1024) {      // (same arithmetic as k_objective_tables)
@@ -3238,7 +3269,10 @@ __global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__
   }
   if (tid == 0) {
     double sa = 0.0, sb = 0.0;
-    for (int sl = 0; sl < D.objslots; sl++) { sa += D.objrow[2 * sl]; sb += D.objrow[2 * sl + 1]; }
+    for (int sl = 0; sl < D.objslots; sl++) {
+      sa += __hip_atomic_load(&D.objrow[2 * sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sb += __hip_atomic_load(&D.objrow[2 * sl + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     D.obj[0] = sa; D.obj[1] = sb;
     D.obj[2] = sa; D.obj[3] = sb; D.obj[4] = ra[0];
     const double err = D.chain_ctl ? (double)D.chain_ctl[1] : 0.0;
