@@ -144,6 +144,7 @@ struct hmx_ctx {
   // profiling of the dominant kernel
   bool profile = false;
   bool fused_ok = false;       // k_tile prologue fold usable (LDS budget) and not disabled
+  bool sold_clean = false;     // Sold_fx + the Snew sets are all zero (left so by k_round_tail)
   bool chain_ok = false; int chain_wgs = 0; uint64_t chain_rounds = 0;   // persistent block chain (one launch per round)
   int tun_impl = -1, tun_tpw = -1, tun_cpw = -1, tun_wps = -1;  // tunables set through hmx_set_int before setup
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
@@ -598,7 +599,9 @@ int update_R(hmx_ctx* ctx) {
       HIPCHK(hipMemsetAsync(D.Sold_rep, 0, sizeof(long long) * (size_t)D.nrep * D.nb * D.B * D.K, ctx->L.stream));
       HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
     } else {           // all blocks in one pass over R
-      HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
+      if (!ctx->sold_clean)   // (k_round_tail of the previous round left them zero)
+        HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
+      ctx->sold_clean = false;
       l_oldsum(ctx->L, D); KCHK();
       CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0)); } }
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
@@ -686,6 +689,7 @@ int update_R(hmx_ctx* ctx) {
     double* slot = nullptr;
     CHK(objective_slot(ctx, &slot));
     l_round_tail(ctx->L, D, slot); KCHK();
+    ctx->sold_clean = !chain_old;
     HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
     ctx->obj_pending++;
   } else {
@@ -1425,7 +1429,10 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
       if (D.chain_wps >= 3 && (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 + (size_t)16 * (D.NT4 + D.tail + 1) * 1024 > 158 * 1024) D.chain_wps = 2; }
     // the folder reads AND resets every replica of the contribution table inside a block step (atomic exchanges on its critical
     // path): 4 replicas measured 0.4 us per step faster than 8 there (2: the workers' atomics start to queue, +2 us)
-    if (ctx->chain_ok && !getenv("HMX_NREP") && D.nrep > 4) D.nrep = 4;
+    if (ctx->chain_ok && !getenv("HMX_NREP") && D.nrep > 4) {
+      D.nrep = 4;
+      for (int i = 0; i < 3; i++) D.Snew_set[i] = D.Sold_fx + (size_t)D.nb * B * K + (size_t)i * D.nrep * B * K;   // keep [Sold | sets] contiguous
+    }
     ctx->chain_rounds = 0;
     D.p2p_world = 0; D.p2p_rank = ctx->p2p_rank;
     for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g]; }
@@ -1437,8 +1444,8 @@ int hmx_restart(hmx_ctx* ctx) {
   if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   const Dev& D = ctx->D;
-  l_copy(ctx->L, D.Zo, D.Zc, (size_t)D.n * D.zs); KCHK();
-  l_normalize(ctx->L, D.Zc, D.n, D.d, D.zs); KCHK();  // Z_corr = normalise(Z_orig) :42
+  l_normalize_from(ctx->L, D.Zo, D.Zc, D.n, D.d, D.zs); KCHK();  // Z_corr = normalise(Z_orig) :42 (one pass)
+  ctx->sold_clean = false;
   HIPCHK(hipStreamSynchronize(ctx->L.stream));
   ctx->obj_pending = 0; ctx->obj_harmony_pending = false;
   ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();

@@ -161,6 +161,7 @@ void l_convert_in(const Launch& L, const void* src, int f32, float* dst, const i
 void l_convert_out(const Launch& L, const float* src, void* dst, int f32, const int* invperm, int n, int w, int ws);
 void l_copy(const Launch& L, const float* src, float* dst, size_t count);
 void l_normalize(const Launch& L, float* Z, int n, int d, int zs);
+void l_normalize_from(const Launch& L, const float* src, float* dst, int n, int d, int zs);
 // mode 0: head (write R, accumulate O_fx, objective partials); mode 1: objective only (read R)
 void l_head(const Launch& L, const Dev& D, int mode);
 void l_tile_static(const Launch& L, const Dev& D, int mode);

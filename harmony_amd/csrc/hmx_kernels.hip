@@ -809,7 +809,7 @@ __device__ __forceinline__ float rowsum16(float v) {
 // arma::normalise(Z, 2, 0) with 16-byte accesses: 16 lanes per row (lane c: float4 c [and c + 16]), four rows per wave instruction, four
 // instructions in flight; the row's sum of squares is a 16-lane DPP reduction.  Rows are zero beyond d (zs = d rounded up to 4).
 template <int NF>
-__global__ __launch_bounds__(TPB) void k_normalize4(float* __restrict__ Z, int n, int nq) {
+__global__ __launch_bounds__(TPB) void k_normalize4(const float* Zsrc, float* Z, int n, int nq) {   // Zsrc == Z: in place
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(TPB) void k_normalize4(float* __restrict__ Z, int n
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const long long cell = min(base + 4 * u + g, (long long)n - 1);
-      const f32x4* row = reinterpret_cast<const f32x4*>(Z) + cell * nq;
+      const f32x4* row = reinterpret_cast<const f32x4*>(Zsrc) + cell * nq;
 #pragma unroll
       for (int f = 0; f < NF; f++) v[u][f] = row[min(c + 16 * f, nq - 1)];
     }
@@ -3124,9 +3124,16 @@ void l_copy(const Launch& L, const float* src, float* dst, size_t count) {
 }
 void l_normalize(const Launch& L, float* Z, int n, int d, int zs) {
   const int nq = zs / 4;
-  if (nq <= 16) hipLaunchKernelGGL(k_normalize4<1>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, Z, n, nq);
-  else if (nq <= 32) hipLaunchKernelGGL(k_normalize4<2>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, Z, n, nq);
+  if (nq <= 16) hipLaunchKernelGGL(k_normalize4<1>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, Z, Z, n, nq);
+  else if (nq <= 32) hipLaunchKernelGGL(k_normalize4<2>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, Z, Z, n, nq);
   else hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, Z, n, d, zs);
+}
+// dst = normalise(src) in one pass (restart: Z_corr = normalise(Z_orig), src/harmony.cpp:42)
+void l_normalize_from(const Launch& L, const float* src, float* dst, int n, int d, int zs) {
+  const int nq = zs / 4;
+  if (nq <= 16) hipLaunchKernelGGL(k_normalize4<1>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, src, dst, n, nq);
+  else if (nq <= 32) hipLaunchKernelGGL(k_normalize4<2>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, src, dst, n, nq);
+  else { l_copy(L, src, dst, (size_t)n * zs); hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, dst, n, d, zs); }
 }
 // MFMA tile passes over the static 16-cell tiles: mode 1 = head, mode 2 = Lloyd, mode 3 = seeding race
 void l_tile_static(const Launch& L, const Dev& D, int mode) {
@@ -3223,6 +3230,10 @@ __global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__
   __shared__ double ra[1024], rb[1024];
   __shared__ int last;
   const int tid = threadIdx.x;
+  {  // the old-contribution tables and the replica sets of the NEXT round start from zero: cleared here instead of by a memset launch
+    const size_t nz = ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K;
+    for (size_t i = (size_t)blockIdx.x * 1024 + tid; i < nz; i += (size_t)gridDim.x * 1024) D.Sold_fx[i] = 0;
+  }
   double a = 0.0, b = 0.0;
   double* row = D.objpart + (size_t)blockIdx.x * D.nwmax * 2;
   for (int i = tid; i < D.nwmax; i += 1024) { a += row[2 * i]; b += row[2 * i + 1]; row[2 * i] = 0.0; row[2 * i + 1] = 0.0; }
