@@ -1956,7 +1956,8 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       lap(wg);
       const unsigned long long t_tab = w_prev;
       curq = -1;                            // the table changed: the penalty row of the first tile must be re-read
-      od = 0.0; oe = 0.0;
+      // (od / oe: this wave's objective partial sums run through ALL blocks of the round in registers, one wave reduction and one
+      //  slot store at the end of the launch instead of two 6-step 64-bit reductions per block on the critical path)
       // geometry of the next block and the (cell, combination) pairs of this wave's first two tiles in it, requested now
       const bool more = jj + 1 < nbk;
       int p0n = 0, ten = 0; bool haveN = false;
@@ -1997,11 +1998,6 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         epi_begin(tile_q(cellC));
         epi_rows(cellC.x, accC, std::true_type{});
         lap(w2);
-        od = wsumd(od); oe = wsumd(oe);
-        if (lane == 0) {
-          double* slot = D.objpart + ((size_t)(jj % D.objslots) * D.nwmax + wave) * 2;
-          if (D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; } else { slot[0] += od; slot[1] += oe; }
-        }
         if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
         store_rows(cellC.x, accC);
         lap(w3);
@@ -2024,6 +2020,11 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       if (have) first_tile();                           // off the critical path: overlaps the folder's work
       if (D.chain_old && jj + 2 < nbk) old_block(jj + 2);
       lap(wm);
+    }
+    od = wsumd(od); oe = wsumd(oe);
+    if (lane == 0) {                        // slot row 0 (the other rows stay zero: k_round_tail sums and clears all of them)
+      double* slot = D.objpart + (size_t)wave * 2;
+      slot[0] += od; slot[1] += oe;
     }
     if (blockIdx.x == 0 && tid == 0 && D.chain_dbg) {
       atomicAdd(&D.chain_dbg[4], wq); atomicAdd(&D.chain_dbg[5], wg); atomicAdd(&D.chain_dbg[6], ww); atomicAdd(&D.chain_dbg[7], wd); atomicAdd(&D.chain_dbg[8], wm);
