@@ -43,6 +43,7 @@ SIGNATURES = {
     "hmx_mt19937_by_array": (None, [C.POINTER(C.c_uint32), C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),
     "hmx_feistel_pos": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "hmx_u01": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint64]),
+    "hmx_cluster_of_column": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "hmx_push_update_order": (C.c_int, [C.c_void_p, _lp]),
     "hmx_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "hmx_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

@@ -905,6 +905,12 @@ uint64_t hmx_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g) 
   } while (x >= N);
   return x;
 }
+int32_t hmx_cluster_of_column(int32_t nct, int32_t ct, int32_t c) {
+  if (nct < 1 || nct > 16 || ct < 0 || ct >= nct || c < 0 || c > 15) return -1;
+  const int k = kcol(nct, ct, c);
+  int qd, i, cc; kcol_inv(nct, k, qd, i, cc);        // (the image builders use the inverse: both must agree)
+  return (4 * qd + i == ct && cc == c) ? k : -2;
+}
 float hmx_u01(uint64_t seed, uint64_t stream, uint64_t idx) {
   const uint64_t h = h_splitmix64(h_splitmix64(seed ^ (stream * 0xD1342543DE82EF95ull)) + idx);
   return ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);

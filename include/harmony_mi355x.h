@@ -160,6 +160,9 @@ void hmx_r_runif(uint32_t seed, int32_t n, double* out);            /* set.seed(
 void hmx_r_shuffle(uint32_t seed, int64_t N, int64_t* out);         /* set.seed(seed); arma::shuffle(0..N-1)         */
 void hmx_mt19937_by_array(const uint32_t* key, int32_t len, int32_t n, uint32_t* out);  /* MT19937 known-answer vector */
 float hmx_u01(uint64_t seed, uint64_t stream, uint64_t idx);
+/* probe (host only): which cluster MFMA column c of cluster tile ct holds when a launch uses nct cluster tiles (the tile kernels
+ * deal a lane consecutive clusters so that its R values are adjacent in memory) */
+int32_t hmx_cluster_of_column(int32_t nct, int32_t ct, int32_t c);
 int hmx_push_update_order(hmx_ctx* ctx, const int64_t* update_order);
 
 /* ---- multi-GPU: one handle per process/GPU, cells sharded contiguously --------------------

@@ -147,3 +147,23 @@ def test_plain_c_host_links_and_fails_loudly_without_gpu(tmp_path):
         pytest.skip("GPU present: the example would run to completion (covered by the gpu tests)")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120, stdin=subprocess.DEVNULL)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr, (r.stdout, r.stderr)
+
+
+def test_cluster_to_column_mapping_is_a_bijection():
+    """kcol (hmx_internal.h): for every instantiated cluster-tile count the 16 x nct MFMA columns hold each cluster index exactly
+    once, a lane's columns ascend with the tile index (arg-min ties -> smallest k), the four columns of a full quad of tiles are
+    four CONSECUTIVE clusters (16-byte R stores) and the r = nct % 4 remaining tiles r consecutive ones; inverse and forward map agree."""
+    lib = _lib.load()
+    for nct in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16):
+        seen = set()
+        for c in range(16):
+            ks = [lib.hmx_cluster_of_column(nct, ct, c) for ct in range(nct)]
+            assert all(k >= 0 for k in ks), (nct, c, ks)
+            assert ks == sorted(ks)
+            nfull, r = nct // 4, nct % 4
+            for q in range(nfull):
+                assert ks[4 * q:4 * q + 4] == [64 * q + 4 * c + j for j in range(4)]
+            assert ks[4 * nfull:] == [64 * nfull + r * c + j for j in range(r)]
+            seen.update(ks)
+        assert seen == set(range(16 * nct))
+    assert lib.hmx_cluster_of_column(7, 7, 0) == -1 and lib.hmx_cluster_of_column(0, 0, 0) == -1
