@@ -144,7 +144,13 @@ struct hmx_ctx {
   // profiling of the dominant kernel
   bool profile = false;
   bool fused_ok = false;       // k_tile prologue fold usable (LDS budget) and not disabled
-  bool sold_clean = false;     // Sold_fx + the Snew sets are all zero (left so by k_round_tail)
+  // Old-contribution tables: two buffers.  `cur` is what this round's block steps subtract; the other one collects, inside this
+  // round's tile kernels, the old contributions of the NEXT round's blocks (carry_ok: the shuffle keys every tile by its cells'
+  // next block) -- then the next round needs no pass over R (k_oldsum).  state: 0 all zero, 1 unknown contents, 2 carried for round sold_round.
+  long long* sold_buf[2] = {nullptr, nullptr}; int sold_cur = 0, sold_state[2] = {1, 1}; int64_t sold_round[2] = {-1, -1}; uint64_t sold_seed[2] = {0, 0};
+  bool sets_clean = false;     // the three Snew replica sets are all zero
+  bool carry_ok = false, last_round_hint = false; bool sorted_nxt[2] = {false, false};
+  int64_t carried_rounds = 0;
   bool chain_ok = false; int chain_wgs = 0; uint64_t chain_rounds = 0;   // persistent block chain (one launch per round)
   int tun_impl = -1, tun_tpw = -1, tun_cpw = -1, tun_wps = -1;  // tunables set through hmx_set_int before setup
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
@@ -157,7 +163,7 @@ struct hmx_ctx {
   // The round's shuffle (counting sort by block) touches no algorithmic state, and with the counter-based generator it depends
   // on (seed, round) only: the sort of round r+1 runs on a SIDE stream while round r's old-sum pass streams on the main one,
   // into the second of two buffer sets.
-  struct SortSet { int* blk; int* lorder; int2* lpair; int* lcombo; int* boff; int* binoff; int* counts; int* offs; };
+  struct SortSet { int* blk; int* lorder; int2* lpair; int* lcombo; int* boff; int* binoff; int* counts; int* offs; int* blkv; };
   SortSet sets[2] = {}; hipStream_t side = nullptr; hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   int64_t sorted_round[2] = {-1, -1}; uint64_t sorted_seed[2] = {0, 0}; bool sorted_on_side[2] = {false, false}; bool sort_overlap = true;
   std::string err, warn, warn_ret;
@@ -337,6 +343,7 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   const bool fused_norm = normalise && tiles && D.NT4 <= 4 && D.NCT <= 7 && D.upd_wps != 4 && !getenv("HMX_HEAD_NORM_SPLIT");
   if (normalise && !fused_norm) { l_normalize(ctx->L, D.Zc, D.n, D.d, D.zs); KCHK(); }
   D.head_norm = fused_norm ? 1 : 0;
+  for (int i = 0; i < 2; i++) if (ctx->sold_state[i] == 2) ctx->sold_state[i] = 1;     // R is rewritten: carried old contributions are void
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
@@ -528,7 +535,7 @@ int kmeans_centers(hmx_ctx* ctx) {
 // counting sort.  Touches no algorithmic state (only blk / lorder / lcombo / lpair / boff).  (Enqueuing it speculatively
 // for the NEXT round before the host waits for this round's objective was measured: no gain, 26.1 vs 25.9 ms per step.)
 void apply_set(Dev& D, const hmx_ctx::SortSet& s) {
-  D.blk = s.blk; D.lorder = s.lorder; D.lpair = s.lpair; D.lcombo = s.lcombo; D.boff = s.boff; D.binoff = s.binoff; D.counts = s.counts; D.offs = s.offs;
+  D.blk = s.blk; D.lorder = s.lorder; D.lpair = s.lpair; D.lcombo = s.lcombo; D.boff = s.boff; D.binoff = s.binoff; D.counts = s.counts; D.offs = s.offs; D.blkv = s.blkv;
 }
 int prepare_round(hmx_ctx* ctx, uint64_t round) {
   Dev& D = ctx->D;
@@ -546,10 +553,11 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
     HIPCHK(hipEventRecord(ctx->ev_free[t], ctx->L.stream));
     HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_free[t], 0));
     Dev Dt = D; apply_set(Dt, ctx->sets[t]);
+    Dt.nxt = ctx->carry_ok ? 1 : 0;
     Launch L2 = ctx->L; L2.stream = ctx->side;
     l_sort_blocks(L2, Dt, true, ctx->seed, round + 1, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
     HIPCHK(hipEventRecord(ctx->ev_sorted[t], ctx->side));
-    ctx->sorted_round[t] = (int64_t)round + 1; ctx->sorted_seed[t] = ctx->seed; ctx->sorted_on_side[t] = true;
+    ctx->sorted_round[t] = (int64_t)round + 1; ctx->sorted_seed[t] = ctx->seed; ctx->sorted_on_side[t] = true; ctx->sorted_nxt[t] = Dt.nxt != 0;
     return 0;
   };
   if (have) return prefetch_next();
@@ -573,7 +581,9 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
     }
     CHK(h2d(ctx, D.blk, pos_blk.data(), pos_blk.size()));
   } else gen_blocks = true;   // block ids from the Feistel bijection, computed inside the sort's histogram kernel
+  D.nxt = (gen_blocks && ctx->carry_ok) ? 1 : 0;
   l_sort_blocks(ctx->L, D, gen_blocks, ctx->seed, round, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
+  ctx->sorted_nxt[sset] = D.nxt != 0;
   if (gen_blocks) { ctx->sorted_round[sset] = (int64_t)round; ctx->sorted_seed[sset] = ctx->seed; }
   return prefetch_next();
 }
@@ -598,12 +608,31 @@ int update_R(hmx_ctx* ctx) {
     if (chain_old) {   // gathered inside the persistent chain, two blocks ahead of their use: only the replica tables are reset here
       HIPCHK(hipMemsetAsync(D.Sold_rep, 0, sizeof(long long) * (size_t)D.nrep * D.nb * D.B * D.K, ctx->L.stream));
       HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
-    } else {           // all blocks in one pass over R
-      if (!ctx->sold_clean)   // (k_round_tail of the previous round left them zero)
-        HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K, ctx->L.stream));   // + Snew_set[0..2]
-      ctx->sold_clean = false;
-      l_oldsum(ctx->L, D); KCHK();
-      CHK(allreduce(ctx, D.Sold_fx, (int64_t)D.nb * D.B * D.K, 0)); } }
+    } else {
+      const size_t nBKs = (size_t)D.B * D.K, nSold = (size_t)D.nb * nBKs, nSets = 3 * (size_t)D.nrep * nBKs;
+      const int cur = ctx->sold_cur, oth = cur ^ 1;
+      const int64_t rnd = (int64_t)ctx->round_counter - 1;          // this round
+      D.Sold_fx = ctx->sold_buf[cur];
+      if (!ctx->sets_clean) { HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * nSets, ctx->L.stream)); ctx->sets_clean = true; }
+      const bool carried = ctx->sold_state[cur] == 2 && ctx->sold_round[cur] == rnd && ctx->sold_seed[cur] == ctx->seed &&
+                           ctx->sorted_round[rnd & 1] == rnd && ctx->sorted_seed[rnd & 1] == ctx->seed;   // (same Feistel permutation as the sort's)
+      if (carried) ctx->carried_rounds++;     // filled by the previous round's tile kernels: no pass over R
+      else {             // all blocks in one pass over R
+        if (ctx->sold_state[cur] != 0) HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * nSold, ctx->L.stream));
+        l_oldsum(ctx->L, D); KCHK();
+      }
+      ctx->sold_state[cur] = 1;
+      CHK(allreduce(ctx, D.Sold_fx, (int64_t)nSold, 0));
+      // this round's tile kernels collect the next round's old contributions if this round's tiles are keyed by the next block
+      const bool write_next = ctx->carry_ok && ctx->sorted_nxt[(rnd & 1)] && !ctx->last_round_hint && !chain_old && D.upd_impl == 0;
+      D.Sold_next = nullptr;
+      if (write_next) {
+        if (ctx->sold_state[oth] != 0) HIPCHK(hipMemsetAsync(ctx->sold_buf[oth], 0, sizeof(long long) * nSold, ctx->L.stream));
+        D.Sold_next = ctx->sold_buf[oth];
+        ctx->sold_state[oth] = 2; ctx->sold_round[oth] = rnd + 1; ctx->sold_seed[oth] = ctx->seed;
+      }
+      ctx->sets_clean = false;
+    } }
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
   const bool fused = merged && ctx->fused_ok;
@@ -688,8 +717,12 @@ int update_R(hmx_ctx* ctx) {
     // second launch), chain control reset.  Resolved by flush_objectives (event) when a value is needed.
     double* slot = nullptr;
     CHK(objective_slot(ctx, &slot));
-    l_round_tail(ctx->L, D, slot); KCHK();
-    ctx->sold_clean = !chain_old;
+    {   // the table this round consumed and the replica sets are cleared by the same launch
+      const size_t nBKs = (size_t)D.B * D.K;
+      l_round_tail(ctx->L, D, slot, chain_old ? nullptr : D.Sold_fx, chain_old ? 0 : (size_t)D.nb * nBKs, D.Snew_set[0], 3 * (size_t)D.nrep * nBKs); KCHK();
+      if (!chain_old) ctx->sold_state[ctx->sold_cur] = 0;
+      ctx->sets_clean = true;
+    }
     HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
     ctx->obj_pending++;
   } else {
@@ -698,6 +731,8 @@ int update_R(hmx_ctx* ctx) {
     l_objective_tables(ctx->L, D); KCHK();
     CHK(push_objective(ctx));  // asynchronous: resolved by flush_objectives when a value is needed
   }
+  if (!chain_old) ctx->sold_cur ^= 1;      // next round subtracts what this round's tile kernels collected (or a fresh k_oldsum pass)
+  D.Sold_next = nullptr;
   if (ctx->profile) { ctx->prof_update_cells += ctx->N; }   // the event pairs are resolved when a "prof:*" field is read
   ctx->timers["update_R"] += now_ms() - t0;
   return 0;
@@ -1276,9 +1311,18 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   }
   qchunk[Q] = (int)schunks.size();
   D.nchunks = (int)schunks.size();
-  if ((int64_t)N + (int64_t)D.nb * Q * 16 > 2147483000ll)
+  { // Old contributions carried from round to round (update_R): tiles keyed by (block, combination, NEXT block) cost up to 16
+    // padding slots per key -- worth it while the expected padding (8 per key) stays below 4 % of the cells.  HMX_SOLD_CARRY=0|1.
+    const char* e = getenv("HMX_SOLD_CARRY"); const char* co = getenv("HMX_CHAIN_OLD");
+    const bool fits = D.nb <= 63 && Q < (1 << 24) && D.upd_impl == 0 && !(co && atoi(co) == 1) &&
+                      (int64_t)N + (int64_t)D.nb * D.nb * Q * 16 <= 2147483000ll;
+    const bool pays = (int64_t)D.nb * D.nb * Q * 8 * 25 <= (int64_t)N;
+    ctx->carry_ok = fits && (e ? atoi(e) == 1 : pays);
+    D.nxt = 0; D.Sold_next = nullptr; ctx->carried_rounds = 0; }
+  const int nV = ctx->carry_ok ? D.nb * D.nb : D.nb;      // sort keys of a round
+  if ((int64_t)N + (int64_t)nV * Q * 16 > 2147483000ll)
     return fail(ctx, HMX_ERR_LIMIT, "padded block order (N + n_blocks * combinations * 16) exceeds the int32 index range of one shard");
-  D.npad = (int)((int64_t)N + (int64_t)D.nb * Q * 16);
+  D.npad = (int)((int64_t)N + (int64_t)nV * Q * 16);
   D.nitems = (int)items.size(); D.naitems = (int)aitems.size(); D.ntitems = (int)titems.size();
   { const char* e = getenv("HMX_TILE_IMPL"); D.tile_impl = (e && std::string(e) == "v1") ? 0 : 1; }
   CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, ((size_t)N + 1) * K));   // + one dummy row (target of masked stores)
@@ -1287,22 +1331,24 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
   // Sold_fx [nb][B][K] and the three rotating replica sets of the fused path share one buffer: one memset per round
-  { long long* s3; CHK(dalloc(ctx, &s3, (size_t)D.nb * B * K + (size_t)3 * D.nrep * B * K)); D.Sold_fx = s3;
-    for (int i = 0; i < 3; i++) D.Snew_set[i] = s3 + (size_t)D.nb * B * K + (size_t)i * D.nrep * B * K; }
+  { long long* s3; CHK(dalloc(ctx, &s3, (size_t)2 * D.nb * B * K + (size_t)3 * D.nrep * B * K)); D.Sold_fx = s3;
+    ctx->sold_buf[0] = s3; ctx->sold_buf[1] = s3 + (size_t)D.nb * B * K; ctx->sold_cur = 0; ctx->sold_state[0] = ctx->sold_state[1] = 1; ctx->sets_clean = false;
+    for (int i = 0; i < 3; i++) D.Snew_set[i] = s3 + (size_t)2 * D.nb * B * K + (size_t)i * D.nrep * B * K; }
   CHK(dalloc(ctx, &D.O_alt, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_alt, (size_t)D.nrep * B * K)); CHK(dalloc(ctx, &D.objpart, (size_t)2 * D.objslots * D.nwmax)); CHK(dalloc(ctx, &D.objrow, (size_t)2 * D.objslots));
   D.trace = nullptr;
   if (const char* e = getenv("HMX_TRACE")) if (atoi(e)) { CHK(dalloc(ctx, &D.trace, (size_t)16 * D.nwmax)); HIPCHK(hipMemsetAsync(D.trace, 0, sizeof(unsigned long long) * 16 * (size_t)D.nwmax, ctx->L.stream)); }
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
   CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)3 * D.npad + 2)); D.lpair = reinterpret_cast<int2*>(D.lorder + (((size_t)D.npad + 1) & ~(size_t)1)); /* lorder + lpair: one 0xFF memset per round */ CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
-  CHK(dalloc(ctx, &D.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
+  CHK(dalloc(ctx, &D.binoff, (size_t)nV * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
+  CHK(dalloc(ctx, &D.blkv, (size_t)N));
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
-  CHK(dalloc(ctx, &D.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)D.nb * D.nchunks));
+  CHK(dalloc(ctx, &D.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)nV * D.nchunks));
   { // second buffer set + side stream for the overlapped shuffle of the next round (HMX_SORT_OVERLAP=0: always sort in line)
-    ctx->sets[0] = {D.blk, D.lorder, D.lpair, D.lcombo, D.boff, D.binoff, D.counts, D.offs};
+    ctx->sets[0] = {D.blk, D.lorder, D.lpair, D.lcombo, D.boff, D.binoff, D.counts, D.offs, D.blkv};
     hmx_ctx::SortSet& t = ctx->sets[1];
     CHK(dalloc(ctx, &t.blk, (size_t)N)); CHK(dalloc(ctx, &t.lorder, (size_t)3 * D.npad + 2)); t.lpair = reinterpret_cast<int2*>(t.lorder + (((size_t)D.npad + 1) & ~(size_t)1));
-    CHK(dalloc(ctx, &t.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &t.binoff, (size_t)D.nb * Q + 1)); CHK(dalloc(ctx, &t.boff, (size_t)D.nb + 1));
-    CHK(dalloc(ctx, &t.counts, (size_t)D.nb * D.nchunks)); CHK(dalloc(ctx, &t.offs, (size_t)D.nb * D.nchunks));
+    CHK(dalloc(ctx, &t.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &t.binoff, (size_t)nV * Q + 1)); CHK(dalloc(ctx, &t.boff, (size_t)D.nb + 1));
+    CHK(dalloc(ctx, &t.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &t.offs, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &t.blkv, (size_t)N));
     const char* e = getenv("HMX_SORT_OVERLAP"); ctx->sort_overlap = !(e && atoi(e) == 0);
     { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lowest priority: the shuffle only fills gaps
       HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, lo)); }
@@ -1437,8 +1483,10 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     // path): 4 replicas measured 0.4 us per step faster than 8 there (2: the workers' atomics start to queue, +2 us)
     if (ctx->chain_ok && !getenv("HMX_NREP") && D.nrep > 4) {
       D.nrep = 4;
-      for (int i = 0; i < 3; i++) D.Snew_set[i] = D.Sold_fx + (size_t)D.nb * B * K + (size_t)i * D.nrep * B * K;   // keep [Sold | sets] contiguous
+      for (int i = 0; i < 3; i++) D.Snew_set[i] = ctx->sold_buf[0] + (size_t)2 * D.nb * B * K + (size_t)i * D.nrep * B * K;   // keep the three sets contiguous
     }
+    { const char* uc = getenv("HMX_UPD_CONTIG");     // launch-per-step path: contiguous tile ranges once a wave has several tiles per block
+      D.upd_contig = uc ? atoi(uc) : ((!ctx->chain_ok && tiles_per_wave >= 4.0) ? 1 : 0); }
     ctx->chain_rounds = 0;
     D.p2p_world = 0; D.p2p_rank = ctx->p2p_rank;
     for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g]; }
@@ -1451,7 +1499,7 @@ int hmx_restart(hmx_ctx* ctx) {
   HIPCHK(hipSetDevice(ctx->device));
   const Dev& D = ctx->D;
   l_normalize_from(ctx->L, D.Zo, D.Zc, D.n, D.d, D.zs); KCHK();  // Z_corr = normalise(Z_orig) :42 (one pass)
-  ctx->sold_clean = false;
+  for (int i = 0; i < 2; i++) if (ctx->sold_state[i] == 2) ctx->sold_state[i] = 1;
   HIPCHK(hipStreamSynchronize(ctx->L.stream));
   ctx->obj_pending = 0; ctx->obj_harmony_pending = false;
   ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();
@@ -1523,6 +1571,7 @@ int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
   int iter;
   for (iter = 0; iter < ctx->max_iter_kmeans; iter++) {
     if (ctx->poll && ctx->poll(ctx->poll_user)) return HMX_ABORTED;  // :233-234
+    ctx->last_round_hint = (iter == ctx->max_iter_kmeans - 1);         // (nothing follows the last round that could use its R sums)
     CHK(update_R(ctx));                                                 // :241 (objective fused, :248)
     if (iter > ctx->window_size) {                                      // :250-256 (the only place a round's value is needed at once)
       CHK(flush_objectives(ctx));
@@ -1685,6 +1734,8 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
   if (f == "prof:update_steps") return scalar((double)ctx->prof_update_steps);
   if (f == "chain") return scalar(ctx->chain_ok ? 1.0 : 0.0);
+  if (f == "sold_carry") return scalar(ctx->carry_ok ? 1.0 : 0.0);
+  if (f == "carried_rounds") return scalar((double)ctx->carried_rounds);
   if (f == "p2p:exchange_us") return scalar(ctx->p2p_exchange_us);
   if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);
   if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them

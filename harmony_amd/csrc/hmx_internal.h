@@ -74,6 +74,10 @@ struct Dev {
   int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
   long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int* tail_ticket;            // k_round_tail: workgroups done (the last one finishes the round's objective)
+  int nxt;                     // this shuffle keys the cells by (block, block of the NEXT round): nb * nb sort keys, lpair.y carries the next block
+  int* blkv;                   // [n] composite sort key of a cell (nxt)
+  long long* Sold_next;        // [nb][B][K] old contributions of the NEXT round's blocks, filled by this round's tile kernels (or nullptr)
+  int upd_contig;              // k_tile MODE 0: a wave owns a contiguous range of the block's tiles (run-length flush) instead of every nw-th
   int head_norm;               // k_tile MODE 1: normalise the tile's Z_corr rows in registers and write them back (fused head of cluster_cpp)
   int rvec;                    // K % 4 == 0: R rows are 16-byte aligned, the tile kernels store them with vector stores
   int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)
@@ -175,7 +179,7 @@ void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long 
 void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
 void l_chain(const Launch& L, const Dev& D, int workgroups);
-void l_round_tail(const Launch& L, const Dev& D, double* host_slot);
+void l_round_tail(const Launch& L, const Dev& D, double* host_slot, long long* z0, size_t n0, long long* z1, size_t n1);
 // Cluster <-> MFMA column mapping of the tile kernels.  Lane (g, c) of a wave holds column c of every 16-wide cluster tile ct.
 // Clusters are dealt so that a lane's columns are CONSECUTIVE clusters: within a full quad of cluster tiles (4q..4q+3) the lane
 // holds clusters 64q + 4c + {0,1,2,3} (one 16-byte store per R row instead of four 4-byte ones), within the remaining r = nct % 4

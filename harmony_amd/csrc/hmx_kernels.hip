@@ -327,12 +327,15 @@ __global__ __launch_bounds__(TPB) void k_head(Dev D) {
 // one wave per sort chunk.  FUSED: the block id is computed here from the Feistel bijection (no separate block-id kernel: saves a
 // launch and a write + read of blk); the histogram is one ds_add_u32 per 64 cells instead of a ballot loop over the
 // distinct block values.
-struct BlockIdArgs { FeistelKeys fk; uint64_t Nglob, goff, cpb; };
+// D.nxt (own shuffle only): the sort key of a cell is (block of this round, block of the NEXT round) -- nV = nb * nb keys --, so that
+// every 16-cell tile also has ONE next block and the tile kernels can file the tile's new R sums as that block's old contribution
+// (flush_tile_fx): 16 padding slots per (block, combination, next block) instead of per (block, combination).
+struct BlockIdArgs { FeistelKeys fk, fk2; uint64_t Nglob, goff, cpb; };
 template <bool FUSED>
 __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
   extern __shared__ int cnt[];
-  const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb;
-  for (int v = lane; v < nb; v += WAVE) cnt[v] = 0;
+  const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb, nV = D.nxt ? nb * nb : nb;
+  for (int v = lane; v < nV; v += WAVE) cnt[v] = 0;
   __syncthreads();
   const Item ch = D.schunks[chunk];
   const int s = ch.start, e = ch.start + ch.cnt;
@@ -345,12 +348,18 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
         const uint64_t bb = pos / A.cpb;
         b = (int)(bb < (uint64_t)(nb - 1) ? bb : (uint64_t)(nb - 1));
         D.blk[i] = b;
+        if (D.nxt) {
+          const uint64_t pos2 = feistel_apply(A.fk2, A.Nglob, A.goff + (uint64_t)D.perm[i]);
+          const uint64_t b2 = pos2 / A.cpb;
+          b = b * nb + (int)(b2 < (uint64_t)(nb - 1) ? b2 : (uint64_t)(nb - 1));
+          D.blkv[i] = b;
+        }
       } else b = D.blk[i];
       atomicAdd(&cnt[b], 1);
     }
   }
   __syncthreads();
-  for (int v = lane; v < nb; v += WAVE) D.counts[(size_t)v * D.nchunks + chunk] = cnt[v];
+  for (int v = lane; v < nV; v += WAVE) D.counts[(size_t)v * D.nchunks + chunk] = cnt[v];
 }
 // one wave per (block, combination) bin: exclusive prefix of the bin's chunk counts -> offs (offset inside the bin),
 // padded bin size -> binoff[bin].  The chunks of a combination are contiguous, so the loads are coalesced.
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_binscan(Dev D) {
 // single workgroup: exclusive scan of the padded bin sizes (block-major) -> binoff; boff[v] = padded start of block v
 __global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
   __shared__ int part[1024];
-  const int t = threadIdx.x, nb = D.nb, Q = D.Q, nbins = nb * Q;
+  const int t = threadIdx.x, nb = D.nb, Q = D.Q, vpb = D.nxt ? nb : 1, nbins = nb * vpb * Q;   // vpb: sort keys per block
   int* bins = D.binoff;
   const int per = (nbins + 1023) / 1024;
   const int s = t * per, e = min(nbins, s + per);
@@ -393,31 +402,53 @@ __global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
   for (int i = s; i < e; i++) { const int c = bins[i]; bins[i] = run; run += c; }
   if (t == 1023) bins[nbins] = part[1023];
   __syncthreads();
-  for (int v = t; v <= nb; v += 1024) D.boff[v] = bins[v < nb ? v * Q : nbins];
+  for (int v = t; v <= nb; v += 1024) D.boff[v] = bins[v < nb ? v * vpb * Q : nbins];
 }
+// ascending bitonic sort of one int per lane across the wave (21 compare-exchange stages, no LDS)
+__device__ __forceinline__ int wave_sort64(int v, const int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int o = __shfl_xor(v, j, 64);
+      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+      v = keep_min ? min(v, o) : max(v, o);
+    }
+  }
+  return v;
+}
+// Stable placement of a chunk's cells into their (key, combination) bins, 64 cells per step.  The rank of a cell among the cells
+// of the SAME key in its step comes from sorting (key, lane) across the wave: equal keys end up adjacent, in lane order -- a fixed
+// ~130 instructions per step, where a ballot per DISTINCT key costs up to 64 rounds with nb * nb keys (D.nxt).
 __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   extern __shared__ int base_[];
-  const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb;
+  const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb, nV = D.nxt ? nb * nb : nb;
   const Item ch = D.schunks[chunk];
-  for (int v = lane; v < nb; v += WAVE) base_[v] = D.binoff[v * D.Q + ch.q] + D.offs[(size_t)v * D.nchunks + chunk];
+  const int* __restrict__ key = D.nxt ? D.blkv : D.blk;
+  for (int v = lane; v < nV; v += WAVE) base_[v] = D.binoff[v * D.Q + ch.q] + D.offs[(size_t)v * D.nchunks + chunk];
   __syncthreads();
   const int s = ch.start, e = ch.start + ch.cnt;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int base = s; base < e; base += WAVE) {
     const int i = base + lane;
-    const int b = ld_or(D.blk, (size_t)min(i, e - 1), i < e, -1);
-    unsigned long long rem = __ballot(b >= 0);
-    while (rem) {
-      const int src = __ffsll((long long)rem) - 1;
-      const int v = __shfl(b, src, 64);
-      const unsigned long long m = __ballot(b == v);
-      const int off = base_[v];  // all lanes read before lane 0 updates
-      if (b == v) { const int dst = off + __popcll(m & lt); D.lorder[dst] = i; D.lcombo[dst] = ch.q; D.lpair[dst] = make_int2(i, ch.q); }
-      __syncthreads();
-      if (lane == 0) base_[v] = off + __popcll(m);
-      __syncthreads();
-      rem &= ~m;
+    const int b = ld_or(key, (size_t)min(i, e - 1), i < e, 0x00FFFFFF);      // (past the end: sorts behind every key)
+    const int sv = wave_sort64((b << 6) | lane, lane);
+    const int ks = sv >> 6, src = sv & 63;
+    const bool valid = ks < nV;
+    const int prev = __shfl_up(ks, 1, 64);
+    const bool head = lane == 0 || ks != prev;
+    const unsigned long long H = __ballot(head);
+    const int start = 63 - __clzll((long long)(H & (~0ull >> (63 - lane))));
+    const unsigned long long T = (lane == 63) ? 0ull : (H & ~((2ull << lane) - 1ull));
+    const int end = T ? (__ffsll((long long)T) - 1) : 64;
+    const int off = valid ? base_[ks] : 0;       // every lane of a group reads the group's base ...
+    __syncthreads();
+    if (valid) {
+      const int dst = off + (lane - start), cell = base + src;
+      D.lorder[dst] = cell; D.lcombo[dst] = ch.q;
+      D.lpair[dst] = make_int2(cell, D.nxt ? (ch.q | ((ks % nb) << 24)) : ch.q);     // (combination, next block): see flush_run in k_tile
+      if (head) base_[ks] = off + (end - start);   // ... and its first lane advances it (distinct keys: no conflicts)
     }
+    __syncthreads();
   }
 }
 
@@ -1026,7 +1057,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // first, then one atomic per cluster from group 0 -- into one of several table replicas, so that the
 // hundreds of waves of a launch do not serialise on the same few L2 atomic addresses.
 template <int NCT>
-__device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const int* __restrict__ qlev, int q, int C,
+__device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, long long* __restrict__ tab2, const int* __restrict__ qlev, int q, int C,
                                               int K, int c, int g, unsigned long long (&oacc)[NCT]) {
   constexpr int NFULL = NCT >> 2, RT = NCT & 3, NG = NFULL + (RT ? 1 : 0);
 #pragma unroll
@@ -1058,7 +1089,11 @@ __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, const
 #pragma unroll
     for (int G = 0; G < NG; G++) {
       const int k = 64 * G + kk;
-      if (k < K && mine[G]) atomicAdd((unsigned long long*)&tab[(size_t)b * K + k], mine[G]);
+      if (k < K && mine[G]) {
+        atomicAdd((unsigned long long*)&tab[(size_t)b * K + k], mine[G]);
+        // the same sums are the cells' OLD contribution to their block of the NEXT round (tiles are keyed by it, D.Sold_next)
+        if (tab2) atomicAdd((unsigned long long*)&tab2[(size_t)b * K + k], mine[G]);
+      }
     }
   }
 #pragma unroll
@@ -1134,10 +1169,14 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // (dealing tiles workgroup-major instead -- equal tiles per CU -- measured 25% SLOWER: the 8 consecutive tiles of a
   //  workgroup share lorder/lcombo cache lines and the lighter half of the CUs finishing early helps the tail)
   const int per = (ntiles + nw - 1) / nw;
-  const int ts = UPD ? wave : wave * per;
-  int te = UPD ? ntiles : min(ntiles, ts + per);     // (MODE 4 re-derives it for every block)
+  // MODE 0 with many tiles per wave (D.upd_contig): contiguous ranges -- consecutive tiles share their (combination, next block)
+  // key, so the wave flushes its O contributions once per RUN of tiles instead of once per tile (the flush atomics were 15 % of
+  // a 10M-cell block step once every tile filed its sums twice, see flush_run)
+  const bool strided = (MODE == 4) || (MODE == 0 && !D.upd_contig);
+  const int ts = strided ? wave : wave * per;
+  int te = strided ? ntiles : min(ntiles, ts + per);     // (MODE 4 re-derives it for every block)
   if (MODE == 4 && blockIdx.x == gridDim.x - 1) te = ts;   // the folder owns no tiles
-  const int tstep = UPD ? nw : 1;
+  const int tstep = strided ? nw : 1;
   // MODE 0: the first tile's cell ids and the first 16 bytes of their embedding rows are requested BEFORE the
   // LDS staging below, so the two dependent HBM round trips overlap with it
   // Software pipeline over tiles (when the rows fit in registers, D.NT4 <= 4): cell ids two tiles ahead, embedding rows
@@ -1292,16 +1331,24 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   const RowRegs* erows = nullptr;   // MODE 2: the A-operand registers of the tile whose epilogue runs (single-accumulator loop)
   // MODE 0/1 epilogue, split so that the fused loop below can interleave it with the next tile's MFMAs:
   // epi_begin: run change -> flush the O contributions of the finished combination, fetch the new penalty row
+  // A tile's combination word (lpair.y): bits 0..23 the covariate combination, bits 24..29 the block its cells belong to in the
+  // NEXT round when the shuffle keyed the tiles by it (D.Sold_next != nullptr) -- their new R rows are at the same time their
+  // old contribution to that block, so the pass over R that used to collect them (k_oldsum) disappears for that round.
+  constexpr int QMASK = 0xFFFFFF;
+  auto flush_run = [&]() __attribute__((always_inline)) {
+    long long* t2 = (UPD && D.Sold_next) ? D.Sold_next + (size_t)(curq >> 24) * D.B * K : nullptr;
+    flush_tile_fx<NCT>(snew, t2, qlevT, curq & QMASK, C, K, c, g, oacc);
+  };
   auto epi_begin = [&](const int q0) __attribute__((always_inline)) {
     if (q0 != curq) {
-      if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+      if (curq >= 0) flush_run();
       curq = q0;
       if constexpr (UPD) {
         float penv[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) penv[ct] = 0.0f;
         for (int cc = 0; cc < C; cc++) {  // penalty of a cell = SUM over its covariates (:322 is a matrix product)
-          const int b = qlevT[q0 * C + cc];
+          const int b = qlevT[(q0 & QMASK) * C + cc];
           const float* __restrict__ pr = penT + (size_t)b * K;
           if (D.rvec) {
             // a lane's clusters are consecutive (kcol): one 16-byte read per quad of cluster tiles, ALL reads of the level in
@@ -1837,7 +1884,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
             double* slot = D.objpart + ((size_t)(jj % D.objslots) * D.nwmax + wave) * 2;
             if (D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; } else { slot[0] += od; slot[1] += oe; }
           }
-          if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+          if (curq >= 0) flush_run();
           store_rows(cellC.x, accC);
           lap(w3);
           __builtin_amdgcn_s_waitcnt(0x0F70 | ((NCT * 4 - 4) & 15) | ((((NCT * 4 - 4) >> 4) & 3) << 14));
@@ -1911,7 +1958,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         for (int i = 0; i < 8; i++)
 #pragma unroll
           for (int e = 0; e < 4; e++) oa[e] += fx_of(v[i][e]);
-        const int q0 = __builtin_amdgcn_readfirstlane(cq.y);
+        const int q0 = __builtin_amdgcn_readfirstlane(cq.y) & 0xFFFFFF;
 #pragma unroll
         for (int e = 0; e < 4; e++) oa[e] += shfl_xor_u64(oa[e], 32);
         if (half == 0 && kv) {
@@ -1998,7 +2045,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         epi_begin(tile_q(cellC));
         epi_rows(cellC.x, accC, std::true_type{});
         lap(w2);
-        if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+        if (curq >= 0) flush_run();
         store_rows(cellC.x, accC);
         lap(w3);
         // in-order retirement: at most the youngest NCT*4 - 4 operations (all of them R stores) may still be in flight
@@ -2154,7 +2201,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     }
   } else {
     if (ts >= te) return;
-    if (curq >= 0) flush_tile_fx<NCT>(snew, qlevT, curq, C, K, c, g, oacc);
+    if (curq >= 0) flush_run();
     od = wsumd(od); oe = wsumd(oe);
     if (lane == 0) {
       const int slotrow = (MODE == 0) ? (j % D.objslots) : 0;
@@ -3176,13 +3223,14 @@ void l_head(const Launch& L, const Dev& D, int mode) {
 // fused = true: D.blk is produced by the histogram kernel from (seed, round); false: the host uploaded D.blk (injected shuffle)
 void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                    uint64_t cells_per_block) {
-  const size_t lds = (size_t)D.nb * sizeof(int);
+  const int nV = D.nxt ? D.nb * D.nb : D.nb;
+  const size_t lds = (size_t)nV * sizeof(int);
   (void)hipMemsetAsync(D.lorder, 0xFF, sizeof(int) * ((size_t)3 * D.npad + 2), L.stream);  // padding slots = -1 (lorder and lpair: one buffer)
   BlockIdArgs A;
-  A.fk = make_keys(seed, round, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
+  A.fk = make_keys(seed, round, Nglob); A.fk2 = make_keys(seed, round + 1, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
   if (fused) hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
   else hipLaunchKernelGGL(k_sort_hist<false>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
-  hipLaunchKernelGGL(k_sort_binscan, dim3(D.nb * D.Q), dim3(WAVE), 0, L.stream, D);
+  hipLaunchKernelGGL(k_sort_binscan, dim3(nV * D.Q), dim3(WAVE), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
 }
@@ -3227,13 +3275,15 @@ void l_penalty(const Launch& L, const Dev& D) {
 }
 // One GPU: the three kernels that close a clustering round (slot rows -> obj[0..1] -> cross-entropy term, snapshot, chain control
 // reset) as ONE launch: every workgroup reduces its slot row, the last one to finish (ticket) does the rest.  Same fixed-order sums.
-__global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__ host_slot) {
+__global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__ host_slot, long long* __restrict__ z0, size_t n0,
+                                                      long long* __restrict__ z1, size_t n1) {
   __shared__ double ra[1024], rb[1024];
   __shared__ int last;
   const int tid = threadIdx.x;
-  {  // the old-contribution tables and the replica sets of the NEXT round start from zero: cleared here instead of by a memset launch
-    const size_t nz = ((size_t)D.nb + 3 * (size_t)D.nrep) * D.B * D.K;
-    for (size_t i = (size_t)blockIdx.x * 1024 + tid; i < nz; i += (size_t)gridDim.x * 1024) D.Sold_fx[i] = 0;
+  {  // the old-contribution table this round consumed and the replica sets start the next rounds from zero: cleared here instead
+     // of by memset launches
+    for (size_t i = (size_t)blockIdx.x * 1024 + tid; i < n0; i += (size_t)gridDim.x * 1024) z0[i] = 0;
+    for (size_t i = (size_t)blockIdx.x * 1024 + tid; i < n1; i += (size_t)gridDim.x * 1024) z1[i] = 0;
   }
   double a = 0.0, b = 0.0;
   double* row = D.objpart + (size_t)blockIdx.x * D.nwmax * 2;
@@ -3300,8 +3350,8 @@ __global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__
   __syncthreads();
   if (D.chain_ctl) for (int i = tid; i < 8 * D.nb + 24; i += 1024) D.chain_ctl[i] = 0;
 }
-void l_round_tail(const Launch& L, const Dev& D, double* host_slot) {
-  hipLaunchKernelGGL(k_round_tail, dim3(D.objslots), dim3(1024), 0, L.stream, D, host_slot);
+void l_round_tail(const Launch& L, const Dev& D, double* host_slot, long long* z0, size_t n0, long long* z1, size_t n1) {
+  hipLaunchKernelGGL(k_round_tail, dim3(D.objslots), dim3(1024), 0, L.stream, D, host_slot, z0, n0, z1, n1);
 }
 void l_obj_reduce(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_obj_reduce, dim3(D.objslots), dim3(1024), 0, L.stream, D);

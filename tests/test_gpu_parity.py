@@ -262,11 +262,14 @@ def _run_sharded(Z, meta, G, K, seed, max_iter):
     return results
 
 
-@pytest.mark.parametrize("G,fused", [(2, "1"), (3, "1"), (2, "0")])
-def test_virtual_shards_equal_single_shard(G, fused, monkeypatch):
+@pytest.mark.parametrize("G,fused,carry", [(2, "1", "0"), (3, "1", "0"), (2, "0", "0"), (2, "1", "1"), (3, "0", "1")])
+def test_virtual_shards_equal_single_shard(G, fused, carry, monkeypatch):
     """fused = "1": block steps = update kernel (fold in its prologue) + in-place all-reduce of the replica set (default);
-    "0": the step-by-step sharded path (k_fold, all-reduce of one table, k_foldpen, update)."""
+    "0": the step-by-step sharded path (k_fold, all-reduce of one table, k_foldpen, update).  carry = "1": the old contributions
+    of a round's blocks come from the previous round's tile kernels (every shard files its cells' sums, the table is all-reduced
+    at the start of the round) instead of a pass over R -- forced on at this size, for the sharded runs and the single-shard one."""
     monkeypatch.setenv("HMX_FUSED_FOLD", fused)
+    monkeypatch.setenv("HMX_SOLD_CARRY", carry)
     Z, meta, _ = synth(30000, d=50, levels=(10,), seed=21)
     K, seed = 100, 4
     skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)

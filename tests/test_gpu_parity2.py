@@ -122,6 +122,45 @@ def test_config5_shape_200k():
     print("config5 200k:", s, "subset clusters", c.subset_clusters)
 
 
+@pytest.mark.parametrize("shape", [dict(N=30000, K=100, levels=(10,)), dict(N=20000, K=60, levels=(3, 4)), dict(N=9000, K=24, levels=(5,))])
+@pytest.mark.parametrize("chain", ["1", "0"])
+def test_carried_old_contributions_equal_a_fresh_pass(monkeypatch, shape, chain):
+    """update_R removes a block's cells from O before it updates them (src/harmony.cpp:312-313).  With the library's own shuffle
+    every tile is keyed by its cells' block of the NEXT round, and the tile kernels file a tile's new R sums as that block's old
+    contribution -- the next round then needs no pass over R.  Forced on (HMX_SOLD_CARRY=1; by default it starts at ~800k cells)
+    against the per-round pass (=0), persistent chain and launch-per-step kernels: bit-identical O and R (integer sums), same
+    iteration count, Z_corr to 1e-6; and O equals the direct sum over R."""
+    Z, meta, _ = synth(shape["N"], d=30, levels=shape["levels"], seed=31)
+    vars_use = list(meta)
+    skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=shape["K"])
+    monkeypatch.setenv("HMX_CHAIN", chain)
+    out = []
+    for carry in ("1", "0"):
+        monkeypatch.setenv("HMX_SOLD_CARRY", carry)
+        g = Harmony(seed=6)
+        g.setup(**skw)
+        g.init_cluster_cpp()
+        it = 0
+        for it in range(1, 4):
+            assert g.cluster_cpp() == 0
+            g.moe_correct_ridge_cpp()
+            if g.check_convergence(1):
+                break
+        assert g.cluster_cpp() == 0
+        assert int(g._scalar("sold_carry")) == int(carry)
+        assert (g._scalar("carried_rounds") > 0) == (carry == "1")
+        out.append((it, g.O.copy(), g.R.copy(), g.getZcorr().copy()))
+    (ia, Oa, Ra, Za), (ib, Ob, Rb, Zb) = out
+    assert ia == ib
+    np.testing.assert_array_equal(Oa, Ob)
+    np.testing.assert_array_equal(Ra, Rb)
+    assert relfro(Za, Zb) < 1e-6
+    lab = meta[vars_use[0]]
+    L0 = shape["levels"][0]
+    Odirect = np.stack([Ra[:, lab == b].sum(axis=1) for b in range(L0)], axis=1)
+    np.testing.assert_allclose(Oa[:, :L0], Odirect, rtol=2e-6, atol=1e-3)
+
+
 @pytest.mark.parametrize("K", [12, 60, 64, 104, 116, 128, 148, 192, 256])
 def test_every_cluster_tile_shape(K):
     """The tile kernels deal clusters to MFMA columns in quads (a lane's columns are consecutive clusters: 16 / 12 / 8 / 4-byte R
@@ -343,6 +382,11 @@ def test_two_processes_peer_to_peer_chain():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dist_two_proc.py"), "--p2p"],
+                       capture_output=True, text=True, timeout=500, stdin=subprocess.DEVNULL)
+    assert "DIST2_OK world=2" in p.stdout and "p2p=1" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+    # the same with the old contributions carried from round to round inside the chain (what a 1M-cells-per-GPU job runs by default)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dist_two_proc.py"), "--p2p", "--carry"],
                        capture_output=True, text=True, timeout=500, stdin=subprocess.DEVNULL)
     assert "DIST2_OK world=2" in p.stdout and "p2p=1" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
 

@@ -21,7 +21,10 @@ ap.add_argument("--backend", default="gloo")
 ap.add_argument("--cells", type=int, default=30000)
 ap.add_argument("--p2p", action="store_true", help="sum the block contributions inside the persistent chain over the peers' inboxes "
                 "(hmx_p2p_*; the handles travel through torch.distributed) instead of one all-reduce per block")
+ap.add_argument("--carry", action="store_true", help="force the round-to-round carry of the old contributions (HMX_SOLD_CARRY=1)")
 a = ap.parse_args()
+if a.carry:
+    os.environ["HMX_SOLD_CARRY"] = "1"
 if a.p2p and a.backend == "gloo":
     os.environ["HMX_CHAIN_WGS"] = "120"     # both ranks share ONE GPU here: two persistent chains must fit its 256 CUs together
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
