@@ -163,7 +163,7 @@ struct hmx_ctx {
   // The round's shuffle (counting sort by block) touches no algorithmic state, and with the counter-based generator it depends
   // on (seed, round) only: the sort of round r+1 runs on a SIDE stream while round r's old-sum pass streams on the main one,
   // into the second of two buffer sets.
-  struct SortSet { int* blk; int* lorder; int2* lpair; int* lcombo; int* boff; int* binoff; int* counts; int* offs; int* blkv; };
+  struct SortSet { int* blk; int* lorder; int2* lpair; int* lcombo; int* boff; int* binoff; int* counts; int* offs; int* blkv; int* bincnt; };
   SortSet sets[2] = {}; hipStream_t side = nullptr; hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   int64_t sorted_round[2] = {-1, -1}; uint64_t sorted_seed[2] = {0, 0}; bool sorted_on_side[2] = {false, false}; bool sort_overlap = true;
   std::string err, warn, warn_ret;
@@ -535,7 +535,7 @@ int kmeans_centers(hmx_ctx* ctx) {
 // counting sort.  Touches no algorithmic state (only blk / lorder / lcombo / lpair / boff).  (Enqueuing it speculatively
 // for the NEXT round before the host waits for this round's objective was measured: no gain, 26.1 vs 25.9 ms per step.)
 void apply_set(Dev& D, const hmx_ctx::SortSet& s) {
-  D.blk = s.blk; D.lorder = s.lorder; D.lpair = s.lpair; D.lcombo = s.lcombo; D.boff = s.boff; D.binoff = s.binoff; D.counts = s.counts; D.offs = s.offs; D.blkv = s.blkv;
+  D.blk = s.blk; D.lorder = s.lorder; D.lpair = s.lpair; D.lcombo = s.lcombo; D.boff = s.boff; D.binoff = s.binoff; D.counts = s.counts; D.offs = s.offs; D.blkv = s.blkv; D.bincnt = s.bincnt;
 }
 int prepare_round(hmx_ctx* ctx, uint64_t round) {
   Dev& D = ctx->D;
@@ -1340,15 +1340,15 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   CHK(dalloc(ctx, &D.pen, (size_t)B * K)); CHK(dalloc(ctx, &D.obj, (size_t)8));
   CHK(dalloc(ctx, &D.blk, (size_t)N)); CHK(dalloc(ctx, &D.lorder, (size_t)3 * D.npad + 2)); D.lpair = reinterpret_cast<int2*>(D.lorder + (((size_t)D.npad + 1) & ~(size_t)1)); /* lorder + lpair: one 0xFF memset per round */ CHK(dalloc(ctx, &D.lcombo, (size_t)D.npad));
   CHK(dalloc(ctx, &D.binoff, (size_t)nV * Q + 1)); CHK(dalloc(ctx, &D.schunks, schunks.size())); CHK(dalloc(ctx, &D.qchunk, (size_t)Q + 1));
-  CHK(dalloc(ctx, &D.blkv, (size_t)N));
+  CHK(dalloc(ctx, &D.blkv, (size_t)N)); CHK(dalloc(ctx, &D.bincnt, (size_t)nV * Q));
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)nV * D.nchunks));
   { // second buffer set + side stream for the overlapped shuffle of the next round (HMX_SORT_OVERLAP=0: always sort in line)
-    ctx->sets[0] = {D.blk, D.lorder, D.lpair, D.lcombo, D.boff, D.binoff, D.counts, D.offs, D.blkv};
+    ctx->sets[0] = {D.blk, D.lorder, D.lpair, D.lcombo, D.boff, D.binoff, D.counts, D.offs, D.blkv, D.bincnt};
     hmx_ctx::SortSet& t = ctx->sets[1];
     CHK(dalloc(ctx, &t.blk, (size_t)N)); CHK(dalloc(ctx, &t.lorder, (size_t)3 * D.npad + 2)); t.lpair = reinterpret_cast<int2*>(t.lorder + (((size_t)D.npad + 1) & ~(size_t)1));
     CHK(dalloc(ctx, &t.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &t.binoff, (size_t)nV * Q + 1)); CHK(dalloc(ctx, &t.boff, (size_t)D.nb + 1));
-    CHK(dalloc(ctx, &t.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &t.offs, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &t.blkv, (size_t)N));
+    CHK(dalloc(ctx, &t.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &t.offs, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &t.blkv, (size_t)N)); CHK(dalloc(ctx, &t.bincnt, (size_t)nV * Q));
     const char* e = getenv("HMX_SORT_OVERLAP"); ctx->sort_overlap = !(e && atoi(e) == 0);
     { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lowest priority: the shuffle only fills gaps
       HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, lo)); }

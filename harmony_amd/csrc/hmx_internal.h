@@ -75,6 +75,7 @@ struct Dev {
   long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int* tail_ticket;            // k_round_tail: workgroups done (the last one finishes the round's objective)
   int nxt;                     // this shuffle keys the cells by (block, block of the NEXT round): nb * nb sort keys, lpair.y carries the next block
+  int* bincnt;                 // [keys * Q] cells of a (key, combination) bin before padding
   int* blkv;                   // [n] composite sort key of a cell (nxt)
   long long* Sold_next;        // [nb][B][K] old contributions of the NEXT round's blocks, filled by this round's tile kernels (or nullptr)
   int upd_contig;              // k_tile MODE 0: a wave owns a contiguous range of the block's tiles (run-length flush) instead of every nw-th

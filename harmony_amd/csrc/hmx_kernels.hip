@@ -339,17 +339,24 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
   __syncthreads();
   const Item ch = D.schunks[chunk];
   const int s = ch.start, e = ch.start + ch.cnt;
-  for (int base = s; base < e; base += WAVE) {
+  constexpr int NSTEP = SORT_CHUNK / WAVE;
+  int pm[NSTEP];      // the chunk's cell ids, all loads in flight together (one exposed latency per chunk instead of one per step)
+#pragma unroll
+  for (int u = 0; u < NSTEP; u++) pm[u] = FUSED ? D.perm[min(s + u * WAVE + lane, e - 1)] : 0;
+#pragma unroll
+  for (int u = 0; u < NSTEP; u++) {
+    const int base = s + u * WAVE;
+    if (base >= e) break;
     const int i = base + lane;
     int b = -1;
     if (i < e) {
       if constexpr (FUSED) {
-        const uint64_t pos = feistel_apply(A.fk, A.Nglob, A.goff + (uint64_t)D.perm[i]);
+        const uint64_t pos = feistel_apply(A.fk, A.Nglob, A.goff + (uint64_t)pm[u]);
         const uint64_t bb = pos / A.cpb;
         b = (int)(bb < (uint64_t)(nb - 1) ? bb : (uint64_t)(nb - 1));
         D.blk[i] = b;
         if (D.nxt) {
-          const uint64_t pos2 = feistel_apply(A.fk2, A.Nglob, A.goff + (uint64_t)D.perm[i]);
+          const uint64_t pos2 = feistel_apply(A.fk2, A.Nglob, A.goff + (uint64_t)pm[u]);
           const uint64_t b2 = pos2 / A.cpb;
           b = b * nb + (int)(b2 < (uint64_t)(nb - 1) ? b2 : (uint64_t)(nb - 1));
           D.blkv[i] = b;
@@ -364,11 +371,11 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
 // one wave per (block, combination) bin: exclusive prefix of the bin's chunk counts -> offs (offset inside the bin),
 // padded bin size -> binoff[bin].  The chunks of a combination are contiguous, so the loads are coalesced.
 __global__ __launch_bounds__(WAVE) void k_sort_binscan(Dev D) {
-  const int lane = threadIdx.x, bin = blockIdx.x, Q = D.Q, nch = D.nchunks;
+  const int lane = threadIdx.x, bin = blockIdx.x, Q = D.Q, nch = D.nchunks, nV = D.nxt ? D.nb * D.nb : D.nb;
   const int v = bin / Q, q = bin - v * Q;
   const int lo = D.qchunk[q], hi = D.qchunk[q + 1];
   const int* __restrict__ cin = D.counts + (size_t)v * nch;
-  int* __restrict__ cout = D.offs + (size_t)v * nch;
+  int* __restrict__ cout = D.offs + v;      // offs[chunk][key]: the scatter kernel reads a chunk's nV offsets as one contiguous run
   int run = 0;
   for (int base = lo; base < hi; base += WAVE) {
     const int i = base + lane;
@@ -376,10 +383,10 @@ __global__ __launch_bounds__(WAVE) void k_sort_binscan(Dev D) {
     int incl = c;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
-    if (i < hi) cout[i] = run + incl - c;
+    if (i < hi) cout[(size_t)i * nV] = run + incl - c;
     run += __shfl(incl, 63, 64);
   }
-  if (lane == 0) D.binoff[bin] = (run + 15) & ~15;
+  if (lane == 0) { D.binoff[bin] = (run + 15) & ~15; D.bincnt[bin] = run; }
 }
 // single workgroup: exclusive scan of the padded bin sizes (block-major) -> binoff; boff[v] = padded start of block v
 __global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
@@ -425,12 +432,27 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb, nV = D.nxt ? nb * nb : nb;
   const Item ch = D.schunks[chunk];
   const int* __restrict__ key = D.nxt ? D.blkv : D.blk;
-  for (int v = lane; v < nV; v += WAVE) base_[v] = D.binoff[v * D.Q + ch.q] + D.offs[(size_t)v * D.nchunks + chunk];
-  __syncthreads();
   const int s = ch.start, e = ch.start + ch.cnt;
-  for (int base = s; base < e; base += WAVE) {
-    const int i = base + lane;
-    const int b = ld_or(key, (size_t)min(i, e - 1), i < e, 0x00FFFFFF);      // (past the end: sorts behind every key)
+  constexpr int NSTEP = SORT_CHUNK / WAVE;
+  for (int v0 = 0; v0 < nV; v0 += 8 * WAVE) {     // (eight independent pairs of loads in flight per pass)
+    int t0[8], t1[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int v = min(v0 + u * WAVE + lane, nV - 1);
+      t0[u] = D.binoff[v * D.Q + ch.q]; t1[u] = D.offs[(size_t)chunk * nV + v];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (v0 + u * WAVE + lane < nV) base_[v0 + u * WAVE + lane] = t0[u] + t1[u];
+  }
+  __syncthreads();
+  int kk[NSTEP];      // the chunk's keys, all loads in flight together
+#pragma unroll
+  for (int u = 0; u < NSTEP; u++) kk[u] = ld_or(key, (size_t)min(s + u * WAVE + lane, e - 1), s + u * WAVE + lane < e, 0x00FFFFFF);   // (past the end: sorts behind every key)
+#pragma unroll
+  for (int u = 0; u < NSTEP; u++) {
+    const int base = s + u * WAVE;
+    if (base >= e) break;
+    const int b = kk[u];
     const int sv = wave_sort64((b << 6) | lane, lane);
     const int ks = sv >> 6, src = sv & 63;
     const bool valid = ks < nV;
@@ -449,6 +471,14 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
       if (head) base_[ks] = off + (end - start);   // ... and its first lane advances it (distinct keys: no conflicts)
     }
     __syncthreads();
+  }
+  // the padding slots (< 16 per bin) of this combination's bins: "no cell" -- written here, so that no memset of the whole order
+  // precedes every shuffle
+  // (the keys are dealt over the combination's chunks: a couple of bins per wave)
+  const int ci = chunk - D.qchunk[ch.q], ncq = D.qchunk[ch.q + 1] - D.qchunk[ch.q];
+  for (int v = ci + ncq * lane; v < nV; v += ncq * WAVE) {
+    const int bin = v * D.Q + ch.q, st = D.binoff[bin], cnt = D.bincnt[bin], pad = (cnt + 15) & ~15;
+    for (int k = cnt; k < pad; k++) { D.lorder[st + k] = -1; D.lpair[st + k] = make_int2(-1, -1); }
   }
 }
 
@@ -1172,9 +1202,20 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // MODE 0 with many tiles per wave (D.upd_contig): contiguous ranges -- consecutive tiles share their (combination, next block)
   // key, so the wave flushes its O contributions once per RUN of tiles instead of once per tile (the flush atomics were 15 % of
   // a 10M-cell block step once every tile filed its sums twice, see flush_run)
-  const bool strided = (MODE == 4) || (MODE == 0 && !D.upd_contig);
-  const int ts = strided ? wave : wave * per;
+  // MODE 4 (two-accumulator chain): contiguous BALANCED ranges, re-derived for every block -- T = base nw + rem tiles: the rem
+  // lowest-numbered waves own base + 1 consecutive tiles, the others base.  A wave's tiles of a block are neighbours in the padded
+  // order: they mostly share their (combination, next block) key, i.e. one contribution flush and one penalty fetch per wave and
+  // block instead of one per tile, and their pair loads share cache lines.
+  constexpr bool CHAIN_CONTIG = (MODE == 4) && !LEAN;
+  auto chain_range = [&](const int T, int& s0, int& e0) {
+    const int base = T / nw, rem = T - base * nw;
+    s0 = wave * base + min(wave, rem);
+    e0 = s0 + base + (wave < rem ? 1 : 0);
+  };
+  const bool strided = (MODE == 4 && !CHAIN_CONTIG) || (MODE == 0 && !D.upd_contig);
+  int ts = strided ? wave : wave * per;
   int te = strided ? ntiles : min(ntiles, ts + per);     // (MODE 4 re-derives it for every block)
+  if constexpr (CHAIN_CONTIG) chain_range(ntiles, ts, te);
   if (MODE == 4 && blockIdx.x == gridDim.x - 1) te = ts;   // the folder owns no tiles
   const int tstep = strided ? nw : 1;
   // MODE 0: the first tile's cell ids and the first 16 bytes of their embedding rows are requested BEFORE the
@@ -1945,7 +1986,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       // reads two whole R rows (16 bytes per lane); the per-cluster sums need one cross-half add and no 16-lane reduction
       const int kq = 4 * (lane & 31), half = lane >> 5;
       const bool kv = kq < K;
-      for (int tile = ts; tile < nt; tile += tstep) {
+      for (int tile = wave; tile < nt; tile += nw) {
         const int2 cq = D.lpair[pb + 16 * tile + c];
         f32x4 v[8];
 #pragma unroll
@@ -2007,13 +2048,14 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       //  slot store at the end of the launch instead of two 6-step 64-bit reductions per block on the critical path)
       // geometry of the next block and the (cell, combination) pairs of this wave's first two tiles in it, requested now
       const bool more = jj + 1 < nbk;
-      int p0n = 0, ten = 0; bool haveN = false;
+      int p0n = 0, ten = 0, tsn = ts; bool haveN = false;
       int2 cN1 = make_int2(-1, -1), cNN1 = make_int2(-1, -1);
       if (more) {
         p0n = D.boff[jj + 1];
         ten = (D.boff[jj + 2] - p0n) >> 4;
-        haveN = ts < ten;
-        if (haveN) { cN1 = D.lpair[p0n + 16 * ts + c]; if (ts + tstep < ten) cNN1 = D.lpair[p0n + 16 * (ts + tstep) + c]; }
+        if constexpr (CHAIN_CONTIG) chain_range(ten, tsn, ten);      // (ten: from here on the end of THIS wave's range)
+        haveN = tsn < ten;
+        if (haveN) { cN1 = D.lpair[p0n + 16 * tsn + c]; if (tsn + tstep < ten) cNN1 = D.lpair[p0n + 16 * (tsn + tstep) + c]; }
       }
       if (have) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the two-accumulator loop below
@@ -2061,7 +2103,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       // wave's contribution atomics have been performed" (each wave waited for its own above).
       __builtin_amdgcn_s_barrier();
       if (tid == 0) atomicAdd(&ctl[8 + 8 * jj + ((int)blockIdx.x & 7)], 1);          // arrival of this workgroup
-      if (more) { p0 = p0n; te = ten; cellN = cN1; cellNN = cNN1; }
+      if (more) { p0 = p0n; ts = tsn; te = ten; cellN = cN1; cellNN = cNN1; }
       lap(wd);
       have = haveN;
       if (have) first_tile();                           // off the critical path: overlaps the folder's work
@@ -3225,7 +3267,7 @@ void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uin
                    uint64_t cells_per_block) {
   const int nV = D.nxt ? D.nb * D.nb : D.nb;
   const size_t lds = (size_t)nV * sizeof(int);
-  (void)hipMemsetAsync(D.lorder, 0xFF, sizeof(int) * ((size_t)3 * D.npad + 2), L.stream);  // padding slots = -1 (lorder and lpair: one buffer)
+  // (padding slots = -1: written by k_sort_binoff, bin by bin)
   BlockIdArgs A;
   A.fk = make_keys(seed, round, Nglob); A.fk2 = make_keys(seed, round + 1, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
   if (fused) hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
