@@ -336,7 +336,18 @@ int push_objective(hmx_ctx* ctx) {
 }
 
 // R, O, E from scratch (src/harmony.cpp:141-150, :221-227); leaves objective partials in obj[0..1]
+int prepare_round(hmx_ctx* ctx, uint64_t round);
 int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- normalise(Z_corr) first (:220)
+  // With the round-to-round carry (update_R) the head of cluster_cpp runs over the padded order of the round that FOLLOWS it and
+  // files its R sums as that round's old contributions: no pass over R between the head and the first round either.
+  const bool sharded_ = ctx->world > 1 || ctx->comm_force;
+  const bool gather = normalise && ctx->carry_ok && ctx->injected.empty() && ctx->rng_mode == 0 && ctx->D.upd_impl == 0 &&
+                      ctx->D.tile_impl && (size_t)ctx->D.NQ * ctx->D.NS * 1024 <= 160 * 1024 && !getenv("HMX_HEAD_GATHER_OFF");
+  if (gather) {
+    PhaseScope ph(ctx, "randomize");
+    CHK(prepare_round(ctx, ctx->round_counter));     // (update_R finds this round sorted and the next one in flight)
+  }
+  (void)sharded_;
   Dev D = ctx->D;
   const bool tiles = D.tile_impl && (size_t)D.NQ * D.NS * 1024 <= 160 * 1024;
   // the register-pipelined head (two accumulator sets, rows of a tile in registers) normalises the rows it has loaded anyway
@@ -344,6 +355,14 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   if (normalise && !fused_norm) { l_normalize(ctx->L, D.Zc, D.n, D.d, D.zs); KCHK(); }
   D.head_norm = fused_norm ? 1 : 0;
   for (int i = 0; i < 2; i++) if (ctx->sold_state[i] == 2) ctx->sold_state[i] = 1;     // R is rewritten: carried old contributions are void
+  D.head_gather = 0; D.Sold_head = nullptr;
+  if (gather && ctx->sorted_nxt[ctx->round_counter & 1] && ctx->sorted_round[ctx->round_counter & 1] == (int64_t)ctx->round_counter) {
+    const int cur = ctx->sold_cur;
+    if (ctx->sold_state[cur] != 0)
+      HIPCHK(hipMemsetAsync(ctx->sold_buf[cur], 0, sizeof(long long) * (size_t)D.nb * D.B * D.K, ctx->L.stream));
+    D.head_gather = 1; D.Sold_head = ctx->sold_buf[cur];
+    ctx->sold_state[cur] = 2; ctx->sold_round[cur] = (int64_t)ctx->round_counter; ctx->sold_seed[cur] = ctx->seed;
+  }
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
@@ -550,6 +569,7 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
   auto prefetch_next = [&]() -> int {   // round + 1 into the other set, on the side stream, behind everything that still reads that set
     if (!ctx->sort_overlap || host_order || !ctx->side) return 0;
     const int t = sset ^ 1;
+    if (ctx->sorted_round[t] == (int64_t)round + 1 && ctx->sorted_seed[t] == ctx->seed) return 0;     // (second call for this round)
     HIPCHK(hipEventRecord(ctx->ev_free[t], ctx->L.stream));
     HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_free[t], 0));
     Dev Dt = D; apply_set(Dt, ctx->sets[t]);
@@ -1314,7 +1334,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   { // Old contributions carried from round to round (update_R): tiles keyed by (block, combination, NEXT block) cost up to 16
     // padding slots per key -- worth it while the expected padding (8 per key) stays below 4 % of the cells.  HMX_SOLD_CARRY=0|1.
     const char* e = getenv("HMX_SOLD_CARRY"); const char* co = getenv("HMX_CHAIN_OLD");
-    const bool fits = D.nb <= 63 && Q < (1 << 24) && D.upd_impl == 0 && !(co && atoi(co) == 1) &&
+    const bool fits = D.nb <= 63 && Q < (1 << 19) && D.upd_impl == 0 && !(co && atoi(co) == 1) &&
                       (int64_t)N + (int64_t)D.nb * D.nb * Q * 16 <= 2147483000ll;
     const bool pays = (int64_t)D.nb * D.nb * Q * 8 * 25 <= (int64_t)N;
     ctx->carry_ok = fits && (e ? atoi(e) == 1 : pays);

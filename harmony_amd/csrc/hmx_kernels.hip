@@ -467,7 +467,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
     if (valid) {
       const int dst = off + (lane - start), cell = base + src;
       D.lorder[dst] = cell; D.lcombo[dst] = ch.q;
-      D.lpair[dst] = make_int2(cell, D.nxt ? (ch.q | ((ks % nb) << 24)) : ch.q);     // (combination, next block): see flush_run in k_tile
+      D.lpair[dst] = make_int2(cell, D.nxt ? (ch.q | ((ks % nb) << 19) | ((ks / nb) << 25)) : ch.q);     // (combination, next block, block): see flush_run in k_tile
       if (head) base_[ks] = off + (end - start);   // ... and its first lane advances it (distinct keys: no conflicts)
     }
     __syncthreads();
@@ -1170,6 +1170,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   int p0 = 0, ntiles;
   if constexpr (MODE == 0) { p0 = D.boff[j]; ntiles = (D.boff[j + 1] - p0) >> 4; }  // padded: combination-pure tiles
   else if constexpr (MODE == 4) { p0 = D.boff[0]; ntiles = (D.boff[1] - p0) >> 4; }
+  else if (MODE == 1 && D.head_gather) ntiles = D.boff[D.nb] >> 4;     // the head runs over the NEXT round's padded order (see flush_run)
   else ntiles = D.ntitems;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   // wave index as a SCALAR: tile numbers and all loop control become SALU work (no exec-mask branches in the tile loop)
@@ -1231,6 +1232,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   auto tile_cell = [&](int tile) -> int2 {     // (-1, .): padding slot / beyond the end
     if (tile >= te) return make_int2(-1, -1);
     if constexpr (UPD) return D.lpair[p0 + 16 * tile + c];
+    else if (MODE == 1 && D.head_gather) return D.lpair[16 * tile + c];
     else {
       // keep this a per-lane (vector) load: with the uniform tile index hipcc would emit load + readfirstlane, i.e. a
       // vmcnt(0) -- a full memory latency per tile that also drains the prefetched rows
@@ -1372,12 +1374,16 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   const RowRegs* erows = nullptr;   // MODE 2: the A-operand registers of the tile whose epilogue runs (single-accumulator loop)
   // MODE 0/1 epilogue, split so that the fused loop below can interleave it with the next tile's MFMAs:
   // epi_begin: run change -> flush the O contributions of the finished combination, fetch the new penalty row
-  // A tile's combination word (lpair.y): bits 0..23 the covariate combination, bits 24..29 the block its cells belong to in the
-  // NEXT round when the shuffle keyed the tiles by it (D.Sold_next != nullptr) -- their new R rows are at the same time their
-  // old contribution to that block, so the pass over R that used to collect them (k_oldsum) disappears for that round.
-  constexpr int QMASK = 0xFFFFFF;
+  // A tile's combination word (lpair.y) when the shuffle keyed the tiles by it (D.nxt): bits 0..18 the covariate combination,
+  // bits 19..24 the block its cells belong to in the NEXT round, bits 25..30 their block in THIS round.  The R rows a block update
+  // writes are at the same time the cells' old contribution to their next block (D.Sold_next), and the R rows the head writes --
+  // run over this round's order -- are their old contribution to this round's blocks (D.Sold_head): the pass over R that used to
+  // collect them (k_oldsum) disappears.
+  constexpr int QMASK = 0x7FFFF;
   auto flush_run = [&]() __attribute__((always_inline)) {
-    long long* t2 = (UPD && D.Sold_next) ? D.Sold_next + (size_t)(curq >> 24) * D.B * K : nullptr;
+    long long* t2 = nullptr;
+    if (UPD && D.Sold_next) t2 = D.Sold_next + (size_t)((curq >> 19) & 63) * D.B * K;
+    if (MODE == 1 && D.head_gather && D.Sold_head) t2 = D.Sold_head + (size_t)((curq >> 25) & 63) * D.B * K;
     flush_tile_fx<NCT>(snew, t2, qlevT, curq & QMASK, C, K, c, g, oacc);
   };
   auto epi_begin = [&](const int q0) __attribute__((always_inline)) {
@@ -1999,7 +2005,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         for (int i = 0; i < 8; i++)
 #pragma unroll
           for (int e = 0; e < 4; e++) oa[e] += fx_of(v[i][e]);
-        const int q0 = __builtin_amdgcn_readfirstlane(cq.y) & 0xFFFFFF;
+        const int q0 = __builtin_amdgcn_readfirstlane(cq.y) & 0x7FFFF;
 #pragma unroll
         for (int e = 0; e < 4; e++) oa[e] += shfl_xor_u64(oa[e], 32);
         if (half == 0 && kv) {
