@@ -1338,7 +1338,8 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
                       (int64_t)N + (int64_t)D.nb * D.nb * Q * 16 <= 2147483000ll;
     const bool pays = (int64_t)D.nb * D.nb * Q * 8 * 25 <= (int64_t)N;
     ctx->carry_ok = fits && (e ? atoi(e) == 1 : pays);
-    D.nxt = 0; D.Sold_next = nullptr; ctx->carried_rounds = 0; }
+    D.nxt = 0; D.Sold_next = nullptr; D.Sold_head = nullptr; D.head_gather = 0; ctx->carried_rounds = 0;
+    D.qmask = ctx->carry_ok ? 0x7FFFF : 0x7FFFFFFF; }
   const int nV = ctx->carry_ok ? D.nb * D.nb : D.nb;      // sort keys of a round
   if ((int64_t)N + (int64_t)nV * Q * 16 > 2147483000ll)
     return fail(ctx, HMX_ERR_LIMIT, "padded block order (N + n_blocks * combinations * 16) exceeds the int32 index range of one shard");

@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // writes are at the same time the cells' old contribution to their next block (D.Sold_next), and the R rows the head writes --
   // run over this round's order -- are their old contribution to this round's blocks (D.Sold_head): the pass over R that used to
   // collect them (k_oldsum) disappears.
-  constexpr int QMASK = 0x7FFFF;
+  const int QMASK = D.qmask;      // 0x7FFFF when shuffles may be keyed (then Q < 2^19), else all bits (Q up to 2^24)
   auto flush_run = [&]() __attribute__((always_inline)) {
     long long* t2 = nullptr;
     if (UPD && D.Sold_next) t2 = D.Sold_next + (size_t)((curq >> 19) & 63) * D.B * K;
@@ -2005,7 +2005,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         for (int i = 0; i < 8; i++)
 #pragma unroll
           for (int e = 0; e < 4; e++) oa[e] += fx_of(v[i][e]);
-        const int q0 = __builtin_amdgcn_readfirstlane(cq.y) & 0x7FFFF;
+        const int q0 = __builtin_amdgcn_readfirstlane(cq.y) & D.qmask;
 #pragma unroll
         for (int e = 0; e < 4; e++) oa[e] += shfl_xor_u64(oa[e], 32);
         if (half == 0 && kv) {
