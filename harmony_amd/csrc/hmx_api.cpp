@@ -341,7 +341,8 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   // With the round-to-round carry (update_R) the head of cluster_cpp runs over the padded order of the round that FOLLOWS it and
   // files its R sums as that round's old contributions: no pass over R between the head and the first round either.
   const bool sharded_ = ctx->world > 1 || ctx->comm_force;
-  const bool gather = normalise && ctx->carry_ok && ctx->injected.empty() && ctx->rng_mode == 0 && ctx->D.upd_impl == 0 &&
+  // (the head of init_cluster_cpp too: the first round then finds its old contributions filed as well -- no pass over R at all)
+  const bool gather = ctx->carry_ok && ctx->injected.empty() && ctx->rng_mode == 0 && ctx->D.upd_impl == 0 &&
                       ctx->D.tile_impl && (size_t)ctx->D.NQ * ctx->D.NS * 1024 <= 160 * 1024 && !getenv("HMX_HEAD_GATHER_OFF");
   if (gather) {
     PhaseScope ph(ctx, "randomize");
