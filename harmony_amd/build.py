@@ -10,8 +10,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", "hmx_kernels.hip"), os.path.join(HERE, "csrc", "hmx_api.cpp")]
-HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "..", "include", "harmony_mi355x.h")]
+SRC = [os.path.join(HERE, "csrc", "hmx_kernels.hip"), os.path.join(HERE, "csrc", "hmx_seq.hip"), os.path.join(HERE, "csrc", "hmx_api.cpp")]
+HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "csrc", "hmx_rrng.h"), os.path.join(HERE, "..", "include", "harmony_mi355x.h")]
 OUT = os.path.join(HERE, "lib", "libharmony_mi355x.so")
 
 
@@ -46,8 +46,24 @@ def build(force=False, verbose=True, trace=False):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-Wno-unused-result", "-o", out] + (["-DHMX_TRACE"] if trace else []) + SRC + ["-lpthread", "-ldl"]
+    # one object per source (kept under lib/obj, rebuilt only when the source or a header is newer), compiled concurrently, then linked
+    objdir = os.path.join(os.path.dirname(OUT), "obj_trace" if trace else "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"] + (["-DHMX_TRACE"] if trace else [])
+    hdr_t = max(os.path.getmtime(p) for p in HDR)
+    procs, objs = [], []
+    for src in SRC:
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs + ["-lpthread", "-ldl"]
     # Share ONE HIP runtime with PyTorch when both live in a process: torch wheels bundle their own
     # libamdhip64.so (no SONAME).  Linking against that file records DT_NEEDED "libamdhip64.so": if torch is
     # already imported the loader reuses torch's runtime (device pointers, streams and RCCL then interoperate),

@@ -133,8 +133,26 @@ struct hmx_ctx {
   bool solve_on_device = true, y_on_device = false, solve_pending = false;
   double* sv_cov = nullptr; double* sv_rhs = nullptr; float* sv_Wall = nullptr; int* sv_mrows = nullptr; int* sv_flags = nullptr;
   float* sv_lambda = nullptr; int* sv_cov_bounds = nullptr;
-  // ridge statistics arithmetic: 0 = exact (fp64 / fixed order), 1 = the reference's (sequential fp32 over the cells)
-  int ridge_arith = 0;
+  // Reference arithmetic: which accumulator groups follow the reference's fp32 operation order instead of the exact /
+  // fp64 default -- the same four groups as the oracle's arithmetic mask.  ridge_arith: the ridge statistics (sequential fp32 sums
+  // over the cells, src/harmony.cpp:567,599-608); oe_arith: the O / E tables (fp32, block sums in the round's shuffled order,
+  // -= / += drift, :149-150,312-313,329-330); obj_arith: my_accu's K*N-term sequential fp32 sums (src/utils.cpp:67-75);
+  // solve_arith: the closed-form fp32 arrowhead inverse (:575-586).  "ref_arith" sets all four.
+  int ridge_arith = 0, oe_arith = 0, obj_arith = 0, solve_arith = 0;
+  // restarted sequential sums (hmx_seq.hip): plans (segments + chains on the device), shared workspace, cell lists
+  struct SeqPlan { SeqSeg* d_segs = nullptr; SeqChain* d_chains = nullptr; size_t cap_segs = 0, cap_chains = 0; int nsegs = 0, nchains = 0;
+                   std::vector<int> seg0;   /* [nchains + 1] first segment of every chain */ };
+  SeqPlan plan_head, plan_ridge, plan_round;
+  float* sq_start = nullptr; float* sq_end = nullptr; size_t sq_cap = 0;
+  float* sq_total = nullptr; size_t sq_total_cap = 0;
+  unsigned* sq_mismatch = nullptr; int seq_passes = 3; int64_t seq_runs = 0;
+  int* headlist = nullptr;                 // [(1 + C) n] cells in original order | cells by (level of covariate c, original order)
+  std::vector<int> lev_off, lev_cnt;       // [B] a level's range inside its covariate's part of headlist
+  int* roundlist = nullptr;                // [(1 + C) n] this round's cells in shuffled order | by (block, level of covariate c), shuffled order
+  std::vector<int> invperm_h, combo_h;     // host copies (internal order)
+  float* Of = nullptr; float* Ef = nullptr; float* Mtab = nullptr;    // [B][K] fp32 O / E (oe_arith), theta log((O+E+1)/(2E+1))
+  float* objT = nullptr; size_t objT_cap = 0;                         // the objective's three K x N term matrices (obj_arith)
+  unsigned char* inset = nullptr;                                      // [K][Q] cells of combination q enter cluster k's regression
   std::map<std::string, double> timers;
   // ---- device -------------------------------------------------------------------------
   int device = -1;
@@ -200,6 +218,15 @@ void free_all(hmx_ctx* ctx) {
     if (ctx->ev_sorted[i]) { (void)hipEventDestroy(ctx->ev_sorted[i]); ctx->ev_sorted[i] = nullptr; }
     if (ctx->ev_free[i]) { (void)hipEventDestroy(ctx->ev_free[i]); ctx->ev_free[i] = nullptr; }
     ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false;
+  }
+  {   // reference-arithmetic buffers (grown on demand, not in `allocs`)
+    void* ps[] = {ctx->sq_start, ctx->sq_end, ctx->sq_total, ctx->sq_mismatch, ctx->headlist, ctx->roundlist, ctx->Of, ctx->Ef, ctx->Mtab, ctx->objT,
+                  ctx->inset, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
+                  ctx->plan_round.d_segs, ctx->plan_round.d_chains};
+    for (void* q : ps) if (q) (void)hipFree(q);
+    ctx->sq_start = ctx->sq_end = ctx->sq_total = nullptr; ctx->sq_mismatch = nullptr; ctx->headlist = ctx->roundlist = nullptr;
+    ctx->Of = ctx->Ef = ctx->Mtab = ctx->objT = nullptr; ctx->inset = nullptr; ctx->sq_cap = ctx->sq_total_cap = ctx->objT_cap = 0;
+    ctx->plan_head = hmx_ctx::SeqPlan(); ctx->plan_ridge = hmx_ctx::SeqPlan(); ctx->plan_round = hmx_ctx::SeqPlan();
   }
   if (ctx->h_obj) { (void)hipHostFree(ctx->h_obj); ctx->h_obj = nullptr; ctx->obj_cap = 0; }
   if (ctx->obj_event) { (void)hipEventDestroy(ctx->obj_event); ctx->obj_event = nullptr; }
@@ -301,6 +328,12 @@ int flush_objectives(hmx_ctx* ctx) {
     const double* o = ctx->h_obj + 4 * i;
     const int chain_err = (int)o[3];
     if (chain_err) { ctx->obj_pending = 0; return fail(ctx, HMX_ERR_DEVICE, "persistent block chain: a workgroup timed out waiting for its peers (code " + std::to_string(chain_err) + ")"); }
+    if (ctx->obj_arith) {   // the three sums are the reference's fp32 accumulators: combined in fp32 as well (:165-168)
+      const float a = (float)o[0], b = (float)o[1], c = (float)o[2];
+      ctx->obj_kmeans.push_back(((a + b) + c) * norm_const);
+      ctx->obj_dist.push_back(a * norm_const); ctx->obj_entropy.push_back(b * norm_const); ctx->obj_cross.push_back(c * norm_const);
+      continue;
+    }
     ctx->obj_kmeans.push_back((float)((o[0] + o[1] + o[2]) * norm_const));
     ctx->obj_dist.push_back((float)(o[0] * norm_const));
     ctx->obj_entropy.push_back((float)(o[1] * norm_const));
@@ -337,6 +370,8 @@ int push_objective(hmx_ctx* ctx) {
 
 // R, O, E from scratch (src/harmony.cpp:141-150, :221-227); leaves objective partials in obj[0..1]
 int prepare_round(hmx_ctx* ctx, uint64_t round);
+int oe_head(hmx_ctx* ctx);
+int objective_snapshot(hmx_ctx* ctx);
 int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- normalise(Z_corr) first (:220)
   // With the round-to-round carry (update_R) the head of cluster_cpp runs over the padded order of the round that FOLLOWS it and
   // files its R sums as that round's old contributions: no pass over R between the head and the first round either.
@@ -376,6 +411,7 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   l_obj_reduce(ctx->L, D); KCHK();
   CHK(allreduce(ctx, D.O_fx, (int64_t)D.B * D.K, 0));
   CHK(allreduce(ctx, D.obj, 2, 1));
+  if (ctx->oe_arith) CHK(oe_head(ctx));        // E = sum(R, 1) Pr_b^T, O = R Phi^T as the reference sums them (:149-150)
   return 0;
 }
 
@@ -609,8 +645,209 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
   return prefetch_next();
 }
 
+// ================================================================================================================================
+// Reference arithmetic: the reference's sequential fp32 accumulators as restarted sequential sums (hmx_seq.hip)
+// ================================================================================================================================
+template <class T> int seq_grow(hmx_ctx* ctx, T*& p, size_t& cap, size_t need) {
+  if (need <= cap && p) return 0;
+  if (p) { HIPCHK(hipStreamSynchronize(ctx->L.stream)); (void)hipFree(p); p = nullptr; cap = 0; }
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, std::max<size_t>(need, 1) * sizeof(T)));
+  p = (T*)q; cap = need;
+  return 0;
+}
+// chains = (first entry of the list, number of cells); every chain is cut into segments of L cells
+int seq_plan_build(hmx_ctx* ctx, hmx_ctx::SeqPlan& P, const std::vector<std::pair<int, int>>& chains, int L) {
+  std::vector<SeqSeg> segs; std::vector<SeqChain> ch(chains.size());
+  P.seg0.assign(chains.size() + 1, 0);
+  for (size_t c = 0; c < chains.size(); c++) {
+    ch[c].seg0 = (int)segs.size(); P.seg0[c] = (int)segs.size();
+    for (int o = 0; o < chains[c].second; o += L) segs.push_back({chains[c].first + o, std::min(L, chains[c].second - o)});
+    ch[c].nseg = (int)segs.size() - ch[c].seg0;
+  }
+  P.seg0[chains.size()] = (int)segs.size();
+  P.nsegs = (int)segs.size(); P.nchains = (int)chains.size();
+  CHK(seq_grow(ctx, P.d_segs, P.cap_segs, segs.size())); CHK(seq_grow(ctx, P.d_chains, P.cap_chains, ch.size()));
+  CHK(h2d(ctx, P.d_segs, segs.data(), segs.size())); CHK(h2d(ctx, P.d_chains, ch.data(), ch.size()));
+  return 0;
+}
+int seq_workspace(hmx_ctx* ctx, size_t seg_floats, size_t total_floats) {
+  if (seg_floats > ctx->sq_cap) { size_t c1 = ctx->sq_cap, c2 = ctx->sq_cap; CHK(seq_grow(ctx, ctx->sq_start, c1, seg_floats)); CHK(seq_grow(ctx, ctx->sq_end, c2, seg_floats)); ctx->sq_cap = seg_floats; }
+  CHK(seq_grow(ctx, ctx->sq_total, ctx->sq_total_cap, total_floats));
+  if (!ctx->sq_mismatch) { size_t c = 0; CHK(seq_grow(ctx, ctx->sq_mismatch, c, 1)); HIPCHK(hipMemsetAsync(ctx->sq_mismatch, 0, sizeof(unsigned), ctx->L.stream)); }
+  return 0;
+}
+// sum_i R[cell_i][k] for the chains [chain0, chain0 + nchains) of plan P, every chain a sequential fp32 sum in list order
+// -> ctx->sq_total[chain][K].  passes x (segments in parallel, then the scan that hands every segment its start).
+int seq_run_rsum(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, int chain0, int nchains) {
+  const int K = ctx->K, lo = P.seg0[chain0], n = P.seg0[chain0 + nchains] - lo;
+  CHK(seq_workspace(ctx, (size_t)P.nsegs * K, (size_t)P.nchains * K));
+  for (int p = 0; p < ctx->seq_passes; p++) {
+    l_seq_rsum_pass(ctx->L, ctx->D.R, K, list, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
+    l_seq_scan(ctx->L, P.d_chains, chain0, nchains, K, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total,
+               p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
+  }
+  ctx->seq_runs++;
+  return 0;
+}
+// static lists and plans of a handle that runs (part of) the reference's arithmetic; called at the end of hmx_setup
+int seq_setup_static(hmx_ctx* ctx) {
+  const int n = (int)ctx->N, C = ctx->C, B = ctx->B, K = ctx->K, Q = ctx->Q;
+  const bool any = ctx->ridge_arith || ctx->oe_arith || ctx->obj_arith || ctx->solve_arith;
+  if (!any) return 0;
+  if (ctx->world > 1 || ctx->comm_force) return fail(ctx, HMX_ERR_ARG, "the reference-arithmetic modes (ridge_arith / oe_arith / obj_arith / solve_arith) run on one GPU");
+  // headlist: [ cells in original order | for every covariate: cells by (level, original order) ]  (internal cell ids)
+  std::vector<int> hl((size_t)(1 + C) * n);
+  for (int i = 0; i < n; i++) hl[i] = ctx->invperm_h[i];
+  ctx->lev_off.assign(B, 0); ctx->lev_cnt.assign(B, 0);
+  for (int c = 0; c < C; c++) {
+    const int b0 = c ? ctx->cov_bounds[c - 1] : 0, nl = ctx->B_vec[c];
+    std::vector<int> cnt(nl + 1, 0);
+    for (int i = 0; i < n; i++) cnt[ctx->qlev[(size_t)ctx->combo_h[ctx->invperm_h[i]] * C + c] - b0 + 1]++;
+    for (int l = 0; l < nl; l++) { ctx->lev_cnt[b0 + l] = cnt[l + 1]; cnt[l + 1] += cnt[l]; ctx->lev_off[b0 + l] = (1 + c) * n + cnt[l]; }
+    std::vector<int> cur(cnt.begin(), cnt.end() - 1);
+    for (int i = 0; i < n; i++) { const int cell = ctx->invperm_h[i]; const int l = ctx->qlev[(size_t)ctx->combo_h[cell] * C + c] - b0; hl[(size_t)(1 + c) * n + cur[l]++] = cell; }
+  }
+  { size_t cap = 0; CHK(seq_grow(ctx, ctx->headlist, cap, hl.size())); CHK(h2d(ctx, ctx->headlist, hl.data(), hl.size())); }
+  { size_t c1 = 0, c2 = 0, c3 = 0; CHK(seq_grow(ctx, ctx->Of, c1, (size_t)B * K)); CHK(seq_grow(ctx, ctx->Ef, c2, (size_t)B * K)); CHK(seq_grow(ctx, ctx->Mtab, c3, (size_t)B * K));
+    HIPCHK(hipMemsetAsync(ctx->Of, 0, sizeof(float) * (size_t)B * K, ctx->L.stream)); HIPCHK(hipMemsetAsync(ctx->Ef, 0, sizeof(float) * (size_t)B * K, ctx->L.stream)); }
+  if (ctx->oe_arith) {       // head: E = sum(R, 1) Pr_b^T over all cells, O = R Phi^T per level (:149-150)
+    std::vector<std::pair<int, int>> ch; ch.push_back({0, n});
+    for (int b = 0; b < B; b++) ch.push_back({ctx->lev_off[b], ctx->lev_cnt[b]});
+    CHK(seq_plan_build(ctx, ctx->plan_head, ch, 256));
+    size_t cap = 0; CHK(seq_grow(ctx, ctx->roundlist, cap, (size_t)(1 + C) * n));
+  }
+  if (ctx->ridge_arith) {
+    if (C != 1) return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 (the reference's summation order) supports one covariate");
+    if (ctx->d > 62) return fail(ctx, HMX_ERR_LIMIT, "ridge_arith = 1 supports d <= 62");
+    if (!ctx->solve_on_device) return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 needs the device-side ridge solve");
+    std::vector<std::pair<int, int>> ch; ch.push_back({0, n});      // the intercept row's chain: all (kept) cells in original order
+    for (int q = 0; q < Q; q++) { const int b = ctx->qlev[q]; ch.push_back({ctx->lev_off[b], ctx->lev_cnt[b]}); }    // a level's cells, ascending
+    CHK(seq_plan_build(ctx, ctx->plan_ridge, ch, 256));
+    size_t cap = 0; CHK(seq_grow(ctx, ctx->inset, cap, (size_t)K * Q));
+  }
+  if ((ctx->solve_arith || ctx->oe_arith) && !ctx->solve_on_device) return fail(ctx, HMX_ERR_ARG, "solve_arith / oe_arith need the device-side ridge solve");
+  return 0;
+}
+// E, O of the head in the reference's arithmetic: R has just been rewritten
+int oe_head(hmx_ctx* ctx) {
+  CHK(seq_run_rsum(ctx, ctx->plan_head, ctx->headlist, 0, ctx->plan_head.nchains));
+  l_oe_fold(ctx->L, ctx->D, ctx->Of, ctx->Ef, ctx->sq_total, nullptr, 0); KCHK();
+  return 0;
+}
+// compute_objective's three my_accu sums (src/harmony.cpp:160-162) as sequential fp32 chains over K*N terms each -> obj[2..4]
+int seq_objective(hmx_ctx* ctx) {
+  const Dev& D = ctx->D;
+  const long long nt = (long long)ctx->N * ctx->K;
+  constexpr int LSEG = 4096;
+  const int nsegs = (int)((nt + LSEG - 1) / LSEG);
+  CHK(seq_grow(ctx, ctx->objT, ctx->objT_cap, (size_t)3 * (size_t)nt));
+  CHK(seq_workspace(ctx, (size_t)3 * nsegs, 3));
+  l_obj_terms(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->oe_arith ? ctx->Ef : nullptr, ctx->Mtab, ctx->objT, nt); KCHK();
+  for (int p = 0; p < ctx->seq_passes; p++) {
+    l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, 3, LSEG, nsegs, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
+    l_seq_scan1(ctx->L, 3, nsegs, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
+  }
+  l_obj_store(ctx->L, ctx->sq_total, D.obj); KCHK();
+  ctx->seq_runs++;
+  return 0;
+}
+// the objective snapshot obj[2..4] from what the last pass over the cells left behind (obj[0..1]: exact per-cell sums)
+int objective_snapshot(hmx_ctx* ctx) {
+  l_objective_tables(ctx->L, ctx->D); KCHK();      // (also resets the block chain's control words)
+  if (ctx->obj_arith) return seq_objective(ctx);
+  if (ctx->oe_arith) { l_obj_cross_f32(ctx->L, ctx->D, ctx->Of, ctx->Ef, ctx->Mtab); KCHK(); }
+  return 0;
+}
+// ridge statistics in the reference's arithmetic (ridge_arith = 1, one covariate): per cluster the intercept row's chain over all kept
+// cells in original order (sum(Z_tmp, 1), :599) and a chain per level over its cells (sum(Z_tmp.cols(index[b]), 1), :605-608;
+// Phi_Rk * Phi_moe_t, :567) -> S0 / n0, Sq / nq
+int seq_ridge_stats(hmx_ctx* ctx) {
+  const Dev& D = ctx->D;
+  const hmx_ctx::SeqPlan& P = ctx->plan_ridge;
+  const int W = ctx->K * 64;
+  CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
+  l_seq_inset(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->sv_cov_bounds, ctx->cutoff, ctx->inset); KCHK();
+  for (int p = 0; p < ctx->seq_passes; p++) {
+    l_seq_ridge_pass(ctx->L, D, ctx->headlist, P.d_segs, 0, P.nsegs, ctx->inset, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
+    l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total,
+               p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
+  }
+  l_seq_ridge_store(ctx->L, D, ctx->sq_total); KCHK();
+  ctx->seq_runs++;
+  return 0;
+}
+
+// update_R with the reference's O / E arithmetic (oe_arith): the tables are fp32 and every block removes / puts back its cells'
+// sums exactly as src/harmony.cpp:312-313,329-330 -- sequential fp32 sums in the round's shuffled order, formed first, then one
+// subtraction / addition per table entry.  One launch of the tile kernel per block (penalty table from memory), the block chain's
+// persistent launch does not apply.  Host-visible shuffle: the order is materialised on the host whatever its source.
+int update_R_ref(hmx_ctx* ctx) {
+  Dev& D = ctx->D;
+  const double t0 = now_ms();
+  const int n = (int)ctx->N, C = ctx->C, B = ctx->B, K = ctx->K, nb = ctx->nb;
+  std::vector<int64_t> order;
+  if (!ctx->injected.empty()) { order = std::move(ctx->injected.front()); ctx->injected.pop_front(); }
+  else if (ctx->rng_mode == 1) { ensure_rrng(ctx); ctx->rrng.arma_shuffle(ctx->N_global, order); }
+  else { order.resize((size_t)n); for (int64_t g = 0; g < n; g++) order[(size_t)hmx_feistel_pos(ctx->seed, ctx->round_counter, (uint64_t)n, (uint64_t)g)] = g; }
+  // this round's lists: the cells in shuffled order, and per covariate by (block, level) in shuffled order
+  std::vector<int> rl((size_t)(1 + C) * n);
+  for (int p = 0; p < n; p++) rl[p] = ctx->invperm_h[(size_t)order[p]];
+  std::vector<std::pair<int, int>> ch;
+  std::vector<int> bs(nb + 1);
+  for (int j = 0; j <= nb; j++) bs[j] = (int)std::min<uint64_t>((uint64_t)n, (uint64_t)j * ctx->cells_per_block);
+  bs[nb] = n;                                                      // the last block takes the rest (:296-300)
+  std::vector<std::vector<std::pair<int, int>>> lev((size_t)nb, std::vector<std::pair<int, int>>(B));
+  for (int c = 0; c < C; c++) {
+    const int b0 = c ? ctx->cov_bounds[c - 1] : 0, nl = ctx->B_vec[c];
+    std::vector<int> cnt(nl + 1);
+    for (int j = 0; j < nb; j++) {
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int p = bs[j]; p < bs[j + 1]; p++) cnt[ctx->qlev[(size_t)ctx->combo_h[rl[p]] * C + c] - b0 + 1]++;
+      for (int l = 0; l < nl; l++) { lev[j][b0 + l] = {(1 + c) * n + bs[j] + cnt[l], cnt[l + 1]}; cnt[l + 1] += cnt[l]; }
+      std::vector<int> cur(cnt.begin(), cnt.end() - 1);
+      for (int p = bs[j]; p < bs[j + 1]; p++) { const int l = ctx->qlev[(size_t)ctx->combo_h[rl[p]] * C + c] - b0; rl[(size_t)(1 + c) * n + bs[j] + cur[l]++] = rl[p]; }
+    }
+  }
+  for (int j = 0; j < nb; j++) { ch.push_back({bs[j], bs[j + 1] - bs[j]}); for (int b = 0; b < B; b++) ch.push_back(lev[j][b]); }
+  CHK(seq_plan_build(ctx, ctx->plan_round, ch, 64));
+  CHK(h2d(ctx, ctx->roundlist, rl.data(), rl.size()));
+  { PhaseScope ph(ctx, "randomize");
+    ctx->injected.push_front(std::move(order));                    // the tile kernels' padded block order comes from the same shuffle
+    CHK(prepare_round(ctx, ctx->round_counter)); }
+  ctx->round_counter++;
+  HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * B * K, ctx->L.stream));   // (the kernel's fixed-point sums are not used here)
+  const int per = 1 + B;
+  { PhaseScope ph(ctx, "EO_update");     // every block's cells are still untouched at this point: the sums each block will remove (:312-313), all at once
+    CHK(seq_run_rsum(ctx, ctx->plan_round, ctx->roundlist, 0, nb * per)); }
+  D.fused_fold = 0; D.Sold_next = nullptr;
+  for (int j = 0; j < nb; j++) {
+    if (bs[j] >= bs[j + 1]) continue;                              // N * block_size rounding can leave trailing empty blocks
+    float* tot = ctx->sq_total + (size_t)j * per * K;
+    { PhaseScope ph(ctx, "EO_update"); l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, tot, D.pen, -1); KCHK(); }
+    if (ctx->profile) {
+      if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); ctx->ev_pool.emplace_back(a, b); }
+      HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
+    }
+    l_update(ctx->L, D, j); KCHK();
+    if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
+    { PhaseScope ph(ctx, "EO_update");
+      CHK(seq_run_rsum(ctx, ctx->plan_round, ctx->roundlist, j * per, per));
+      l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, tot, nullptr, +1); KCHK(); }
+  }
+  l_obj_reduce(ctx->L, D); KCHK();
+  CHK(objective_snapshot(ctx));
+  CHK(push_objective(ctx));
+  ctx->sets_clean = false;
+  for (int i = 0; i < 2; i++) if (ctx->sold_state[i] == 2) ctx->sold_state[i] = 1;
+  if (ctx->profile) ctx->prof_update_cells += ctx->N;
+  ctx->timers["update_R"] += now_ms() - t0;
+  return 0;
+}
+
 // ---- update_R (src/harmony.cpp:269-342) ---------------------------------------------------------
 int update_R(hmx_ctx* ctx) {
+  if (ctx->oe_arith) return update_R_ref(ctx);
   Dev& D = ctx->D;
   const bool sharded = ctx->world > 1 || ctx->comm_force;
   const char* fold_env = getenv("HMX_FOLD_IMPL");   // "split": force the two-kernel fold + penalty fallback (tests)
@@ -733,7 +970,7 @@ int update_R(hmx_ctx* ctx) {
     l_update(ctx->L, D, j); KCHK();
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
   }
-  if (!sharded) {
+  if (!sharded && !ctx->obj_arith) {
     // one launch: slot rows -> objective terms -> snapshot written STRAIGHT into the pinned host slot (no copy engine, no
     // second launch), chain control reset.  Resolved by flush_objectives (event) when a value is needed.
     double* slot = nullptr;
@@ -749,7 +986,7 @@ int update_R(hmx_ctx* ctx) {
   } else {
     l_obj_reduce(ctx->L, D); KCHK();
     CHK(allreduce(ctx, D.obj, 2, 1));
-    l_objective_tables(ctx->L, D); KCHK();
+    CHK(objective_snapshot(ctx));
     CHK(push_objective(ctx));  // asynchronous: resolved by flush_objectives when a value is needed
   }
   if (!chain_old) ctx->sold_cur ^= 1;      // next round subtracts what this round's tile kernels collected (or a fresh k_oldsum pass)
@@ -1151,7 +1388,15 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   if (f == "max_iter_kmeans") ctx->max_iter_kmeans = (int)v;
   else if (f == "seed") { ctx->seed = (uint64_t)v; ctx->rrng_seeded = false; }
   else if (f == "rng") { if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, "rng: 0 (counter-based) or 1 (R-compatible)"); ctx->rng_mode = (int)v; ctx->rrng_seeded = false; }
-  else if (f == "ridge_arith") { if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, "ridge_arith: 0 (exact) or 1 (reference fp32 order)"); ctx->ridge_arith = (int)v; }
+  else if (f == "ridge_arith" || f == "oe_arith" || f == "obj_arith" || f == "solve_arith" || f == "ref_arith") {
+    if (v != 0 && v != 1) return fail(ctx, HMX_ERR_ARG, f + ": 0 (exact accumulators) or 1 (the reference's fp32 operation order)");
+    if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, f + " must be set before setup");
+    if (f == "ridge_arith" || f == "ref_arith") ctx->ridge_arith = (int)v;
+    if (f == "oe_arith" || f == "ref_arith") ctx->oe_arith = (int)v;
+    if (f == "obj_arith" || f == "ref_arith") ctx->obj_arith = (int)v;
+    if (f == "solve_arith" || f == "ref_arith") ctx->solve_arith = (int)v;
+  }
+  else if (f == "seq_passes") { if (v < 2 || v > 16) return fail(ctx, HMX_ERR_ARG, "seq_passes: 2..16"); ctx->seq_passes = (int)v; }
   else if (f == "device") ctx->device = (int)v;
   else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->prof_update_steps = 0; ctx->ev_used = 0;
                              ctx->ph_used = 0; ctx->gpu_timers.clear(); }
@@ -1338,7 +1583,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     const bool fits = D.nb <= 63 && Q < (1 << 19) && D.upd_impl == 0 && !(co && atoi(co) == 1) &&
                       (int64_t)N + (int64_t)D.nb * D.nb * Q * 16 <= 2147483000ll;
     const bool pays = (int64_t)D.nb * D.nb * Q * 8 * 25 <= (int64_t)N;
-    ctx->carry_ok = fits && (e ? atoi(e) == 1 : pays);
+    ctx->carry_ok = fits && (e ? atoi(e) == 1 : pays) && !ctx->oe_arith;      // (oe_arith: the tables follow the reference, nothing is carried)
     D.nxt = 0; D.Sold_next = nullptr; D.Sold_head = nullptr; D.head_gather = 0; ctx->carried_rounds = 0;
     D.qmask = ctx->carry_ok ? 0x7FFFF : 0x7FFFFFFF; }
   const int nV = ctx->carry_ok ? D.nb * D.nb : D.nb;      // sort keys of a round
@@ -1512,6 +1757,8 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     ctx->chain_rounds = 0;
     D.p2p_world = 0; D.p2p_rank = ctx->p2p_rank;
     for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g]; }
+  ctx->invperm_h = invperm; ctx->combo_h = combo_sorted;
+  CHK(seq_setup_static(ctx));
   ctx->ran_setup = true;
   return hmx_restart(ctx);
 }
@@ -1550,7 +1797,7 @@ int hmx_init_cluster(hmx_ctx* ctx, const double* Y0) {  // src/harmony.cpp:131-1
   normalise_cols(ctx->Y, ctx->d, ctx->K);  // :136
   CHK(upload_Y(ctx));
   CHK(head_pass(ctx));
-  l_objective_tables(ctx->L, ctx->D); KCHK();
+  CHK(objective_snapshot(ctx));
   CHK(push_objective(ctx));
   CHK(flush_objectives(ctx));
   ctx->obj_harmony.push_back(ctx->obj_kmeans.back());
@@ -1566,7 +1813,7 @@ int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the cur
   l_head(ctx->L, ctx->D, 1); KCHK();
   l_obj_reduce(ctx->L, ctx->D); KCHK();
   CHK(allreduce(ctx, ctx->D.obj, 2, 1));
-  l_objective_tables(ctx->L, ctx->D); KCHK();
+  CHK(objective_snapshot(ctx));
   CHK(push_objective(ctx));
   return flush_objectives(ctx);
 }
@@ -1615,13 +1862,11 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   const Dev& D = ctx->D;
   const int K = ctx->K, B = ctx->B, d = ctx->d, Q = ctx->Q;
   const bool seq = ctx->ridge_arith == 1;
-  if (seq && (ctx->C != 1 || ctx->world > 1 || ctx->comm_force || B > 1024))
-    return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 (reference summation order) supports one covariate on one GPU");
   { PhaseScope pall(ctx, "correct_ridge_loop");
   { PhaseScope ph(ctx, "ridge_statistics");   // reference timers Phi_Rk + Phi_cov + Z_tmp + Z_intercept + batch_exprod: ONE pass here
     HIPCHK(hipMemsetAsync(D.Sq, 0, sizeof(double) * (size_t)Q * d * K, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.nq, 0, sizeof(double) * (size_t)Q * K, ctx->L.stream));
-    if (seq) { l_moe_stats_seq(ctx->L, D, ctx->cutoff); KCHK(); }
+    if (seq) CHK(seq_ridge_stats(ctx));
     else if (D.moe_mfma) { l_moe_stats_mfma(ctx->L, D); KCHK(); } else { l_moe_stats(ctx->L, D); KCHK(); }
     CHK(allreduce(ctx, D.Sq, (int64_t)Q * d * K, 1));
     CHK(allreduce(ctx, D.nq, (int64_t)Q * K, 1)); }
@@ -1632,6 +1877,7 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
     A.cov = ctx->sv_cov; A.rhs = ctx->sv_rhs; A.Wall = ctx->sv_Wall; A.mrows = ctx->sv_mrows; A.flags = ctx->sv_flags;
     A.lambda = ctx->lambda_estimation ? nullptr : ctx->sv_lambda; A.cov_bounds = ctx->sv_cov_bounds;
     A.alpha = ctx->alpha; A.cutoff = ctx->cutoff; A.use_s0 = seq ? 1 : 0;
+    A.Of = ctx->oe_arith ? ctx->Of : nullptr; A.Ef = ctx->oe_arith ? ctx->Ef : nullptr; A.solve_f32 = ctx->solve_arith;
     { PhaseScope ph(ctx, "arma_inv"); l_moe_solve(ctx->L, D, A); KCHK(); }
     { PhaseScope ph(ctx, "update_Zcorr");
       if (D.moe_mfma) { l_moe_apply_mfma(ctx->L, D); KCHK(); } else { l_moe_apply(ctx->L, D); KCHK(); } }
@@ -1687,6 +1933,64 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   HIPCHK(hipStreamSynchronize(ctx->L.stream));
   ctx->timers["moe_correct_ridge"] += now_ms() - t0;
   return 0;
+}
+
+// ---- diagnostics of the restarted sequential sums (tests/test_gpu_seq.py): the machinery alone, on caller-provided data -----------
+// totals[c][k] = the fp32 value of   s = 0; for i in chain c: s += R[list[off_c + i]][k]   (one add after the other)
+int hmx_debug_seq_rsum(const float* R, int64_t n, int32_t K, const int32_t* list, int64_t nlist, const int32_t* chain_off,
+                       const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals, int64_t* mismatch) {
+  if (!R || !list || !chain_off || !chain_cnt || !totals || n <= 0 || K <= 0 || nchains <= 0 || seg_cells <= 0 || passes < 2) return HMX_ERR_ARG;
+  hmx_ctx* ctx = hmx_create();
+  int st = 0;
+  float* dR = nullptr; int* dl = nullptr;
+  auto run = [&]() -> int {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ctx, HMX_ERR_DEVICE, "no HIP device");
+    HIPCHK(hipStreamCreateWithFlags(&ctx->L.stream, hipStreamNonBlocking)); ctx->own_stream = true;
+    HIPCHK(hipMalloc((void**)&dR, sizeof(float) * (size_t)n * K)); HIPCHK(hipMalloc((void**)&dl, sizeof(int) * (size_t)nlist));
+    CHK(h2d(ctx, dR, R, (size_t)n * K)); CHK(h2d(ctx, dl, list, (size_t)nlist));
+    ctx->K = K; ctx->D.R = dR; ctx->seq_passes = passes;
+    std::vector<std::pair<int, int>> ch;
+    for (int c = 0; c < nchains; c++) ch.push_back({chain_off[c], chain_cnt[c]});
+    CHK(seq_plan_build(ctx, ctx->plan_round, ch, seg_cells));
+    CHK(seq_run_rsum(ctx, ctx->plan_round, dl, 0, nchains));
+    CHK(d2h(ctx, totals, ctx->sq_total, (size_t)nchains * K));
+    unsigned mm = 0; CHK(d2h(ctx, &mm, ctx->sq_mismatch, 1));
+    if (mismatch) *mismatch = (int64_t)mm;
+    return 0;
+  };
+  st = run();
+  if (dR) (void)hipFree(dR);
+  if (dl) (void)hipFree(dl);
+  hmx_destroy(ctx);
+  return st;
+}
+// total[a] = the fp32 value of   s = 0; for i < n: s += T[a * n + i]
+int hmx_debug_seq_arr(const float* T, int64_t n, int32_t narr, int32_t seg_terms, int32_t passes, float* total, int64_t* mismatch) {
+  if (!T || !total || n <= 0 || narr <= 0 || narr > 64 || seg_terms <= 0 || passes < 2) return HMX_ERR_ARG;
+  hmx_ctx* ctx = hmx_create();
+  float* dT = nullptr;
+  auto run = [&]() -> int {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ctx, HMX_ERR_DEVICE, "no HIP device");
+    HIPCHK(hipStreamCreateWithFlags(&ctx->L.stream, hipStreamNonBlocking)); ctx->own_stream = true;
+    HIPCHK(hipMalloc((void**)&dT, sizeof(float) * (size_t)n * narr));
+    CHK(h2d(ctx, dT, T, (size_t)n * narr));
+    const int nsegs = (int)((n + seg_terms - 1) / seg_terms);
+    CHK(seq_workspace(ctx, (size_t)narr * nsegs, (size_t)narr));
+    for (int p = 0; p < passes; p++) {
+      l_seq_arr_pass(ctx->L, dT, n, n, narr, seg_terms, nsegs, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
+      l_seq_scan1(ctx->L, narr, nsegs, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, p == passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
+    }
+    CHK(d2h(ctx, total, ctx->sq_total, (size_t)narr));
+    unsigned mm = 0; CHK(d2h(ctx, &mm, ctx->sq_mismatch, 1));
+    if (mismatch) *mismatch = (int64_t)mm;
+    return 0;
+  };
+  const int st = run();
+  if (dT) (void)hipFree(dT);
+  hmx_destroy(ctx);
+  return st;
 }
 
 // host-only micro-benchmark of the ridge solves (no device needed): returns microseconds per call of the full K-cluster loop
@@ -1791,14 +2095,25 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "kmeans_rounds") return vec(ctx->kmeans_rounds);
   if (!ctx->ran_setup) return -1;
   if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  if (f == "seq:mismatch") {      // segments of the restarted sequential sums whose final start was not the end of the segment before (0: every chain certified bit-exact)
+    if (!ctx->sq_mismatch) return scalar(0.0);
+    unsigned mm = 0; if (d2h(ctx, &mm, ctx->sq_mismatch, 1)) return -1;
+    return scalar((double)mm);
+  }
+  if (f == "seq:runs") return scalar((double)ctx->seq_runs);
   if (f == "O" || f == "E" || f == "Lambda") {
     const int K = ctx->K, B = ctx->B;
     const int64_t cnt = (f == "Lambda") ? (int64_t)K * (B + 1) : (int64_t)K * B;
     if (!out) return cnt;
     std::vector<long long> ofx((size_t)B * K);
     if (d2h(ctx, ofx.data(), ctx->D.O_fx, ofx.size())) return -1;
-    if (f == "O") return vec(table_O(ctx, ofx));
-    const std::vector<float> E = table_E(ctx, ofx);
+    std::vector<float> Of_h, Ef_h;
+    if (ctx->oe_arith) {       // the tables ARE fp32 in this mode
+      Of_h.resize((size_t)B * K); Ef_h.resize((size_t)B * K);
+      if (d2h(ctx, Of_h.data(), ctx->Of, Of_h.size()) || d2h(ctx, Ef_h.data(), ctx->Ef, Ef_h.size())) return -1;
+    }
+    if (f == "O") return vec(ctx->oe_arith ? Of_h : table_O(ctx, ofx));
+    const std::vector<float> E = ctx->oe_arith ? Ef_h : table_E(ctx, ofx);
     if (f == "E") return vec(E);
     std::vector<double> L((size_t)K * (B + 1), 0.0);  // getLambda :657-669
     for (int k = 0; k < K; k++) for (int b = 0; b < B; b++)

@@ -156,6 +156,8 @@ struct SolveArgs {
   const float* lambda;             // [B+1] fixed lambda or nullptr (estimation: alpha * E)
   const int* cov_bounds;           // [C] cumulative level counts
   float alpha, cutoff; int use_s0;
+  const float* Of; const float* Ef;   // oe_arith: the fp32 O / E tables that replace the exact fixed-point O (keep rule, lambda = alpha E); else nullptr
+  int solve_f32;                      // solve_arith: one covariate -> the reference's closed-form fp32 arrowhead inverse (src/harmony.cpp:575-586)
   size_t lds_b_bytes;              // LDS bytes available for the right-hand sides during the substitution (0: leave them in HBM)
 };
 
@@ -205,7 +207,6 @@ void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term o
 void l_moe_stats(const Launch& L, const Dev& D);
 void l_moe_apply(const Launch& L, const Dev& D);
 void l_moe_stats_mfma(const Launch& L, const Dev& D);
-void l_moe_stats_seq(const Launch& L, const Dev& D, float cutoff);
 void l_moe_solve(const Launch& L, const Dev& D, const SolveArgs& A);
 void l_moe_apply_mfma(const Launch& L, const Dev& D);
 void l_seed_probe(const Launch& L, const Dev& D, uint64_t seed, uint64_t goff, const unsigned* excl, int nexcl);
@@ -215,5 +216,25 @@ void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint6
 void l_lloyd(const Launch& L, const Dev& D);
 void l_lloyd_finish(const Launch& L, const Dev& D);
 size_t lds_bytes_y(const Dev& D);
+
+// ---- reference arithmetic: restarted sequential fp32 sums (hmx_seq.hip) ------------------------------------------------------------
+struct SeqSeg { int off; int cnt; };       // a segment of a chain: cells list[off .. off + cnt) (or the cells off .. off + cnt - 1 themselves)
+struct SeqChain { int seg0; int nseg; };   // the segments of one chain, in chain order
+void l_seq_rsum_pass(const Launch& L, const float* R, int K, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start,
+                     float* end, int zero_start);
+void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
+                      const float* start, float* end, int zero_start);
+void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
+                    int zero_start);
+void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains, int W, const float* start_in, const float* end, float* start_out,
+                float* total, unsigned* mismatch, int zero_start);
+void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, const float* end, float* start_out, float* total,
+                 unsigned* mismatch, int zero_start);
+void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot, float* pen, int mode);
+void l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
+void l_obj_store(const Launch& L, const float* total, double* obj);
+void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M);
+void l_seq_inset(const Launch& L, const Dev& D, const float* Of, const int* cov_bounds, float cutoff, unsigned char* inset);
+void l_seq_ridge_store(const Launch& L, const Dev& D, const float* total);
 
 }  // namespace hmx

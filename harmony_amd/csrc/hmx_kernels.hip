@@ -2424,67 +2424,6 @@ __global__ __launch_bounds__(TPB) void k_moe_apply(Dev D) {
   }
 }
 
-// k_moe_stats_seq ("ridge_arith" = 1, one covariate): the ridge statistics in the REFERENCE'S arithmetic -- every accumulator a
-// sequential fp32 sum over the cells in ascending cell order, products rounded to fp32 first:
-//   Z_tmp = Z_orig % R_k (:592);  W.row(0) <- sum(Z_tmp, 1) (:599: arma::sum adds column after column);  level rows
-//   sum(Z_tmp.cols(index[b]), 1) (:605-608, index[b] ascending);  Phi_Rk * Phi_moe_t (:567) adds R_ki cell after cell.
-// These sums lose the many tiny R_ki z_i of far-away cells once the accumulator has grown (a systematic, N-dependent bias of
-// the reference: DESIGN.md section 2); the default path sums exactly instead.  One wave per (cluster, row): row 0 = the
-// intercept chain over ALL kept cells in original order (gathered through invperm), row 1+q = the cells of level/combination q
-// (contiguous and ascending in the internal order).  lanes = PCs; a chain of N dependent fp32 adds per wave: slow by design.
-__global__ __launch_bounds__(64) void k_moe_stats_seq(Dev D, float cutoff) {
-  __shared__ unsigned char keep[1024];
-  const int k = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
-  const int K = D.K, d = D.d, zs = D.zs, B = D.B;
-  // kept levels of this cluster (:358-402, one covariate): O[k,b] / N_b > cutoff, and at least two such levels
-  int nk = 0;
-  for (int b0 = 0; b0 < B; b0 += 64) {
-    const int b = b0 + lane;
-    bool kp = false;
-    if (b < B) { const float o = (float)((double)D.O_fx[(size_t)b * K + k] * FX_INV); kp = (o / D.sizes[b]) > cutoff; }
-    if (b < B) keep[b] = kp ? 1 : 0;
-    nk += __popcll(__ballot(kp));
-  }
-  __syncthreads();
-  const bool any = nk > 1;
-  float a0 = 0.0f, a1 = 0.0f, an = 0.0f;
-  int lo, hi;
-  if (row == 0) { lo = 0; hi = D.n; } else { lo = D.qstart[row - 1]; hi = D.qstart[row]; }
-  const int j0 = min(lane, zs - 1), j1 = min(lane + 64, zs - 1);
-  for (int base = lo; base < hi; base += 64) {
-    const int i = min(base + lane, hi - 1);
-    const int p = (row == 0) ? D.invperm[i] : i;
-    const float r = D.R[(size_t)p * K + k];
-    bool in = base + lane < hi;
-    if (row == 0) in = in && any && keep[D.qlev[D.combo[p]]];     // cells of dropped levels do not enter (:400,456-460)
-    const int nc = min(64, hi - base);
-    for (int c0 = 0; c0 < nc; c0 += 8) {
-      float z0[8], z1[8], rr[8]; bool ok[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int c = min(c0 + u, nc - 1);
-        const int pc = __builtin_amdgcn_readlane(p, c);
-        rr[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), c));
-        ok[u] = (c0 + u < nc) && __builtin_amdgcn_readlane((int)in, c);
-        z0[u] = D.Zo[(size_t)pc * zs + j0];
-        z1[u] = D.Zo[(size_t)pc * zs + j1];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        if (ok[u]) {
-          a0 = __fadd_rn(a0, __fmul_rn(z0[u], rr[u]));
-          a1 = __fadd_rn(a1, __fmul_rn(z1[u], rr[u]));
-          an = __fadd_rn(an, rr[u]);
-        }
-      }
-    }
-  }
-  double* S = (row == 0) ? D.S0 + (size_t)k * d : D.Sq + ((size_t)(row - 1) * K + k) * d;
-  if (lane < d) S[lane] = (double)a0;
-  if (lane + 64 < d) S[lane + 64] = (double)a1;
-  if (lane == 0) { if (row == 0) D.n0[k] = (double)an; else D.nq[(size_t)(row - 1) * K + k] = (double)an; }
-}
-
 // index of centroid entry (PC j, cluster k) in the MFMA B-operand image (inverse of the host builder in upload_Y)
 __device__ __forceinline__ size_t yimg_index(const Dev& D, int j, int k) {
   int s_, p_;
@@ -2514,7 +2453,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
   double* cov = A.cov + (size_t)k * M * M;
   double* rhs = A.rhs + (size_t)k * d * M;
   for (int b = tid; b < B; b += nt) {
-    const float o = (float)((double)D.O_fx[(size_t)b * K + k] * FX_INV);
+    const float o = A.Of ? A.Of[(size_t)b * K + k] : (float)((double)D.O_fx[(size_t)b * K + k] * FX_INV);
     okb[b] = (o / D.sizes[b]) > A.cutoff ? 1 : 0;
   }
   __syncthreads();
@@ -2559,10 +2498,46 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
     const double rsd = (double)rs * FX_INV;
     for (int a = 1 + tid; a < m; a += nt) {
       const int b = keepl[a - 1];
-      const float lam = A.lambda ? A.lambda[b + 1] : (float)(rsd * (double)D.Pr_b[b]) * A.alpha;
-      cov[(size_t)a * m + a] += (double)lam;
+      const float lam = A.lambda ? A.lambda[b + 1] : (A.Ef ? A.Ef[(size_t)b * K + k] : (float)(rsd * (double)D.Pr_b[b])) * A.alpha;
+      if (A.solve_f32) cov[(size_t)a * m + a] = (double)__fadd_rn((float)cov[(size_t)a * m + a], lam);     // an fp32 matrix in the reference
+      else cov[(size_t)a * m + a] += (double)lam;
     }
     __syncthreads();
+    if (A.solve_f32 && C == 1) {
+      // The reference's own inverse for one covariate (src/harmony.cpp:575-586): Phi_cov is an arrowhead matrix, inverted in closed
+      // form in fp32, and W = inv_cov * (the right-hand sides) accumulates in fp32, column of inv_cov after column (:599-608).
+      float* const ac = reinterpret_cast<float*>(sm_ + ((3 * B + 4 + C + 1) & ~1));     // [m] each (the Cholesky's panel space)
+      float* const bb = ac + m; float* const acb = bb + m; float* const uu = acb + m;
+      for (int a = tid; a < m; a += nt) {
+        ac[a] = (a == 0) ? 1.0f : -(float)cov[(size_t)a * m];
+        bb[a] = (a == 0) ? 0.0f : 1.0f / (float)cov[(size_t)a * m + a];
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float u = 0.0f;
+        for (int a = 0; a < m; a++) u = __fadd_rn(u, __fmul_rn(__fmul_rn(ac[a], ac[a]), bb[a]));
+        uu[0] = 1.0f / __fsub_rn((float)cov[0], u);
+        if (!(__fsub_rn((float)cov[0], u) != 0.0f)) misc[3] = 1;
+      }
+      for (int a = tid; a < m; a += nt) acb[a] = (a == 0) ? 1.0f : __fmul_rn(ac[a], bb[a]);
+      __syncthreads();
+      const float iu = uu[0];
+      // W[r2][j] = sum_c2 inv[r2][c2] rhs[c2][j], c2 ascending; the result replaces rhs only after every entry has been computed
+      float* const Wtmp = A.Wall + (size_t)k * d * M;
+      for (int i = tid; i < m * d; i += nt) {
+        const int j = i / m, r2 = i - j * m;
+        float sacc = 0.0f;
+        for (int c2 = 0; c2 < m; c2++) {
+          float iv = __fmul_rn(iu, __fmul_rn(acb[r2], acb[c2]));
+          if (c2 == r2) iv = __fadd_rn(iv, bb[r2]);
+          sacc = __fadd_rn(sacc, __fmul_rn(iv, (float)rhs[(size_t)j * m + c2]));
+        }
+        Wtmp[i] = sacc;
+      }
+      __syncthreads();
+      for (int i = tid; i < m * d; i += nt) rhs[i] = (double)Wtmp[i];
+      __syncthreads();
+    } else {
     // ---- blocked right-looking Cholesky (lower, column-major, in place in the L2-resident scratch).  Panels of NBW columns
     // are factored in LDS; the trailing matrix then receives ONE rank-NBW update per panel (16 fused multiply-adds per global
     // read-modify-write) instead of one rank-1 update per column -- at m = 201 (configs[4]: 200 levels) 13 passes over the
@@ -2635,6 +2610,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       __syncthreads();
       if (blds) { for (int i = tid; i < d * m; i += nt) rhs[i] = bl[i]; }
     }
+    }   // (fp64 Cholesky branch)
     __syncthreads();
   }
   if (tid == 0) {
@@ -3543,9 +3519,6 @@ void l_moe_solve(const Launch& L, const Dev& D, const SolveArgs& A0) {
   A.lds_b_bytes = (body >= ball) ? ball : 0;
   const int threads = M > 48 ? 1024 : 256;
   hipLaunchKernelGGL(k_moe_solve, dim3(D.K), dim3(threads), ints + body, L.stream, D, A);
-}
-void l_moe_stats_seq(const Launch& L, const Dev& D, float cutoff) {
-  hipLaunchKernelGGL(k_moe_stats_seq, dim3(D.K, D.Q + 1), dim3(64), 0, L.stream, D, cutoff);
 }
 void l_moe_stats_mfma(const Launch& L, const Dev& D) {
   const int npt = (D.d + 15) / 16;

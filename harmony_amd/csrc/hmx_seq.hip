@@ -1,0 +1,388 @@
+// hmx_seq.hip -- the reference's SEQUENTIAL fp32 accumulators, reproduced on the GPU ("reference arithmetic").
+//
+// The reference sums in fp32, one term after the other, in a fixed order:
+//   my_accu                       src/utils.cpp:67-75      objective terms, K*N terms per chain (cell-major, k fastest)
+//   sum(R, 1), R * Phi_t          src/harmony.cpp:149-150  E / O of the head: per cluster over all cells / the cells of a level
+//   sum(Rcells, 1), Rcells*Phi_t  src/harmony.cpp:312-313,329-330  per block, in the round's shuffled order
+//   sum(Z_tmp, 1), sum(Z_tmp.cols(index[b]), 1), Phi_Rk * Phi_moe_t   src/harmony.cpp:567,599-608   ridge statistics
+// Once such an accumulator has grown, terms below half an ulp of it are dropped: a systematic, N-dependent bias that a parity
+// claim "against the reference's own arithmetic" has to reproduce.  A chain of 10^6..10^8 dependent adds cannot run as ONE
+// dependency chain on a GPU, and it need not:
+//
+// RESTARTED SEQUENTIAL SUMS.  Cut a chain into segments.  Given the accumulator value at the START of a segment, the segment is an
+// ordinary sequential fp32 loop and all segments run in parallel.  The starts are found by fixed-point iteration:
+//   pass 1: every segment starts from 0            -> deltas (end - start) ~ the exact segment sums
+//   scan  : start[s] = sum of the deltas before s  (fp64 arithmetic on fp32-representable values: exact)
+//   pass 2: segments restart from these values     -> deltas carry the rounding of an accumulator of the right magnitude
+//   scan, pass 3, scan ...
+// A segment's delta depends on its start only through the binade the running sum is in (inside one binade every term is rounded to
+// the same grid, whatever multiple of the grid the start is) and through exact ties, so the iteration settles after 2-3 passes.
+// The last scan CERTIFIES the result: if every segment's start equals the end of the segment before it, bit for bit, the
+// concatenation of the segment loops IS the sequential loop -- the chain total is then bit-identical to the reference's
+// accumulator for the same terms (hmx_get "seq:mismatch" counts the segments that failed the check; tests assert 0).
+#include "hmx_internal.h"
+#include <float.h>
+
+namespace hmx {
+
+// ---- pass kernels ----------------------------------------------------------------------------------------------------------------
+// (a) R sums: W = K lane-chains per segment, lane = cluster, a chain runs over a LIST of cells (list == nullptr: cells off..off+cnt-1)
+//     term(cell, k) = R[cell][k].  One wave per (segment, 64 clusters); the cell ids of 64 cells are fetched with one load, the rows
+//     eight at a time (loads in flight together), the adds are the only dependent chain.
+__global__ __launch_bounds__(256) void k_seq_rsum_pass(const float* __restrict__ R, int K, const int* __restrict__ list,
+                                                       const SeqSeg* __restrict__ segs, int seg0, int nsegs,
+                                                       const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+  const int lane = threadIdx.x & 63;
+  const int sl = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sl >= nsegs) return;
+  const int seg = seg0 + sl;
+  const int k = blockIdx.y * 64 + lane, ks = min(k, K - 1);
+  const SeqSeg sg = segs[seg];
+  float s = (zero_start || k >= K) ? 0.0f : start[(size_t)seg * K + k];
+  for (int base = 0; base < sg.cnt; base += 64) {
+    const int nc = min(64, sg.cnt - base);
+    const int ci = sg.off + min(base + lane, sg.cnt - 1);
+    const int myc = list ? list[ci] : ci;
+    for (int c0 = 0; c0 < nc; c0 += 8) {
+      float r[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int cell = __builtin_amdgcn_readlane(myc, min(c0 + u, nc - 1));
+        r[u] = R[(size_t)cell * K + ks];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (c0 + u < nc) s = __fadd_rn(s, r[u]);
+    }
+  }
+  if (k < K) end[(size_t)seg * K + k] = s;
+}
+
+// (b) ridge statistics of KPW clusters per wave: W = K * 64 lane-chains per segment.  lane j < d: sum_i fl(z_ij * R_ki)
+//     (Z_tmp = Z_orig % R_k is rounded to fp32 first, src/harmony.cpp:592); lane 63: sum_i R_ki (the matching entry of
+//     Phi* diag(R_k) Phi*^T, :567).  inset != nullptr (the intercept chain): a cell enters cluster k's regression only if one of its
+//     levels is kept for k (:400,456-460): inset[k][combination].
+template <int KPW>
+__global__ __launch_bounds__(64) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
+                                                       int K, int d, int zs, int Q, const int* __restrict__ list,
+                                                       const SeqSeg* __restrict__ segs, int seg0, const unsigned char* __restrict__ inset,
+                                                       const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+  const int lane = threadIdx.x;
+  const int seg = seg0 + blockIdx.x, k0 = blockIdx.y * KPW;
+  const SeqSeg sg = segs[seg];
+  float s[KPW];
+#pragma unroll
+  for (int kk = 0; kk < KPW; kk++) s[kk] = (zero_start || k0 + kk >= K) ? 0.0f : start[((size_t)seg * K + k0 + kk) * 64 + lane];
+  const int js = min(lane, d - 1);
+  const int kl = min(k0 + (lane & (KPW - 1)), K - 1);
+  for (int base = 0; base < sg.cnt; base += 64) {
+    const int nc = min(64, sg.cnt - base);
+    const int ci = sg.off + min(base + lane, sg.cnt - 1);
+    const int myc = list ? list[ci] : ci;
+    const int myq = inset ? combo[myc] : 0;
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+      float z[4], rv[4]; int q[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = min(c0 + u, nc - 1);
+        const int cell = __builtin_amdgcn_readlane(myc, c);
+        q[u] = __builtin_amdgcn_readlane(myq, c);
+        const float zl = Zo[(size_t)cell * zs + js];
+        z[u] = (lane == 63) ? 1.0f : (lane < d ? zl : 0.0f);
+        rv[u] = R[(size_t)cell * K + kl];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (c0 + u < nc) {
+#pragma unroll
+          for (int kk = 0; kk < KPW; kk++) {
+            if (k0 + kk < K) {
+              const bool in = !inset || inset[(size_t)(k0 + kk) * Q + q[u]] != 0;
+              if (in) {
+                const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv[u]), kk));
+                s[kk] = __fadd_rn(s[kk], __fmul_rn(z[u], r));
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < KPW; kk++)
+    if (k0 + kk < K) end[((size_t)seg * K + k0 + kk) * 64 + lane] = s[kk];
+}
+
+// (c) a contiguous array of terms (the objective's three K*N-term chains, one array each): thread = segment of L terms
+__global__ __launch_bounds__(256) void k_seq_arr_pass(const float* __restrict__ T, long long n, long long stride, int L, int nsegs,
+                                                      const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nsegs) return;
+  const float* __restrict__ t = T + (size_t)blockIdx.y * (size_t)stride;
+  const size_t so = (size_t)blockIdx.y * nsegs + seg;
+  const long long off = (long long)seg * L;
+  const int cnt = (int)min((long long)L, n - off);
+  float s = zero_start ? 0.0f : start[so];
+  int i = 0;
+  if ((((uintptr_t)(t + off)) & 15) == 0) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* __restrict__ t4 = reinterpret_cast<const f4*>(t + off);
+    for (; i + 16 <= cnt; i += 16) {
+      const f4 a = t4[i / 4], b = t4[i / 4 + 1], c = t4[i / 4 + 2], e = t4[i / 4 + 3];
+      s = __fadd_rn(s, a[0]); s = __fadd_rn(s, a[1]); s = __fadd_rn(s, a[2]); s = __fadd_rn(s, a[3]);
+      s = __fadd_rn(s, b[0]); s = __fadd_rn(s, b[1]); s = __fadd_rn(s, b[2]); s = __fadd_rn(s, b[3]);
+      s = __fadd_rn(s, c[0]); s = __fadd_rn(s, c[1]); s = __fadd_rn(s, c[2]); s = __fadd_rn(s, c[3]);
+      s = __fadd_rn(s, e[0]); s = __fadd_rn(s, e[1]); s = __fadd_rn(s, e[2]); s = __fadd_rn(s, e[3]);
+    }
+  }
+  for (; i < cnt; i++) s = __fadd_rn(s, t[off + i]);
+  end[so] = s;
+}
+
+// ---- scans: start[s] <- sum of (end - start) over the chain's segments before s ------------------------------------------------
+// lanes = lane-chains (w), 16 waves split the chain's segments; the differences and their partial sums are fp64 operations on values
+// that fp32 can hold: exact.  mismatch counts the (segment, lane-chain) pairs whose new start differs from the one the pass used.
+__global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ chains, int chain0, int W, const float* start_in,
+                                                   const float* __restrict__ end, float* start_out, float* __restrict__ total,
+                                                   unsigned* __restrict__ mismatch, int zero_start) {
+  __shared__ double tot[16][64];
+  const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
+  const int chain = chain0 + blockIdx.x, w = blockIdx.y * 64 + lane, ws = min(w, W - 1);
+  const SeqChain c = chains[chain];
+  const int per = (c.nseg + 15) / 16;
+  const int s0 = c.seg0 + min(v * per, c.nseg), s1 = c.seg0 + min((v + 1) * per, c.nseg);
+  double acc = 0.0;
+  for (int s = s0; s < s1; s++) acc += (double)end[(size_t)s * W + ws] - (zero_start ? 0.0 : (double)start_in[(size_t)s * W + ws]);
+  tot[v][lane] = acc;
+  __syncthreads();
+  double run = 0.0;
+  for (int u = 0; u < v; u++) run += tot[u][lane];
+  unsigned mm = 0;
+  for (int s = s0; s < s1; s++) {
+    const float ns = (float)run;
+    const float old = zero_start ? 0.0f : start_in[(size_t)s * W + ws];
+    const float e = end[(size_t)s * W + ws];
+    if (w < W) {
+      if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) mm++;
+      start_out[(size_t)s * W + w] = ns;
+    }
+    run += (double)e - (double)old;
+  }
+  if (v == 15 && w < W) total[(size_t)chain * W + w] = (float)run;     // (empty chunks: run = the sum of all chunks before)
+  if (mismatch && !zero_start) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mm += __shfl_xor(mm, m, 64);
+    if (lane == 0 && mm) atomicAdd(mismatch, mm);
+  }
+}
+// one lane-chain per chain (the objective's arrays): threads along the segments, one workgroup per chain
+__global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* start_in, const float* __restrict__ end, float* start_out,
+                                                    float* __restrict__ total, unsigned* __restrict__ mismatch, int zero_start) {
+  __shared__ double part[1024];
+  const int t = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * nsegs;
+  const int per = (nsegs + 1023) / 1024;
+  const int s0 = min(t * per, nsegs), s1 = min((t + 1) * per, nsegs);
+  double acc = 0.0;
+  for (int s = s0; s < s1; s++) acc += (double)end[base + s] - (zero_start ? 0.0 : (double)start_in[base + s]);
+  part[t] = acc;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const double vv = (t >= off) ? part[t - off] : 0.0;
+    __syncthreads();
+    part[t] += vv;
+    __syncthreads();
+  }
+  double run = part[t] - acc;
+  unsigned mm = 0;
+  for (int s = s0; s < s1; s++) {
+    const float ns = (float)run;
+    const float old = zero_start ? 0.0f : start_in[base + s];
+    if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) mm++;
+    start_out[base + s] = ns;
+    run += (double)end[base + s] - (double)old;
+  }
+  if (t == 1023) total[blockIdx.x] = (float)part[1023];
+  if (mismatch && mm) atomicAdd(mismatch, mm);
+}
+
+// ---- O / E tables in the reference's fp32 arithmetic (oe_arith) ----------------------------------------------------------------
+// tot: [(1 + B)][K] chain totals of one block (or of the head): row 0 = sum(Rcells, 1), row 1 + b = Rcells * Phi_tcells column b.
+//   mode  0: head      E = rs Pr_b^T, O = tmp                                  (src/harmony.cpp:149-150, 226-227)
+//   mode -1: remove    E -= rs Pr_b^T, O -= tmp, then the block's penalty table (:312-313, :322)
+//   mode +1: put back  E += rs Pr_b^T, O += tmp                                 (:329-330)
+__global__ void k_oe_fold(float* __restrict__ Of, float* __restrict__ Ef, const float* __restrict__ tot, const float* __restrict__ Pr_b,
+                          const float* __restrict__ theta, float* __restrict__ pen, int B, int K, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * K) return;
+  const int b = i / K, k = i - b * K;
+  const float de = __fmul_rn(tot[k], Pr_b[b]), dO = tot[(size_t)(1 + b) * K + k];
+  float e, o;
+  if (mode == 0) { e = de; o = dO; }
+  else if (mode < 0) { e = __fsub_rn(Ef[i], de); o = __fsub_rn(Of[i], dO); }
+  else { e = __fadd_rn(Ef[i], de); o = __fadd_rn(Of[i], dO); }
+  Ef[i] = e; Of[i] = o;
+  if (mode < 0 && pen) {
+    const float num = __fadd_rn(__fmul_rn(2.0f, e), 1.0f), den = __fadd_rn(__fadd_rn(o, e), 1.0f);
+    pen[i] = powf(num / den, theta[b]);      // harmony_pow(((2E+1)/(O+E+1)), theta) :322 (not on any critical path here: the accurate powf)
+  }
+}
+
+// ---- objective terms (obj_arith): the three K x N matrices my_accu walks, in the reference's memory order ------------------------
+// T[0] = R % dist_mat, T[1] = safe_entropy(R).each_col() % sigma, T[2] = (R.each_col() % sigma) % ((theta^T (x) 1) % log((O+E+1)/(2E+1))) * Phi
+// (src/harmony.cpp:160-162), each stored cell-major in ORIGINAL cell order, k fastest -- the order of arma's column-major K x N memory.
+// One wave per cell, lane = cluster (k, k + 64, ...); distances recomputed from the embedding row (cluster-lane dot products, Y in LDS).
+// M: [B][K] table theta_b * log((O+E+1)/(2E+1)), fp32.
+__global__ __launch_bounds__(256) void k_obj_terms(Dev D, const float* __restrict__ M, float* __restrict__ T, long long stride) {
+  extern __shared__ __attribute__((aligned(16))) float ldsY[];      // [d][KP]
+  const int d = D.d, K = D.K, KP = D.KP, C = D.C;
+  for (int i = threadIdx.x; i < d * KP; i += blockDim.x) {
+    const int j = i / KP, k = i - j * KP;
+    ldsY[i] = (k < K) ? D.Yt[(size_t)j * K + k] : 0.0f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  for (int cell = wave; cell < D.n; cell += nw) {          // internal order; the row goes to its original position
+    const int orig = D.perm[cell], q = D.combo[cell];
+    const float* __restrict__ z = D.Zc + (size_t)cell * D.zs;
+    const float za = z[min(lane, d - 1)], zb = z[min(lane + 64, d - 1)];
+    for (int kq = 0; kq < KP; kq += 64) {
+      const int k = kq + lane;
+      float dot = 0.0f;
+      for (int j = 0; j < d; j++) {
+        const float zj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? za : zb), j & 63));
+        dot = fmaf(zj, ldsY[j * KP + k], dot);
+      }
+      if (k < K) {
+        const float dist = 2.0f * (1.0f - dot);
+        const float r = D.R[(size_t)cell * K + k], sg = D.sigma[k];
+        float m = 0.0f;
+        for (int c = 0; c < C; c++) m = __fadd_rn(m, M[(size_t)D.qlev[q * C + c] * K + k]);
+        const float lg = (r > 0.0f) ? logf(r) : logf(FLT_MIN);      // arma::trunc_log
+        const size_t o = (size_t)orig * K + k;
+        T[o] = __fmul_rn(r, dist);
+        T[o + (size_t)stride] = __fmul_rn(__fmul_rn(r, lg), sg);
+        T[o + 2 * (size_t)stride] = __fmul_rn(__fmul_rn(r, sg), m);
+      }
+    }
+  }
+}
+// M[b][k] = theta_b * log((O + E + 1) / (2E + 1))   (:162), from the fp32 tables (oe_arith) or from the exact fixed-point O
+__global__ void k_obj_mtable(Dev D, const float* __restrict__ Of, const float* __restrict__ Ef, float* __restrict__ M) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.B * D.K) return;
+  const int b = i / D.K, k = i - b * D.K;
+  float o, e;
+  if (Of) { o = Of[i]; e = Ef[i]; }
+  else {
+    long long rs = 0;
+    for (int b0 = 0; b0 < D.B0; b0++) rs += D.O_fx[(size_t)b0 * D.K + k];
+    o = (float)((double)D.O_fx[i] * FX_INV); e = (float)(((double)rs * FX_INV) * (double)D.Pr_b[b]);
+  }
+  M[i] = D.theta[b] * logf((o + e + 1.0f) / ((2.0f * e) + 1.0f));
+}
+// the three totals -> the objective snapshot obj[2..4] (+ the chain error word's slot, 0)
+__global__ void k_obj_store(const float* __restrict__ total, double* __restrict__ obj) {
+  if (threadIdx.x == 0) { obj[2] = (double)total[0]; obj[3] = (double)total[1]; obj[4] = (double)total[2]; obj[5] = 0.0; obj[0] = 0.0; obj[1] = 0.0; }
+}
+// cross-entropy term from the fp32 tables when only the tables follow the reference (oe_arith without obj_arith): obj[0..1] hold the
+// exact per-cell sums, the cross term is sum_kb sigma_k M[b][k] O[b][k]
+__global__ __launch_bounds__(256) void k_obj_cross_f32(Dev D, const float* __restrict__ Of, const float* __restrict__ M) {
+  __shared__ double red[256];
+  double cross = 0.0;
+  for (int i = threadIdx.x; i < D.B * D.K; i += 256) cross += (double)D.sigma[i % D.K] * (double)M[i] * (double)Of[i];
+  red[threadIdx.x] = cross;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) { D.obj[2] = D.obj[0]; D.obj[3] = D.obj[1]; D.obj[4] = red[0]; D.obj[5] = 0.0; }
+}
+
+// ---- ridge statistics: which combinations enter cluster k's regression, and the hand-over of the chain totals ---------------------
+// inset[k][q] = 1 if a cell of combination q enters the regression of cluster k: one of its levels is kept, i.e. O[k,b] / N_b > cutoff
+// and its covariate has at least two such levels (src/harmony.cpp:368-402).  One workgroup per cluster.
+__global__ __launch_bounds__(256) void k_seq_inset(Dev D, const float* __restrict__ Of, const int* __restrict__ cov_bounds, float cutoff,
+                                                   unsigned char* __restrict__ inset) {
+  extern __shared__ int sm[];      // [B] ok, [B] keep, [C] levels per covariate
+  const int k = blockIdx.x, B = D.B, C = D.C, K = D.K, Q = D.Q;
+  int* ok = sm; int* keep = sm + B; int* lev = sm + 2 * B;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float o = Of ? Of[(size_t)b * K + k] : (float)((double)D.O_fx[(size_t)b * K + k] * FX_INV);
+    ok[b] = (o / D.sizes[b]) > cutoff ? 1 : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < C; c++) lev[c] = 0;
+    for (int b = 0, cv = 0; b < B; b++) { if (!(b < cov_bounds[cv])) cv++; if (ok[b]) lev[cv]++; }
+    for (int b = 0, cv = 0; b < B; b++) { if (cv < C && !(b < cov_bounds[cv])) cv++; keep[b] = (ok[b] && lev[cv] > 1) ? 1 : 0; }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < Q; q += blockDim.x) {
+    int in = 0;
+    for (int c = 0; c < C; c++) in |= keep[D.qlev[q * C + c]];
+    inset[(size_t)k * Q + q] = (unsigned char)in;
+  }
+}
+// chain totals [1 + Q][K][64] -> S0 / n0 (chain 0: the intercept row) and Sq / nq (chain 1 + q: combination = level q's row)
+__global__ void k_seq_ridge_store(Dev D, const float* __restrict__ total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)D.K * 64;
+  if (i >= (size_t)(1 + D.Q) * per) return;
+  const int chain = (int)(i / per), k = (int)((i - (size_t)chain * per) >> 6), j = (int)(i & 63);
+  const double v = (double)total[i];
+  if (j < D.d) { if (chain == 0) D.S0[(size_t)k * D.d + j] = v; else D.Sq[((size_t)(chain - 1) * D.K + k) * D.d + j] = v; }
+  else if (j == 63) { if (chain == 0) D.n0[k] = v; else D.nq[(size_t)(chain - 1) * D.K + k] = v; }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------------------
+void l_seq_rsum_pass(const Launch& L, const float* R, int K, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start,
+                     float* end, int zero_start) {
+  if (nsegs <= 0) return;
+  hipLaunchKernelGGL(k_seq_rsum_pass, dim3((nsegs + 3) / 4, (K + 63) / 64), dim3(256), 0, L.stream, R, K, list, segs, seg0, nsegs, start, end,
+                     zero_start);
+}
+void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
+                      const float* start, float* end, int zero_start) {
+  if (nsegs <= 0) return;
+  hipLaunchKernelGGL(k_seq_ridge_pass<8>, dim3(nsegs, (D.K + 7) / 8), dim3(64), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, D.zs, D.Q, list, segs,
+                     seg0, inset, start, end, zero_start);
+}
+void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
+                    int zero_start) {
+  hipLaunchKernelGGL(k_seq_arr_pass, dim3((nsegs + 255) / 256, narr), dim3(256), 0, L.stream, T, n, stride, Lseg, nsegs, start, end, zero_start);
+}
+void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains, int W, const float* start_in, const float* end, float* start_out,
+                float* total, unsigned* mismatch, int zero_start) {
+  if (nchains <= 0) return;
+  hipLaunchKernelGGL(k_seq_scan, dim3(nchains, (W + 63) / 64), dim3(1024), 0, L.stream, chains, chain0, W, start_in, end, start_out, total, mismatch,
+                     zero_start);
+}
+void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, const float* end, float* start_out, float* total,
+                 unsigned* mismatch, int zero_start) {
+  hipLaunchKernelGGL(k_seq_scan1, dim3(narr), dim3(1024), 0, L.stream, nsegs, start_in, end, start_out, total, mismatch, zero_start);
+}
+void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot, float* pen, int mode) {
+  const int n = D.B * D.K;
+  hipLaunchKernelGGL(k_oe_fold, dim3((n + 255) / 256), dim3(256), 0, L.stream, Of, Ef, tot, D.Pr_b, D.theta, pen, D.B, D.K, mode);
+}
+void l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride) {
+  const int n = D.B * D.K;
+  hipLaunchKernelGGL(k_obj_mtable, dim3((n + 255) / 256), dim3(256), 0, L.stream, D, Of, Ef, M);
+  int blocks = (D.n + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_obj_terms, dim3(blocks), dim3(256), (size_t)D.d * D.KP * sizeof(float), L.stream, D, M, T, stride);
+}
+void l_obj_store(const Launch& L, const float* total, double* obj) { hipLaunchKernelGGL(k_obj_store, dim3(1), dim3(64), 0, L.stream, total, obj); }
+void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M) {
+  const int n = D.B * D.K;
+  hipLaunchKernelGGL(k_obj_mtable, dim3((n + 255) / 256), dim3(256), 0, L.stream, D, Of, Ef, M);
+  hipLaunchKernelGGL(k_obj_cross_f32, dim3(1), dim3(256), 0, L.stream, D, Of, M);
+}
+void l_seq_inset(const Launch& L, const Dev& D, const float* Of, const int* cov_bounds, float cutoff, unsigned char* inset) {
+  hipLaunchKernelGGL(k_seq_inset, dim3(D.K), dim3(256), (size_t)(2 * D.B + D.C) * sizeof(int), L.stream, D, Of, cov_bounds, cutoff, inset);
+}
+void l_seq_ridge_store(const Launch& L, const Dev& D, const float* total) {
+  const size_t n = (size_t)(1 + D.Q) * D.K * 64;
+  hipLaunchKernelGGL(k_seq_ridge_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, L.stream, D, total);
+}
+
+}  // namespace hmx

@@ -30,10 +30,12 @@ def _iptr(a):
 class Harmony(object):
     """new(harmony)  (R/ui.R:269)."""
 
-    def __init__(self, device=None, seed=None, rng=None, ridge_arith=None):
+    def __init__(self, device=None, seed=None, rng=None, ridge_arith=None, oe_arith=None, obj_arith=None, solve_arith=None,
+                 ref_arith=None):
         """rng: None/0 = the library's documented counter-based generator; 1 / "R" = R-compatible stream (MT19937 seeded like
-        set.seed(seed), RcppArmadillo's randu / shuffle draw order).  ridge_arith: 0 exact ridge statistics (default),
-        1 = the reference's sequential fp32 accumulation order (slow; for parity studies against the reference's arithmetic)."""
+        set.seed(seed), RcppArmadillo's randu / shuffle draw order).  ref_arith = 1: every accumulator group follows the reference's
+        fp32 operation order (ridge statistics, O / E tables, objective sums, closed-form inverse; the groups can also be switched
+        one by one: ridge_arith, oe_arith, obj_arith, solve_arith); default: exact accumulators."""
         self._lib = _lib.load()
         self._h = C.c_void_p(self._lib.hmx_create())
         if not self._h:
@@ -46,8 +48,10 @@ class Harmony(object):
             self._set("seed", int(seed))
         if rng:
             self._set("rng", 1)
-        if ridge_arith:
-            self._set("ridge_arith", int(ridge_arith))
+        for name, v in (("ref_arith", ref_arith), ("ridge_arith", ridge_arith), ("oe_arith", oe_arith), ("obj_arith", obj_arith),
+                        ("solve_arith", solve_arith)):
+            if v:
+                self._set(name, int(v))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

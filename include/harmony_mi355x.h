@@ -123,9 +123,7 @@ int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype
 /* writable fields: "max_iter_kmeans" (vignettes/detailedWalkthrough.Rmd:364), "seed",
  * "device" (before setup), "profile" (HIP-event timing of the update kernel, see below),
  * "rng" (0 counter-based generator | 1 R-compatible stream, see "randomness"),
- * "ridge_arith" (0 exact ridge statistics: fp64, fixed order | 1 the reference's arithmetic: fp32 sums over the cells in
- *  ascending cell order as arma::sum / the sparse products do, src/harmony.cpp:561-609 -- one covariate, single GPU;
- *  slow, for parity studies against the reference's own rounding).
+ * "ridge_arith" / "oe_arith" / "obj_arith" / "solve_arith" / "ref_arith" (see "reference arithmetic" below), "seq_passes".
  * Tuning / fallback selectors (tests and measurements; the defaults are the measured best):
  *   fields "grid", "upd_wps" (before setup), "upd_tpw", "upd_cpw", "upd_impl", "comm_force";
  *   environment, read by hmx_setup: HMX_GRID, HMX_NREP, HMX_UPD_WPS (2|4), HMX_USIG=0 (general-sigma kernels),
@@ -200,6 +198,22 @@ int hmx_set_stream(hmx_ctx* ctx, void* hip_stream);
 /* optional user-interrupt poll, checked once per clustering round and per correction
  * (Progress::check_abort(), src/harmony.cpp:233,355); non-zero return aborts */
 int hmx_set_abort_poll(hmx_ctx* ctx, int (*poll)(void*), void* user);
+
+/* ---- reference arithmetic --------------------------------------------------------------------------------
+ * By default every cross-cell accumulator is exact (64-bit fixed point / fp64 in a fixed order).  The reference accumulates in
+ * fp32, one term after the other; at 10^6 cells that is a visible, systematic bias (terms below half an ulp of a grown
+ * accumulator are dropped).  Four switches (hmx_set_int, before hmx_setup; one GPU) make the library reproduce it, group by group:
+ *   "ridge_arith"  Phi* diag(R_k) Phi*^T and Phi* diag(R_k) Z^T as sequential fp32 sums over the cells  (src/harmony.cpp:567,599-608)
+ *   "oe_arith"     O, E as fp32 tables: block sums in the round's shuffled order, -= / += drift       (:149-150,312-313,329-330)
+ *   "obj_arith"    compute_objective's three K*N-term my_accu sums                                       (src/utils.cpp:67-75)
+ *   "solve_arith"  the closed-form fp32 arrowhead inverse of the one-covariate ridge system               (src/harmony.cpp:575-586)
+ *   "ref_arith"    all four.
+ * The sequential sums are computed as RESTARTED sequential sums (segments in parallel, starts by fixed-point iteration, a final
+ * check that certifies bit-equality with the one-after-the-other loop; hmx_get "seq:mismatch" = segments that failed it,
+ * "seq_passes" = passes per sum, default 3).  Probes of that machinery on caller-provided data (device needed): */
+int hmx_debug_seq_rsum(const float* R, int64_t n, int32_t K, const int32_t* list, int64_t nlist, const int32_t* chain_off,
+                       const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals, int64_t* mismatch);
+int hmx_debug_seq_arr(const float* T, int64_t n, int32_t narr, int32_t seg_terms, int32_t passes, float* total, int64_t* mismatch);
 
 /* ---- measurement ----------------------------------------------------------------------------
  * HIP-event timing of the dominant kernel on the library's stream: after

@@ -456,7 +456,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
         std::memcpy(&Dr[p * K], &dist[update_order[p] * K], sizeof(float) * K);
       }
     }
-    std::vector<float> pen((size_t)K * B); std::vector<ACC> rs(K);
+    std::vector<float> pen((size_t)K * B); std::vector<ACC> rs(K), tmpO((size_t)K * B);
     for (unsigned blk = 0; blk < n_blocks; blk++) {
       int64_t idx_min = (int64_t)blk * cells_per_block;
       int64_t idx_max = (int64_t)(blk + 1) * cells_per_block - 1;
@@ -467,8 +467,13 @@ template <unsigned MASK> struct Oracle : OracleBase {
         std::fill(rs.begin(), rs.end(), (ACC)0);
         for (int64_t p = idx_min; p <= idx_max; p++) for (int k = 0; k < K; k++) rs[k] += Rr[p * K + k];
         for (int b = 0; b < B; b++) for (int k = 0; k < K; k++) E[(size_t)b * K + k] -= rs[k] * (ACC)Pr_b[b];
+        // O -= Rcells * Phi_tcells: the dense x sparse product is formed FIRST (per (k, b) a sequential sum over the block's cells of
+        // level b in ascending position -- Armadillo walks the sparse operand's non-zeros column by column, rows ascending), then ONE
+        // subtraction per table entry (:313).
+        std::fill(tmpO.begin(), tmpO.end(), (ACC)0);
         for (int64_t p = idx_min; p <= idx_max; p++) { int64_t i = update_order[p];
-          for (int c = 0; c < C; c++) { size_t b = codes[(size_t)c * N + i]; for (int k = 0; k < K; k++) O[b * K + k] -= Rr[p * K + k]; } }
+          for (int c = 0; c < C; c++) { size_t b = codes[(size_t)c * N + i]; for (int k = 0; k < K; k++) tmpO[b * K + k] += Rr[p * K + k]; } }
+        for (size_t e = 0; e < tmpO.size(); e++) O[e] -= tmpO[e];
       }
       {
         Timers::Scope t(timers.ms["Rcells_update"]);  // :318-323
@@ -496,8 +501,10 @@ template <unsigned MASK> struct Oracle : OracleBase {
         std::fill(rs.begin(), rs.end(), (ACC)0);
         for (int64_t p = idx_min; p <= idx_max; p++) for (int k = 0; k < K; k++) rs[k] += Rr[p * K + k];
         for (int b = 0; b < B; b++) for (int k = 0; k < K; k++) E[(size_t)b * K + k] += rs[k] * (ACC)Pr_b[b];
+        std::fill(tmpO.begin(), tmpO.end(), (ACC)0);   // product first, then ONE addition per entry (:330)
         for (int64_t p = idx_min; p <= idx_max; p++) { int64_t i = update_order[p];
-          for (int c = 0; c < C; c++) { size_t b = codes[(size_t)c * N + i]; for (int k = 0; k < K; k++) O[b * K + k] += Rr[p * K + k]; } }
+          for (int c = 0; c < C; c++) { size_t b = codes[(size_t)c * N + i]; for (int k = 0; k < K; k++) tmpO[b * K + k] += Rr[p * K + k]; } }
+        for (size_t e = 0; e < tmpO.size(); e++) O[e] += tmpO[e];
       }
     }
     {
