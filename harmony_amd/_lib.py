@@ -55,9 +55,9 @@ SIGNATURES = {
     "hmx_p2p_status": (C.c_char_p, [C.c_void_p]),
     "hmx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hmx_set_abort_poll": (C.c_int, [C.c_void_p, POLL_FN, C.c_void_p]),
-    "hmx_debug_seq_rsum": (C.c_int, [C.POINTER(C.c_float), C.c_int64, C.c_int32, _ip, C.c_int64, _ip, _ip, C.c_int32, C.c_int32,
-                                     C.c_int32, C.POINTER(C.c_float), _lp]),
-    "hmx_debug_seq_arr": (C.c_int, [C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), _lp]),
+    "hmx_debug_seq_oe": (C.c_int, [C.POINTER(C.c_float), C.c_int64, C.c_int32, _ip, C.c_int32, _ip, C.c_int64, _ip, _ip, C.c_int32, C.c_int32,
+                                   C.c_int32, C.POINTER(C.c_float), _lp, _dp]),
+    "hmx_debug_seq_arr": (C.c_int, [C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), _lp, _dp]),
 }
 
 _lib = None

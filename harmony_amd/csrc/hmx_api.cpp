@@ -674,17 +674,18 @@ int seq_plan_build(hmx_ctx* ctx, hmx_ctx::SeqPlan& P, const std::vector<std::pai
 int seq_workspace(hmx_ctx* ctx, size_t seg_floats, size_t total_floats) {
   if (seg_floats > ctx->sq_cap) { size_t c1 = ctx->sq_cap, c2 = ctx->sq_cap; CHK(seq_grow(ctx, ctx->sq_start, c1, seg_floats)); CHK(seq_grow(ctx, ctx->sq_end, c2, seg_floats)); ctx->sq_cap = seg_floats; }
   CHK(seq_grow(ctx, ctx->sq_total, ctx->sq_total_cap, total_floats));
-  if (!ctx->sq_mismatch) { size_t c = 0; CHK(seq_grow(ctx, ctx->sq_mismatch, c, 1)); HIPCHK(hipMemsetAsync(ctx->sq_mismatch, 0, sizeof(unsigned), ctx->L.stream)); }
+  if (!ctx->sq_mismatch) { size_t c = 0; CHK(seq_grow(ctx, ctx->sq_mismatch, c, 2)); HIPCHK(hipMemsetAsync(ctx->sq_mismatch, 0, 2 * sizeof(unsigned), ctx->L.stream)); }
   return 0;
 }
-// sum_i R[cell_i][k] for the chains [chain0, chain0 + nchains) of plan P, every chain a sequential fp32 sum in list order
-// -> ctx->sq_total[chain][K].  passes x (segments in parallel, then the scan that hands every segment its start).
-int seq_run_rsum(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, int chain0, int nchains) {
-  const int K = ctx->K, lo = P.seg0[chain0], n = P.seg0[chain0 + nchains] - lo;
-  CHK(seq_workspace(ctx, (size_t)P.nsegs * K, (size_t)P.nchains * K));
+// O / E sums of the chain sets [chain0, chain0 + nchains) of plan P over `list`: per chain set (1 + B) * K sequential fp32 sums
+// (row 0: all its cells, row 1 + b: its cells of level b) -> ctx->sq_total[chain][1 + B][K].  passes x (segments in parallel, then the
+// scan that hands every segment its start).
+int seq_run_oe(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, int chain0, int nchains) {
+  const int W = (1 + ctx->B) * ctx->K, lo = P.seg0[chain0], n = P.seg0[chain0 + nchains] - lo;
+  CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
   for (int p = 0; p < ctx->seq_passes; p++) {
-    l_seq_rsum_pass(ctx->L, ctx->D.R, K, list, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
-    l_seq_scan(ctx->L, P.d_chains, chain0, nchains, K, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total,
+    l_seq_oe_pass(ctx->L, ctx->D, list, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
+    l_seq_scan(ctx->L, P.d_chains, chain0, nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total,
                p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
   }
   ctx->seq_runs++;
@@ -711,11 +712,18 @@ int seq_setup_static(hmx_ctx* ctx) {
   { size_t cap = 0; CHK(seq_grow(ctx, ctx->headlist, cap, hl.size())); CHK(h2d(ctx, ctx->headlist, hl.data(), hl.size())); }
   { size_t c1 = 0, c2 = 0, c3 = 0; CHK(seq_grow(ctx, ctx->Of, c1, (size_t)B * K)); CHK(seq_grow(ctx, ctx->Ef, c2, (size_t)B * K)); CHK(seq_grow(ctx, ctx->Mtab, c3, (size_t)B * K));
     HIPCHK(hipMemsetAsync(ctx->Of, 0, sizeof(float) * (size_t)B * K, ctx->L.stream)); HIPCHK(hipMemsetAsync(ctx->Ef, 0, sizeof(float) * (size_t)B * K, ctx->L.stream)); }
-  if (ctx->oe_arith) {       // head: E = sum(R, 1) Pr_b^T over all cells, O = R Phi^T per level (:149-150)
-    std::vector<std::pair<int, int>> ch; ch.push_back({0, n});
-    for (int b = 0; b < B; b++) ch.push_back({ctx->lev_off[b], ctx->lev_cnt[b]});
-    CHK(seq_plan_build(ctx, ctx->plan_head, ch, 256));
-    size_t cap = 0; CHK(seq_grow(ctx, ctx->roundlist, cap, (size_t)(1 + C) * n));
+  if (ctx->oe_arith) {
+    // head: E = sum(R, 1) Pr_b^T, O = R Phi^T (:149-150): one chain set over all cells in original order
+    CHK(seq_plan_build(ctx, ctx->plan_head, {{0, n}}, 256));
+    // rounds: one chain set per block over the round's shuffled order; block j = positions [j cpb, (j + 1) cpb), the last takes the rest (:296-300)
+    std::vector<std::pair<int, int>> ch;
+    for (int j = 0; j < ctx->nb; j++) {
+      const int lo = (int)std::min<uint64_t>((uint64_t)n, (uint64_t)j * ctx->cells_per_block);
+      const int hi = (j == ctx->nb - 1) ? n : (int)std::min<uint64_t>((uint64_t)n, (uint64_t)(j + 1) * ctx->cells_per_block);
+      ch.push_back({lo, hi - lo});
+    }
+    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 64));
+    size_t cap = 0; CHK(seq_grow(ctx, ctx->roundlist, cap, (size_t)n));
   }
   if (ctx->ridge_arith) {
     if (C != 1) return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 (the reference's summation order) supports one covariate");
@@ -731,7 +739,7 @@ int seq_setup_static(hmx_ctx* ctx) {
 }
 // E, O of the head in the reference's arithmetic: R has just been rewritten
 int oe_head(hmx_ctx* ctx) {
-  CHK(seq_run_rsum(ctx, ctx->plan_head, ctx->headlist, 0, ctx->plan_head.nchains));
+  CHK(seq_run_oe(ctx, ctx->plan_head, ctx->headlist, 0, 1));
   l_oe_fold(ctx->L, ctx->D, ctx->Of, ctx->Ef, ctx->sq_total, nullptr, 0); KCHK();
   return 0;
 }
@@ -785,45 +793,26 @@ int seq_ridge_stats(hmx_ctx* ctx) {
 int update_R_ref(hmx_ctx* ctx) {
   Dev& D = ctx->D;
   const double t0 = now_ms();
-  const int n = (int)ctx->N, C = ctx->C, B = ctx->B, K = ctx->K, nb = ctx->nb;
-  std::vector<int64_t> order;
-  if (!ctx->injected.empty()) { order = std::move(ctx->injected.front()); ctx->injected.pop_front(); }
-  else if (ctx->rng_mode == 1) { ensure_rrng(ctx); ctx->rrng.arma_shuffle(ctx->N_global, order); }
-  else { order.resize((size_t)n); for (int64_t g = 0; g < n; g++) order[(size_t)hmx_feistel_pos(ctx->seed, ctx->round_counter, (uint64_t)n, (uint64_t)g)] = g; }
-  // this round's lists: the cells in shuffled order, and per covariate by (block, level) in shuffled order
-  std::vector<int> rl((size_t)(1 + C) * n);
-  for (int p = 0; p < n; p++) rl[p] = ctx->invperm_h[(size_t)order[p]];
-  std::vector<std::pair<int, int>> ch;
-  std::vector<int> bs(nb + 1);
-  for (int j = 0; j <= nb; j++) bs[j] = (int)std::min<uint64_t>((uint64_t)n, (uint64_t)j * ctx->cells_per_block);
-  bs[nb] = n;                                                      // the last block takes the rest (:296-300)
-  std::vector<std::vector<std::pair<int, int>>> lev((size_t)nb, std::vector<std::pair<int, int>>(B));
-  for (int c = 0; c < C; c++) {
-    const int b0 = c ? ctx->cov_bounds[c - 1] : 0, nl = ctx->B_vec[c];
-    std::vector<int> cnt(nl + 1);
-    for (int j = 0; j < nb; j++) {
-      std::fill(cnt.begin(), cnt.end(), 0);
-      for (int p = bs[j]; p < bs[j + 1]; p++) cnt[ctx->qlev[(size_t)ctx->combo_h[rl[p]] * C + c] - b0 + 1]++;
-      for (int l = 0; l < nl; l++) { lev[j][b0 + l] = {(1 + c) * n + bs[j] + cnt[l], cnt[l + 1]}; cnt[l + 1] += cnt[l]; }
-      std::vector<int> cur(cnt.begin(), cnt.end() - 1);
-      for (int p = bs[j]; p < bs[j + 1]; p++) { const int l = ctx->qlev[(size_t)ctx->combo_h[rl[p]] * C + c] - b0; rl[(size_t)(1 + c) * n + bs[j] + cur[l]++] = rl[p]; }
-    }
-  }
-  for (int j = 0; j < nb; j++) { ch.push_back({bs[j], bs[j + 1] - bs[j]}); for (int b = 0; b < B; b++) ch.push_back(lev[j][b]); }
-  CHK(seq_plan_build(ctx, ctx->plan_round, ch, 64));
-  CHK(h2d(ctx, ctx->roundlist, rl.data(), rl.size()));
+  const int n = (int)ctx->N, B = ctx->B, K = ctx->K, nb = ctx->nb;
+  const hmx_ctx::SeqPlan& P = ctx->plan_round;
   { PhaseScope ph(ctx, "randomize");
-    ctx->injected.push_front(std::move(order));                    // the tile kernels' padded block order comes from the same shuffle
-    CHK(prepare_round(ctx, ctx->round_counter)); }
+    if (!ctx->injected.empty() || ctx->rng_mode == 1) {       // the host owns the shuffle: its order goes to the device as it is
+      if (ctx->injected.empty()) { ensure_rrng(ctx); std::vector<int64_t> o; ctx->rrng.arma_shuffle(ctx->N_global, o); ctx->injected.push_back(std::move(o)); }
+      const std::vector<int64_t>& order = ctx->injected.front();
+      std::vector<int> po((size_t)n);
+      for (int p = 0; p < n; p++) po[p] = ctx->invperm_h[(size_t)order[p]];
+      CHK(h2d(ctx, ctx->roundlist, po.data(), po.size()));
+    } else { l_ref_posord(ctx->L, D, ctx->seed, ctx->round_counter, (uint64_t)ctx->N_global, ctx->roundlist); KCHK(); }
+    CHK(prepare_round(ctx, ctx->round_counter)); }             // the tile kernels' padded block order, from the same shuffle
   ctx->round_counter++;
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * B * K, ctx->L.stream));   // (the kernel's fixed-point sums are not used here)
-  const int per = 1 + B;
+  const int W = (1 + B) * K;
   { PhaseScope ph(ctx, "EO_update");     // every block's cells are still untouched at this point: the sums each block will remove (:312-313), all at once
-    CHK(seq_run_rsum(ctx, ctx->plan_round, ctx->roundlist, 0, nb * per)); }
+    CHK(seq_run_oe(ctx, P, ctx->roundlist, 0, nb)); }
   D.fused_fold = 0; D.Sold_next = nullptr;
   for (int j = 0; j < nb; j++) {
-    if (bs[j] >= bs[j + 1]) continue;                              // N * block_size rounding can leave trailing empty blocks
-    float* tot = ctx->sq_total + (size_t)j * per * K;
+    if (P.seg0[j + 1] == P.seg0[j]) continue;                      // N * block_size rounding can leave trailing empty blocks
+    float* tot = ctx->sq_total + (size_t)j * W;
     { PhaseScope ph(ctx, "EO_update"); l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, tot, D.pen, -1); KCHK(); }
     if (ctx->profile) {
       if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); ctx->ev_pool.emplace_back(a, b); }
@@ -832,11 +821,12 @@ int update_R_ref(hmx_ctx* ctx) {
     l_update(ctx->L, D, j); KCHK();
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
     { PhaseScope ph(ctx, "EO_update");
-      CHK(seq_run_rsum(ctx, ctx->plan_round, ctx->roundlist, j * per, per));
+      CHK(seq_run_oe(ctx, P, ctx->roundlist, j, 1));
       l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, tot, nullptr, +1); KCHK(); }
   }
-  l_obj_reduce(ctx->L, D); KCHK();
-  CHK(objective_snapshot(ctx));
+  { PhaseScope ph(ctx, "objective");
+    l_obj_reduce(ctx->L, D); KCHK();
+    CHK(objective_snapshot(ctx)); }
   CHK(push_objective(ctx));
   ctx->sets_clean = false;
   for (int i = 0; i < 2; i++) if (ctx->sold_state[i] == 2) ctx->sold_state[i] = 1;
@@ -1936,37 +1926,41 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
 }
 
 // ---- diagnostics of the restarted sequential sums (tests/test_gpu_seq.py): the machinery alone, on caller-provided data -----------
-// totals[c][k] = the fp32 value of   s = 0; for i in chain c: s += R[list[off_c + i]][k]   (one add after the other)
-int hmx_debug_seq_rsum(const float* R, int64_t n, int32_t K, const int32_t* list, int64_t nlist, const int32_t* chain_off,
-                       const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals, int64_t* mismatch) {
-  if (!R || !list || !chain_off || !chain_cnt || !totals || n <= 0 || K <= 0 || nchains <= 0 || seg_cells <= 0 || passes < 2) return HMX_ERR_ARG;
+// totals[c][0][k] = the fp32 value of   s = 0; for i in chain c: s += R[list[off_c + i]][k]   (one add after the other);
+// totals[c][1 + b][k] = the same loop over the chain's cells of level b only
+int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level, int32_t B, const int32_t* list, int64_t nlist,
+                     const int32_t* chain_off, const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals,
+                     int64_t* mismatch, double* residual) {
+  if (!R || !list || !level || !chain_off || !chain_cnt || !totals || n <= 0 || K <= 0 || B <= 0 || nchains <= 0 || seg_cells <= 0 || passes < 2) return HMX_ERR_ARG;
   hmx_ctx* ctx = hmx_create();
-  int st = 0;
-  float* dR = nullptr; int* dl = nullptr;
+  float* dR = nullptr; int* dl = nullptr; int* dlev = nullptr; int* dq = nullptr;
   auto run = [&]() -> int {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ctx, HMX_ERR_DEVICE, "no HIP device");
     HIPCHK(hipStreamCreateWithFlags(&ctx->L.stream, hipStreamNonBlocking)); ctx->own_stream = true;
     HIPCHK(hipMalloc((void**)&dR, sizeof(float) * (size_t)n * K)); HIPCHK(hipMalloc((void**)&dl, sizeof(int) * (size_t)nlist));
-    CHK(h2d(ctx, dR, R, (size_t)n * K)); CHK(h2d(ctx, dl, list, (size_t)nlist));
-    ctx->K = K; ctx->D.R = dR; ctx->seq_passes = passes;
+    HIPCHK(hipMalloc((void**)&dlev, sizeof(int) * (size_t)n)); HIPCHK(hipMalloc((void**)&dq, sizeof(int) * (size_t)B));
+    std::vector<int> ident(B); std::iota(ident.begin(), ident.end(), 0);
+    CHK(h2d(ctx, dR, R, (size_t)n * K)); CHK(h2d(ctx, dl, list, (size_t)nlist)); CHK(h2d(ctx, dlev, level, (size_t)n)); CHK(h2d(ctx, dq, ident.data(), (size_t)B));
+    ctx->K = K; ctx->B = B; ctx->seq_passes = passes;
+    ctx->D.R = dR; ctx->D.K = K; ctx->D.B = B; ctx->D.C = 1; ctx->D.combo = dlev; ctx->D.qlev = dq;      // one covariate: combination == level
     std::vector<std::pair<int, int>> ch;
     for (int c = 0; c < nchains; c++) ch.push_back({chain_off[c], chain_cnt[c]});
     CHK(seq_plan_build(ctx, ctx->plan_round, ch, seg_cells));
-    CHK(seq_run_rsum(ctx, ctx->plan_round, dl, 0, nchains));
-    CHK(d2h(ctx, totals, ctx->sq_total, (size_t)nchains * K));
-    unsigned mm = 0; CHK(d2h(ctx, &mm, ctx->sq_mismatch, 1));
-    if (mismatch) *mismatch = (int64_t)mm;
+    CHK(seq_run_oe(ctx, ctx->plan_round, dl, 0, nchains));
+    CHK(d2h(ctx, totals, ctx->sq_total, (size_t)nchains * (1 + B) * K));
+    unsigned mm[2] = {0, 0}; CHK(d2h(ctx, mm, ctx->sq_mismatch, 2));
+    if (mismatch) *mismatch = (int64_t)mm[0];
+    if (residual) { float r; std::memcpy(&r, &mm[1], 4); *residual = (double)r; }
     return 0;
   };
-  st = run();
-  if (dR) (void)hipFree(dR);
-  if (dl) (void)hipFree(dl);
+  const int st = run();
+  for (void* q : {(void*)dR, (void*)dl, (void*)dlev, (void*)dq}) if (q) (void)hipFree(q);
   hmx_destroy(ctx);
   return st;
 }
 // total[a] = the fp32 value of   s = 0; for i < n: s += T[a * n + i]
-int hmx_debug_seq_arr(const float* T, int64_t n, int32_t narr, int32_t seg_terms, int32_t passes, float* total, int64_t* mismatch) {
+int hmx_debug_seq_arr(const float* T, int64_t n, int32_t narr, int32_t seg_terms, int32_t passes, float* total, int64_t* mismatch, double* residual) {
   if (!T || !total || n <= 0 || narr <= 0 || narr > 64 || seg_terms <= 0 || passes < 2) return HMX_ERR_ARG;
   hmx_ctx* ctx = hmx_create();
   float* dT = nullptr;
@@ -1983,8 +1977,9 @@ int hmx_debug_seq_arr(const float* T, int64_t n, int32_t narr, int32_t seg_terms
       l_seq_scan1(ctx->L, narr, nsegs, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, p == passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
     }
     CHK(d2h(ctx, total, ctx->sq_total, (size_t)narr));
-    unsigned mm = 0; CHK(d2h(ctx, &mm, ctx->sq_mismatch, 1));
-    if (mismatch) *mismatch = (int64_t)mm;
+    unsigned mm[2] = {0, 0}; CHK(d2h(ctx, mm, ctx->sq_mismatch, 2));
+    if (mismatch) *mismatch = (int64_t)mm[0];
+    if (residual) { float r; std::memcpy(&r, &mm[1], 4); *residual = (double)r; }
     return 0;
   };
   const int st = run();
@@ -2099,6 +2094,12 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
     if (!ctx->sq_mismatch) return scalar(0.0);
     unsigned mm = 0; if (d2h(ctx, &mm, ctx->sq_mismatch, 1)) return -1;
     return scalar((double)mm);
+  }
+  if (f == "seq:residual") {      // largest relative move of a segment start in the final scans (0: at the fixed point)
+    if (!ctx->sq_mismatch) return scalar(0.0);
+    unsigned bits = 0; if (d2h(ctx, &bits, ctx->sq_mismatch + 1, 1)) return -1;
+    float r; std::memcpy(&r, &bits, 4);
+    return scalar((double)r);
   }
   if (f == "seq:runs") return scalar((double)ctx->seq_runs);
   if (f == "O" || f == "E" || f == "Lambda") {

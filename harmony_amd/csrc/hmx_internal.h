@@ -220,8 +220,9 @@ size_t lds_bytes_y(const Dev& D);
 // ---- reference arithmetic: restarted sequential fp32 sums (hmx_seq.hip) ------------------------------------------------------------
 struct SeqSeg { int off; int cnt; };       // a segment of a chain: cells list[off .. off + cnt) (or the cells off .. off + cnt - 1 themselves)
 struct SeqChain { int seg0; int nseg; };   // the segments of one chain, in chain order
-void l_seq_rsum_pass(const Launch& L, const float* R, int K, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start,
-                     float* end, int zero_start);
+void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
+                   int zero_start);
+void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord);
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start);
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,

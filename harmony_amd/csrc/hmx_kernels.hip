@@ -3258,6 +3258,15 @@ void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uin
   hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
 }
+// oe_arith: the round's shuffled order itself, posord[position] = internal cell id (arma::shuffle's update_order, src/harmony.cpp:272-273,
+// for the documented generator: cell g sits at position feistel(seed, round, g))
+__global__ void k_ref_posord(Dev D, FeistelKeys fk, uint64_t Nglob, int* __restrict__ posord) {
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < D.n; g += gridDim.x * blockDim.x)
+    posord[feistel_apply(fk, Nglob, (uint64_t)g)] = D.invperm[g];
+}
+void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord) {
+  hipLaunchKernelGGL(k_ref_posord, dim3(1024), dim3(256), 0, L.stream, D, make_keys(seed, round, Nglob), Nglob, posord);
+}
 void l_oldsum(const Launch& L, const Dev& D) {
   const size_t tab = (size_t)D.nb * D.K * sizeof(unsigned long long);
   if (D.oldsum_stream && tab <= 64 * 1024) {   // sequential pass over R with LDS accumulators

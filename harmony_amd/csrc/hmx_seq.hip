@@ -16,33 +16,47 @@
 //   pass 2: segments restart from these values     -> deltas carry the rounding of an accumulator of the right magnitude
 //   scan, pass 3, scan ...
 // A segment's delta depends on its start only through the binade the running sum is in (inside one binade every term is rounded to
-// the same grid, whatever multiple of the grid the start is) and through exact ties, so the iteration settles after 2-3 passes.
-// The last scan CERTIFIES the result: if every segment's start equals the end of the segment before it, bit for bit, the
-// concatenation of the segment loops IS the sequential loop -- the chain total is then bit-identical to the reference's
-// accumulator for the same terms (hmx_get "seq:mismatch" counts the segments that failed the check; tests assert 0).
+// the same grid, whatever multiple of the grid the start is) and through exact ties, so every pass shrinks the distance to the fixed
+// point by about the relative size of the rounding bias itself (1e-2 .. 1e-4): three passes (the default) leave starts that are
+// ~1e-8 from the fixed point -- far below what the bias being reproduced amounts to -- and at the fixed point, where every
+// segment's start equals the end of the segment before it bit for bit, the concatenated segment loops ARE the sequential loop, i.e.
+// the chain total is bit-identical to the one-after-the-other accumulator (tests: equality for enough passes).  The last scan
+// reports how far the starts still moved: hmx_get "seq:mismatch" (segments), "seq:residual" (largest relative move).
 #include "hmx_internal.h"
 #include <float.h>
 
 namespace hmx {
 
 // ---- pass kernels ----------------------------------------------------------------------------------------------------------------
-// (a) R sums: W = K lane-chains per segment, lane = cluster, a chain runs over a LIST of cells (list == nullptr: cells off..off+cnt-1)
-//     term(cell, k) = R[cell][k].  One wave per (segment, 64 clusters); the cell ids of 64 cells are fetched with one load, the rows
-//     eight at a time (loads in flight together), the adds are the only dependent chain.
-__global__ __launch_bounds__(256) void k_seq_rsum_pass(const float* __restrict__ R, int K, const int* __restrict__ list,
-                                                       const SeqSeg* __restrict__ segs, int seg0, int nsegs,
-                                                       const float* __restrict__ start, float* __restrict__ end, int zero_start) {
-  const int lane = threadIdx.x & 63;
-  const int sl = blockIdx.x * 4 + (threadIdx.x >> 6);
+// (a) O / E sums: a chain set runs over a LIST of cells (the round's shuffled order, or the original order for the head) and carries
+//     (1 + B) * K lane-chains: row 0 = sum(Rcells, 1) (every cell), row 1 + b = the cells of level b only (Rcells * Phi_tcells: Armadillo
+//     walks the sparse operand column by column, i.e. per level in ascending position).  One wave per (segment, 64 clusters), lane =
+//     cluster: row 0 lives in a register, the level rows in LDS (one column per lane: no cross-lane traffic, the read-modify-write of
+//     a lane's own slot is its sequential chain).  The 64 cell ids / level codes of a batch are fetched with one load each, the R rows
+//     eight at a time.
+__global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R, int K, int B, int C, const int* __restrict__ list,
+                                                     const int* __restrict__ combo, const int* __restrict__ qlev,
+                                                     const SeqSeg* __restrict__ segs, int seg0, int nsegs,
+                                                     const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+  extern __shared__ float acc_[];                        // [waves][B][64]
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int sl = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wib));      // wave-uniform: scalar loop control below
   if (sl >= nsegs) return;
   const int seg = seg0 + sl;
   const int k = blockIdx.y * 64 + lane, ks = min(k, K - 1);
   const SeqSeg sg = segs[seg];
-  float s = (zero_start || k >= K) ? 0.0f : start[(size_t)seg * K + k];
+  float* const acc = acc_ + (size_t)wib * B * 64 + lane;
+  const size_t so = (size_t)seg * (1 + B) * K + ks;
+  float s0 = (zero_start || k >= K) ? 0.0f : start[so];
+  for (int b = 0; b < B; b++) acc[b * 64] = (zero_start || k >= K) ? 0.0f : start[so + (size_t)(1 + b) * K];
   for (int base = 0; base < sg.cnt; base += 64) {
     const int nc = min(64, sg.cnt - base);
     const int ci = sg.off + min(base + lane, sg.cnt - 1);
     const int myc = list ? list[ci] : ci;
+    const int myq = combo[myc];
+    int mylev[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) mylev[c] = qlev[myq * C + min(c, C - 1)];
     for (int c0 = 0; c0 < nc; c0 += 8) {
       float r[8];
 #pragma unroll
@@ -51,11 +65,28 @@ __global__ __launch_bounds__(256) void k_seq_rsum_pass(const float* __restrict__
         r[u] = R[(size_t)cell * K + ks];
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (c0 + u < nc) s = __fadd_rn(s, r[u]);
+      for (int u = 0; u < 8; u++) {
+        if (c0 + u < nc) {
+          s0 = __fadd_rn(s0, r[u]);
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            if (c < C) {
+              const int b = __builtin_amdgcn_readlane(mylev[c], c0 + u);
+              acc[b * 64] = __fadd_rn(acc[b * 64], r[u]);
+            }
+          }
+          for (int c = 4; c < C; c++) {       // (more than four covariates: level codes straight from the table)
+            const int b = qlev[__builtin_amdgcn_readlane(myq, c0 + u) * C + c];
+            acc[b * 64] = __fadd_rn(acc[b * 64], r[u]);
+          }
+        }
+      }
     }
   }
-  if (k < K) end[(size_t)seg * K + k] = s;
+  if (k < K) {
+    end[so] = s0;
+    for (int b = 0; b < B; b++) end[so + (size_t)(1 + b) * K] = acc[b * 64];
+  }
 }
 
 // (b) ridge statistics of KPW clusters per wave: W = K * 64 lane-chains per segment.  lane j < d: sum_i fl(z_ij * R_ki)
@@ -157,22 +188,22 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
   __syncthreads();
   double run = 0.0;
   for (int u = 0; u < v; u++) run += tot[u][lane];
-  unsigned mm = 0;
+  unsigned mm = 0; float res = 0.0f;
   for (int s = s0; s < s1; s++) {
     const float ns = (float)run;
     const float old = zero_start ? 0.0f : start_in[(size_t)s * W + ws];
     const float e = end[(size_t)s * W + ws];
     if (w < W) {
-      if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) mm++;
+      if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) { mm++; res = fmaxf(res, fabsf(ns - old) / fmaxf(fabsf(ns), fabsf(old))); }
       start_out[(size_t)s * W + w] = ns;
     }
     run += (double)e - (double)old;
   }
   if (v == 15 && w < W) total[(size_t)chain * W + w] = (float)run;     // (empty chunks: run = the sum of all chunks before)
-  if (mismatch && !zero_start) {
+  if (mismatch && !zero_start) {      // [0] segments whose start moved in this scan, [1] the largest relative move (float bits)
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) mm += __shfl_xor(mm, m, 64);
-    if (lane == 0 && mm) atomicAdd(mismatch, mm);
+    for (int m = 32; m >= 1; m >>= 1) { mm += __shfl_xor(mm, m, 64); res = fmaxf(res, __shfl_xor(res, m, 64)); }
+    if (lane == 0 && mm) { atomicAdd(mismatch, mm); atomicMax(mismatch + 1, __float_as_uint(res)); }
   }
 }
 // one lane-chain per chain (the objective's arrays): threads along the segments, one workgroup per chain
@@ -194,16 +225,16 @@ __global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* star
     __syncthreads();
   }
   double run = part[t] - acc;
-  unsigned mm = 0;
+  unsigned mm = 0; float res = 0.0f;
   for (int s = s0; s < s1; s++) {
     const float ns = (float)run;
     const float old = zero_start ? 0.0f : start_in[base + s];
-    if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) mm++;
+    if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) { mm++; res = fmaxf(res, fabsf(ns - old) / fmaxf(fabsf(ns), fabsf(old))); }
     start_out[base + s] = ns;
     run += (double)end[base + s] - (double)old;
   }
   if (t == 1023) total[blockIdx.x] = (float)part[1023];
-  if (mismatch && mm) atomicAdd(mismatch, mm);
+  if (mismatch && mm) { atomicAdd(mismatch, mm); atomicMax(mismatch + 1, __float_as_uint(res)); }
 }
 
 // ---- O / E tables in the reference's fp32 arithmetic (oe_arith) ----------------------------------------------------------------
@@ -282,9 +313,9 @@ __global__ void k_obj_mtable(Dev D, const float* __restrict__ Of, const float* _
   }
   M[i] = D.theta[b] * logf((o + e + 1.0f) / ((2.0f * e) + 1.0f));
 }
-// the three totals -> the objective snapshot obj[2..4] (+ the chain error word's slot, 0)
+// the three totals -> the objective snapshot obj[2..4]
 __global__ void k_obj_store(const float* __restrict__ total, double* __restrict__ obj) {
-  if (threadIdx.x == 0) { obj[2] = (double)total[0]; obj[3] = (double)total[1]; obj[4] = (double)total[2]; obj[5] = 0.0; obj[0] = 0.0; obj[1] = 0.0; }
+  if (threadIdx.x == 0) { obj[2] = (double)total[0]; obj[3] = (double)total[1]; obj[4] = (double)total[2]; }      // (obj[5]: the chain's error word, left alone)
 }
 // cross-entropy term from the fp32 tables when only the tables follow the reference (oe_arith without obj_arith): obj[0..1] hold the
 // exact per-cell sums, the cross term is sum_kb sigma_k M[b][k] O[b][k]
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(256) void k_obj_cross_f32(Dev D, const float* __res
   red[threadIdx.x] = cross;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
-  if (threadIdx.x == 0) { D.obj[2] = D.obj[0]; D.obj[3] = D.obj[1]; D.obj[4] = red[0]; D.obj[5] = 0.0; }
+  if (threadIdx.x == 0) { D.obj[2] = D.obj[0]; D.obj[3] = D.obj[1]; D.obj[4] = red[0]; }
 }
 
 // ---- ridge statistics: which combinations enter cluster k's regression, and the hand-over of the chain totals ---------------------
@@ -335,11 +366,13 @@ __global__ void k_seq_ridge_store(Dev D, const float* __restrict__ total) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------
-void l_seq_rsum_pass(const Launch& L, const float* R, int K, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start,
-                     float* end, int zero_start) {
+void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
+                   int zero_start) {
   if (nsegs <= 0) return;
-  hipLaunchKernelGGL(k_seq_rsum_pass, dim3((nsegs + 3) / 4, (K + 63) / 64), dim3(256), 0, L.stream, R, K, list, segs, seg0, nsegs, start, end,
-                     zero_start);
+  int wpb = 4;                                           // waves per workgroup, limited by the level rows in LDS
+  while (wpb > 1 && (size_t)wpb * D.B * 256 > 60 * 1024) wpb >>= 1;
+  hipLaunchKernelGGL(k_seq_oe_pass, dim3((nsegs + wpb - 1) / wpb, (D.K + 63) / 64), dim3(64 * wpb), (size_t)wpb * D.B * 256, L.stream, D.R, D.K, D.B,
+                     D.C, list, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start);
 }
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start) {

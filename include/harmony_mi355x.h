@@ -208,12 +208,14 @@ int hmx_set_abort_poll(hmx_ctx* ctx, int (*poll)(void*), void* user);
  *   "obj_arith"    compute_objective's three K*N-term my_accu sums                                       (src/utils.cpp:67-75)
  *   "solve_arith"  the closed-form fp32 arrowhead inverse of the one-covariate ridge system               (src/harmony.cpp:575-586)
  *   "ref_arith"    all four.
- * The sequential sums are computed as RESTARTED sequential sums (segments in parallel, starts by fixed-point iteration, a final
- * check that certifies bit-equality with the one-after-the-other loop; hmx_get "seq:mismatch" = segments that failed it,
- * "seq_passes" = passes per sum, default 3).  Probes of that machinery on caller-provided data (device needed): */
-int hmx_debug_seq_rsum(const float* R, int64_t n, int32_t K, const int32_t* list, int64_t nlist, const int32_t* chain_off,
-                       const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals, int64_t* mismatch);
-int hmx_debug_seq_arr(const float* T, int64_t n, int32_t narr, int32_t seg_terms, int32_t passes, float* total, int64_t* mismatch);
+ * The sequential sums are computed as RESTARTED sequential sums (segments in parallel, their starting values by fixed-point
+ * iteration; at the fixed point the result is bit-identical to the one-after-the-other loop.  "seq_passes" = passes per sum,
+ * default 3; hmx_get "seq:mismatch" / "seq:residual" = how many segment starts still moved in the last scans and by how much,
+ * relatively).  Probes of that machinery on caller-provided data (device needed): */
+int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level, int32_t B, const int32_t* list, int64_t nlist,
+                     const int32_t* chain_off, const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals,
+                     int64_t* mismatch, double* residual);
+int hmx_debug_seq_arr(const float* T, int64_t n, int32_t narr, int32_t seg_terms, int32_t passes, float* total, int64_t* mismatch, double* residual);
 
 /* ---- measurement ----------------------------------------------------------------------------
  * HIP-event timing of the dominant kernel on the library's stream: after

@@ -44,11 +44,11 @@ def _flips(Ra, Rb, margin):
 @pytest.mark.timeout(1500, method="thread")
 @pytest.mark.parametrize("N", [20000, 100000, 1000000])
 def test_arithmetic_gap_table(N):
-    """GPU (default: exact ridge statistics) and GPU (ridge_arith = 1: the reference's sequential fp32 statistics) against the
-    oracle in accurate (fp64 accumulators) AND faithful (the reference's fp32 arithmetic) mode: N x 50, K = 100, 10 batches,
-    reference defaults, to convergence -- N = 1M is BASELINE configs[2] exactly.  Shared random choices: the GPU's k-means
-    centres, the documented Feistel block partitions (same seed).  The numbers go to gpurun_out/r2_parity_table_<N>.json
-    (copied to profiles/ and quoted in DESIGN.md section 2)."""
+    """GPU (default: exact accumulators) and GPU (ref_arith = 1: every accumulator group in the reference's fp32 operation order --
+    ridge statistics, O / E tables, objective sums, closed-form inverse) against the oracle in accurate (fp64 accumulators) AND
+    faithful (the reference's fp32 arithmetic) mode: N x 50, K = 100, 10 batches, reference defaults, to convergence -- N = 1M is
+    BASELINE configs[2] exactly.  Shared random choices: the GPU's k-means centres, the documented Feistel block partitions (same
+    seed).  The numbers go to gpurun_out/r3_parity_table_<N>.json (copied to profiles/ and quoted in DESIGN.md section 2)."""
     K, B, seed = 100, 10, 3
     Z, meta, _ = synth(N, d=50, levels=(B,), seed=7)
     skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
@@ -57,15 +57,17 @@ def test_arithmetic_gap_table(N):
     Y0 = g.kmeans_centers()
     res, timing = {}, {}
 
-    def gpu(name, ridge_arith):
-        o = g if ridge_arith == 0 else Harmony(seed=seed, ridge_arith=1)
-        if ridge_arith:
+    def gpu(name, ref_arith):
+        o = g if ref_arith == 0 else Harmony(seed=seed, ref_arith=1)
+        if ref_arith:
             o.setup(**skw)
         t0 = time.time()
         o.init_cluster_cpp(Y0)
         it = _iterate(o)
         timing[name] = time.time() - t0
         res[name] = dict(Z=o.getZcorr(), R=o.R, it=it, obj=o.objective_kmeans.copy(), rounds=o.kmeans_rounds.copy())
+        if ref_arith:
+            res[name]["seq_residual"] = float(o._scalar("seq:residual"))
 
     def cpu(name, mask):
         o = OracleHarmony(mask=mask, seed=seed)
@@ -94,17 +96,20 @@ def test_arithmetic_gap_table(N):
             "argmax_diff": f, "argmax_diff_margin_ge_1e-5": f5, "iterations": [int(ra["it"]), int(rb["it"])],
             "objective_rel_max": float(np.max(np.abs(ra["obj"][:n] - rb["obj"][:n]) / np.abs(rb["obj"][:n]))),
             "final_objective": [float(ra["obj"][-1]), float(rb["obj"][-1])]}
-    out = {"workload": {"cells": N, "pcs": 50, "clusters": K, "batches": B}, "seconds": timing, "pairs": rows}
+    out = {"workload": {"cells": N, "pcs": 50, "clusters": K, "batches": B}, "seconds": timing, "pairs": rows,
+           "seq_residual": res["gpu_ref_arith"]["seq_residual"]}
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "r2_parity_table_%d.json" % N), "w") as fh:
+    with open(os.path.join(OUT, "r3_parity_table_%d.json" % N), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
     ga, gf, rf = rows["gpu_vs_oracle_accurate"], rows["gpu_vs_oracle_faithful"], rows["gpu_ref_arith_vs_oracle_faithful"]
     # the parity target proper: same algorithm, exact accumulators -> tight bar, SURVEY's 1e-5 assignment margin
     assert ga["Z_rel"] <= 2e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1], ga
     assert ga["objective_rel_max"] <= 1e-4, ga
-    # the reference's own arithmetic: with its summation order reproduced the GPU is inside north_star's 1e-4
-    assert rf["Z_rel"] <= 1e-4 and rf["iterations"][0] == rf["iterations"][1], rf
+    # the reference's own arithmetic: with its operation order reproduced the GPU follows the reference's fp32 results, not the exact ones
+    assert rf["Z_rel"] <= 1e-5 and rf["argmax_diff_margin_ge_1e-5"] == 0 and rf["iterations"][0] == rf["iterations"][1], rf
+    assert rf["objective_rel_max"] <= 1e-4, rf
+    assert out["seq_residual"] <= 1e-3, out["seq_residual"]     # (largest relative move of a segment start in the last scans of the restarted sums)
     # (gf -- default GPU vs the reference's fp32 drift -- is REPORTED, not asserted: it is the reference's N-dependent bias)
     assert gf["iterations"][0] == gf["iterations"][1], gf
 
