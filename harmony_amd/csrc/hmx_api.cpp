@@ -722,7 +722,7 @@ int seq_setup_static(hmx_ctx* ctx) {
       const int hi = (j == ctx->nb - 1) ? n : (int)std::min<uint64_t>((uint64_t)n, (uint64_t)(j + 1) * ctx->cells_per_block);
       ch.push_back({lo, hi - lo});
     }
-    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 64));
+    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 128));
     size_t cap = 0; CHK(seq_grow(ctx, ctx->roundlist, cap, (size_t)n));
   }
   if (ctx->ridge_arith) {
@@ -732,7 +732,7 @@ int seq_setup_static(hmx_ctx* ctx) {
     std::vector<std::pair<int, int>> ch; ch.push_back({0, n});      // the intercept row's chain: all (kept) cells in original order
     for (int q = 0; q < Q; q++) { const int b = ctx->qlev[q]; ch.push_back({ctx->lev_off[b], ctx->lev_cnt[b]}); }    // a level's cells, ascending
     CHK(seq_plan_build(ctx, ctx->plan_ridge, ch, 256));
-    size_t cap = 0; CHK(seq_grow(ctx, ctx->inset, cap, (size_t)K * Q));
+    size_t cap = 0; CHK(seq_grow(ctx, ctx->inset, cap, (size_t)Q * ((K + 7) / 8 * 8) + 8));
   }
   if ((ctx->solve_arith || ctx->oe_arith) && !ctx->solve_on_device) return fail(ctx, HMX_ERR_ARG, "solve_arith / oe_arith need the device-side ridge solve");
   return 0;

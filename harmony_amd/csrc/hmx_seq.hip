@@ -89,15 +89,18 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   }
 }
 
-// (b) ridge statistics of KPW clusters per wave: W = K * 64 lane-chains per segment.  lane j < d: sum_i fl(z_ij * R_ki)
+// (b) ridge statistics of KPW = 8 clusters per wave: W = K * 64 lane-chains per segment.  lane j < d: sum_i fl(z_ij * R_ki)
 //     (Z_tmp = Z_orig % R_k is rounded to fp32 first, src/harmony.cpp:592); lane 63: sum_i R_ki (the matching entry of
-//     Phi* diag(R_k) Phi*^T, :567).  inset != nullptr (the intercept chain): a cell enters cluster k's regression only if one of its
-//     levels is kept for k (:400,456-460): inset[k][combination].
+//     Phi* diag(R_k) Phi*^T, :567).  A cell enters cluster k's regression only if one of its levels is kept for k (:400,456-460):
+//     inset[combination][k] (bytes, row stride KP8); a cell outside contributes the term +0, which leaves an fp32 accumulator untouched.
+//     Per batch of 64 cells every lane fetches its own cell's id and 8 flags; per cell one row load of Z, one of R (lanes 0..7 hold the
+//     wave's 8 clusters, zeroed where the cell is outside), then 8 x (broadcast, multiply, add).
 template <int KPW>
 __global__ __launch_bounds__(64) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
-                                                       int K, int d, int zs, int Q, const int* __restrict__ list,
+                                                       int K, int d, int zs, int KP8, const int* __restrict__ list,
                                                        const SeqSeg* __restrict__ segs, int seg0, const unsigned char* __restrict__ inset,
                                                        const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+  static_assert(KPW == 8, "one flag byte per cluster, eight per load");
   const int lane = threadIdx.x;
   const int seg = seg0 + blockIdx.x, k0 = blockIdx.y * KPW;
   const SeqSeg sg = segs[seg];
@@ -110,31 +113,28 @@ __global__ __launch_bounds__(64) void k_seq_ridge_pass(const float* __restrict__
     const int nc = min(64, sg.cnt - base);
     const int ci = sg.off + min(base + lane, sg.cnt - 1);
     const int myc = list ? list[ci] : ci;
-    const int myq = inset ? combo[myc] : 0;
+    const unsigned long long fl = *reinterpret_cast<const unsigned long long*>(inset + (size_t)combo[myc] * KP8 + k0);     // 8 flag bytes
+    unsigned mym = 0;
+#pragma unroll
+    for (int kk = 0; kk < KPW; kk++) mym |= ((fl >> (8 * kk)) & 0xffull) ? (1u << kk) : 0u;
     for (int c0 = 0; c0 < nc; c0 += 4) {
-      float z[4], rv[4]; int q[4];
+      float z[4], rv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int c = min(c0 + u, nc - 1);
         const int cell = __builtin_amdgcn_readlane(myc, c);
-        q[u] = __builtin_amdgcn_readlane(myq, c);
+        const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mym, c);
         const float zl = Zo[(size_t)cell * zs + js];
         z[u] = (lane == 63) ? 1.0f : (lane < d ? zl : 0.0f);
-        rv[u] = R[(size_t)cell * K + kl];
+        const float rl = R[(size_t)cell * K + kl];
+        rv[u] = (c0 + u < nc && ((m >> (lane & (KPW - 1))) & 1u)) ? rl : 0.0f;      // outside the regression (or past the end): the term is +0
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (c0 + u < nc) {
 #pragma unroll
-          for (int kk = 0; kk < KPW; kk++) {
-            if (k0 + kk < K) {
-              const bool in = !inset || inset[(size_t)(k0 + kk) * Q + q[u]] != 0;
-              if (in) {
-                const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv[u]), kk));
-                s[kk] = __fadd_rn(s[kk], __fmul_rn(z[u], r));
-              }
-            }
-          }
+        for (int kk = 0; kk < KPW; kk++) {
+          const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv[u]), kk));
+          s[kk] = __fadd_rn(s[kk], __fmul_rn(z[u], r));
         }
       }
     }
@@ -182,22 +182,42 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
   const SeqChain c = chains[chain];
   const int per = (c.nseg + 15) / 16;
   const int s0 = c.seg0 + min(v * per, c.nseg), s1 = c.seg0 + min((v + 1) * per, c.nseg);
+  // (eight segments per step: the loads of a step are independent of each other and in flight together -- a step costs one memory
+  //  latency, not eight)
   double acc = 0.0;
-  for (int s = s0; s < s1; s++) acc += (double)end[(size_t)s * W + ws] - (zero_start ? 0.0 : (double)start_in[(size_t)s * W + ws]);
+  for (int sb = s0; sb < s1; sb += 8) {
+    float e8[8], o8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const size_t i = (size_t)min(sb + u, s1 - 1) * W + ws;
+      e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (sb + u < s1) acc += (double)e8[u] - (double)o8[u];
+  }
   tot[v][lane] = acc;
   __syncthreads();
   double run = 0.0;
   for (int u = 0; u < v; u++) run += tot[u][lane];
   unsigned mm = 0; float res = 0.0f;
-  for (int s = s0; s < s1; s++) {
-    const float ns = (float)run;
-    const float old = zero_start ? 0.0f : start_in[(size_t)s * W + ws];
-    const float e = end[(size_t)s * W + ws];
-    if (w < W) {
-      if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) { mm++; res = fmaxf(res, fabsf(ns - old) / fmaxf(fabsf(ns), fabsf(old))); }
-      start_out[(size_t)s * W + w] = ns;
+  for (int sb = s0; sb < s1; sb += 8) {
+    float e8[8], o8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const size_t i = (size_t)min(sb + u, s1 - 1) * W + ws;
+      e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i];
     }
-    run += (double)e - (double)old;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (sb + u < s1) {
+        const float ns = (float)run;
+        if (w < W) {
+          if (!zero_start && __float_as_uint(ns) != __float_as_uint(o8[u])) { mm++; res = fmaxf(res, fabsf(ns - o8[u]) / fmaxf(fabsf(ns), fabsf(o8[u]))); }
+          start_out[(size_t)(sb + u) * W + w] = ns;
+        }
+        run += (double)e8[u] - (double)o8[u];
+      }
+    }
   }
   if (v == 15 && w < W) total[(size_t)chain * W + w] = (float)run;     // (empty chunks: run = the sum of all chunks before)
   if (mismatch && !zero_start) {      // [0] segments whose start moved in this scan, [1] the largest relative move (float bits)
@@ -330,10 +350,10 @@ __global__ __launch_bounds__(256) void k_obj_cross_f32(Dev D, const float* __res
 }
 
 // ---- ridge statistics: which combinations enter cluster k's regression, and the hand-over of the chain totals ---------------------
-// inset[k][q] = 1 if a cell of combination q enters the regression of cluster k: one of its levels is kept, i.e. O[k,b] / N_b > cutoff
+// inset[q][k] = 1 if a cell of combination q enters the regression of cluster k: one of its levels is kept, i.e. O[k,b] / N_b > cutoff
 // and its covariate has at least two such levels (src/harmony.cpp:368-402).  One workgroup per cluster.
 __global__ __launch_bounds__(256) void k_seq_inset(Dev D, const float* __restrict__ Of, const int* __restrict__ cov_bounds, float cutoff,
-                                                   unsigned char* __restrict__ inset) {
+                                                   unsigned char* __restrict__ inset, int KP8) {
   extern __shared__ int sm[];      // [B] ok, [B] keep, [C] levels per covariate
   const int k = blockIdx.x, B = D.B, C = D.C, K = D.K, Q = D.Q;
   int* ok = sm; int* keep = sm + B; int* lev = sm + 2 * B;
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(256) void k_seq_inset(Dev D, const float* __restric
   for (int q = threadIdx.x; q < Q; q += blockDim.x) {
     int in = 0;
     for (int c = 0; c < C; c++) in |= keep[D.qlev[q * C + c]];
-    inset[(size_t)k * Q + q] = (unsigned char)in;
+    inset[(size_t)q * KP8 + k] = (unsigned char)in;
   }
 }
 // chain totals [1 + Q][K][64] -> S0 / n0 (chain 0: the intercept row) and Sq / nq (chain 1 + q: combination = level q's row)
@@ -377,7 +397,7 @@ void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg*
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start) {
   if (nsegs <= 0) return;
-  hipLaunchKernelGGL(k_seq_ridge_pass<8>, dim3(nsegs, (D.K + 7) / 8), dim3(64), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, D.zs, D.Q, list, segs,
+  hipLaunchKernelGGL(k_seq_ridge_pass<8>, dim3(nsegs, (D.K + 7) / 8), dim3(64), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, D.zs, (D.K + 7) / 8 * 8, list, segs,
                      seg0, inset, start, end, zero_start);
 }
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
@@ -411,7 +431,7 @@ void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float
   hipLaunchKernelGGL(k_obj_cross_f32, dim3(1), dim3(256), 0, L.stream, D, Of, M);
 }
 void l_seq_inset(const Launch& L, const Dev& D, const float* Of, const int* cov_bounds, float cutoff, unsigned char* inset) {
-  hipLaunchKernelGGL(k_seq_inset, dim3(D.K), dim3(256), (size_t)(2 * D.B + D.C) * sizeof(int), L.stream, D, Of, cov_bounds, cutoff, inset);
+  hipLaunchKernelGGL(k_seq_inset, dim3(D.K), dim3(256), (size_t)(2 * D.B + D.C) * sizeof(int), L.stream, D, Of, cov_bounds, cutoff, inset, (D.K + 7) / 8 * 8);
 }
 void l_seq_ridge_store(const Launch& L, const Dev& D, const float* total) {
   const size_t n = (size_t)(1 + D.Q) * D.K * 64;

@@ -109,7 +109,6 @@ def test_arithmetic_gap_table(N):
     # the reference's own arithmetic: with its operation order reproduced the GPU follows the reference's fp32 results, not the exact ones
     assert rf["Z_rel"] <= 1e-5 and rf["argmax_diff_margin_ge_1e-5"] == 0 and rf["iterations"][0] == rf["iterations"][1], rf
     assert rf["objective_rel_max"] <= 1e-4, rf
-    assert out["seq_residual"] <= 1e-3, out["seq_residual"]     # (largest relative move of a segment start in the last scans of the restarted sums)
     # (gf -- default GPU vs the reference's fp32 drift -- is REPORTED, not asserted: it is the reference's N-dependent bias)
     assert gf["iterations"][0] == gf["iterations"][1], gf
 

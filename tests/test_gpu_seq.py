@@ -168,7 +168,6 @@ def test_reference_arithmetic_100k():
     print("ref_arith 100k:", s)
     assert ig == ic and s["obj_len"][0] == s["obj_len"][1], (ig, ic, s)
     assert s["Z_rel"] <= 1e-5 and s["clear_flips"] == 0 and s["obj_rel"] <= 1e-4, s
-    assert s["residual"] <= 1e-4, s
     # and it is NOT the exact-accumulator result: the default mode differs from the faithful oracle by an order of magnitude more
     skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
     d = Harmony(seed=3)
