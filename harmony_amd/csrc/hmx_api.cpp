@@ -152,7 +152,11 @@ struct hmx_ctx {
   std::vector<int> invperm_h, combo_h;     // host copies (internal order)
   float* Of = nullptr; float* Ef = nullptr; float* Mtab = nullptr;    // [B][K] fp32 O / E (oe_arith), theta log((O+E+1)/(2E+1))
   float* objT = nullptr; size_t objT_cap = 0;                         // the objective's three K x N term matrices (obj_arith)
-  unsigned char* inset = nullptr;                                      // [K][Q] cells of combination q enter cluster k's regression
+  unsigned char* inset = nullptr;                                      // [Q][K] cells of combination q enter cluster k's regression
+  // the objective's and the ridge statistics' segment starts live in their own buffers and survive from one evaluation to the next
+  // (same chains, slowly changing terms): every evaluation after the first starts warm and needs one pass less
+  float* obj_start = nullptr; size_t obj_start_cap = 0; bool obj_warm = false;
+  float* rg_start = nullptr; size_t rg_start_cap = 0; bool rg_warm = false;
   std::map<std::string, double> timers;
   // ---- device -------------------------------------------------------------------------
   int device = -1;
@@ -221,11 +225,12 @@ void free_all(hmx_ctx* ctx) {
   }
   {   // reference-arithmetic buffers (grown on demand, not in `allocs`)
     void* ps[] = {ctx->sq_start, ctx->sq_end, ctx->sq_total, ctx->sq_mismatch, ctx->headlist, ctx->roundlist, ctx->Of, ctx->Ef, ctx->Mtab, ctx->objT,
-                  ctx->inset, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
+                  ctx->inset, ctx->obj_start, ctx->rg_start, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
                   ctx->plan_round.d_segs, ctx->plan_round.d_chains};
     for (void* q : ps) if (q) (void)hipFree(q);
     ctx->sq_start = ctx->sq_end = ctx->sq_total = nullptr; ctx->sq_mismatch = nullptr; ctx->headlist = ctx->roundlist = nullptr;
     ctx->Of = ctx->Ef = ctx->Mtab = ctx->objT = nullptr; ctx->inset = nullptr; ctx->sq_cap = ctx->sq_total_cap = ctx->objT_cap = 0;
+    ctx->obj_start = ctx->rg_start = nullptr; ctx->obj_start_cap = ctx->rg_start_cap = 0; ctx->obj_warm = ctx->rg_warm = false;
     ctx->plan_head = hmx_ctx::SeqPlan(); ctx->plan_ridge = hmx_ctx::SeqPlan(); ctx->plan_round = hmx_ctx::SeqPlan();
   }
   if (ctx->h_obj) { (void)hipHostFree(ctx->h_obj); ctx->h_obj = nullptr; ctx->obj_cap = 0; }
@@ -680,10 +685,12 @@ int seq_workspace(hmx_ctx* ctx, size_t seg_floats, size_t total_floats) {
 // O / E sums of the chain sets [chain0, chain0 + nchains) of plan P over `list`: per chain set (1 + B) * K sequential fp32 sums
 // (row 0: all its cells, row 1 + b: its cells of level b) -> ctx->sq_total[chain][1 + B][K].  passes x (segments in parallel, then the
 // scan that hands every segment its start).
-int seq_run_oe(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, int chain0, int nchains) {
+// warm: the workspace still holds these segments' starts from a run over (nearly) the same terms -- the first pass starts from them
+// instead of from zero, which is worth one pass.
+int seq_run_oe(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, int chain0, int nchains, bool warm = false) {
   const int W = (1 + ctx->B) * ctx->K, lo = P.seg0[chain0], n = P.seg0[chain0 + nchains] - lo;
   CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
-  for (int p = 0; p < ctx->seq_passes; p++) {
+  for (int p = warm ? 1 : 0; p < ctx->seq_passes; p++) {
     l_seq_oe_pass(ctx->L, ctx->D, list, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
     l_seq_scan(ctx->L, P.d_chains, chain0, nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total,
                p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
@@ -722,7 +729,7 @@ int seq_setup_static(hmx_ctx* ctx) {
       const int hi = (j == ctx->nb - 1) ? n : (int)std::min<uint64_t>((uint64_t)n, (uint64_t)(j + 1) * ctx->cells_per_block);
       ch.push_back({lo, hi - lo});
     }
-    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 128));
+    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 256));
     size_t cap = 0; CHK(seq_grow(ctx, ctx->roundlist, cap, (size_t)n));
   }
   if (ctx->ridge_arith) {
@@ -751,11 +758,13 @@ int seq_objective(hmx_ctx* ctx) {
   const int nsegs = (int)((nt + LSEG - 1) / LSEG);
   CHK(seq_grow(ctx, ctx->objT, ctx->objT_cap, (size_t)3 * (size_t)nt));
   CHK(seq_workspace(ctx, (size_t)3 * nsegs, 3));
+  if ((size_t)3 * nsegs > ctx->obj_start_cap) { CHK(seq_grow(ctx, ctx->obj_start, ctx->obj_start_cap, (size_t)3 * nsegs)); ctx->obj_warm = false; }
   l_obj_terms(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->oe_arith ? ctx->Ef : nullptr, ctx->Mtab, ctx->objT, nt); KCHK();
-  for (int p = 0; p < ctx->seq_passes; p++) {
-    l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, 3, LSEG, nsegs, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
-    l_seq_scan1(ctx->L, 3, nsegs, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
+  for (int p = ctx->obj_warm ? 1 : 0; p < ctx->seq_passes; p++) {
+    l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, 3, LSEG, nsegs, ctx->obj_start, ctx->sq_end, p == 0); KCHK();
+    l_seq_scan1(ctx->L, 3, nsegs, ctx->obj_start, ctx->sq_end, ctx->obj_start, ctx->sq_total, p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
   }
+  ctx->obj_warm = true;
   l_obj_store(ctx->L, ctx->sq_total, D.obj); KCHK();
   ctx->seq_runs++;
   return 0;
@@ -775,12 +784,14 @@ int seq_ridge_stats(hmx_ctx* ctx) {
   const hmx_ctx::SeqPlan& P = ctx->plan_ridge;
   const int W = ctx->K * 64;
   CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
+  if ((size_t)P.nsegs * W > ctx->rg_start_cap) { CHK(seq_grow(ctx, ctx->rg_start, ctx->rg_start_cap, (size_t)P.nsegs * W)); ctx->rg_warm = false; }
   l_seq_inset(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->sv_cov_bounds, ctx->cutoff, ctx->inset); KCHK();
-  for (int p = 0; p < ctx->seq_passes; p++) {
-    l_seq_ridge_pass(ctx->L, D, ctx->headlist, P.d_segs, 0, P.nsegs, ctx->inset, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
-    l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total,
+  for (int p = ctx->rg_warm ? 1 : 0; p < ctx->seq_passes; p++) {
+    l_seq_ridge_pass(ctx->L, D, ctx->headlist, P.d_segs, 0, P.nsegs, ctx->inset, ctx->rg_start, ctx->sq_end, p == 0); KCHK();
+    l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->rg_start, ctx->sq_end, ctx->rg_start, ctx->sq_total,
                p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
   }
+  ctx->rg_warm = true;
   l_seq_ridge_store(ctx->L, D, ctx->sq_total); KCHK();
   ctx->seq_runs++;
   return 0;
@@ -821,7 +832,8 @@ int update_R_ref(hmx_ctx* ctx) {
     l_update(ctx->L, D, j); KCHK();
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
     { PhaseScope ph(ctx, "EO_update");
-      CHK(seq_run_oe(ctx, P, ctx->roundlist, j, 1));
+      // the same cells in the same order as the sums removed above, their R rows updated: that run's segment starts are this run's first guess
+      CHK(seq_run_oe(ctx, P, ctx->roundlist, j, 1, true));
       l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, tot, nullptr, +1); KCHK(); }
   }
   { PhaseScope ph(ctx, "objective");
@@ -1764,6 +1776,7 @@ int hmx_restart(hmx_ctx* ctx) {
   ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();
   ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear(); ctx->rrng_seeded = false;
   ctx->y_on_device = false; ctx->solve_pending = false;
+  ctx->obj_warm = ctx->rg_warm = false;            // (a run never depends on what the handle computed before it)
   if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
   for (int i = 0; i < 2; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
   return 0;
