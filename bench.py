@@ -11,6 +11,9 @@ or the run exits non-zero.
 Other driver-reproducible modes:
     --cells-per-gpu 10000000 --batches 20          north_star target: 10M x 50 x K=100 on ONE GPU (configs[3]'s size)
     --workload c5 [--cells-per-gpu N]              configs[4] shape: K=200, 3 nested covariates 8 > 64 > 128 (200 levels)
+    --total-cells 10000000 --batches 20 --gpus N   STRONG scaling: configs[3] = 10M cells in total, sharded over the N GPUs
+    --also ref,10M,c5 (default at N=1; "none")     extra legs of the same invocation, reported under "also": the reference-arithmetic
+                                                   mode on the main workload, 10M cells on this one GPU, the configs[4] shape at 1M
 
 A "step" = one full run from HBM-resident inputs: hmx_restart -> init_cluster_cpp (k-means seeding + 10 Lloyd)
 -> {cluster_cpp, moe_correct_ridge_cpp, check_convergence}* until converged.  Prints ONE JSON line (rank 0).
@@ -48,8 +51,9 @@ def run_to_convergence(obj, max_iter=10):
 def cpu_baseline(cells, d, K, levels, nested, seed):
     """The oracle (a port: the reference itself cannot be built here) in faithful fp32 mode on a bounded sample of the same
     workload, GEMM through OpenBLAS: 1 thread (the reference's default ncores = 1, R/ui.R:101) = `value`; and all host cores
-    (`all_cores`; like the reference's ncores > 1, only the BLAS calls are threaded)."""
-    from harmony_amd import prepare_setup_args
+    (`all_cores`; like the reference's ncores > 1, only the BLAS calls are threaded).  The timed single-thread run doubles as the
+    checker of the GPU's reference-arithmetic mode on the same sample (`gpu_reference_arith_vs_this_run`)."""
+    from harmony_amd import Harmony, prepare_setup_args
     from oracle.oracle import OracleHarmony, use_openblas
     Z, meta, _ = synth(cells, d=d, levels=levels, seed=seed, nested=nested)
     skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
@@ -61,6 +65,8 @@ def cpu_baseline(cells, d, K, levels, nested, seed):
         o.setup(**skw)
         t0 = time.time()
         o.init_cluster_cpp()
+        if tag == "one":
+            Y0 = np.array(o.Y, copy=True)          # (normalised centroids after the oracle's own k-means: shared with the GPU check below)
         it = 0
         for it in range(1, 11):
             o.cluster_cpp()
@@ -69,6 +75,30 @@ def cpu_baseline(cells, d, K, levels, nested, seed):
                 break
         dt = time.time() - t0
         out[tag] = (cells / dt, it, dt, blas)
+        if tag == "one":
+            ref_check = None
+            if len(levels) == 1:
+                try:       # the GPU in reference arithmetic on the same sample, same centroids, same documented shuffles
+                    g = Harmony(seed=1, ref_arith=1)
+                    g.setup(**skw)
+                    g.init_cluster_cpp(Y0)
+                    ig = 0
+                    for ig in range(1, 11):
+                        g.cluster_cpp()
+                        g.moe_correct_ridge_cpp()
+                        if g.check_convergence(1):
+                            break
+                    Zg, Zc, Rg, Rc = g.getZcorr(), o.getZcorr(), g.R, o.R
+                    bad = np.where(Rg.argmax(axis=0) != Rc.argmax(axis=0))[0]
+                    srt = np.sort(Rc[:, bad], axis=0) if bad.size else np.zeros((2, 0))
+                    nob = min(len(g.objective_kmeans), len(o.objective_kmeans))
+                    ref_check = {"Z_rel_frobenius": float(np.linalg.norm(Zg - Zc) / np.linalg.norm(Zc)), "hard_assignment_flips": int(bad.size),
+                                 "flips_with_margin_ge_1e-5": int(((srt[-1] - srt[-2]) >= 1e-5).sum()) if bad.size else 0,
+                                 "objective_rel_max": float(np.max(np.abs(g.objective_kmeans[:nob] - o.objective_kmeans[:nob]) / np.abs(o.objective_kmeans[:nob]))),
+                                 "iterations_gpu_cpu": [int(ig), int(it)]}
+                    del g
+                except Exception as e:                # pragma: no cover
+                    ref_check = {"error": repr(e)}
         if ncpu == 1:
             out["all"] = out["one"]
             break
@@ -79,7 +109,52 @@ def cpu_baseline(cells, d, K, levels, nested, seed):
                       "algorithm is O(N) per iteration, so cells/s at the full size is the same figure up to the iteration count"
                       % (", OpenBLAS sgemm" if blas else "", cells, d, K, "x".join(map(str, levels)), it, dt),
             "all_cores": {"value": va, "cores": ncpu, "seconds": dta},
-            "host_cores_available": ncpu}
+            "host_cores_available": ncpu, "full_size": _full_size_cpu(),
+            "gpu_reference_arith_vs_this_run": ref_check}
+
+
+def _full_size_cpu():
+    """the same oracle at the FULL configs[2] size, from the committed parity table (profiles/, a builder run: ~1 minute of CPU)"""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r3_parity_table_1000000.json")))
+        s = j["seconds"]["oracle_faithful"]
+        return {"cells": j["workload"]["cells"], "seconds": s, "value": j["workload"]["cells"] / s, "unit": "cells/s",
+                "source": "profiles/r3_parity_table_1000000.json (tests/test_gpu_parity2.py::test_arithmetic_gap_table[1000000]; 4 BLAS threads, "
+                          "shared k-means centres: the init is not in this figure)"}
+    except Exception:
+        return None
+
+
+def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps, warmup, sync, **hkw):
+    """one extra workload / mode on this GPU: time to convergence from HBM-resident inputs, same step definition as the main line"""
+    Z, meta, _ = synth(n, d=d, levels=levels, seed=seed, nested=nested)
+    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
+    o = Harmony(seed=1, **hkw)
+    o.setup(**skw)
+    del Z
+    for _ in range(warmup):
+        run_to_convergence(o)
+    o.set_profile(True)
+    sync()
+    t0 = time.perf_counter()
+    its = [run_to_convergence(o) for _ in range(steps)]
+    sync()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    ph = {k: round(o._scalar("gputimer:" + k) / steps, 3) for k in ("kmeans_centers", "cluster_head", "randomize", "EO_update", "Rcells_update",
+                                                                     "objective", "ridge_statistics", "arma_inv", "update_Zcorr")}
+    upd_ms, upd_steps = o._scalar("prof:update_ms"), max(o._scalar("prof:update_steps"), 1)
+    kr = np.asarray(o.kmeans_rounds, dtype=np.int64)
+    run_bytes = float(n) * float(np.sum(4.0 * d * (4 + kr) + 4.0 * K * (3 + 2 * kr)))
+    out = {"workload": "synthetic %d cells x %d PCs, K=%d, levels %s%s" % (n, d, K, "x".join(map(str, levels)), " nested" if nested else ""),
+           "ms_per_step": ms, "cells_per_s": n / (ms * 1e-3), "harmony_iterations": its, "steps": steps, "gpu_phase_ms_per_step": ph,
+           "block_chain": bool(o._scalar("chain")), "avg_block_step_us": 1e3 * upd_ms / upd_steps,
+           "roofline_run_frac": run_bytes / (ms * 1e-3) / 8e12}
+    if hkw:
+        out["mode"] = hkw
+        out["seq_residual"] = o._scalar("seq:residual")
+    del o
+    return out
+
 
 
 def _free_port():
@@ -98,6 +173,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"], help="c3: one covariate (--batches levels), K=--clusters; "
                     "c5: configs[4] shape, K=200, nested covariates 8 > 64 > 128")
     ap.add_argument("--cells-per-gpu", type=int, default=1000000)
+    ap.add_argument("--total-cells", type=int, default=0, help="strong scaling: this many cells in TOTAL, sharded over --gpus (overrides --cells-per-gpu)")
+    ap.add_argument("--also", default=None, help="extra legs at N=1, comma separated: ref (reference arithmetic on the main workload), 10M, c5; "
+                    "default 'ref,10M,c5' for the default workload on one GPU, 'none' otherwise")
     ap.add_argument("--pcs", type=int, default=50)
     ap.add_argument("--clusters", type=int, default=None)
     ap.add_argument("--batches", type=int, default=10)
@@ -137,7 +215,10 @@ def main():
         levels, nested, K = (8, 64, 128), True, (a.clusters or 200)
     else:
         levels, nested, K = (a.batches,), False, (a.clusters or 100)
-    n, d = a.cells_per_gpu, a.pcs
+    strong = a.total_cells > 0
+    if strong and a.total_cells % world:
+        raise SystemExit("--total-cells must be a multiple of --gpus")
+    n, d = (a.total_cells // world if strong else a.cells_per_gpu), a.pcs
     N = n * world
     Z, meta, _ = synth(n, d=d, levels=levels, seed=a.seed, shard=rank, nested=nested)
     vars_use = list(meta)
@@ -298,18 +379,27 @@ def main():
     alg_bytes = upd_cells * (4.0 * d + 4.0 * K)
     achieved = alg_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     traffic = mfma_util = None  # HBM bytes / MFMA busy per launch from the PMC passes (collected separately, profiles/)
+    pm_note = ""
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_update_kernel.json")))
         if pm["workload"] == {"cells_per_gpu": n, "pcs": d, "clusters": K, "batches": levels[0]} and len(levels) == 1:
             traffic = pm["hbm_bytes_per_launch"]
             mfma_util = pm.get("mfma_busy_frac")
+            pm_note = "collected %s" % pm.get("collected", "in an earlier round")
     except Exception:
         pass
     # SURVEY 8(d) whole-run figure: compulsory bytes per cell per harmony iteration = 4d(4 + I_k) + 4K(3 + 2 I_k)
     run_bytes = float(n) * float(np.sum(4.0 * d * (4 + kr) + 4.0 * K * (3 + 2 * kr)))
     run_gbs = run_bytes / (ms_per_step * 1e-3) / 1e9
-    roofline = {"kernel": "k_tile<NCT,0> (block update of update_R)", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+    nct = (K + 15) // 16
+    on_chain = bool(obj._scalar("chain")) and (world == 1 or bool(obj._scalar("p2p")))
+    kname = ("k_tile<%d,4,2,%s> -- the persistent block chain: ONE launch = one round of update_R (%d block steps, every cell once)"
+             % (nct, "true" if obj._scalar("usig") else "false", int(obj._scalar("n_blocks")))) if on_chain else \
+            ("k_tile<%d,0,%d,%s> -- one launch = the block update of one block of update_R" % (nct, int(obj._scalar("upd_wps")), "true" if obj._scalar("usig") else "false"))
+    roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "mfma_busy_frac": mfma_util,
+                "traffic_and_mfma_busy_are": ("replayed from profiles/pmc_traffic_update_kernel.json (separate rocprofv3 --pmc passes over this kernel, "
+                                              "%s); not collected in this run" % pm_note) if traffic is not None else None,
                 "avg_launch_us": 1e3 * upd_ms / max(upd_launches, 1), "launches": int(upd_launches),
                 "avg_block_step_us": 1e3 * upd_ms / max(obj._scalar("prof:update_steps"), 1),
                 "alg_bytes_per_launch": alg_bytes / max(upd_launches, 1),
@@ -322,7 +412,7 @@ def main():
     chain = None
     if obj._scalar("chain"):   # persistent block chain: where its workgroups spent their time (100 MHz ticks -> us per block step)
         dbg = obj._get("chain_dbg")
-        steps_ = max(float(dbg[3]) * 20.0, 1.0)
+        steps_ = max(float(dbg[3]) * float(obj._scalar("n_blocks")), 1.0)      # chain launches x block steps per launch
         names = ["folder_wait_arrivals", "folder_fold", "folder_publish", None, "worker_wait_flag", "worker_copy_table",
                  "worker_wait_stores_issued_to_retired", "worker_barrier_arrive", "worker_next_mfma", "worker_tiles_but_last",
                  "worker_last_epilogue", "worker_flush_and_store_issue", "worker_next_mfma_cyclecounter_x100"]
@@ -350,7 +440,7 @@ def main():
     out = {
         "metric": "cells_per_sec_to_convergence", "value": N / (ms_per_step * 1e-3), "unit": "cells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic %d cells x %d PCs, K=%d, levels %s%s%s (BASELINE %s per GPU)"
                                % (N, d, K, "x".join(map(str, levels)), " nested" if nested else "",
                                   "" if world == 1 else ", %d cells/GPU cell-sharded" % n,
@@ -361,6 +451,24 @@ def main():
                    "gpu_phase_ms_per_step": gpu_phase, "chain_us_per_block_step": chain, "e2e": e2e},
         "roofline": roofline,
     }
+    default_main = world == 1 and a.workload == "c3" and n == 1000000 and levels == (10,) and K == 100 and d == 50
+    also = a.also if a.also is not None else ("ref,10M,c5" if default_main else "none")
+    if world == 1 and also != "none":
+        # extra legs of this invocation (never part of `value`): each one is a full run to convergence from HBM-resident inputs
+        del obj
+        legs = {}
+        for leg in also.split(","):
+            try:
+                if leg == "ref":       # every accumulator group in the reference's fp32 operation order on the main workload
+                    legs["reference_arith"] = bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, a.seed, 2, 1, sync, ref_arith=1)
+                    legs["reference_arith"]["parity"] = "vs the faithful oracle: cpu_baseline.gpu_reference_arith_vs_this_run (live, sample) and profiles/r3_parity_table_*.json (full size)"
+                elif leg == "10M":     # north_star's target size on ONE GPU: 10M x 50, K = 100, 20 batches (configs[3]'s total size)
+                    legs["10M_one_gpu"] = bench_leg(Harmony, prepare_setup_args, 10000000, 50, 100, (20,), False, a.seed, 2, 1, sync)
+                elif leg == "c5":      # configs[4] shape at 1M cells
+                    legs["c5_shape_1M"] = bench_leg(Harmony, prepare_setup_args, 1000000, 50, 200, (8, 64, 128), True, a.seed, 2, 1, sync)
+            except Exception as e:     # pragma: no cover  (an extra leg never costs the main line)
+                legs[leg] = {"error": repr(e)}
+        out["also"] = legs
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(a.cpu_sample, d, K, levels, nested, a.seed)
     elif rank == 0:

@@ -729,7 +729,7 @@ int seq_setup_static(hmx_ctx* ctx) {
       const int hi = (j == ctx->nb - 1) ? n : (int)std::min<uint64_t>((uint64_t)n, (uint64_t)(j + 1) * ctx->cells_per_block);
       ch.push_back({lo, hi - lo});
     }
-    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 256));
+    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 128));
     size_t cap = 0; CHK(seq_grow(ctx, ctx->roundlist, cap, (size_t)n));
   }
   if (ctx->ridge_arith) {

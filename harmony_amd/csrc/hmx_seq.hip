@@ -33,7 +33,7 @@ namespace hmx {
 //     walks the sparse operand column by column, i.e. per level in ascending position).  One wave per (segment, 64 clusters), lane =
 //     cluster: row 0 lives in a register, the level rows in LDS (one column per lane: no cross-lane traffic, the read-modify-write of
 //     a lane's own slot is its sequential chain).  The 64 cell ids / level codes of a batch are fetched with one load each, the R rows
-//     sixteen at a time (a segment is latency-bound: what counts is the number of memory round trips).
+//     32 at a time (a segment is latency-bound: what counts is the number of memory round trips).
 __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R, int K, int B, int C, const int* __restrict__ list,
                                                      const int* __restrict__ combo, const int* __restrict__ qlev,
                                                      const SeqSeg* __restrict__ segs, int seg0, int nsegs,
@@ -57,15 +57,15 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
     int mylev[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) mylev[c] = qlev[myq * C + min(c, C - 1)];
-    for (int c0 = 0; c0 < nc; c0 += 16) {
-      float r[16];
+    for (int c0 = 0; c0 < nc; c0 += 32) {
+      float r[32];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
+      for (int u = 0; u < 32; u++) {
         const int cell = __builtin_amdgcn_readlane(myc, min(c0 + u, nc - 1));
         r[u] = R[(size_t)cell * K + ks];
       }
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
+      for (int u = 0; u < 32; u++) {
         if (c0 + u < nc) {
           s0 = __fadd_rn(s0, r[u]);
 #pragma unroll
