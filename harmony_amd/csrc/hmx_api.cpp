@@ -331,7 +331,8 @@ int flush_objectives(hmx_ctx* ctx) {
   const float norm_const = 2000 / ((float)ctx->N_global);
   for (int i = 0; i < ctx->obj_pending; i++) {
     const double* o = ctx->h_obj + 4 * i;
-    const int chain_err = (int)o[3];
+    const int chain_err = (int)o[3] & 15, solve_err = (int)o[3] >> 4;
+    if (solve_err) { ctx->obj_pending = 0; return fail(ctx, HMX_ERR_SOLVE, "singular ridge system (moe_correct_ridge_cpp; reported with the objective of the clustering round that followed it)"); }
     if (chain_err) { ctx->obj_pending = 0; return fail(ctx, HMX_ERR_DEVICE, "persistent block chain: a workgroup timed out waiting for its peers (code " + std::to_string(chain_err) + ")"); }
     if (ctx->obj_arith) {   // the three sums are the reference's fp32 accumulators: combined in fp32 as well (:165-168)
       const float a = (float)o[0], b = (float)o[1], c = (float)o[2];
@@ -853,7 +854,10 @@ int update_R(hmx_ctx* ctx) {
   Dev& D = ctx->D;
   const bool sharded = ctx->world > 1 || ctx->comm_force;
   const char* fold_env = getenv("HMX_FOLD_IMPL");   // "split": force the two-kernel fold + penalty fallback (tests)
-  const bool merged = (size_t)D.B * 128 <= 64 * 1024 && !(fold_env && std::string(fold_env) == "split");   // LDS budget of k_foldpen
+  // k_foldpen (one launch, K/16 workgroups, every thread walks B/16 levels x the replicas) suits small tables; with thousands of
+  // entries (configs[4]: 200 levels x 200 clusters) one thread per entry in two launches is faster, unless the fused / chain paths apply
+  const bool merged = (size_t)D.B * 128 <= 64 * 1024 && !(fold_env && std::string(fold_env) == "split") &&
+                      (ctx->fused_ok || (size_t)D.B * D.K <= 8192 || (fold_env && std::string(fold_env) == "merged"));   // LDS budget of k_foldpen
   const double t0 = now_ms();
   { PhaseScope ph(ctx, "randomize");      // the round's shuffle (:272-291, timers "randomize")
     CHK(prepare_round(ctx, ctx->round_counter)); }
@@ -898,7 +902,8 @@ int update_R(hmx_ctx* ctx) {
   const bool fused = merged && ctx->fused_ok;
   if (chain_path) {
     // default on one GPU: the whole block chain in ONE persistent launch (k_tile MODE 4)
-    // (chain_ctl was reset by k_sort_binoff of this round's shuffle)
+    // (chain_ctl was reset by the launch that closed the previous round: k_round_tail / k_objective_tables.  The shuffle kernels must
+    //  not touch chain_ctl, pen_g or the Sold buffers: prefetch_next() runs them on the side stream while a chain may be in flight)
     D.chain_tag = (unsigned)(1 + (ctx->chain_rounds++ % (1u << 24)) * 64);
     long long* const keep_snew = D.Snew_fx;
     D.Snew_fx = D.Snew_set[0];     // one replica set: the folder resets it by exchange (zeroed by the round's memset)
@@ -1624,7 +1629,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); } }
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K));
-  { const char* e = getenv("HMX_MOE_SOLVE"); ctx->solve_on_device = !(e && std::string(e) == "host") && (size_t)(B + 1) * 16 * 8 + (size_t)(3 * B + 8 + C) * 4 <= 158 * 1024; }   // (LDS panel of the device Cholesky)
+  { const char* e = getenv("HMX_MOE_SOLVE"); ctx->solve_on_device = !(e && std::string(e) == "host") && (size_t)(B + 1) * 16 * 8 + (size_t)(4 * B + 8 + C) * 4 <= 158 * 1024; }   // (LDS panel of the device Cholesky)
   ctx->y_on_device = false; ctx->solve_pending = false;
   if (ctx->solve_on_device) {
     const size_t M = (size_t)B + 1;
@@ -1635,6 +1640,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     HIPCHK(hipMemsetAsync(ctx->sv_flags, 0, sizeof(int) * (size_t)K, ctx->L.stream));
     HIPCHK(hipMemsetAsync(ctx->sv_mrows, 0, sizeof(int) * (size_t)K, ctx->L.stream));
   }
+  CHK(dalloc(ctx, &D.solve_err, (size_t)1)); HIPCHK(hipMemsetAsync(D.solve_err, 0, sizeof(int), ctx->L.stream));
   CHK(dalloc(ctx, &D.S0, (size_t)K * d)); CHK(dalloc(ctx, &D.n0, (size_t)K)); CHK(dalloc(ctx, &D.qstart, (size_t)Q + 1)); CHK(dalloc(ctx, &D.sizes, (size_t)B));
   CHK(h2d(ctx, D.qstart, start.data(), (size_t)Q + 1)); CHK(h2d(ctx, D.sizes, ctx->sizes.data(), (size_t)B)); CHK(dalloc(ctx, &D.Wq, (size_t)Q * K * d)); CHK(dalloc(ctx, &D.Wimg, D.moe_mfma ? (size_t)Q * D.wNQ * D.wNS * 256 : 1));
   { // deterministic statistics pass (k_moe_stats_q): static split of the 16-cell tiles over ~2 workgroups per CU; one partial
@@ -1733,7 +1739,8 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     // step takes 21 us against 27.5 + 3 us of launch gap).  At 10M cells per GPU (15 tiles per wave) the per-step launches
     // stream just as well and were measured 6 % faster (142 vs 151 us per step): HMX_CHAIN=1 forces the chain there.
     const double tiles_per_wave = (double)N / std::max(D.nb, 1) / 16.0 / (8.0 * std::max(cus - 1, 1));
-    const bool chain_fits = (e && std::string(e) == "1") || tiles_per_wave <= 6.0;
+    double max_tpw = 6.0; if (const char* m = getenv("HMX_CHAIN_MAX_TPW")) max_tpw = atof(m);       // (tests: move the threshold between two shards)
+    const bool chain_fits = (e && std::string(e) == "1") || tiles_per_wave <= max_tpw;
     ctx->chain_ok = !(e && std::string(e) == "0") && chain_fits && ctx->fused_ok && cus >= 8 && D.NCT <= 7 && D.NT4 <= 4 && D.nb <= 64 &&
                     (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024;
     CHK(dalloc(ctx, &D.tail_ticket, (size_t)1)); HIPCHK(hipMemsetAsync(D.tail_ticket, 0, sizeof(int), ctx->L.stream));
@@ -1756,6 +1763,14 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     }
     { const char* uc = getenv("HMX_UPD_CONTIG");     // launch-per-step path: contiguous tile ranges once a wave has several tiles per block
       D.upd_contig = uc ? atoi(uc) : ((!ctx->chain_ok && tiles_per_wave >= 4.0) ? 1 : 0); }
+    if (ctx->world > 1 || ctx->comm_force) {
+      // The flags pick the inter-rank PROTOCOL of update_R (in-launch exchange of the persistent chain / one all-reduce per block
+      // step): every rank must take the same path, but chain_ok depends on the LOCAL cell count and CU count.  Agree on the minimum.
+      long long* dflag; long long hf[2] = {ctx->chain_ok ? 1 : 0, ctx->fused_ok ? 1 : 0};
+      CHK(dalloc(ctx, &dflag, (size_t)2));
+      CHK(h2d(ctx, dflag, hf, 2)); CHK(allreduce(ctx, dflag, 2, 2)); CHK(d2h(ctx, hf, dflag, 2));
+      ctx->chain_ok = hf[0] != 0; ctx->fused_ok = hf[1] != 0;
+    }
     ctx->chain_rounds = 0;
     D.p2p_world = 0; D.p2p_rank = ctx->p2p_rank;
     for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g]; }
@@ -1777,6 +1792,7 @@ int hmx_restart(hmx_ctx* ctx) {
   ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear(); ctx->rrng_seeded = false;
   ctx->y_on_device = false; ctx->solve_pending = false;
   ctx->obj_warm = ctx->rg_warm = false;            // (a run never depends on what the handle computed before it)
+  HIPCHK(hipMemsetAsync(ctx->D.solve_err, 0, sizeof(int), ctx->L.stream));
   if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
   for (int i = 0; i < 2; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
   return 0;
@@ -1824,7 +1840,9 @@ int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the cur
 int hmx_check_convergence(hmx_ctx* ctx, int32_t type) {
   if (!ctx) return -HMX_ERR_ARG;
   if (flush_objectives(ctx)) return -HMX_ERR_DEVICE;
-  { const int st = sync_solve_results(ctx); if (st) return -st; }   // a singular system of the last correction surfaces here
+  // (The results of the last device-side correction are NOT waited for here: the decision needs the objective only, and the
+  //  host is free to queue the next clustering call while the correction kernels still run.  A singular ridge system surfaces with
+  //  the next objective snapshot -- flush_objectives -- or, after the last correction, when a result is read: hmx_get / hmx_get_matrix.)
   if ((type == 0 && ctx->obj_kmeans.size() < (size_t)ctx->window_size + 1) || (type == 1 && ctx->obj_harmony.size() < 2)) {
     fail(ctx, HMX_ERR_STATE, "not enough objective values"); return -HMX_ERR_STATE;
   }
@@ -1879,7 +1897,7 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
     SolveArgs A;
     A.cov = ctx->sv_cov; A.rhs = ctx->sv_rhs; A.Wall = ctx->sv_Wall; A.mrows = ctx->sv_mrows; A.flags = ctx->sv_flags;
     A.lambda = ctx->lambda_estimation ? nullptr : ctx->sv_lambda; A.cov_bounds = ctx->sv_cov_bounds;
-    A.alpha = ctx->alpha; A.cutoff = ctx->cutoff; A.use_s0 = seq ? 1 : 0;
+    A.alpha = ctx->alpha; A.cutoff = ctx->cutoff; A.use_s0 = seq ? 1 : 0; A.err = ctx->D.solve_err;
     A.Of = ctx->oe_arith ? ctx->Of : nullptr; A.Ef = ctx->oe_arith ? ctx->Ef : nullptr; A.solve_f32 = ctx->solve_arith;
     { PhaseScope ph(ctx, "arma_inv"); l_moe_solve(ctx->L, D, A); KCHK(); }
     { PhaseScope ph(ctx, "update_Zcorr");
@@ -2020,6 +2038,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (!ctx || !field) return -1;
   const std::string f(field);
   if (f.rfind("objective_", 0) == 0 || f == "kmeans_rounds") { if (flush_objectives(ctx)) return -1; }
+  // (-1 with hmx_last_error = "singular ridge system": the deferred verdict of the last device-side correction, not an unknown field)
   if (f == "Y" || f == "W" || f == "W_rows" || f == "subset_clusters" || f == "skipped_clusters") { if (sync_solve_results(ctx)) return -1; }
   auto scalar = [&](double v) -> int64_t { if (out && cap >= 1) out[0] = v; return 1; };
   auto vec = [&](const auto& v) -> int64_t {
@@ -2135,6 +2154,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
     return vec(L);
   }
   if (f == "Z_corr" || f == "Z_orig" || f == "R") return hmx_get_matrix(ctx, field, out, HMX_F64, HMX_HOST, cap);
+  ctx->err = "hmx_get: unknown field '" + f + "'";
   return -1;
 }
 
@@ -2144,9 +2164,10 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
 int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype, int32_t location, int64_t cap) {
   if (!ctx || !field || !ctx->ran_setup) return -1;
   const std::string f(field);
-  if (f != "Z_corr" && f != "Z_orig" && f != "R") return -1;
+  if (f != "Z_corr" && f != "Z_orig" && f != "R") { ctx->err = "hmx_get_matrix: unknown field " + f; return -1; }
   if ((dtype != HMX_F64 && dtype != HMX_F32) || (location != HMX_HOST && location != HMX_DEVICE)) { ctx->err = "bad dtype / location"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  if (out && f == "Z_corr" && sync_solve_results(ctx)) return -1;      // a singular system of the last correction surfaces here (hmx_last_error says so)
   const int w = (f == "R") ? ctx->K : ctx->d;
   const int64_t cnt = ctx->N * w;
   if (!out || cap < cnt) return cnt;

@@ -74,6 +74,7 @@ struct Dev {
   int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
   long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int* tail_ticket;            // k_round_tail: workgroups done (the last one finishes the round's objective)
+  int* solve_err;              // set by k_moe_solve when a ridge system is singular; rides to the host with the next objective snapshot
   int nxt;                     // this shuffle keys the cells by (block, block of the NEXT round): nb * nb sort keys, lpair.y carries the next block
   int* bincnt;                 // [keys * Q] cells of a (key, combination) bin before padding
   int* blkv;                   // [n] composite sort key of a cell (nxt)
@@ -153,6 +154,7 @@ struct Dev {
 struct SolveArgs {
   double* cov; double* rhs;        // scratch: [K][M*M], [K][d*M]   (M = B + 1)
   float* Wall; int* mrows; int* flags;   // [K][d*M] W of every cluster (column-major m x d), its rows m, flags
+  int* err;                              // device word: |= 1 when a system is singular
   const float* lambda;             // [B+1] fixed lambda or nullptr (estimation: alpha * E)
   const int* cov_bounds;           // [C] cumulative level counts
   float alpha, cutoff; int use_s0;

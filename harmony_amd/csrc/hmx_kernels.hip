@@ -2294,7 +2294,7 @@ __global__ __launch_bounds__(TPB) void k_objective_tables(Dev D) {
   }
   if (threadIdx.x == 0) {
     D.obj[2] = D.obj[0]; D.obj[3] = D.obj[1]; D.obj[4] = red[0];
-    D.obj[5] = D.chain_ctl ? (double)D.chain_ctl[1] : 0.0;      // the chain's error word rides along with the objective snapshot
+    D.obj[5] = (D.chain_ctl ? (double)D.chain_ctl[1] : 0.0) + ((D.solve_err && *D.solve_err) ? 16.0 : 0.0);      // the chain's error word (+ 16: singular ridge system) rides along with the objective snapshot
   }
   // (this single-workgroup kernel closes every round: it also resets the chain's control block for the next one -- one memset
   //  launch less per round; the shuffle kernels cannot do it, they may run on the side stream while a chain is in flight)
@@ -2438,8 +2438,9 @@ __device__ __forceinline__ size_t yimg_index(const Dev& D, int j, int k) {
 // chain of kernels with no host synchronisation.  Per cluster k:
 //   kept levels (O[k,b] / N_b > cutoff and >= 2 such levels in the covariate, :368-402), lambda_k (fixed or alpha * E, :434-439),
 //   cov = Phi* diag(R_k) Phi*^T + Lambda and rhs = Phi* diag(R_k) Z^T assembled from the per-combination statistics
-//   (subset path = masks, :440-547), Cholesky (LU with partial pivoting if a pivot is not positive -- what arma::inv falls
-//   back to), W = cov^-1 rhs, Y[:,k] = W[0,:], W[0,:] = 0 (:610-611), correction table Wq[q][k][:] = sum of the kept
+//   (subset path = masks, :440-547), blocked Cholesky -- Phi* diag(R_k) Phi*^T + Lambda is symmetric positive definite whenever the
+//   reference's arma::inv succeeds; a non-positive pivot raises flag bit 2 (HMX_ERR_SOLVE at the next objective read or getter; the
+//   host solve path, HMX_MOE_SOLVE=host, retries with LU) --, W = cov^-1 rhs, Y[:,k] = W[0,:], W[0,:] = 0 (:610-611), correction table Wq[q][k][:] = sum of the kept
 //   levels' rows of combination q (+ its MFMA image), Y <- normalise (:633).
 // flags[k]: bit 0 subset path, bit 1 skipped (no covariate with two kept levels), bit 2 singular system.
 __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
@@ -2450,6 +2451,9 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
   int* keepl = sm_ + B;              // [B] kept levels in order
   int* okb = sm_ + 2 * B;            // [B]
   int* misc = sm_ + 3 * B;           // [0] m, [1] active, [2] full, [3] fail, [4..4+C) cov_levels
+  int* prow = sm_ + 3 * B + 4 + C;   // [B + 1] design row (reference order: intercept, kept levels ascending) -> row of the system as it is solved
+  const int PAN_OFF = (4 * B + 6 + C) & ~1;      // ints in front of the fp64 panel space
+  __shared__ int sch_nd;             // levels of the covariate whose (diagonal) block is eliminated first, 0: none
   double* cov = A.cov + (size_t)k * M * M;
   double* rhs = A.rhs + (size_t)k * d * M;
   for (int b = tid; b < B; b += nt) {
@@ -2467,6 +2471,20 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
     }
     int act = 0; for (int c = 0; c < C; c++) if (misc[4 + c] > 1) act++;
     misc[0] = nk + 1; misc[1] = act; misc[2] = (nk == B) ? 1 : 0; misc[3] = 0;
+    // Every covariate's own block of Phi* diag(R_k) Phi*^T + Lambda is DIAGONAL (a cell has one level per covariate).  The rows of
+    // the covariate with the most kept levels go LAST and are eliminated in closed form (Schur complement): the dense Cholesky
+    // shrinks from m to m - nd rows -- 201 -> 73 at configs[4]'s 8 > 64 > 128 levels, 1 + B -> 1 for a single covariate.
+    int cstar = -1, nd = 0;
+    for (int c = 0; c < C; c++) if (misc[4 + c] > 1 && misc[4 + c] > nd) { nd = misc[4 + c]; cstar = c; }
+    if (nd < 8 || A.solve_f32) { nd = 0; cstar = -1; }
+    sch_nd = nd;
+    prow[0] = 0;
+    int nx = 1, nl = nk + 1 - nd;
+    for (int a = 1; a <= nk; a++) {
+      const int b = keepl[a - 1];
+      int cv = 0; while (cv < C - 1 && !(b < A.cov_bounds[cv])) cv++;
+      prow[a] = (cv == cstar) ? nl++ : nx++;
+    }
   }
   __syncthreads();
   const int m = misc[0];
@@ -2479,7 +2497,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
     __syncthreads();
     for (int q = 0; q < Q; q++) {   // sequential over combinations (fixed order), parallel inside
       int rows[17]; int nr = 1; rows[0] = 0;
-      for (int c = 0; c < C; c++) { const int ro = row_of[D.qlev[q * C + c]]; if (ro >= 0) rows[nr++] = ro; }
+      for (int c = 0; c < C; c++) { const int ro = row_of[D.qlev[q * C + c]]; if (ro >= 0) rows[nr++] = prow[ro]; }
       if (nr > 1) {   // (none of its levels kept: the combination's cells do not enter, :400,456-460)
         const double n = D.nq[(size_t)q * K + k];
         for (int i = tid; i < nr * nr; i += nt) { const int a = i / nr, b2 = i - a * nr; cov[(size_t)rows[b2] * m + rows[a]] += n; }
@@ -2499,14 +2517,15 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
     for (int a = 1 + tid; a < m; a += nt) {
       const int b = keepl[a - 1];
       const float lam = A.lambda ? A.lambda[b + 1] : (A.Ef ? A.Ef[(size_t)b * K + k] : (float)(rsd * (double)D.Pr_b[b])) * A.alpha;
-      if (A.solve_f32) cov[(size_t)a * m + a] = (double)__fadd_rn((float)cov[(size_t)a * m + a], lam);     // an fp32 matrix in the reference
-      else cov[(size_t)a * m + a] += (double)lam;
+      const int pa = prow[a];
+      if (A.solve_f32) cov[(size_t)pa * m + pa] = (double)__fadd_rn((float)cov[(size_t)pa * m + pa], lam);     // an fp32 matrix in the reference
+      else cov[(size_t)pa * m + pa] += (double)lam;
     }
     __syncthreads();
     if (A.solve_f32 && C == 1) {
       // The reference's own inverse for one covariate (src/harmony.cpp:575-586): Phi_cov is an arrowhead matrix, inverted in closed
       // form in fp32, and W = inv_cov * (the right-hand sides) accumulates in fp32, column of inv_cov after column (:599-608).
-      float* const ac = reinterpret_cast<float*>(sm_ + ((3 * B + 4 + C + 1) & ~1));     // [m] each (the Cholesky's panel space)
+      float* const ac = reinterpret_cast<float*>(sm_ + PAN_OFF);     // [m] each (the Cholesky's panel space; solve_f32: no elimination, prow is the identity)
       float* const bb = ac + m; float* const acb = bb + m; float* const uu = acb + m;
       for (int a = tid; a < m; a += nt) {
         ac[a] = (a == 0) ? 1.0f : -(float)cov[(size_t)a * m];
@@ -2543,9 +2562,31 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
     // read-modify-write) instead of one rank-1 update per column -- at m = 201 (configs[4]: 200 levels) 13 passes over the
     // trailing matrix and ~40 workgroup barriers instead of 201 passes and 600 barriers (8.3 ms -> well under 1 ms per correction).
     constexpr int NBW = 16;
-    double* const P = reinterpret_cast<double*>(sm_ + ((3 * B + 4 + C + 1) & ~1));     // [rows of the panel][NBW], LDS
-    for (int c0 = 0; c0 < m && !misc[3]; c0 += NBW) {
-      const int nbw = min(NBW, m - c0), h = m - c0;
+    double* const P = reinterpret_cast<double*>(sm_ + PAN_OFF);     // [rows of the panel][NBW], LDS
+    const int nd = sch_nd, ms = m - nd;      // rows [ms, m): the diagonal block D; [0, ms): everything else
+    if (nd > 0) {
+      // S = A - B^T D^-1 B, rhs_A -= B^T D^-1 rhs_D   (cov = [[A, B^T], [B, D]], B = rows >= ms of the first ms columns)
+      for (int r = ms + tid; r < m; r += nt) { const double dv = cov[(size_t)r * m + r]; if (!(dv > 0.0)) misc[3] = 1; cov[(size_t)r * m + r] = 1.0 / dv; }
+      __syncthreads();
+      for (int i = tid; i < ms * ms; i += nt) {
+        const int cb = i / ms, ra = i - cb * ms;
+        if (ra < cb) continue;                      // the Cholesky reads the lower triangle only
+        const double* ca = cov + (size_t)ra * m; const double* cc = cov + (size_t)cb * m;
+        double sacc = 0.0;
+        for (int r = ms; r < m; r++) sacc += ca[r] * cov[(size_t)r * m + r] * cc[r];
+        cov[(size_t)cb * m + ra] -= sacc;
+      }
+      for (int i = tid; i < ms * d; i += nt) {
+        const int j = i / ms, ra = i - j * ms;
+        const double* ca = cov + (size_t)ra * m;
+        double sacc = 0.0;
+        for (int r = ms; r < m; r++) sacc += ca[r] * cov[(size_t)r * m + r] * rhs[(size_t)j * m + r];
+        rhs[(size_t)j * m + ra] -= sacc;
+      }
+      __syncthreads();
+    }
+    for (int c0 = 0; c0 < ms && !misc[3]; c0 += NBW) {
+      const int nbw = min(NBW, ms - c0), h = ms - c0;
       for (int i = tid; i < h * nbw; i += nt) { const int kk = i / h, r = i - kk * h; P[r * NBW + kk] = cov[(size_t)(c0 + kk) * m + c0 + r]; }
       __syncthreads();
       for (int kk = 0; kk < nbw; kk++) {
@@ -2566,12 +2607,12 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       for (int i = tid; i < h * nbw; i += nt) { const int kk = i / h, r = i - kk * h; if (r >= kk) cov[(size_t)(c0 + kk) * m + c0 + r] = P[r * NBW + kk]; }
       // trailing update: 32 consecutive rows per column and thread row (coalesced), the column's panel row cached in registers
       const int tx = tid & 31, ty = tid >> 5, TY = nt >> 5;
-      for (int c2 = c0 + nbw + ty; c2 < m; c2 += TY) {
+      for (int c2 = c0 + nbw + ty; c2 < ms; c2 += TY) {
         double pc[NBW];
 #pragma unroll
         for (int kk = 0; kk < NBW; kk++) pc[kk] = (kk < nbw) ? P[(c2 - c0) * NBW + kk] : 0.0;
         double* colp = cov + (size_t)c2 * m;
-        for (int r = c2 + tx; r < m; r += 32) {
+        for (int r = c2 + tx; r < ms; r += 32) {
           const double* pr = P + (r - c0) * NBW;
           double sacc = 0.0;
 #pragma unroll
@@ -2591,17 +2632,17 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       for (int j = tid >> 4; j < d; j += nt >> 4) {
         double* b = bl + (size_t)j * m;
         // L y = b, column by column: y_r = b_r / L_rr, then b_k -= L_kr y_r (k > r): L's column r is contiguous in k
-        for (int r = 0; r < m; r++) {
+        for (int r = 0; r < ms; r++) {
           const double* Lc = cov + (size_t)r * m;
           const double y = b[r] / Lc[r];
           if (ln == 0) b[r] = y;
-          for (int kk = r + 1 + ln; kk < m; kk += 16) b[kk] -= Lc[kk] * y;
+          for (int kk = r + 1 + ln; kk < ms; kk += 16) b[kk] -= Lc[kk] * y;
         }
         // L^T x = y, row by row from the bottom: x_r = (y_r - sum_{k>r} L_kr x_k) / L_rr
-        for (int r = m - 1; r >= 0; r--) {
+        for (int r = ms - 1; r >= 0; r--) {
           const double* Lc = cov + (size_t)r * m;
           double t = 0.0;
-          for (int kk = r + 1 + ln; kk < m; kk += 16) t += Lc[kk] * b[kk];
+          for (int kk = r + 1 + ln; kk < ms; kk += 16) t += Lc[kk] * b[kk];
           t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
           const double x = (b[r] - t) / Lc[r];
           if (ln == 0) b[r] = x;
@@ -2609,12 +2650,22 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       }
       __syncthreads();
       if (blds) { for (int i = tid; i < d * m; i += nt) rhs[i] = bl[i]; }
+      if (nd > 0) {      // x_D = D^-1 (rhs_D - B x_A): B's entries (rows >= ms of the first ms columns) were never touched
+        __syncthreads();
+        for (int i = tid; i < nd * d; i += nt) {
+          const int j = i / nd, r = ms + (i - j * nd);
+          double sacc = rhs[(size_t)j * m + r];
+          for (int a = 0; a < ms; a++) sacc -= cov[(size_t)a * m + r] * rhs[(size_t)j * m + a];
+          rhs[(size_t)j * m + r] = sacc * cov[(size_t)r * m + r];
+        }
+      }
     }
     }   // (fp64 Cholesky branch)
     __syncthreads();
   }
   if (tid == 0) {
     A.flags[k] = (full ? 0 : 1) | (skipped ? 2 : 0) | (misc[3] ? 4 : 0);
+    if (misc[3] && A.err) atomicOr(A.err, 1);
     A.mrows[k] = skipped ? 0 : m;
   }
   const bool solved = !skipped && !misc[3];
@@ -2627,7 +2678,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
   }
   __syncthreads();
   if (solved) {
-    for (int i = tid; i < m * d; i += nt) Wk[i] = (float)rhs[i];
+    for (int i = tid; i < m * d; i += nt) { const int j = i / m, a = i - j * m; Wk[i] = (float)rhs[(size_t)j * m + prow[a]]; }     // reference row order
     __syncthreads();
     for (int i = tid; i < Q * d; i += nt) {
       const int q = i / d, j = i - q * d;
@@ -3249,7 +3300,7 @@ void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uin
                    uint64_t cells_per_block) {
   const int nV = D.nxt ? D.nb * D.nb : D.nb;
   const size_t lds = (size_t)nV * sizeof(int);
-  // (padding slots = -1: written by k_sort_binoff, bin by bin)
+  // (padding slots = -1: written by k_sort_scatter, bin by bin)
   BlockIdArgs A;
   A.fk = make_keys(seed, round, Nglob); A.fk2 = make_keys(seed, round + 1, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
   if (fused) hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
@@ -3370,7 +3421,8 @@ __global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__
     }
     D.obj[0] = sa; D.obj[1] = sb;
     D.obj[2] = sa; D.obj[3] = sb; D.obj[4] = ra[0];
-    const double err = D.chain_ctl ? (double)D.chain_ctl[1] : 0.0;
+    // error word of the snapshot: the chain's code (< 16) + 16 if a ridge system of the correction before this round was singular
+    const double err = (D.chain_ctl ? (double)D.chain_ctl[1] : 0.0) + ((D.solve_err && *D.solve_err) ? 16.0 : 0.0);
     D.obj[5] = err;
     if (host_slot) {     // pinned host memory, mapped into the device: visible to the host once the event behind this launch completed
       __hip_atomic_store(&host_slot[0], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3520,7 +3572,7 @@ void l_moe_apply(const Launch& L, const Dev& D) {
 void l_moe_solve(const Launch& L, const Dev& D, const SolveArgs& A0) {
   SolveArgs A = A0;
   const size_t M = (size_t)D.B + 1;
-  const size_t ints = (((size_t)3 * D.B + 4 + D.C + 1) & ~(size_t)1) * sizeof(int);
+  const size_t ints = (((size_t)4 * D.B + 6 + D.C) & ~(size_t)1) * sizeof(int);
   const size_t panel = M * 16 * sizeof(double), ball = M * D.d * sizeof(double);
   size_t body = panel;
   if (ints + ball <= 150 * 1024) body = std::max(panel, ball);     // the d right-hand sides live in LDS during the substitution

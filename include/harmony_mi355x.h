@@ -96,7 +96,10 @@ int hmx_kmeans_centers(hmx_ctx* ctx, double* Y_out);
 
 /* ---- harmony::cluster_cpp (src/harmony.cpp:208-262): 0 ok, -1 aborted, >0 error */
 int hmx_cluster(hmx_ctx* ctx);
-/* ---- harmony::moe_correct_ridge_cpp (src/harmony.cpp:345-638) */
+/* ---- harmony::moe_correct_ridge_cpp (src/harmony.cpp:345-638).  The whole correction is queued on the device and NOT waited for:
+ * an error of its ridge solves (HMX_ERR_SOLVE: singular system) is DEFERRED -- it is returned by the next call that reads a result
+ * of that correction (hmx_cluster's objective read, hmx_check_convergence of the following iteration, hmx_get / hmx_get_matrix,
+ * which then return -1 with hmx_last_error = "singular ridge system ..."). */
 int hmx_moe_correct_ridge(hmx_ctx* ctx);
 /* ---- harmony::check_convergence (src/harmony.cpp:173-205): returns 1/0, or <0 on error */
 int hmx_check_convergence(hmx_ctx* ctx, int32_t type);

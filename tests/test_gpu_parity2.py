@@ -375,6 +375,20 @@ def test_two_processes_sharded_run():
     assert "DIST2_OK world=2" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
 
 
+def test_two_processes_unequal_shards_agree_on_the_protocol():
+    """Shards of 90 % / 10 % of the cells with the chain threshold moved between them (HMX_CHAIN_MAX_TPW): left alone, the small rank
+    would run the persistent chain with the in-launch exchange while the large one waits in a per-block all-reduce -- a deadlock.
+    hmx_setup agrees on the minimum over the ranks: both take the per-block path, the run matches the unsharded one."""
+    import subprocess
+    import sys
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dist_two_proc.py"), "--p2p", "--split", "0.9",
+                        "--chain-max-tpw", "0.02"], capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
+    assert "DIST2_OK world=2" in p.stdout and "chain=0" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
 def test_two_processes_peer_to_peer_chain():
     """The same two-process run with the per-block all-reduce replaced by the in-launch exchange of the persistent chain: each
     rank's folder writes its K x B contribution table into the other's inbox (fine-grained device memory shared through HIP IPC)

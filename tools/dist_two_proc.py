@@ -22,9 +22,13 @@ ap.add_argument("--cells", type=int, default=30000)
 ap.add_argument("--p2p", action="store_true", help="sum the block contributions inside the persistent chain over the peers' inboxes "
                 "(hmx_p2p_*; the handles travel through torch.distributed) instead of one all-reduce per block")
 ap.add_argument("--carry", action="store_true", help="force the round-to-round carry of the old contributions (HMX_SOLD_CARRY=1)")
+ap.add_argument("--split", type=float, default=0.0, help="two ranks: rank 0 holds this fraction of the cells (unequal shards)")
+ap.add_argument("--chain-max-tpw", default=None, help="HMX_CHAIN_MAX_TPW: tiles per wave up to which a rank would pick the persistent chain")
 a = ap.parse_args()
 if a.carry:
     os.environ["HMX_SOLD_CARRY"] = "1"
+if a.chain_max_tpw:
+    os.environ["HMX_CHAIN_MAX_TPW"] = a.chain_max_tpw
 if a.p2p and a.backend == "gloo":
     os.environ["HMX_CHAIN_WGS"] = "120"     # both ranks share ONE GPU here: two persistent chains must fit its 256 CUs together
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -39,7 +43,11 @@ from harmony_amd.dist import TorchAllReduce, shard_bounds  # noqa: E402
 
 N, K, B = a.cells, 100, 10
 Z, meta, _ = synth(N, d=50, levels=(B,), seed=21)          # every rank generates the global problem, keeps its shard
-lo, hi = shard_bounds(N, world)[rank]
+bounds = shard_bounds(N, world)
+if a.split > 0 and world == 2:
+    cut = int(N * a.split)
+    bounds = [(0, cut), (cut, N)]
+lo, hi = bounds[rank]
 N_b = np.bincount(meta["cov0"], minlength=B).astype(float)
 skw, _ = prepare_setup_args(Z[lo:hi], {"cov0": meta["cov0"][lo:hi]}, "cov0", nclust=K, N_b=N_b, levels={"cov0": np.arange(B)})
 
@@ -74,11 +82,11 @@ dist.barrier(); t_run = time.perf_counter()
 it = run(g)
 g.getZcorr(); dist.barrier(); t_run = time.perf_counter() - t_run
 Zs = torch.from_numpy(np.ascontiguousarray(g.getZcorr().T))          # [n_local, d]
-parts = [torch.empty((h - l, Zs.shape[1]), dtype=Zs.dtype) for l, h in shard_bounds(N, world)] if rank == 0 else None
+parts = [torch.empty((h - l, Zs.shape[1]), dtype=Zs.dtype) for l, h in bounds] if rank == 0 else None
 if a.backend == "gloo":
     dist.gather(Zs, parts, dst=0)
 else:
-    gl = [torch.empty((h - l, Zs.shape[1]), dtype=Zs.dtype, device=dev) for l, h in shard_bounds(N, world)]
+    gl = [torch.empty((h - l, Zs.shape[1]), dtype=Zs.dtype, device=dev) for l, h in bounds]
     dist.all_gather(gl, Zs.to(dev))
     parts = [p.cpu() for p in gl]
 O_sh, obj_sh = g.O, g.objective_kmeans
@@ -95,9 +103,9 @@ if rank == 0:
     np.testing.assert_allclose(obj_sh, one.objective_kmeans, rtol=1e-6)
     rel = np.linalg.norm(Zall - one.getZcorr()) / np.linalg.norm(one.getZcorr())
     assert rel < 1e-6, rel
-    if a.p2p:
+    if a.p2p and not a.chain_max_tpw:
         assert g._scalar("p2p") == 1 and g._scalar("chain") == 1, (g.p2p_status, g._scalar("chain"))
-    print("DIST2_OK world=%d backend=%s p2p=%d iterations=%d collectives/rank=%d Z_rel=%.1e run=%.1f ms (%s)"
-          % (world, a.backend, int(a.p2p), it, hook.calls, rel, 1e3 * t_run, g.p2p_status), flush=True)
+    print("DIST2_OK world=%d backend=%s p2p=%d chain=%d iterations=%d collectives/rank=%d Z_rel=%.1e run=%.1f ms (%s)"
+          % (world, a.backend, int(a.p2p), int(g._scalar("chain")), it, hook.calls, rel, 1e3 * t_run, g.p2p_status), flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Timeline of one bench step from a rocprofv3 --kernel-trace CSV: per kernel name the busy time, and the idle gaps between
+consecutive kernels (all streams merged) attributed to the kernel that FOLLOWS the gap.  Usage: trace_gaps.py t_kernel_trace.csv"""
+import csv
+import sys
+from collections import defaultdict
+
+rows = []
+with open(sys.argv[1]) as fh:
+    for r in csv.DictReader(fh):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60]))
+rows.sort()
+# the LAST run = everything after the last restart kernel (k_normalize4 with src != dst is the first kernel of hmx_restart)
+starts = [i for i, r in enumerate(rows) if "k_normalize4" in r[2]]
+if len(starts) >= 2:
+    rows = rows[starts[-2]:starts[-1]] if len(starts) >= 3 else rows[starts[-1]:]
+t0, t1 = rows[0][0], max(r[1] for r in rows)
+busy = defaultdict(float); cnt = defaultdict(int); gap = defaultdict(float)
+cover_end = rows[0][0]
+union = 0.0
+for s, e, n in rows:
+    busy[n] += (e - s) / 1e3; cnt[n] += 1
+    if s > cover_end:
+        gap[n] += (s - cover_end) / 1e3
+        cover_end_new = e
+    union += max(0, e - max(s, cover_end)) / 1e3
+    cover_end = max(cover_end, e)
+print("window %.3f ms, kernels busy (union over streams) %.3f ms, idle %.3f ms, %d launches" % ((t1 - t0) / 1e6, union / 1e3, ((t1 - t0) / 1e3 - union) / 1e3, len(rows)))
+print("%-62s %6s %10s %10s" % ("kernel", "calls", "busy us", "idle-before us"))
+for n in sorted(busy, key=lambda k: -(busy[k] + gap[k])):
+    print("%-62s %6d %10.1f %10.1f" % (n, cnt[n], busy[n], gap[n]))
