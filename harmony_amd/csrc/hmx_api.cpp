@@ -1743,6 +1743,15 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     const bool chain_fits = (e && std::string(e) == "1") || tiles_per_wave <= max_tpw;
     ctx->chain_ok = !(e && std::string(e) == "0") && chain_fits && ctx->fused_ok && cus >= 8 && D.NCT <= 7 && D.NT4 <= 4 && D.nb <= 64 &&
                     (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 <= 150 * 1024;
+    if (ctx->world > 1 || ctx->comm_force) {
+      // The flags pick the inter-rank PROTOCOL of update_R (in-launch exchange of the persistent chain / one all-reduce per block
+      // step): every rank must take the same path, but chain_ok depends on the LOCAL cell count and CU count.  Agree on the minimum
+      // -- before anything is derived from the flags (the replica count below sizes a per-block all-reduce).
+      long long* dflag; long long hf[2] = {ctx->chain_ok ? 1 : 0, ctx->fused_ok ? 1 : 0};
+      CHK(dalloc(ctx, &dflag, (size_t)2));
+      CHK(h2d(ctx, dflag, hf, 2)); CHK(allreduce(ctx, dflag, 2, 2)); CHK(d2h(ctx, hf, dflag, 2));
+      ctx->chain_ok = hf[0] != 0; ctx->fused_ok = hf[1] != 0;
+    }
     CHK(dalloc(ctx, &D.tail_ticket, (size_t)1)); HIPCHK(hipMemsetAsync(D.tail_ticket, 0, sizeof(int), ctx->L.stream));
     CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)48));
     CHK(dalloc(ctx, &D.Sold_rep, (size_t)D.nrep * D.nb * B * K));
@@ -1763,14 +1772,6 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     }
     { const char* uc = getenv("HMX_UPD_CONTIG");     // launch-per-step path: contiguous tile ranges once a wave has several tiles per block
       D.upd_contig = uc ? atoi(uc) : ((!ctx->chain_ok && tiles_per_wave >= 4.0) ? 1 : 0); }
-    if (ctx->world > 1 || ctx->comm_force) {
-      // The flags pick the inter-rank PROTOCOL of update_R (in-launch exchange of the persistent chain / one all-reduce per block
-      // step): every rank must take the same path, but chain_ok depends on the LOCAL cell count and CU count.  Agree on the minimum.
-      long long* dflag; long long hf[2] = {ctx->chain_ok ? 1 : 0, ctx->fused_ok ? 1 : 0};
-      CHK(dalloc(ctx, &dflag, (size_t)2));
-      CHK(h2d(ctx, dflag, hf, 2)); CHK(allreduce(ctx, dflag, 2, 2)); CHK(d2h(ctx, hf, dflag, 2));
-      ctx->chain_ok = hf[0] != 0; ctx->fused_ok = hf[1] != 0;
-    }
     ctx->chain_rounds = 0;
     D.p2p_world = 0; D.p2p_rank = ctx->p2p_rank;
     for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g]; }

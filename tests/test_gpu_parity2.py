@@ -307,6 +307,98 @@ def test_update_order_must_be_a_permutation(cell_lines_small):
     g.push_update_order(np.arange(300)[::-1].copy())
 
 
+def _run_pair_to_convergence(Z, meta, K, seed, gpu_kw, masks, max_iter=10, blas_threads=4):
+    """one GPU handle and one oracle per arithmetic mask on the same problem (shared k-means centres, shared documented shuffles), each to
+    convergence; the oracles run in threads next to the GPU.  Returns {name: dict(Z, R, it, obj, rounds, subset)}."""
+    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
+    res, timing = {}, {}
+    g0 = Harmony(seed=seed)
+    g0.setup(**skw)
+    Y0 = g0.kmeans_centers()
+    del g0
+
+    def drive(name, o):
+        t0 = time.time()
+        o.init_cluster_cpp(Y0)
+        subset, it = [], 0
+        for it in range(1, max_iter + 1):
+            assert o.cluster_cpp() == 0
+            o.moe_correct_ridge_cpp()
+            subset.append(int(o._scalar("subset_clusters")) if hasattr(o, "_scalar") else int(o.subset_clusters))
+            if o.check_convergence(1):
+                break
+        timing[name] = time.time() - t0
+        res[name] = dict(Z=o.getZcorr(), R=o.R, it=it, obj=np.array(o.objective_kmeans), rounds=np.array(o.kmeans_rounds), subset=subset)
+
+    def cpu(name, mask):
+        o = OracleHarmony(mask=mask, seed=seed)
+        o.setup(**skw)
+        drive(name, o)
+
+    orc.use_openblas(blas_threads)
+    th = [threading.Thread(target=cpu, args=(nm, mk)) for nm, mk in masks.items()]
+    [t.start() for t in th]
+    for nm, kw in gpu_kw.items():
+        o = Harmony(seed=seed, **kw)
+        o.setup(**skw)
+        drive(nm, o)
+        del o
+    [t.join() for t in th]
+    return res, timing
+
+
+def _pair_row(ra, rb):
+    n = min(len(ra["obj"]), len(rb["obj"]))
+    f, f5 = _flips(ra["R"], rb["R"], 1e-5)
+    return {"Z_rel": relfro(ra["Z"], rb["Z"]), "R_maxabs": float(np.abs(ra["R"] - rb["R"]).max()), "argmax_diff": f, "argmax_diff_margin_ge_1e-5": f5,
+            "iterations": [int(ra["it"]), int(rb["it"])], "objective_rel_max": float(np.max(np.abs(ra["obj"][:n] - rb["obj"][:n]) / np.abs(rb["obj"][:n]))),
+            "subset_clusters_per_iteration": [ra["subset"], rb["subset"]], "kmeans_rounds_equal": bool(np.array_equal(ra["rounds"], rb["rounds"]))}
+
+
+# ---------------------------------------------------------------- VERDICT r2 item 2: configs[4] shape at 1M cells TO CONVERGENCE against the oracle
+@pytest.mark.timeout(1500, method="thread")
+def test_config5_shape_1M_to_convergence():
+    """BASELINE configs[4]'s shape at 1M cells: K = 200, three nested covariates 8 > 64 > 128 = 200 levels, reference defaults, to convergence
+    (7 harmony iterations): GPU (default arithmetic) against the oracle with exact accumulators AND against the faithful oracle (fp32
+    accumulators, arma::inv as fp32 LU, src/harmony.cpp:572-574), the batch-subset ridge path counted per iteration (:440-547).
+    Table -> gpurun_out/r3_parity_c5_1M.json (profiles/)."""
+    Z, meta, _ = synth(1_000_000, d=50, levels=(8, 64, 128), seed=11, nested=True)
+    res, timing = _run_pair_to_convergence(Z, meta, 200, 5, {"gpu": {}}, {"oracle_accurate": 15, "oracle_faithful": 0})
+    rows = {"gpu_vs_oracle_accurate": _pair_row(res["gpu"], res["oracle_accurate"]), "gpu_vs_oracle_faithful": _pair_row(res["gpu"], res["oracle_faithful"]),
+            "oracle_faithful_vs_oracle_accurate": _pair_row(res["oracle_faithful"], res["oracle_accurate"])}
+    out = {"workload": {"cells": 1000000, "pcs": 50, "clusters": 200, "levels": [8, 64, 128], "nested": True}, "seconds": timing, "pairs": rows}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "r3_parity_c5_1M.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+    ga = rows["gpu_vs_oracle_accurate"]
+    assert ga["Z_rel"] <= 2e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1] and ga["kmeans_rounds_equal"], ga
+    assert ga["objective_rel_max"] <= 1e-4, ga
+    assert ga["subset_clusters_per_iteration"][0] == ga["subset_clusters_per_iteration"][1] and max(ga["subset_clusters_per_iteration"][0]) > 0, ga
+    gf = rows["gpu_vs_oracle_faithful"]      # reported: the reference's fp32 drift at this shape (multi-covariate reference arithmetic is not reproduced)
+    assert gf["iterations"][0] == gf["iterations"][1], gf
+
+
+@pytest.mark.timeout(3000, method="thread")
+@pytest.mark.skipif(os.environ.get("HMX_SLOW", "0") != "1", reason="builder run (HMX_SLOW=1): ~15 minutes of CPU for the oracle at 10M cells; table in profiles/")
+def test_config4_10M_against_the_oracle():
+    """BASELINE configs[3] at FULL size on one GPU -- 10M x 50, K = 100, 20 batches, to convergence: GPU default vs the oracle with exact
+    accumulators, and GPU reference arithmetic vs the faithful oracle.  Table -> gpurun_out/r3_parity_c4_10M.json (profiles/)."""
+    Z, meta, _ = synth(10_000_000, d=50, levels=(20,), seed=7)
+    res, timing = _run_pair_to_convergence(Z, meta, 100, 3, {"gpu": {}, "gpu_ref_arith": {"ref_arith": 1}}, {"oracle_accurate": 15, "oracle_faithful": 0},
+                                           blas_threads=8)
+    rows = {"gpu_vs_oracle_accurate": _pair_row(res["gpu"], res["oracle_accurate"]), "gpu_ref_arith_vs_oracle_faithful": _pair_row(res["gpu_ref_arith"], res["oracle_faithful"]),
+            "gpu_vs_oracle_faithful": _pair_row(res["gpu"], res["oracle_faithful"]), "oracle_faithful_vs_oracle_accurate": _pair_row(res["oracle_faithful"], res["oracle_accurate"])}
+    out = {"workload": {"cells": 10000000, "pcs": 50, "clusters": 100, "batches": 20}, "seconds": timing, "pairs": rows}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "r3_parity_c4_10M.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+    ga, rf = rows["gpu_vs_oracle_accurate"], rows["gpu_ref_arith_vs_oracle_faithful"]
+    assert ga["Z_rel"] <= 2e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1], ga
+    assert rf["Z_rel"] <= 1e-4 and rf["iterations"][0] == rf["iterations"][1], rf
+
+
 # ---------------------------------------------------------------- VERDICT r1 item 5: the sharded path through two PROCESSES
 @pytest.mark.timeout(600, method="thread")
 @pytest.mark.parametrize("cfg", ["C4", "C5"])
