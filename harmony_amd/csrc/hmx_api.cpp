@@ -87,6 +87,7 @@ RcclApi* rccl_api(std::string* err) {
 struct ChainGate { std::mutex mu; std::map<int, hipEvent_t> last; };
 ChainGate& chain_gate() { static ChainGate g; return g; }
 
+bool host_pin_enabled() { const char* e = getenv("HMX_PIN"); return !(e && atoi(e) == 0); }
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -139,6 +140,10 @@ struct hmx_ctx {
   // -= / += drift, :149-150,312-313,329-330); obj_arith: my_accu's K*N-term sequential fp32 sums (src/utils.cpp:67-75);
   // solve_arith: the closed-form fp32 arrowhead inverse (:575-586).  "ref_arith" sets all four.
   int ridge_arith = 0, oe_arith = 0, obj_arith = 0, solve_arith = 0;
+  // "stale_dist" = 1: a stand-alone compute_objective between a correction and the next cluster_cpp evaluates the k-means term on the
+  // distances of the LAST head (the reference's stored dist_mat, src/harmony.cpp:160, which moe_correct_ridge_cpp does not refresh):
+  // the correction keeps a snapshot of the normalised Z_corr and of Y it is about to overwrite
+  int stale_dist = 0; float* Zc_head = nullptr; float* Yt_head = nullptr; bool head_is_stale = false;
   // restarted sequential sums (hmx_seq.hip): plans (segments + chains on the device), shared workspace, cell lists
   struct SeqPlan { SeqSeg* d_segs = nullptr; SeqChain* d_chains = nullptr; size_t cap_segs = 0, cap_chains = 0; int nsegs = 0, nchains = 0;
                    std::vector<int> seg0;   /* [nchains + 1] first segment of every chain */ };
@@ -391,6 +396,7 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   }
   (void)sharded_;
   Dev D = ctx->D;
+  ctx->head_is_stale = false;      // (dist_mat is recomputed here)
   const bool tiles = D.tile_impl && (size_t)D.NQ * D.NS * 1024 <= 160 * 1024;
   // the register-pipelined head (two accumulator sets, rows of a tile in registers) normalises the rows it has loaded anyway
   const bool fused_norm = normalise && tiles && D.NT4 <= 4 && D.NCT <= 7 && D.upd_wps != 4 && !getenv("HMX_HEAD_NORM_SPLIT");
@@ -1403,6 +1409,7 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
     if (f == "obj_arith" || f == "ref_arith") ctx->obj_arith = (int)v;
     if (f == "solve_arith" || f == "ref_arith") ctx->solve_arith = (int)v;
   }
+  else if (f == "stale_dist") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "stale_dist must be set before setup"); ctx->stale_dist = v != 0; }
   else if (f == "seq_passes") { if (v < 2 || v > 16) return fail(ctx, HMX_ERR_ARG, "seq_passes: 2..16"); ctx->seq_passes = (int)v; }
   else if (f == "device") ctx->device = (int)v;
   else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->prof_update_steps = 0; ctx->ev_used = 0;
@@ -1701,6 +1708,11 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
       const int64_t slab = std::max<int64_t>(1, (int64_t)(128ll << 20) / ((int64_t)esz * d));
       const int64_t scnt = std::min<int64_t>(slab, N);
       void* stage[2] = {nullptr, nullptr}; hipStream_t cs = nullptr; hipEvent_t copied[2] = {nullptr, nullptr}, used[2] = {nullptr, nullptr};
+      // The caller's matrix is pageable (R's heap): page-lock it for the duration of the ingest, so that the slab copies are real DMA
+      // at PCIe speed instead of the runtime's staged pageable path (HMX_PIN=0 leaves it pageable; a failed registration is not an error).
+      const bool pinned = host_pin_enabled() && hipHostRegister(const_cast<void*>(Z), (size_t)N * d * esz, hipHostRegisterDefault) == hipSuccess;
+      if (!pinned) (void)hipGetLastError();
+      ctx->timers["ingest_pinned"] = pinned ? 1.0 : 0.0;
       hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
       for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipMalloc(&stage[i], (size_t)scnt * d * esz);
@@ -1721,6 +1733,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
       for (int i = 0; i < 2; i++) { if (stage[i]) (void)hipFree(stage[i]); if (copied[i]) (void)hipEventDestroy(copied[i]); if (used[i]) (void)hipEventDestroy(used[i]); }
       if (cs) (void)hipStreamDestroy(cs);
+      if (pinned) (void)hipHostUnregister(const_cast<void*>(Z));
       if (e != hipSuccess) return fail(ctx, HMX_ERR_DEVICE, hipGetErrorString(e));
     }
     ctx->timers["ingest_Z"] = now_ms() - t_in;
@@ -1776,6 +1789,8 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     D.p2p_world = 0; D.p2p_rank = ctx->p2p_rank;
     for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g]; }
   ctx->invperm_h = invperm; ctx->combo_h = combo_sorted;
+  ctx->Zc_head = nullptr; ctx->Yt_head = nullptr; ctx->head_is_stale = false;
+  if (ctx->stale_dist) { CHK(dalloc(ctx, &ctx->Zc_head, (size_t)N * D.zs)); CHK(dalloc(ctx, &ctx->Yt_head, (size_t)d * K)); }
   CHK(seq_setup_static(ctx));
   ctx->ran_setup = true;
   return hmx_restart(ctx);
@@ -1793,6 +1808,7 @@ int hmx_restart(hmx_ctx* ctx) {
   ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear(); ctx->rrng_seeded = false;
   ctx->y_on_device = false; ctx->solve_pending = false;
   ctx->obj_warm = ctx->rg_warm = false;            // (a run never depends on what the handle computed before it)
+  ctx->head_is_stale = false;
   HIPCHK(hipMemsetAsync(ctx->D.solve_err, 0, sizeof(int), ctx->L.stream));
   if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
   for (int i = 0; i < 2; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
@@ -1830,7 +1846,8 @@ int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the cur
   if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemsetAsync(ctx->D.objpart, 0, sizeof(double) * 2 * (size_t)ctx->D.objslots * ctx->D.nwmax, ctx->L.stream));
-  l_head(ctx->L, ctx->D, 1); KCHK();
+  if (ctx->stale_dist && ctx->head_is_stale) { Dev Ds = ctx->D; Ds.Zc = ctx->Zc_head; Ds.Yt = ctx->Yt_head; l_head(ctx->L, Ds, 1); KCHK(); }   // the reference's stored dist_mat
+  else { l_head(ctx->L, ctx->D, 1); KCHK(); }
   l_obj_reduce(ctx->L, ctx->D); KCHK();
   CHK(allreduce(ctx, ctx->D.obj, 2, 1));
   CHK(objective_snapshot(ctx));
@@ -1884,6 +1901,11 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   const Dev& D = ctx->D;
   const int K = ctx->K, B = ctx->B, d = ctx->d, Q = ctx->Q;
   const bool seq = ctx->ridge_arith == 1;
+  if (ctx->stale_dist && !ctx->head_is_stale) {      // what dist_mat was computed from (:141 / :221): kept for a stand-alone compute_objective
+    l_copy(ctx->L, D.Zc, ctx->Zc_head, (size_t)ctx->N * D.zs); KCHK();
+    l_copy(ctx->L, D.Yt, ctx->Yt_head, (size_t)d * K); KCHK();
+    ctx->head_is_stale = true;
+  }
   { PhaseScope pall(ctx, "correct_ridge_loop");
   { PhaseScope ph(ctx, "ridge_statistics");   // reference timers Phi_Rk + Phi_cov + Z_tmp + Z_intercept + batch_exprod: ONE pass here
     HIPCHK(hipMemsetAsync(D.Sq, 0, sizeof(double) * (size_t)Q * d * K, ctx->L.stream));
@@ -2186,6 +2208,8 @@ int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype
     const int64_t slab = std::max<int64_t>(1, (int64_t)(128ll << 20) / ((int64_t)esz * w));
     const int64_t scnt = std::min<int64_t>(slab, ctx->N);
     void* stage[2] = {nullptr, nullptr}; hipStream_t cs = nullptr; hipEvent_t conv[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    const bool pinned = host_pin_enabled() && hipHostRegister(out, (size_t)cnt * esz, hipHostRegisterDefault) == hipSuccess;     // (see hmx_setup_ex)
+    if (!pinned) (void)hipGetLastError();
     e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
       e = hipMalloc(&stage[i], (size_t)scnt * w * esz);
@@ -2207,6 +2231,7 @@ int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
     for (int i = 0; i < 2; i++) { if (stage[i]) (void)hipFree(stage[i]); if (conv[i]) (void)hipEventDestroy(conv[i]); if (copied[i]) (void)hipEventDestroy(copied[i]); }
     if (cs) (void)hipStreamDestroy(cs);
+    if (pinned) (void)hipHostUnregister(out);
   }
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
   ctx->timers["egress_" + f] = now_ms() - t0;

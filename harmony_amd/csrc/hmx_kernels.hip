@@ -3413,12 +3413,13 @@ __global__ __launch_bounds__(1024) void k_round_tail(Dev D, double* __restrict__
     if (tid < off) ra[tid] += ra[tid + off];
     __syncthreads();
   }
+  // the slot rows' sums: fetched by 2 x objslots threads at once (objslots <= 64), added in slot order by one -- the 40 device-scope
+  // loads used to be ONE thread's dependent chain, ~20 us of every round
+  if (tid < 2 * D.objslots) rb[tid] = __hip_atomic_load(&D.objrow[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   if (tid == 0) {
     double sa = 0.0, sb = 0.0;
-    for (int sl = 0; sl < D.objslots; sl++) {
-      sa += __hip_atomic_load(&D.objrow[2 * sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sb += __hip_atomic_load(&D.objrow[2 * sl + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int sl = 0; sl < D.objslots; sl++) { sa += rb[2 * sl]; sb += rb[2 * sl + 1]; }
     D.obj[0] = sa; D.obj[1] = sb;
     D.obj[2] = sa; D.obj[3] = sb; D.obj[4] = ra[0];
     // error word of the snapshot: the chain's code (< 16) + 16 if a ridge system of the correction before this round was singular

@@ -31,7 +31,7 @@ class Harmony(object):
     """new(harmony)  (R/ui.R:269)."""
 
     def __init__(self, device=None, seed=None, rng=None, ridge_arith=None, oe_arith=None, obj_arith=None, solve_arith=None,
-                 ref_arith=None):
+                 ref_arith=None, stale_dist=None):
         """rng: None/0 = the library's documented counter-based generator; 1 / "R" = R-compatible stream (MT19937 seeded like
         set.seed(seed), RcppArmadillo's randu / shuffle draw order).  ref_arith = 1: every accumulator group follows the reference's
         fp32 operation order (ridge statistics, O / E tables, objective sums, closed-form inverse; the groups can also be switched
@@ -49,7 +49,7 @@ class Harmony(object):
         if rng:
             self._set("rng", 1)
         for name, v in (("ref_arith", ref_arith), ("ridge_arith", ridge_arith), ("oe_arith", oe_arith), ("obj_arith", obj_arith),
-                        ("solve_arith", solve_arith)):
+                        ("solve_arith", solve_arith), ("stale_dist", stale_dist)):
             if v:
                 self._set(name, int(v))
 

@@ -108,7 +108,9 @@ int hmx_check_convergence(hmx_ctx* ctx, int32_t type);
  * moe_correct_ridge_cpp does not refresh; this library keeps no K x N distance matrix and recomputes the distances from
  * the current Z_corr and Y.  Inside the reference's own call sequence (init_cluster_cpp / cluster_cpp, where dist_mat is
  * current) the values agree; a stand-alone call made between a correction and the next cluster_cpp sees the corrected,
- * un-normalised Z_corr and the new Y instead of the stale distances. */
+ * un-normalised Z_corr and the new Y instead of the stale distances -- unless hmx_set_int(ctx, "stale_dist", 1) was set before
+ * hmx_setup: every correction then keeps a snapshot of the normalised Z_corr and of Y it overwrites (N x d floats more), and such a
+ * call reproduces the reference's value. */
 int hmx_compute_objective(hmx_ctx* ctx);
 
 /* ---- fields and getters (src/harmony.cpp:675-707, 640-669).
@@ -126,7 +128,8 @@ int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype
 /* writable fields: "max_iter_kmeans" (vignettes/detailedWalkthrough.Rmd:364), "seed",
  * "device" (before setup), "profile" (HIP-event timing of the update kernel, see below),
  * "rng" (0 counter-based generator | 1 R-compatible stream, see "randomness"),
- * "ridge_arith" / "oe_arith" / "obj_arith" / "solve_arith" / "ref_arith" (see "reference arithmetic" below), "seq_passes".
+ * "ridge_arith" / "oe_arith" / "obj_arith" / "solve_arith" / "ref_arith" (see "reference arithmetic" below), "seq_passes",
+ * "stale_dist" (before setup; see hmx_compute_objective).
  * Tuning / fallback selectors (tests and measurements; the defaults are the measured best):
  *   fields "grid", "upd_wps" (before setup), "upd_tpw", "upd_cpw", "upd_impl", "comm_force";
  *   environment, read by hmx_setup: HMX_GRID, HMX_NREP, HMX_UPD_WPS (2|4), HMX_USIG=0 (general-sigma kernels),

@@ -123,6 +123,31 @@ def test_synthetic_shapes(N, d, K, levels, nested):
         assert c.subset_clusters > 0 and int(g._scalar("subset_clusters")) == c.subset_clusters
 
 
+def test_single_cluster(cell_lines_small):
+    """nclust = 1 (R/ui.R:192-194 allows it): R == 1 everywhere, one ridge system"""
+    g, c, ig, ic = run_both(cell_lines_small["pcs"], _meta(cell_lines_small), "dataset", max_iter=3, nclust=1, seed=2)
+    assert_parity(g, c, ig, ic)
+    assert np.allclose(g.R, 1.0)
+
+
+def test_stand_alone_compute_objective_after_a_correction(cell_lines):
+    """harmony::compute_objective called between moe_correct_ridge_cpp and the next cluster_cpp reads the reference's STORED dist_mat
+    (src/harmony.cpp:160): with "stale_dist" the library reproduces that value; without, it documents a deviation (recomputed distances)"""
+    skw, _ = prepare_setup_args(cell_lines["pcs"], _meta(cell_lines), "dataset", nclust=20)
+    Y0 = np.asfortranarray(cell_lines["pcs"][:20].T)
+    vals = {}
+    for name, obj in (("stale", Harmony(seed=1, stale_dist=1)), ("fresh", Harmony(seed=1)), ("oracle", OracleHarmony(accurate=True, seed=1))):
+        obj.setup(**skw)
+        obj.init_cluster_cpp(Y0)
+        assert obj.cluster_cpp() == 0
+        obj.moe_correct_ridge_cpp()
+        obj.compute_objective()
+        vals[name] = np.array(obj.objective_kmeans)
+    assert len(vals["stale"]) == len(vals["oracle"])
+    np.testing.assert_allclose(vals["stale"], vals["oracle"], rtol=1e-5)
+    assert abs(vals["fresh"][-1] - vals["oracle"][-1]) > 1e-3 * abs(vals["oracle"][-1])      # (the documented deviation is real)
+
+
 def test_tiny_N_block_size_warning():
     rng = np.random.default_rng(1)
     Z = rng.normal(size=(30, 8)); meta = {"b": np.arange(30) % 2}

@@ -519,3 +519,36 @@ def test_torch_free_c_host_with_builtin_rccl(tmp_path):
     r = subprocess.run([exe, "0", "1", str(tmp_path / "uid")], capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
     assert r.returncode == 0 and "COMM_EXAMPLE_OK rank 0/1" in r.stdout, (r.stdout, r.stderr[-2000:])
     assert int(r.stdout.split("collectives")[1].split()[0]) > 100
+
+
+def test_torch_free_two_ranks_on_two_gpus(tmp_path):
+    """examples/comm_example.c with world 2: two torch-free processes, one GPU each, hmx_comm_init alone bootstraps the RCCL communicator
+    (unique id through a file) AND the peer inboxes of the block chain; the checksum of O must equal the one-rank run's.  Needs two
+    GPUs in the box (RCCL refuses two ranks on one device): skipped on the single-GPU boxes this repository is developed on."""
+    import shutil
+    import subprocess
+    try:
+        import torch
+        ndev = torch.cuda.device_count()
+    except Exception:
+        ndev = 0
+    if ndev < 2:
+        pytest.skip("needs two GPUs")
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc on this box")
+    exe = str(tmp_path / "comm_example")
+    libdir = os.path.join(ROOT, "harmony_amd", "lib")
+    p = subprocess.run([gcc, "-std=c11", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "comm_example.c"),
+                        "-L" + libdir, "-lharmony_mi355x", "-Wl,-rpath," + libdir, "-lm", "-o", exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    one = subprocess.run([exe, "0", "1", str(tmp_path / "uid1")], capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
+    assert "COMM_EXAMPLE_OK" in one.stdout, (one.stdout, one.stderr[-2000:])
+    procs = [subprocess.Popen([exe, str(r), "2", str(tmp_path / "uid2")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, stdin=subprocess.DEVNULL)
+             for r in range(2)]
+    outs = [pr.communicate(timeout=400) for pr in procs]
+    chk = lambda txt: [w for w in txt.split("COMM_EXAMPLE_OK")[1].split() if w][txt.split("COMM_EXAMPLE_OK")[1].split().index("O-checksum") + 1]
+    for (so, se) in outs:
+        assert "COMM_EXAMPLE_OK" in so, (so, se[-2000:])
+        assert chk(so) == chk(one.stdout), (so, one.stdout)
+
