@@ -905,6 +905,7 @@ int update_R(hmx_ctx* ctx) {
     } }
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
+  bool chain_tail = false;   // the persistent chain closed the round by itself
   const bool fused = merged && ctx->fused_ok;
   if (chain_path) {
     // default on one GPU: the whole block chain in ONE persistent launch (k_tile MODE 4)
@@ -918,6 +919,16 @@ int update_R(hmx_ctx* ctx) {
       HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
     }
     const int keep_old = D.chain_old; D.chain_old = chain_old ? 1 : 0;
+    // one GPU: the chain's folder also closes the round (objective snapshot, table clears, control reset): no k_round_tail launch
+    chain_tail = !sharded && !ctx->obj_arith && D.chain_wps == 2 && !getenv("HMX_CHAIN_TAIL_OFF");
+    D.chain_tail = chain_tail ? 1 : 0;
+    if (chain_tail) {
+      double* slot = nullptr;
+      CHK(objective_slot(ctx, &slot));
+      const size_t nBKs = (size_t)D.B * D.K;
+      D.tail_host_slot = slot; D.tail_z0 = chain_old ? nullptr : D.Sold_fx; D.tail_n0 = chain_old ? 0 : (unsigned long long)D.nb * nBKs;
+      D.tail_z1 = D.Snew_set[0]; D.tail_n1 = 3ull * (unsigned long long)D.nrep * nBKs;
+    }
     {
       ChainGate& gate = chain_gate();
       std::lock_guard<std::mutex> lk(gate.mu);
@@ -927,7 +938,7 @@ int update_R(hmx_ctx* ctx) {
       l_chain(ctx->L, D, ctx->chain_wgs); KCHK();
       HIPCHK(hipEventRecord(ev, ctx->L.stream));
     }
-    D.chain_old = keep_old;
+    D.chain_old = keep_old; D.chain_tail = 0;
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps += D.nb; }
     D.Snew_fx = keep_snew;
     ctx->chain_check = true;
@@ -983,7 +994,12 @@ int update_R(hmx_ctx* ctx) {
     l_update(ctx->L, D, j); KCHK();
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
   }
-  if (!sharded && !ctx->obj_arith) {
+  if (chain_tail) {
+    if (!chain_old) ctx->sold_state[ctx->sold_cur] = 0;
+    ctx->sets_clean = true;
+    HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
+    ctx->obj_pending++;
+  } else if (!sharded && !ctx->obj_arith) {
     // one launch: slot rows -> objective terms -> snapshot written STRAIGHT into the pinned host slot (no copy engine, no
     // second launch), chain control reset.  Resolved by flush_objectives (event) when a value is needed.
     double* slot = nullptr;

@@ -74,6 +74,9 @@ struct Dev {
   int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
   long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int* tail_ticket;            // k_round_tail: workgroups done (the last one finishes the round's objective)
+  // round tail inside the persistent chain (one GPU): the folder closes the round itself -- objective snapshot into the pinned host
+  // slot, consumed tables cleared, control words reset -- instead of a k_round_tail launch behind every chain launch
+  int chain_tail; double* tail_host_slot; long long* tail_z0; unsigned long long tail_n0; long long* tail_z1; unsigned long long tail_n1;
   int* solve_err;              // set by k_moe_solve when a ridge system is singular; rides to the host with the next objective snapshot
   int nxt;                     // this shuffle keys the cells by (block, block of the NEXT round): nb * nb sort keys, lpair.y carries the next block
   int* bincnt;                 // [keys * Q] cells of a (key, combination) bin before padding

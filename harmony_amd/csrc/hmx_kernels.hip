@@ -1847,6 +1847,65 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         { const unsigned long long t = wall_clock64(); tp += t - t_prev; t_prev = t; }
       }
       if (tid == 0 && D.chain_dbg) { atomicAdd(&D.chain_dbg[0], tw); atomicAdd(&D.chain_dbg[1], tf); atomicAdd(&D.chain_dbg[2], tp); atomicAdd(&D.chain_dbg[3], 1ull); }
+      if (D.chain_tail) {
+        // ---- the round's tail, by the folder (compute_objective, src/harmony.cpp:158-170): the workers' per-wave objective sums, the
+        // cross-entropy term from the O / E tables this workgroup holds in LDS anyway, the snapshot straight into the pinned host slot;
+        // then the tables this round consumed are cleared and the control words reset.  (k_round_tail does the same after the
+        // launch-per-step paths; here it would be one more launch + ~60 us of gap behind every round.)
+        if (tid == 0) {
+          int spins = 0;
+          const int* arr = &ctl[16 + 8 * nbk];
+          auto arrived = [&]() { int t = 0; for (int x = 0; x < 8; x++) t += __hip_atomic_load(&arr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return t; };
+          while (arrived() < nworkWG) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 6); break; }
+            if (dead(spins)) break;
+          }
+        }
+        __syncthreads();
+        double* const red = reinterpret_cast<double*>(lds4) + 256;      // [3][bd] (the centroid image's space: the folder never stages it)
+        const int nwv = nworkWG * (bd >> 6);
+        double pa = 0.0, pb = 0.0;
+        for (int w2 = tid; w2 < nwv; w2 += bd) {       // fixed order per thread, fixed tree below: deterministic
+          pa += __hip_atomic_load(&D.objpart[2 * w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pb += __hip_atomic_load(&D.objpart[2 * w2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&D.objpart[2 * w2], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&D.objpart[2 * w2 + 1], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double cr = 0.0;
+        for (int k = tid; k < K; k += bd) {              // (same arithmetic as k_objective_tables)
+          const double rsd = (double)ldsRS[k] * FX_INV;
+          double ck = 0.0;
+          for (int bb = 0; bb < D.B; bb++) {
+            const double od = (double)ldsO[bb * K + k] * FX_INV;
+            const float o = (float)od, e = (float)(rsd * (double)D.Pr_b[bb]);
+            const float m = D.theta[bb] * logf((o + e + 1.0f) / ((2.0f * e) + 1.0f));
+            ck += od * (double)m;
+          }
+          cr += ck * (double)D.sigma[k];
+        }
+        red[tid] = pa; red[bd + tid] = pb; red[2 * bd + tid] = cr;
+        __syncthreads();
+        for (int off = bd >> 1; off > 0; off >>= 1) {
+          if (tid < off) { red[tid] += red[tid + off]; red[bd + tid] += red[bd + tid + off]; red[2 * bd + tid] += red[2 * bd + tid + off]; }
+          __syncthreads();
+        }
+        if (tid == 0) {
+          const double sa = red[0], sb = red[bd], sc = red[2 * bd];
+          const double err = (double)__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((D.solve_err && *D.solve_err) ? 16.0 : 0.0);
+          D.obj[0] = sa; D.obj[1] = sb; D.obj[2] = sa; D.obj[3] = sb; D.obj[4] = sc; D.obj[5] = err;
+          if (D.tail_host_slot) {     // pinned host memory, mapped into the device: visible to the host once the event behind this launch completed
+            __hip_atomic_store(&D.tail_host_slot[0], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&D.tail_host_slot[1], sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&D.tail_host_slot[2], sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&D.tail_host_slot[3], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        for (unsigned long long i = tid; i < D.tail_n0; i += bd) D.tail_z0[i] = 0;
+        for (unsigned long long i = tid; i < D.tail_n1; i += bd) D.tail_z1[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < 8 * nbk + 24; i += bd) ctl[i] = 0;
+      }
       return;
     }
     // ---------------- the workers
@@ -2117,7 +2176,16 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       lap(wm);
     }
     od = wsumd(od); oe = wsumd(oe);
-    if (lane == 0) {                        // slot row 0 (the other rows stay zero: k_round_tail sums and clears all of them)
+    if (D.chain_tail) {                     // the folder closes the round: the wave's sums go out write-through, then the workgroup arrives once more
+      if (lane == 0) {
+        double* slot = D.objpart + (size_t)wave * 2;
+        __hip_atomic_store(&slot[0], od, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slot[1], oe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) atomicAdd(&ctl[16 + 8 * nbk + ((int)blockIdx.x & 7)], 1);
+    } else if (lane == 0) {                 // slot row 0 (the other rows stay zero: k_round_tail sums and clears all of them)
       double* slot = D.objpart + (size_t)wave * 2;
       slot[0] += od; slot[1] += oe;
     }

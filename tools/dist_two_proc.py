@@ -83,7 +83,11 @@ it = run(g)
 g.getZcorr(); dist.barrier(); t_run = time.perf_counter() - t_run
 Zs = torch.from_numpy(np.ascontiguousarray(g.getZcorr().T))          # [n_local, d]
 parts = [torch.empty((h - l, Zs.shape[1]), dtype=Zs.dtype) for l, h in bounds] if rank == 0 else None
-if a.backend == "gloo":
+if a.backend == "gloo" and a.split > 0:
+    objs = [None] * world if rank == 0 else None          # (gloo's gather wants equal shapes)
+    dist.gather_object(Zs, objs, dst=0)
+    parts = objs
+elif a.backend == "gloo":
     dist.gather(Zs, parts, dst=0)
 else:
     gl = [torch.empty((h - l, Zs.shape[1]), dtype=Zs.dtype, device=dev) for l, h in bounds]

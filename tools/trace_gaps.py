@@ -29,3 +29,13 @@ print("window %.3f ms, kernels busy (union over streams) %.3f ms, idle %.3f ms, 
 print("%-62s %6s %10s %10s" % ("kernel", "calls", "busy us", "idle-before us"))
 for n in sorted(busy, key=lambda k: -(busy[k] + gap[k])):
     print("%-62s %6d %10.1f %10.1f" % (n, cnt[n], busy[n], gap[n]))
+
+# the sequence of one clustering round in the middle of the run: from the end of a chain launch to the end of the next
+ch = [i for i, r in enumerate(rows) if "k_tile<7, 4" in r[2] or ", 4, 2" in r[2]]
+if len(ch) > 12:
+    a, b = ch[9], ch[10]
+    print("\none round, chain launch #9 (end) -> chain launch #10 (end); times in us relative to the end of #9")
+    base = rows[a][1]
+    for s_, e_, n_ in rows[a + 1:b + 1]:
+        print("  %-58s start %8.1f  end %8.1f  (%.1f us)" % (n_, (s_ - base) / 1e3, (e_ - base) / 1e3, (e_ - s_) / 1e3))
+
