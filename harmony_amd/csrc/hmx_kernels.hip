@@ -1863,10 +1863,10 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           }
         }
         __syncthreads();
-        double* const red = reinterpret_cast<double*>(lds4) + 256;      // [3][bd] (the centroid image's space: the folder never stages it)
+        double* const red = reinterpret_cast<double*>(lds4) + ((K + 1) & ~1);      // [waves][3], behind the cluster masses (the centroid image's space: the folder never stages it)
         const int nwv = nworkWG * (bd >> 6);
         double pa = 0.0, pb = 0.0;
-        for (int w2 = tid; w2 < nwv; w2 += bd) {       // fixed order per thread, fixed tree below: deterministic
+        for (int w2 = tid; w2 < nwv; w2 += bd) {       // fixed order per thread, fixed order of the reduction below: deterministic
           pa += __hip_atomic_load(&D.objpart[2 * w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           pb += __hip_atomic_load(&D.objpart[2 * w2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&D.objpart[2 * w2], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1884,14 +1884,13 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           }
           cr += ck * (double)D.sigma[k];
         }
-        red[tid] = pa; red[bd + tid] = pb; red[2 * bd + tid] = cr;
+        pa = wsumd(pa); pb = wsumd(pb); cr = wsumd(cr);
+        __syncthreads();                                  // (every wave is done reading the masses next to `red`)
+        if (lane == 0) { red[3 * (tid >> 6)] = pa; red[3 * (tid >> 6) + 1] = pb; red[3 * (tid >> 6) + 2] = cr; }
         __syncthreads();
-        for (int off = bd >> 1; off > 0; off >>= 1) {
-          if (tid < off) { red[tid] += red[tid + off]; red[bd + tid] += red[bd + tid + off]; red[2 * bd + tid] += red[2 * bd + tid + off]; }
-          __syncthreads();
-        }
         if (tid == 0) {
-          const double sa = red[0], sb = red[bd], sc = red[2 * bd];
+          double sa = 0.0, sb = 0.0, sc = 0.0;
+          for (int w2 = 0; w2 < (bd >> 6); w2++) { sa += red[3 * w2]; sb += red[3 * w2 + 1]; sc += red[3 * w2 + 2]; }
           const double err = (double)__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((D.solve_err && *D.solve_err) ? 16.0 : 0.0);
           D.obj[0] = sa; D.obj[1] = sb; D.obj[2] = sa; D.obj[3] = sb; D.obj[4] = sc; D.obj[5] = err;
           if (D.tail_host_slot) {     // pinned host memory, mapped into the device: visible to the host once the event behind this launch completed
