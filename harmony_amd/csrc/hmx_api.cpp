@@ -1433,7 +1433,8 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "grid") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "grid must be set before setup"); ctx->L.grid = (int)v; }
   else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
   else if (f == "comm_force") ctx->comm_force = v != 0;
-  else if (f == "upd_impl") { ctx->tun_impl = (int)v; if (ctx->ran_setup) ctx->D.upd_impl = (int)v; }
+  else if (f == "upd_impl") { ctx->tun_impl = (int)v; if (ctx->ran_setup) { ctx->D.upd_impl = (int)v;
+                                if (v == 1 && !ctx->D.need_lorder) { ctx->D.need_lorder = 1; for (int i = 0; i < 2; i++) ctx->sorted_round[i] = -1; } } }   // (the v1 kernel reads lorder: re-sort with it)
   else if (f == "upd_wps") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "upd_wps must be set before setup"); ctx->tun_wps = (int)v; }
   else if (f == "upd_debug") { if (ctx->ran_setup) ctx->D.upd_debug = (int)v; }
   else if (f == "upd_tpw") { ctx->tun_tpw = (int)v; if (ctx->ran_setup) ctx->D.upd_tpw = (int)(v < 1 ? 1 : v); }
@@ -1598,6 +1599,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   // per SIMD the K > 64 kernels get) re-stages the centroid image once instead of four times: head 213 -> 200 us at 1M
   { const char* e = getenv("HMX_STATIC_MAXBLOCKS"); D.static_maxblocks = e ? atoi(e) : (D.NCT >= 5 ? 512 : D.NCT >= 3 ? 768 : 1024); }
   { const char* e = getenv("HMX_OLDSUM_IMPL"); D.oldsum_stream = (e && std::string(e) == "gather") ? 0 : (e && std::string(e) == "stream1") ? 2 : 1; }   // 1: 16-byte stream, 2: dword stream
+  D.need_lorder = (D.upd_impl == 1 || D.oldsum_stream == 0 || (size_t)D.nb * K * 8 > 64 * 1024 || getenv("HMX_NEED_LORDER")) ? 1 : 0;
   { const char* e = getenv("HMX_UPD_TPW"); D.upd_tpw = ctx->tun_tpw > 0 ? ctx->tun_tpw : (e ? atoi(e) : 1); if (D.upd_tpw < 1) D.upd_tpw = 1; }
   { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = ctx->tun_cpw > 0 ? ctx->tun_cpw : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
   std::vector<Item> schunks; std::vector<int> qchunk((size_t)Q + 1, 0);

@@ -82,6 +82,7 @@ struct Dev {
   int* bincnt;                 // [keys * Q] cells of a (key, combination) bin before padding
   int* blkv;                   // [n] composite sort key of a cell (nxt)
   long long* Sold_next;        // [nb][B][K] old contributions of the NEXT round's blocks, filled by this round's tile kernels (or nullptr)
+  int need_lorder;             // the first-generation kernels (k_update, k_oldsum's gather variant) read lorder / lcombo; the tile kernels read lpair only
   int upd_contig;              // k_tile MODE 0: a wave owns a contiguous range of the block's tiles (run-length flush) instead of every nw-th
   int qmask;                   // mask of the combination in a tile's combination word: 0x7FFFF if shuffles may be keyed by blocks, else 0x7FFFFFFF
   int head_gather;             // k_tile MODE 1 runs over the padded order of the upcoming round (lpair) instead of the static tiles

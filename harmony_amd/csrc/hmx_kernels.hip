@@ -330,7 +330,16 @@ __global__ __launch_bounds__(TPB) void k_head(Dev D) {
 // D.nxt (own shuffle only): the sort key of a cell is (block of this round, block of the NEXT round) -- nV = nb * nb keys --, so that
 // every 16-cell tile also has ONE next block and the tile kernels can file the tile's new R sums as that block's old contribution
 // (flush_tile_fx): 16 padding slots per (block, combination, next block) instead of per (block, combination).
-struct BlockIdArgs { FeistelKeys fk, fk2; uint64_t Nglob, goff, cpb; };
+struct BlockIdArgs { FeistelKeys fk, fk2; uint64_t Nglob, goff, cpb; float inv_cpb; };
+// block of a position: min(pos / cells_per_block, n_blocks - 1) (src/harmony.cpp:296-300) without the 64-bit division (~100 instructions
+// per cell, twice per cell and round): a float estimate, corrected exactly by two integer comparisons
+__device__ __forceinline__ int block_of(uint64_t pos, const BlockIdArgs& A, int nb) {
+  long long b = (long long)((float)pos * A.inv_cpb);
+  if (b > nb) b = nb;                                        // (keeps the products below in range)
+  if ((uint64_t)b * A.cpb > pos) b--;
+  else if ((uint64_t)(b + 1) * A.cpb <= pos) b++;
+  return (int)(b < (long long)(nb - 1) ? b : (long long)(nb - 1));
+}
 template <bool FUSED>
 __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
   extern __shared__ int cnt[];
@@ -352,13 +361,11 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
     if (i < e) {
       if constexpr (FUSED) {
         const uint64_t pos = feistel_apply(A.fk, A.Nglob, A.goff + (uint64_t)pm[u]);
-        const uint64_t bb = pos / A.cpb;
-        b = (int)(bb < (uint64_t)(nb - 1) ? bb : (uint64_t)(nb - 1));
+        b = block_of(pos, A, nb);
         D.blk[i] = b;
         if (D.nxt) {
           const uint64_t pos2 = feistel_apply(A.fk2, A.Nglob, A.goff + (uint64_t)pm[u]);
-          const uint64_t b2 = pos2 / A.cpb;
-          b = b * nb + (int)(b2 < (uint64_t)(nb - 1) ? b2 : (uint64_t)(nb - 1));
+          b = b * nb + block_of(pos2, A, nb);
           D.blkv[i] = b;
         }
       } else b = D.blk[i];
@@ -411,22 +418,8 @@ __global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
   __syncthreads();
   for (int v = t; v <= nb; v += 1024) D.boff[v] = bins[v < nb ? v * vpb * Q : nbins];
 }
-// ascending bitonic sort of one int per lane across the wave (21 compare-exchange stages, no LDS)
-__device__ __forceinline__ int wave_sort64(int v, const int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const int o = __shfl_xor(v, j, 64);
-      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-      v = keep_min ? min(v, o) : max(v, o);
-    }
-  }
-  return v;
-}
-// Stable placement of a chunk's cells into their (key, combination) bins, 64 cells per step.  The rank of a cell among the cells
-// of the SAME key in its step comes from sorting (key, lane) across the wave: equal keys end up adjacent, in lane order -- a fixed
-// ~130 instructions per step, where a ballot per DISTINCT key costs up to 64 rounds with nb * nb keys (D.nxt).
+// Placement of a chunk's cells into their (key, combination) bins, 64 cells per step; the chunk's first slot in every bin comes from
+// k_sort_binscan / k_sort_binoff, the rank inside the chunk from an LDS atomic (see below).
 __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   extern __shared__ int base_[];
   const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb, nV = D.nxt ? nb * nb : nb;
@@ -452,25 +445,17 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   for (int u = 0; u < NSTEP; u++) {
     const int base = s + u * WAVE;
     if (base >= e) break;
-    const int b = kk[u];
-    const int sv = wave_sort64((b << 6) | lane, lane);
-    const int ks = sv >> 6, src = sv & 63;
-    const bool valid = ks < nV;
-    const int prev = __shfl_up(ks, 1, 64);
-    const bool head = lane == 0 || ks != prev;
-    const unsigned long long H = __ballot(head);
-    const int start = 63 - __clzll((long long)(H & (~0ull >> (63 - lane))));
-    const unsigned long long T = (lane == 63) ? 0ull : (H & ~((2ull << lane) - 1ull));
-    const int end = T ? (__ffsll((long long)T) - 1) : 64;
-    const int off = valid ? base_[ks] : 0;       // every lane of a group reads the group's base ...
-    __syncthreads();
-    if (valid) {
-      const int dst = off + (lane - start), cell = base + src;
-      D.lorder[dst] = cell; D.lcombo[dst] = ch.q;
+    // rank of a cell among the chunk's cells of the same key = the value its LDS atomic returns: the 64 lanes of one ds_add_rtn are
+    // served one after the other, the chunk's steps run in order on this one wave -- every cell gets a distinct slot of its bin, and
+    // which slot is irrelevant (a bin only has to be PURE: same block, combination and next block).  (The first version ranked the
+    // cells with a 21-stage bitonic sort of (key, lane) per step to keep the sort stable: 44 us per round, all of it on the critical
+    // path between two chain launches.)
+    const int ks = kk[u];
+    if (base + lane < e) {
+      const int dst = atomicAdd(&base_[ks], 1), cell = base + lane;
+      if (D.need_lorder) { D.lorder[dst] = cell; D.lcombo[dst] = ch.q; }
       D.lpair[dst] = make_int2(cell, D.nxt ? (ch.q | ((ks % nb) << 19) | ((ks / nb) << 25)) : ch.q);     // (combination, next block, block): see flush_run in k_tile
-      if (head) base_[ks] = off + (end - start);   // ... and its first lane advances it (distinct keys: no conflicts)
     }
-    __syncthreads();
   }
   // the padding slots (< 16 per bin) of this combination's bins: "no cell" -- written here, so that no memset of the whole order
   // precedes every shuffle
@@ -478,7 +463,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   const int ci = chunk - D.qchunk[ch.q], ncq = D.qchunk[ch.q + 1] - D.qchunk[ch.q];
   for (int v = ci + ncq * lane; v < nV; v += ncq * WAVE) {
     const int bin = v * D.Q + ch.q, st = D.binoff[bin], cnt = D.bincnt[bin], pad = (cnt + 15) & ~15;
-    for (int k = cnt; k < pad; k++) { D.lorder[st + k] = -1; D.lpair[st + k] = make_int2(-1, -1); }
+    for (int k = cnt; k < pad; k++) { if (D.need_lorder) D.lorder[st + k] = -1; D.lpair[st + k] = make_int2(-1, -1); }
   }
 }
 
@@ -3370,6 +3355,7 @@ void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uin
   // (padding slots = -1: written by k_sort_scatter, bin by bin)
   BlockIdArgs A;
   A.fk = make_keys(seed, round, Nglob); A.fk2 = make_keys(seed, round + 1, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
+  A.inv_cpb = 1.0f / (float)cells_per_block;
   if (fused) hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
   else hipLaunchKernelGGL(k_sort_hist<false>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
   hipLaunchKernelGGL(k_sort_binscan, dim3(nV * D.Q), dim3(WAVE), 0, L.stream, D);
