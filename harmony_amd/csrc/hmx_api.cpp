@@ -146,11 +146,13 @@ struct hmx_ctx {
   int stale_dist = 0; float* Zc_head = nullptr; float* Yt_head = nullptr; bool head_is_stale = false;
   // restarted sequential sums (hmx_seq.hip): plans (segments + chains on the device), shared workspace, cell lists
   struct SeqPlan { SeqSeg* d_segs = nullptr; SeqChain* d_chains = nullptr; size_t cap_segs = 0, cap_chains = 0; int nsegs = 0, nchains = 0;
-                   std::vector<int> seg0;   /* [nchains + 1] first segment of every chain */ };
+                   std::vector<int> seg0;   /* [nchains + 1] first segment of every chain */ int seg_cells = 0; };
   SeqPlan plan_head, plan_ridge, plan_round;
   float* sq_start = nullptr; float* sq_end = nullptr; size_t sq_cap = 0;
   float* sq_total = nullptr; size_t sq_total_cap = 0;
   unsigned* sq_mismatch = nullptr; int seq_passes = 3; int64_t seq_runs = 0;
+  // long chains (>= seq_adaptive_cells cells) are iterated until the starts stop moving (chain-relative residual <= 2^-22) or seq_max_passes
+  unsigned* sq_conv = nullptr; int seq_max_passes = 24; int64_t seq_adaptive_cells = 200000, seq_extra_passes = 0; double seq_resid_max = 0.0; uint64_t seq_mismatch_sum = 0;
   int* headlist = nullptr;                 // [(1 + C) n] cells in original order | cells by (level of covariate c, original order)
   std::vector<int> lev_off, lev_cnt;       // [B] a level's range inside its covariate's part of headlist
   int* roundlist = nullptr;                // [(1 + C) n] this round's cells in shuffled order | by (block, level of covariate c), shuffled order
@@ -233,7 +235,7 @@ void free_all(hmx_ctx* ctx) {
                   ctx->inset, ctx->obj_start, ctx->rg_start, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
                   ctx->plan_round.d_segs, ctx->plan_round.d_chains};
     for (void* q : ps) if (q) (void)hipFree(q);
-    ctx->sq_start = ctx->sq_end = ctx->sq_total = nullptr; ctx->sq_mismatch = nullptr; ctx->headlist = ctx->roundlist = nullptr;
+    ctx->sq_start = ctx->sq_end = ctx->sq_total = nullptr; ctx->sq_mismatch = nullptr; ctx->sq_conv = nullptr; ctx->headlist = ctx->roundlist = nullptr;
     ctx->Of = ctx->Ef = ctx->Mtab = ctx->objT = nullptr; ctx->inset = nullptr; ctx->sq_cap = ctx->sq_total_cap = ctx->objT_cap = 0;
     ctx->obj_start = ctx->rg_start = nullptr; ctx->obj_start_cap = ctx->rg_start_cap = 0; ctx->obj_warm = ctx->rg_warm = false;
     ctx->plan_head = hmx_ctx::SeqPlan(); ctx->plan_ridge = hmx_ctx::SeqPlan(); ctx->plan_round = hmx_ctx::SeqPlan();
@@ -678,7 +680,7 @@ int seq_plan_build(hmx_ctx* ctx, hmx_ctx::SeqPlan& P, const std::vector<std::pai
     ch[c].nseg = (int)segs.size() - ch[c].seg0;
   }
   P.seg0[chains.size()] = (int)segs.size();
-  P.nsegs = (int)segs.size(); P.nchains = (int)chains.size();
+  P.nsegs = (int)segs.size(); P.nchains = (int)chains.size(); P.seg_cells = L;
   CHK(seq_grow(ctx, P.d_segs, P.cap_segs, segs.size())); CHK(seq_grow(ctx, P.d_chains, P.cap_chains, ch.size()));
   CHK(h2d(ctx, P.d_segs, segs.data(), segs.size())); CHK(h2d(ctx, P.d_chains, ch.data(), ch.size()));
   return 0;
@@ -686,7 +688,40 @@ int seq_plan_build(hmx_ctx* ctx, hmx_ctx::SeqPlan& P, const std::vector<std::pai
 int seq_workspace(hmx_ctx* ctx, size_t seg_floats, size_t total_floats) {
   if (seg_floats > ctx->sq_cap) { size_t c1 = ctx->sq_cap, c2 = ctx->sq_cap; CHK(seq_grow(ctx, ctx->sq_start, c1, seg_floats)); CHK(seq_grow(ctx, ctx->sq_end, c2, seg_floats)); ctx->sq_cap = seg_floats; }
   CHK(seq_grow(ctx, ctx->sq_total, ctx->sq_total_cap, total_floats));
-  if (!ctx->sq_mismatch) { size_t c = 0; CHK(seq_grow(ctx, ctx->sq_mismatch, c, 2)); HIPCHK(hipMemsetAsync(ctx->sq_mismatch, 0, 2 * sizeof(unsigned), ctx->L.stream)); }
+  if (!ctx->sq_mismatch) { size_t c = 0; CHK(seq_grow(ctx, ctx->sq_mismatch, c, 4)); HIPCHK(hipMemsetAsync(ctx->sq_mismatch, 0, 4 * sizeof(unsigned), ctx->L.stream)); ctx->sq_conv = ctx->sq_mismatch + 2; }
+  return 0;
+}
+// after a checked scan (the scan wrote {segments that moved, largest chain-relative move} into sq_conv): did the starts settle?
+int seq_settled(hmx_ctx* ctx, bool* settled) {
+  unsigned w[2] = {0, 0};
+  CHK(d2h(ctx, w, ctx->sq_conv, 2));
+  float r; std::memcpy(&r, &w[1], 4);
+  *settled = w[0] == 0 || r <= 2.4e-7f;
+  ctx->seq_mismatch_sum += w[0]; if ((double)r > ctx->seq_resid_max) ctx->seq_resid_max = (double)r;
+  return 0;
+}
+// one restarted-sum iteration scheme for all users: `pass(p, zero_start)` runs the segments, `scan(p, zero_start, conv)` the scan.  The first
+// `seq_passes` passes always run (warm: one less); long chains continue until the starts settled.
+template <class PASS, class SCAN> int seq_iterate(hmx_ctx* ctx, bool warm, bool adaptive, PASS pass, SCAN scan) {
+  int p = warm ? 1 : 0;
+  for (; p < ctx->seq_passes; p++) {
+    const bool last = p == ctx->seq_passes - 1;
+    if (last) HIPCHK(hipMemsetAsync(ctx->sq_conv, 0, 2 * sizeof(unsigned), ctx->L.stream));
+    CHK(pass(p == 0));
+    CHK(scan(p == 0, last ? ctx->sq_conv : nullptr));
+  }
+  if (!adaptive) {      // (short chains: three passes are far inside fp32 noise; their last scan's statistics are read when a getter asks)
+    return 0;
+  }
+  bool ok = false;
+  CHK(seq_settled(ctx, &ok));
+  for (; !ok && p < ctx->seq_max_passes; p++) {
+    HIPCHK(hipMemsetAsync(ctx->sq_conv, 0, 2 * sizeof(unsigned), ctx->L.stream));
+    CHK(pass(false));
+    CHK(scan(false, ctx->sq_conv));
+    CHK(seq_settled(ctx, &ok));
+    ctx->seq_extra_passes++;
+  }
   return 0;
 }
 // O / E sums of the chain sets [chain0, chain0 + nchains) of plan P over `list`: per chain set (1 + B) * K sequential fp32 sums
@@ -697,11 +732,12 @@ int seq_workspace(hmx_ctx* ctx, size_t seg_floats, size_t total_floats) {
 int seq_run_oe(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, int chain0, int nchains, bool warm = false) {
   const int W = (1 + ctx->B) * ctx->K, lo = P.seg0[chain0], n = P.seg0[chain0 + nchains] - lo;
   CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
-  for (int p = warm ? 1 : 0; p < ctx->seq_passes; p++) {
-    l_seq_oe_pass(ctx->L, ctx->D, list, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, p == 0); KCHK();
-    l_seq_scan(ctx->L, P.d_chains, chain0, nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total,
-               p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
-  }
+  int longest = 0;
+  for (int c = chain0; c < chain0 + nchains; c++) longest = std::max(longest, P.seg0[c + 1] - P.seg0[c]);
+  const bool adaptive = (int64_t)longest * P.seg_cells >= ctx->seq_adaptive_cells;
+  CHK(seq_iterate(ctx, warm, adaptive,
+                  [&](bool zero) -> int { l_seq_oe_pass(ctx->L, ctx->D, list, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
+                  [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, chain0, nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->seq_runs++;
   return 0;
 }
@@ -767,10 +803,9 @@ int seq_objective(hmx_ctx* ctx) {
   CHK(seq_workspace(ctx, (size_t)3 * nsegs, 3));
   if ((size_t)3 * nsegs > ctx->obj_start_cap) { CHK(seq_grow(ctx, ctx->obj_start, ctx->obj_start_cap, (size_t)3 * nsegs)); ctx->obj_warm = false; }
   l_obj_terms(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->oe_arith ? ctx->Ef : nullptr, ctx->Mtab, ctx->objT, nt); KCHK();
-  for (int p = ctx->obj_warm ? 1 : 0; p < ctx->seq_passes; p++) {
-    l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, 3, LSEG, nsegs, ctx->obj_start, ctx->sq_end, p == 0); KCHK();
-    l_seq_scan1(ctx->L, 3, nsegs, ctx->obj_start, ctx->sq_end, ctx->obj_start, ctx->sq_total, p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
-  }
+  CHK(seq_iterate(ctx, ctx->obj_warm, nt >= ctx->seq_adaptive_cells,
+                  [&](bool zero) -> int { l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, 3, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
+                  [&](bool zero, unsigned* conv) -> int { l_seq_scan1(ctx->L, 3, nsegs, ctx->obj_start, ctx->sq_end, ctx->obj_start, ctx->sq_total, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->obj_warm = true;
   l_obj_store(ctx->L, ctx->sq_total, D.obj); KCHK();
   ctx->seq_runs++;
@@ -793,11 +828,9 @@ int seq_ridge_stats(hmx_ctx* ctx) {
   CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
   if ((size_t)P.nsegs * W > ctx->rg_start_cap) { CHK(seq_grow(ctx, ctx->rg_start, ctx->rg_start_cap, (size_t)P.nsegs * W)); ctx->rg_warm = false; }
   l_seq_inset(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->sv_cov_bounds, ctx->cutoff, ctx->inset); KCHK();
-  for (int p = ctx->rg_warm ? 1 : 0; p < ctx->seq_passes; p++) {
-    l_seq_ridge_pass(ctx->L, D, ctx->headlist, P.d_segs, 0, P.nsegs, ctx->inset, ctx->rg_start, ctx->sq_end, p == 0); KCHK();
-    l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->rg_start, ctx->sq_end, ctx->rg_start, ctx->sq_total,
-               p == ctx->seq_passes - 1 ? ctx->sq_mismatch : nullptr, p == 0); KCHK();
-  }
+  CHK(seq_iterate(ctx, ctx->rg_warm, ctx->N >= ctx->seq_adaptive_cells,
+                  [&](bool zero) -> int { l_seq_ridge_pass(ctx->L, D, ctx->headlist, P.d_segs, 0, P.nsegs, ctx->inset, ctx->rg_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
+                  [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->rg_start, ctx->sq_end, ctx->rg_start, ctx->sq_total, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->rg_warm = true;
   l_seq_ridge_store(ctx->L, D, ctx->sq_total); KCHK();
   ctx->seq_runs++;
@@ -1428,7 +1461,8 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
     if (f == "solve_arith" || f == "ref_arith") ctx->solve_arith = (int)v;
   }
   else if (f == "stale_dist") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "stale_dist must be set before setup"); ctx->stale_dist = v != 0; }
-  else if (f == "seq_passes") { if (v < 2 || v > 16) return fail(ctx, HMX_ERR_ARG, "seq_passes: 2..16"); ctx->seq_passes = (int)v; }
+  else if (f == "seq_passes") { if (v < 2 || v > 64) return fail(ctx, HMX_ERR_ARG, "seq_passes: 2..64"); ctx->seq_passes = (int)v; if (ctx->seq_max_passes < (int)v) ctx->seq_max_passes = (int)v; }
+  else if (f == "seq_max_passes") { if (v < 2 || v > 256) return fail(ctx, HMX_ERR_ARG, "seq_max_passes: 2..256"); ctx->seq_max_passes = (int)v; }
   else if (f == "device") ctx->device = (int)v;
   else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->prof_update_steps = 0; ctx->ev_used = 0;
                              ctx->ph_used = 0; ctx->gpu_timers.clear(); }
@@ -2023,7 +2057,7 @@ int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level,
     CHK(seq_plan_build(ctx, ctx->plan_round, ch, seg_cells));
     CHK(seq_run_oe(ctx, ctx->plan_round, dl, 0, nchains));
     CHK(d2h(ctx, totals, ctx->sq_total, (size_t)nchains * (1 + B) * K));
-    unsigned mm[2] = {0, 0}; CHK(d2h(ctx, mm, ctx->sq_mismatch, 2));
+    unsigned mm[2] = {0, 0}; CHK(d2h(ctx, mm, ctx->sq_conv, 2));
     if (mismatch) *mismatch = (int64_t)mm[0];
     if (residual) { float r; std::memcpy(&r, &mm[1], 4); *residual = (double)r; }
     return 0;
@@ -2165,17 +2199,14 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "kmeans_rounds") return vec(ctx->kmeans_rounds);
   if (!ctx->ran_setup) return -1;
   if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-  if (f == "seq:mismatch") {      // segments of the restarted sequential sums whose final start was not the end of the segment before (0: every chain certified bit-exact)
+  if (f == "seq:mismatch" || f == "seq:residual") {      // last scans of the restarted sequential sums: segment starts that still moved / the largest move relative to its chain's largest start
     if (!ctx->sq_mismatch) return scalar(0.0);
-    unsigned mm = 0; if (d2h(ctx, &mm, ctx->sq_mismatch, 1)) return -1;
-    return scalar((double)mm);
+    bool dummy = false;
+    if (seq_settled(ctx, &dummy)) return -1;          // (folds the last unchecked scan's words in)
+    (void)hipMemsetAsync(ctx->sq_conv, 0, 2 * sizeof(unsigned), ctx->L.stream);
+    return scalar(f == "seq:mismatch" ? (double)ctx->seq_mismatch_sum : ctx->seq_resid_max);
   }
-  if (f == "seq:residual") {      // largest relative move of a segment start in the final scans (0: at the fixed point)
-    if (!ctx->sq_mismatch) return scalar(0.0);
-    unsigned bits = 0; if (d2h(ctx, &bits, ctx->sq_mismatch + 1, 1)) return -1;
-    float r; std::memcpy(&r, &bits, 4);
-    return scalar((double)r);
-  }
+  if (f == "seq:extra_passes") return scalar((double)ctx->seq_extra_passes);
   if (f == "seq:runs") return scalar((double)ctx->seq_runs);
   if (f == "O" || f == "E" || f == "Lambda") {
     const int K = ctx->K, B = ctx->B;

@@ -21,7 +21,9 @@
 // ~1e-8 from the fixed point -- far below what the bias being reproduced amounts to -- and at the fixed point, where every
 // segment's start equals the end of the segment before it bit for bit, the concatenated segment loops ARE the sequential loop, i.e.
 // the chain total is bit-identical to the one-after-the-other accumulator (tests: equality for enough passes).  The last scan
-// reports how far the starts still moved: hmx_get "seq:mismatch" (segments), "seq:residual" (largest relative move).
+// reports how far the starts still moved: hmx_get "seq:mismatch" (segments), "seq:residual" (largest move of a start relative to the
+// largest start of its chain).  Long chains are iterated until that residual is below 2^-22 (at most "seq_max_passes" passes): when an
+// accumulator SATURATES -- my_accu over 10^9 terms at 10M cells stalls 25 % below the exact sum -- the iteration needs more than three.
 #include "hmx_internal.h"
 #include <float.h>
 
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
                                                    const float* __restrict__ end, float* start_out, float* __restrict__ total,
                                                    unsigned* __restrict__ mismatch, int zero_start) {
   __shared__ double tot[16][64];
+  __shared__ float dmx[16][64], smx[16][64];
   const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
   const int chain = chain0 + blockIdx.x, w = blockIdx.y * 64 + lane, ws = min(w, W - 1);
   const SeqChain c = chains[chain];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
   __syncthreads();
   double run = 0.0;
   for (int u = 0; u < v; u++) run += tot[u][lane];
-  unsigned mm = 0; float res = 0.0f;
+  unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;       // how far this lane-chain's starts moved, against the largest start of the chain
   for (int sb = s0; sb < s1; sb += 8) {
     float e8[8], o8[8];
 #pragma unroll
@@ -212,7 +215,8 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
       if (sb + u < s1) {
         const float ns = (float)run;
         if (w < W) {
-          if (!zero_start && __float_as_uint(ns) != __float_as_uint(o8[u])) { mm++; res = fmaxf(res, fabsf(ns - o8[u]) / fmaxf(fabsf(ns), fabsf(o8[u]))); }
+          if (!zero_start && __float_as_uint(ns) != __float_as_uint(o8[u])) { mm++; dmax = fmaxf(dmax, fabsf(ns - o8[u])); }
+          smax = fmaxf(smax, fabsf(ns));
           start_out[(size_t)(sb + u) * W + w] = ns;
         }
         run += (double)e8[u] - (double)o8[u];
@@ -220,16 +224,24 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
     }
   }
   if (v == 15 && w < W) total[(size_t)chain * W + w] = (float)run;     // (empty chunks: run = the sum of all chunks before)
-  if (mismatch && !zero_start) {      // [0] segments whose start moved in this scan, [1] the largest relative move (float bits)
+  if (mismatch && !zero_start) {      // [0] segments whose start moved in this scan, [1] the largest move of a start relative to its chain's largest start (float bits)
+    dmx[v][lane] = dmax; smx[v][lane] = fmaxf(smax, fabsf((float)run));
+    __syncthreads();
+    // (relative to the largest start among the 64 lane-chains of this block -- the 64 clusters of a level row, or the PCs of one
+    //  cluster together with its mass: a chain that hovers around zero next to chains of size 1e4 has not "moved by 100 %")
+    float dd = 0.0f, ss = 0.0f;
+    if (v == 0 && w < W) for (int u = 0; u < 16; u++) { dd = fmaxf(dd, dmx[u][lane]); ss = fmaxf(ss, smx[u][lane]); }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { mm += __shfl_xor(mm, m, 64); res = fmaxf(res, __shfl_xor(res, m, 64)); }
-    if (lane == 0 && mm) { atomicAdd(mismatch, mm); atomicMax(mismatch + 1, __float_as_uint(res)); }
+    for (int m = 32; m >= 1; m >>= 1) { mm += __shfl_xor(mm, m, 64); dd = fmaxf(dd, __shfl_xor(dd, m, 64)); ss = fmaxf(ss, __shfl_xor(ss, m, 64)); }
+    if (lane == 0 && mm) atomicAdd(mismatch, mm);
+    if (lane == 0 && v == 0 && ss > 0.0f && dd > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dd / ss));
   }
 }
 // one lane-chain per chain (the objective's arrays): threads along the segments, one workgroup per chain
 __global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* start_in, const float* __restrict__ end, float* start_out,
                                                     float* __restrict__ total, unsigned* __restrict__ mismatch, int zero_start) {
   __shared__ double part[1024];
+  __shared__ float dm1[1024], sm1[1024];
   const int t = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * nsegs;
   const int per = (nsegs + 1023) / 1024;
@@ -245,16 +257,26 @@ __global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* star
     __syncthreads();
   }
   double run = part[t] - acc;
-  unsigned mm = 0; float res = 0.0f;
+  unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;
   for (int s = s0; s < s1; s++) {
     const float ns = (float)run;
     const float old = zero_start ? 0.0f : start_in[base + s];
-    if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) { mm++; res = fmaxf(res, fabsf(ns - old) / fmaxf(fabsf(ns), fabsf(old))); }
+    if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) { mm++; dmax = fmaxf(dmax, fabsf(ns - old)); }
+    smax = fmaxf(smax, fabsf(ns));
     start_out[base + s] = ns;
     run += (double)end[base + s] - (double)old;
   }
   if (t == 1023) total[blockIdx.x] = (float)part[1023];
-  if (mismatch && mm) { atomicAdd(mismatch, mm); atomicMax(mismatch + 1, __float_as_uint(res)); }
+  if (mismatch && !zero_start) {
+    dm1[t] = dmax; sm1[t] = fmaxf(smax, fabsf((float)run));
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+      if (t < off) { dm1[t] = fmaxf(dm1[t], dm1[t + off]); sm1[t] = fmaxf(sm1[t], sm1[t + off]); }
+      __syncthreads();
+    }
+    if (mm) atomicAdd(mismatch, mm);
+    if (t == 0 && sm1[0] > 0.0f && dm1[0] > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dm1[0] / sm1[0]));
+  }
 }
 
 // ---- O / E tables in the reference's fp32 arithmetic (oe_arith) ----------------------------------------------------------------

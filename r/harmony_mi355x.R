@@ -6,8 +6,11 @@
 ## (R/utils.R:50-81), the Seurat / SingleCellExperiment methods (R/RunHarmony.R) -- runs unchanged, because the
 ## returned environment exposes the same `$` names as class_<harmony> (src/harmony.cpp:675-707).
 
-new_harmony_mi355x <- function(seed = NULL, r_rng = FALSE) {
+new_harmony_mi355x <- function(seed = NULL, r_rng = FALSE, reference_arithmetic = FALSE) {
     ptr <- .Call("C_hmx_new")
+    ## reference_arithmetic: every accumulator follows the reference's fp32 operation order (ridge statistics, O / E tables, objective
+    ## sums, closed-form inverse; one covariate, one GPU) -- for users who need the CPU package's numbers rather than the exact ones
+    if (reference_arithmetic) .Call("C_hmx_set_int", ptr, "ref_arith", 1)
     if (r_rng) {
         ## exact reference randomness: the library consumes R's own stream (unif_rand) in RcppArmadillo's draw order --
         ## `set.seed(x); RunHarmony(...)` then walks the same seeds and shuffles as the reference package (slower: N draws per round)
