@@ -436,7 +436,8 @@ def main():
         e2e = {"T_conv_ms": ms_per_step, "ingest_Z_f64_ms": ingest_ms, "egress_Zcorr_f64_ms": egress_ms,
                "egress_Zcorr_f32_ms": egress32_ms, "T_e2e_ms": ms_per_step + ingest_ms + egress_ms,
                "cells_per_sec_e2e": n / ((ms_per_step + ingest_ms + egress_ms) * 1e-3), "setup_total_ms": 1e3 * t_setup,
-               "note": "pageable host buffers, per GPU; setup_total also holds Phi -> level codes and the combination sort on the host"}
+               "note": "per GPU; the caller's (pageable) buffers are page-locked for the transfer (HMX_PIN=0: left pageable); the fp64 egress is mostly the "
+                       "first touch of the fresh host array; setup_total also holds Phi -> level codes and the combination sort on the host"}
     out = {
         "metric": "cells_per_sec_to_convergence", "value": N / (ms_per_step * 1e-3), "unit": "cells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
