@@ -241,7 +241,8 @@ def main():
             # node, every rank falls back to the torch.distributed hook instead of hanging the whole job
             import threading
             res = {}
-            os.environ["HMX_P2P"] = "0"              # (the peer-to-peer chain is bootstrapped below through torch.distributed)
+            # hmx_comm_init also connects the ranks' inboxes and runs the transport self-test (the path a torch-free C / R host takes);
+            # the torch.distributed bootstrap below is only used where that did not switch the peer-to-peer chain on
 
             def _init():
                 try:
@@ -272,8 +273,17 @@ def main():
         # Peer-to-peer block chain: the 20 dependent K x B sums of a clustering round happen INSIDE the persistent launch (every
         # GPU writes its table into every peer's inbox over xGMI) instead of 20 launches + 20 all-reduces.  The inbox handles
         # travel through torch.distributed; it is switched on only if the transport self-test passed on EVERY rank.
-        p2p_note = "off"
-        if world <= 8 and os.environ.get("HMX_BENCH_P2P", "1") != "0":
+        p2p_note = obj.p2p_status
+        builtin_p2p = bool(ok) and torch.tensor([1 if obj._scalar("p2p") else 0], device=dev)
+        if ok:
+            dist.all_reduce(builtin_p2p, op=dist.ReduceOp.MIN)
+            builtin_p2p = bool(builtin_p2p.item())
+        if os.environ.get("HMX_BENCH_P2P", "1") == "0":
+            obj.p2p_enable(False)
+            p2p_note = "switched off (HMX_BENCH_P2P=0)"
+        elif builtin_p2p:
+            p2p_note = "bootstrapped by hmx_comm_init: " + obj.p2p_status
+        elif world <= 8:
             def agree(flag):
                 t = torch.tensor([1 if flag else 0], device=dev if a.backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)

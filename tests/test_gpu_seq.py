@@ -205,3 +205,35 @@ def test_reference_arithmetic_needs_one_gpu_and_one_covariate(cell_lines):
     ig, ic = _iterate(g, 3), _iterate(c, 3)
     s = _report(g, c)
     assert ig == ic and s["Z_rel"] <= 1e-5 and s["obj_rel"] <= 2e-5 and s["clear_flips"] == 0, s
+
+
+def test_reference_arithmetic_with_the_hosts_shuffles(cell_lines):
+    """the sequential sums run in the round's shuffled order, whoever drew it: with the R-compatible stream (arma::shuffle restated on the
+    host) and with injected update orders the library follows the faithful oracle just as it does with its own generator"""
+    orc.use_openblas(1)
+    meta = {"dataset": cell_lines["dataset_levels"][cell_lines["dataset"]]}
+    skw, _ = prepare_setup_args(cell_lines["pcs"], meta, "dataset", nclust=20)
+    N = cell_lines["pcs"].shape[0]
+    # (a) rng = R on both sides, nothing shared: seeds and shuffles from MT19937
+    g = Harmony(seed=42, rng="R", ref_arith=1); g.setup(**skw)
+    c = OracleHarmony(mask=0, seed=42, rng=1); c.setup(**skw)
+    g.init_cluster_cpp(); c.init_cluster_cpp()
+    assert relfro(g.Y, c.Y) < 1e-4
+    ig, ic = _iterate(g, 4), _iterate(c, 4)
+    s = _report(g, c)
+    print("ref_arith, R stream:", s)
+    assert ig == ic and s["Z_rel"] <= 2e-5 and s["clear_flips"] == 0 and s["obj_rel"] <= 2e-5, (ig, ic, s)
+    # (b) injected orders, one clustering pass + one correction
+    rng = np.random.default_rng(0)
+    g = Harmony(seed=1, ref_arith=1); g.setup(**skw)
+    c = OracleHarmony(mask=0, seed=1); c.setup(**skw)
+    Y0 = g.kmeans_centers()
+    g.init_cluster_cpp(Y0); c.init_cluster_cpp(Y0)
+    for _ in range(3):
+        o = rng.permutation(N).astype(np.int64)
+        g.push_update_order(o); c.push_update_order(o)
+    assert g.cluster_cpp() == 0 and c.cluster_cpp() == 0
+    g.moe_correct_ridge_cpp(); c.moe_correct_ridge_cpp()
+    s = _report(g, c)
+    print("ref_arith, injected orders:", s)
+    assert s["Z_rel"] <= 1e-5 and s["O_rel"] <= 1e-5 and s["clear_flips"] == 0 and s["obj_rel"] <= 2e-5, s
