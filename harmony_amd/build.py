@@ -10,7 +10,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", "hmx_kernels.hip"), os.path.join(HERE, "csrc", "hmx_seq.hip"), os.path.join(HERE, "csrc", "hmx_api.cpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("hmx_kernels.hip", "hmx_tile_bf.hip", "hmx_seq.hip", "hmx_api.cpp")]
+# (hmx_tile_bf.hip is hmx_kernels.hip's tile kernel built a second time with the split-bf16 distance GEMM: it includes that file)
+EXTRA_DEP = {"hmx_tile_bf.hip": [os.path.join(HERE, "csrc", "hmx_kernels.hip")]}
 HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "csrc", "hmx_rrng.h"), os.path.join(HERE, "..", "include", "harmony_mi355x.h")]
 OUT = os.path.join(HERE, "lib", "libharmony_mi355x.so")
 
@@ -55,7 +57,8 @@ def build(force=False, verbose=True, trace=False):
     for src in SRC:
         obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        dep_t = max([os.path.getmtime(src), hdr_t] + [os.path.getmtime(q) for q in EXTRA_DEP.get(os.path.basename(src), [])])
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep_t:
             cmd = [hipcc] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

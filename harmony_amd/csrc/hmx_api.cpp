@@ -327,7 +327,10 @@ int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Yt[j*K+k] and the MFMA 
       if (k < K) img[((((size_t)qd * D.NS + s) * 4 + p) * 16 + c) * 4 + i] = ctx->Y[(size_t)k * d + j];
     }
   }
-  return h2d(ctx, D.Yimg, img.data(), img.size());
+  CHK(h2d(ctx, D.Yimg, img.data(), img.size()));
+  std::vector<unsigned short> img3((size_t)D.NCT * D.NS2 * 3 * 512, 0);
+  for (int k = 0; k < K; k++) for (int j = 0; j < d; j++) bfimg_store(img3.data(), D.NCT, D.NS2, j, k, ctx->Y[(size_t)k * d + j]);
+  return h2d(ctx, D.Yimg3, img3.data(), img3.size());
 }
 
 // objective snapshot obj[2..4] -> the four series (src/harmony.cpp:165-168).  The copy is enqueued into a pinned slot;
@@ -1617,6 +1620,10 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   D.pen_lds = ((size_t)D.NQ * 0 + (size_t)B * K * 4 + (size_t)Q * C * 4 <= 24576) ? 1 : 0;
   D.rvec = (K % 4 == 0) ? 1 : 0;
   D.NQ = (D.NCT + 3) / 4; D.NT4 = D.zs / 16; D.tail = (D.zs - 16 * D.NT4) / 4; D.NS = 4 * D.NT4 + D.tail;
+  // split-bf16 form of the tile kernels' distance GEMM (hmx_tile_bf.hip): offered where its register form covers the shapes the fp32
+  // register form covers (rows of <= 64 PCs in four 16-byte groups); each launch takes it when its LDS image fits (l_update & co)
+  D.NS2 = (D.zs + 31) / 32;
+  { const char* e = getenv("HMX_DOT"); D.dot_bf = !(e && std::string(e) == "f32") && (D.NT4 > 4 || D.NS2 <= 2) && D.NS2 <= 4; }
   { const char* e = getenv("HMX_UPDATE_IMPL"); D.upd_impl = ctx->tun_impl >= 0 ? ctx->tun_impl : ((e && std::string(e) == "v1") ? 1 : 0); }
   { const char* e = getenv("HMX_UPD_THREADS"); D.upd_threads = (e && atoi(e) == 256) ? 256 : 512; }
   { // uniform sigma (the reference's default): scalar-constant kernel variants; with K <= 64 they also fit the register
@@ -1663,7 +1670,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, ((size_t)N + 1) * K));   // + one dummy row (target of masked stores)
   CHK(dalloc(ctx, &D.perm, (size_t)N)); CHK(dalloc(ctx, &D.invperm, (size_t)N)); CHK(dalloc(ctx, &D.combo, (size_t)N));
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
-  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
+  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.Yimg3, (size_t)D.NCT * D.NS2 * 3 * 512)); HIPCHK(hipMemsetAsync(D.Yimg3, 0, (size_t)D.NCT * D.NS2 * 3 * 1024, ctx->L.stream)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
   // Sold_fx [nb][B][K] and the three rotating replica sets of the fused path share one buffer: one memset per round
   { long long* s3; CHK(dalloc(ctx, &s3, (size_t)2 * D.nb * B * K + (size_t)3 * D.nrep * B * K)); D.Sold_fx = s3;
@@ -2164,6 +2171,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
   if (f == "prof:update_steps") return scalar((double)ctx->prof_update_steps);
   if (f == "chain") return scalar(ctx->chain_ok ? 1.0 : 0.0);
+  if (f == "dot_bf") return scalar(ctx->D.dot_bf ? 1.0 : 0.0);     // split-bf16 tile kernels offered (each launch still checks its LDS budget)
   if (f == "sold_carry") return scalar(ctx->carry_ok ? 1.0 : 0.0);
   if (f == "carried_rounds") return scalar((double)ctx->carried_rounds);
   if (f == "p2p:exchange_us") return scalar(ctx->p2p_exchange_us);

@@ -30,6 +30,11 @@ struct Dev {
   int NQ;           // quads of cluster tiles (ceil(NCT/4))
   int NT4, tail, NS;  // PC steps: NT4 float4 groups of 4 steps + tail single steps; NS = 4*NT4 + tail
   float* Yimg;      // [NQ][NS][4][16][4] LDS image of the centroids in MFMA B-operand order
+  // split-bf16 form of the distance GEMM (v_mfma_f32_16x16x32_bf16, see bf3_split): NS2 steps of 32 PCs, the centroids as three
+  // bf16 parts in B-operand order [NCT][NS2][part][lane = 16 g + c][8 bf16] (PC j: step j >> 5, lane group g = (j & 31) >> 3, slot j & 7)
+  int NS2;
+  unsigned short* Yimg3;
+  int dot_bf;       // 1: tile kernels built for the split-bf16 form are launched where their LDS image fits (HMX_DOT=f32 turns it off)
   int upd_impl;     // 0: MFMA tile kernel, 1: cluster-lane VALU kernel (v1)
   int upd_tpw;      // tiles per wave target of the MFMA update kernel
   int upd_wps;      // waves per SIMD the update/head kernels are built for: 2 | 4 (lean: uniform sigma, K <= 64)
@@ -191,6 +196,10 @@ void l_foldpen(const Launch& L, const Dev& D, int j, const long long* Oin, long 
 void l_obj_reduce(const Launch& L, const Dev& D);
 void l_update(const Launch& L, const Dev& D, int j);
 void l_chain(const Launch& L, const Dev& D, int workgroups);
+// the same three launchers of the translation unit built with HMX_TILE_BF=1 (hmx_tile_bf.hip): k_tile with the split-bf16 distance GEMM
+void l_tile_static_bf(const Launch& L, const Dev& D, int mode);
+void l_update_bf(const Launch& L, const Dev& D, int j);
+void l_chain_bf(const Launch& L, const Dev& D, int workgroups);
 void l_round_tail(const Launch& L, const Dev& D, double* host_slot, long long* z0, size_t n0, long long* z1, size_t n1);
 // Cluster <-> MFMA column mapping of the tile kernels.  Lane (g, c) of a wave holds column c of every 16-wide cluster tile ct.
 // Clusters are dealt so that a lane's columns are CONSECUTIVE clusters: within a full quad of cluster tiles (4q..4q+3) the lane
@@ -204,6 +213,32 @@ __host__ __device__ inline void kcol_inv(int nct, int k, int& qd, int& i, int& c
   const int nfull = nct >> 2, r = nct & 3;
   if (k < 64 * nfull) { qd = k >> 6; c = (k & 63) >> 2; i = k & 3; }
   else { qd = nfull; const int kk = k - 64 * nfull; c = kk / r; i = kk - c * r; }
+}
+// fp32 -> three bf16 parts by truncation: x = hi + mid + lo EXACTLY (8 + 8 + 8 mantissa bits; both differences are exact in fp32),
+// so a product of two fp32 numbers is the sum of nine exact bf16 x bf16 products; the tile kernels keep the six largest
+// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi: what is dropped is below 2^-25 of |x||y|) and add them in fp32 on the matrix cores.
+__host__ __device__ inline void bf3_split(float x, unsigned short (&p)[3]) {
+  union { float f; unsigned u; } a, b;
+  a.f = x;
+  p[0] = (unsigned short)(a.u >> 16);
+  b.u = a.u & 0xffff0000u;
+  a.f = x - b.f;
+  p[1] = (unsigned short)(a.u >> 16);
+  b.u = a.u & 0xffff0000u;
+  a.f = a.f - b.f;
+  p[2] = (unsigned short)(a.u >> 16);
+}
+// bf16 index of (PC j, cluster k, part) in the split image
+__host__ __device__ inline size_t bfimg_index(int nct, int ns2, int j, int k, int part) {
+  int qd, i, c;
+  kcol_inv(nct, k, qd, i, c);
+  const int ct = 4 * qd + i, s = j >> 5, g = (j & 31) >> 3;
+  return ((((size_t)ct * ns2 + s) * 3 + part) * 64 + 16 * g + c) * 8 + (j & 7);
+}
+__host__ __device__ inline void bfimg_store(unsigned short* img, int nct, int ns2, int j, int k, float y) {
+  unsigned short p[3];
+  bf3_split(y, p);
+  for (int part = 0; part < 3; part++) img[bfimg_index(nct, ns2, j, k, part)] = p[part];
 }
 constexpr int P2P_CAP = 16384;                       // K x B entries an inbox holds per (parity, source)
 constexpr size_t P2P_TEST_BASE = (size_t)2 * 8 * P2P_CAP * 2;   // 64 granules behind the tables: the connection self-test

@@ -22,6 +22,9 @@
 #ifndef HMX_CHAIN_BALANCE
 #define HMX_CHAIN_BALANCE 1
 #endif
+#ifndef HMX_TILE_BF
+#define HMX_TILE_BF 0         // 1 (hmx_tile_bf.hip): this translation unit builds ONLY k_tile, with the split-bf16 distance GEMM, and its three launchers
+#endif
 #ifndef HMX_TILE_LB
 #define HMX_TILE_LB(NCT) 1   // waves/SIMD the tile kernel is register-budgeted for; 3 measured slower than unconstrained
 #endif
@@ -198,6 +201,7 @@ __device__ __forceinline__ void flush_fx(long long* __restrict__ tab, const int*
 // --------------------------------------------------------------------------------------
 // src: [n][d] doubles or floats in local original order (host slab staged in HBM, or the caller's device buffer)
 // -> dst: [n][zs] floats in internal order
+#if !HMX_TILE_BF   // (the split-bf16 translation unit builds k_tile and its launchers only)
 template <class T>
 __global__ void k_convert_in(const T* __restrict__ src, float* __restrict__ dst, const int* __restrict__ invperm,
                              int n, int d, int zs) {
@@ -809,6 +813,7 @@ __global__ __launch_bounds__(TPB) void k_update(Dev D, int j) {
   if (lane == 0) { D.objpart[2 * wave] += od; D.objpart[2 * wave + 1] += oe; }  // private slot (slot row 0): no atomics
 }
 
+#endif  // !HMX_TILE_BF
 // --------------------------------------------------------------------------------------
 // MFMA tile variant of the block update (the dominant kernel).
 //
@@ -1059,6 +1064,97 @@ __device__ __forceinline__ void tile_dots_regs(const f32x4* __restrict__ ldsY4, 
   }
 }
 
+// ---- split-bf16 form of the distance GEMM ---------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate on gfx950 (32 cycles per SIMD, on the datapath the epilogue's VALU work needs);
+// v_mfma_f32_16x16x32_bf16 takes ~17 cycles for 8x the products on the matrix cores proper.  With x = hi + mid + lo (three bf16 parts,
+// exact: bf3_split) the 16 x 16 x 32 product of fp32 operands is six bf16 MFMAs (the three dropped cross terms are < 2^-25 |x||y|),
+// fp32 accumulation: 12 NCT MFMAs per 64 PCs instead of 16 NCT per 64, at half the cycles each, and VALU work of the SIMD's other
+// wave overlaps them.  A operand (cells): lane (c, g) holds PCs 32 s + 8 g + {0..7} of cell c in step s -- two 16-byte loads -- and
+// splits them in registers (5.5 VALU per value); B operand (centroids): the three parts from the LDS image D.Yimg3, one ds_read_b128 each.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Bf3 { u32x4 p[3]; };
+__device__ __forceinline__ Bf3 bf3_split8(const f32x4 lo4, const f32x4 hi4) {
+  Bf3 o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float x0 = i < 2 ? lo4[2 * i] : hi4[2 * i - 4], x1 = i < 2 ? lo4[2 * i + 1] : hi4[2 * i - 3];
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    o.p[0][i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);      // { bf16(x0), bf16(x1) }: the upper halves
+    o.p[1][i] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    o.p[2][i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+  return o;
+}
+// one step (32 PCs) of all cluster tiles: smallest terms first
+template <int NCT>
+__device__ __forceinline__ void bf_step(const u32x4* __restrict__ ldsB, const Bf3& a, int s, int NS2, int lane, f32x4 (&acc)[NCT]) {
+  auto mf = [](const u32x4 A, const u32x4 B, const f32x4 C) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0);
+  };
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) {
+    const u32x4* b = ldsB + ((size_t)(ct * NS2 + s) * 3) * 64 + lane;
+    const u32x4 b0 = b[0], b1 = b[64], b2 = b[128];
+    f32x4 v = acc[ct];
+    v = mf(a.p[0], b2, v);
+    v = mf(a.p[2], b0, v);
+    v = mf(a.p[1], b1, v);
+    v = mf(a.p[0], b1, v);
+    v = mf(a.p[1], b0, v);
+    v = mf(a.p[0], b0, v);
+    acc[ct] = v;
+  }
+}
+// rows in registers: r.v[2 s + h] = the 16 bytes at PC 32 s + 8 g + 4 h (clamped into the row; rowmask bit 2 s + h = inside the row)
+__device__ __forceinline__ void load_rows_bf(const float* __restrict__ zrow, int g, int zs, RowRegs& r) {
+#pragma unroll
+  for (int t = 0; t < 4; t++) r.v[t] = *reinterpret_cast<const f32x4*>(zrow + min(32 * (t >> 1) + 8 * g + 4 * (t & 1), zs - 4));
+}
+__device__ __forceinline__ int rows_mask_bf(int g, int zs) {
+  int m = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) m |= (32 * (t >> 1) + 8 * g + 4 * (t & 1) < zs) ? (1 << t) : 0;
+  return m;
+}
+template <int NCT>
+__device__ __forceinline__ void tile_dots_bf_regs(const u32x4* __restrict__ ldsB, const RowRegs& r, bool valid, int rowmask, int lane,
+                                                  int NS2, f32x4 (&acc)[NCT]) {
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) acc[ct] = zero4;
+  const int m = valid ? rowmask : 0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    if (s < NS2) {
+      const Bf3 a = bf3_split8((m >> (2 * s)) & 1 ? r.v[2 * s] : zero4, (m >> (2 * s + 1)) & 1 ? r.v[2 * s + 1] : zero4);
+      bf_step<NCT>(ldsB, a, s, NS2, lane, acc);
+    }
+  }
+}
+// rows streamed from memory one step ahead (any NS2 <= 4)
+template <int NCT>
+__device__ __forceinline__ void tile_dots_bf(const u32x4* __restrict__ ldsB, const float* __restrict__ zrow, bool valid, int rowmask, int g,
+                                             int lane, int NS2, int zs, f32x4 (&acc)[NCT]) {
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) acc[ct] = zero4;
+  const int m = valid ? rowmask : 0;
+  f32x4 c0 = *reinterpret_cast<const f32x4*>(zrow + min(8 * g, zs - 4)), c1 = *reinterpret_cast<const f32x4*>(zrow + min(8 * g + 4, zs - 4));
+  for (int s = 0; s < NS2; s++) {
+    const f32x4 a0 = (m >> (2 * s)) & 1 ? c0 : zero4, a1 = (m >> (2 * s + 1)) & 1 ? c1 : zero4;
+    if (s + 1 < NS2) {
+      c0 = *reinterpret_cast<const f32x4*>(zrow + min(32 * (s + 1) + 8 * g, zs - 4));
+      c1 = *reinterpret_cast<const f32x4*>(zrow + min(32 * (s + 1) + 8 * g + 4, zs - 4));
+    }
+    const Bf3 a = bf3_split8(a0, a1);
+    bf_step<NCT>(ldsB, a, s, NS2, lane, acc);
+  }
+}
+
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int srclane) {
   const unsigned lo = (unsigned)__shfl((int)(unsigned)v, srclane, 64), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), srclane, 64);
   return ((unsigned long long)hi << 32) | lo;
@@ -1135,14 +1231,15 @@ constexpr int tile_threads(int nct) { return 256; }
 //         path; the centroid image is staged once per round instead of once per block step.
 // WPS: waves per SIMD the register budget is cut for (update workgroup = 256*WPS threads).  USIG: one sigma for all clusters
 // (the reference's default, R/ui.R:219-221): ce / cl become scalars, 2-3 register arrays of NCT floats disappear.
-template <int NCT, int MODE, int WPS = 2, bool USIG = false>
+template <int NCT, int MODE, int WPS = 2, bool USIG = false, bool BF = (HMX_TILE_BF != 0)>
 __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   constexpr bool LEAN = WPS > 2;
   // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits):
   //   [ centroid image: NQ*NS*64 float4 | MODE 0: pen[B][K] + qlev[Q][C] (if they fit) | MODE 2: int64 sums[K][d] + counts[K] ]
   extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
   const int K = D.K, C = D.C, zs = D.zs;
-  const int nY4 = D.NQ * D.NS * 64;
+  const int nY4 = BF ? NCT * D.NS2 * 3 * 64 : D.NQ * D.NS * 64;     // 16-byte entries of the centroid image (f32 steps | three bf16 parts)
+  const u32x4* const ldsB = reinterpret_cast<const u32x4*>(lds4);
   // MODE 0 with D.fused_fold: [ image | O' int64 [B][K] | pen | qlev ] -- the fold + penalty of this block step is
   // recomputed by EVERY workgroup in its own LDS (k_foldpen's launch and its boundary disappear); workgroup 0 also
   // publishes O' and zeroes the replica set of the NEXT launch (three sets rotate, so nobody reads what is zeroed).
@@ -1209,6 +1306,20 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // Software pipeline over tiles (when the rows fit in registers, D.NT4 <= 4): cell ids two tiles ahead, embedding rows
   // one tile ahead.  MODE 0 requests the first tile's ids and rows BEFORE the LDS staging below.
   const bool pre = !LEAN && D.NT4 <= 4 && NCT <= 8;    // (K > 128: the extra row registers would spill)
+  // the three forms of a tile's distance GEMM (rows in registers | rows streamed), fp32 MFMA or split bf16 (BF; hmx_setup offers BF
+  // only where the register form exists for the same shapes: NS2 <= 2 whenever NT4 <= 4)
+  const int rowmask = BF ? rows_mask_bf(g, zs) : 0;
+  auto ld_rows = [&](const float* __restrict__ zr, RowRegs& r) __attribute__((always_inline)) {
+    if constexpr (BF) load_rows_bf(zr, g, zs, r); else load_rows(zr, g, D.NT4, D.tail, r);
+  };
+  auto dots_regs = [&](const RowRegs& r, const bool valid, f32x4 (&acc)[NCT]) __attribute__((always_inline)) {
+    if constexpr (BF) tile_dots_bf_regs<NCT>(ldsB, r, valid, rowmask, lane, D.NS2, acc);
+    else tile_dots_regs<NCT>(lds4, r, valid, lane, D.NS, D.NT4, D.tail, acc);
+  };
+  auto dots_stream = [&](const float* __restrict__ zr, const bool valid, f32x4 (&acc)[NCT]) __attribute__((always_inline)) {
+    if constexpr (BF) tile_dots_bf<NCT>(ldsB, zr, valid, rowmask, g, lane, D.NS2, zs, acc);
+    else tile_dots<NCT>(lds4, zr, valid, g, lane, D.NS, D.NT4, D.tail, acc);
+  };
   // (cell id, combination) of this lane's A-operand row, ONE vector load per tile: a separate uniform load of the tile's
   // combination ends in a readfirstlane right behind the load, i.e. a vmcnt(0) -- a drain of the 28 outstanding R stores
   // of the previous tile plus a full memory latency -- in every iteration.
@@ -1277,7 +1388,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     int qlv0 = 0;
     if (fold) qlv0 = D.qlev[min(tid, nQC - 1)];
     if (ts < te) { cellN = tile_cell(ts); cellNN = tile_cell(ts + tstep); }   // first tiles' (cell, combination) pairs
-    const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
+    const f32x4* src = BF ? reinterpret_cast<const f32x4*>(D.Yimg3) : reinterpret_cast<const f32x4*>(D.Yimg);
     {   // first chunk straight-line (a loop header here would make hipcc drain the loads above before the first image load)
       f32x4 t[4];
 #pragma unroll
@@ -1286,7 +1397,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       for (int k = 0; k < 4; k++) if (tid + k * bd < nY4) lds4[tid + k * bd] = t[k];
     }
     stamp(12);
-    if (ts < te && pre) load_rows(D.Zc + (size_t)(cellN.x >= 0 ? cellN.x : 0) * zs, g, D.NT4, D.tail, rowsN);
+    if (ts < te && pre) ld_rows(D.Zc + (size_t)(cellN.x >= 0 ? cellN.x : 0) * zs, rowsN);
     stamp(13);
     for (int base = 4 * bd; base < nY4; base += 4 * bd) {
       f32x4 t[4];
@@ -1369,6 +1480,14 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     long long* t2 = nullptr;
     if (UPD && D.Sold_next) t2 = D.Sold_next + (size_t)((curq >> 19) & 63) * D.B * K;
     if (MODE == 1 && D.head_gather && D.Sold_head) t2 = D.Sold_head + (size_t)((curq >> 25) & 63) * D.B * K;
+#ifdef HMX_TRACE
+    if (D.upd_debug & 16) t2 = nullptr;                   // timing experiments (WRONG RESULTS): no carry atomics | no contribution atomics at all
+    if (D.upd_debug & 8) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) oacc[ct] = 0ull;
+      return;
+    }
+#endif
     flush_tile_fx<NCT>(snew, t2, qlevT, curq & QMASK, C, K, c, g, oacc);
   };
   auto epi_begin = [&](const int q0) __attribute__((always_inline)) {
@@ -1523,6 +1642,9 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   };
   // the deferred stores of epi_rows<DEFER>: `acc` holds the normalised rows
   auto store_rows = [&](const int cellA, const f32x4 (&acc)[NCT]) __attribute__((always_inline)) {
+#ifdef HMX_TRACE
+    if (D.upd_debug & 4) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int cell = __shfl(cellA, 4 * g + i, 64);
@@ -1584,6 +1706,18 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         const int kc = ((c & 3) == 0) ? t4[0] : ((c & 3) == 1) ? t4[1] : ((c & 3) == 2) ? t4[2] : t4[3];
         if (cellA >= 0) {
           long long* row = ltab + (size_t)kc * dd;
+          if constexpr (BF) {      // split-bf16 row layout: v[2 s + h][e] = PC 32 s + 8 g + 4 h + e
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const int jj = 32 * (t >> 1) + 8 * g + 4 * (t & 1) + e;
+                if (t < 2 * D.NS2 && jj < dd) atomicAdd((unsigned long long*)&row[jj], (unsigned long long)(long long)__float2int_rn(erows->v[t][e] * 1073741824.0f));
+              }
+            }
+            if (g == 0) atomicAdd((unsigned long long*)&ltab[K * dd + kc], 1ull);
+            return;
+          }
 #pragma unroll
           for (int t = 0; t < 4; t++) {
             if (t < D.NT4) {
@@ -1894,6 +2028,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     }
     // ---------------- the workers
     if constexpr (LEAN) {
+      static_assert(!BF, "the lean chain reads its rows from an LDS image in fp32-step order");
       // 4 waves per SIMD (1024-thread workgroups, <= 128 VGPRs): one accumulator set, rows streamed inside the MFMA loop.  With
       // ~4000 resident waves a block's ~3100 tiles are ONE tile per wave: after the flag only a single epilogue remains.
       f32x4 accC[NCT];
@@ -1904,9 +2039,9 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         // all of the row's operand loads in flight at once (tile_dots streams them one group ahead: three exposed latencies)
         if (D.NT4 <= 4) {
           RowRegs rr;
-          load_rows(D.Zc + (size_t)(cq.x >= 0 ? cq.x : 0) * zs, g, D.NT4, D.tail, rr);
-          tile_dots_regs<NCT>(lds4, rr, cq.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
-        } else tile_dots<NCT>(lds4, D.Zc + (size_t)(cq.x >= 0 ? cq.x : 0) * zs, cq.x >= 0, g, lane, D.NS, D.NT4, D.tail, accC);
+          ld_rows(D.Zc + (size_t)(cq.x >= 0 ? cq.x : 0) * zs, rr);
+          dots_regs(rr, cq.x >= 0, accC);
+        } else dots_stream(D.Zc + (size_t)(cq.x >= 0 ? cq.x : 0) * zs, cq.x >= 0, accC);
       };
       if (have) mfma_tile(cellN);
       // rows of the NEXT block's first tile travel global -> LDS by LDS-DMA while this block's epilogue runs (no registers, no
@@ -2007,24 +2142,26 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     bool have = ts < te, have2 = false;
     // BOTH accumulator sets are filled ahead of the flag: the MFMAs of this wave's first tile of the current block (rows were
     // requested earlier) and, if it owns a second one, of that too -- after the flag only epilogues remain for up to two tiles
-    auto first_tile = [&]() __attribute__((always_inline)) {
+    auto first_tile_a = [&]() __attribute__((always_inline)) {
       cellC = cellN;
       const RowRegs rowsA = rowsN;
       cellN = cellNN;
       cellNN = tile_cell(ts + 2 * tstep);
-      load_rows(next_rows(cellN, cellC), g, D.NT4, D.tail, rowsN);
-      tile_dots_regs<NCT>(lds4, rowsA, cellC.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
+      ld_rows(next_rows(cellN, cellC), rowsN);
+      dots_regs(rowsA, cellC.x >= 0, accC);
       have2 = HMX_CHAIN_PRE2 && USIG && ts + tstep < te;    // (the general-sigma variant has no registers to spare: 95 spills)
+    };
+    auto first_tile_b = [&]() __attribute__((always_inline)) {
       if (have2) {
         cellS = cellN;
         const RowRegs rowsB = rowsN;
         cellN = cellNN;
         cellNN = tile_cell(ts + 3 * tstep);
-        load_rows(next_rows(cellN, cellS), g, D.NT4, D.tail, rowsN);
-        tile_dots_regs<NCT>(lds4, rowsB, cellS.x >= 0, lane, D.NS, D.NT4, D.tail, accS);
+        ld_rows(next_rows(cellN, cellS), rowsN);
+        dots_regs(rowsB, cellS.x >= 0, accS);
       }
     };
-    if (have) first_tile();
+    if (have) { first_tile_a(); first_tile_b(); }
     // Old contributions inside the chain (D.chain_old): the sums "remove block b's cells from O" (:312-313) of block b are
     // gathered by the waves that will update it, TWO blocks ahead, in the slack between their arrival and the next flag --
     // one pass over R per round disappears (k_oldsum).  Same fixed-point sums, same replica scheme as the new contributions.
@@ -2067,6 +2204,22 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       __builtin_amdgcn_s_barrier();
       if (tid == 0) atomicAdd(&ctl[8 + 8 * nbk + ((int)blockIdx.x & 7)], 1);
     }
+    // Geometry of the block AFTER the current one and the (cell, combination) pairs of this wave's first two tiles in it.  Requested
+    // in the slack behind an arrival, a whole block ahead of their use: at the top of the epilogue phase the two dependent round trips
+    // (scalar load of the block offsets, then the pairs) were 1.6 us of every block step's critical path.
+    int p0n = 0, ten = 0, tsn = ts; bool haveN = false;
+    int2 cN1 = make_int2(-1, -1), cNN1 = make_int2(-1, -1);
+    auto fetch_next = [&](const int jb) __attribute__((always_inline)) {
+      p0n = 0; ten = 0; haveN = false; cN1 = make_int2(-1, -1); cNN1 = make_int2(-1, -1);
+      if (jb < nbk) {
+        p0n = D.boff[jb];
+        ten = (D.boff[jb + 1] - p0n) >> 4;
+        if constexpr (CHAIN_CONTIG) chain_range(ten, tsn, ten);      // (ten: from here on the end of THIS wave's range)
+        haveN = tsn < ten;
+        if (haveN) { cN1 = D.lpair[p0n + 16 * tsn + c]; if (tsn + tstep < ten) cNN1 = D.lpair[p0n + 16 * (tsn + tstep) + c]; }
+      }
+    };
+    fetch_next(1);
     unsigned long long wq = 0, wg = 0, ww = 0, wd = 0, wm = 0, w1 = 0, w2 = 0, w3 = 0, w_prev = wall_clock64();   // diagnostics (workgroup 0, wave 0)
     unsigned long long wv_busy = 0, wv_tiles = 0;    // per wave: table in LDS -> own work done (before the barrier), tiles owned
     auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - w_prev; w_prev = t; };
@@ -2095,67 +2248,77 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       curq = -1;                            // the table changed: the penalty row of the first tile must be re-read
       // (od / oe: this wave's objective partial sums run through ALL blocks of the round in registers, one wave reduction and one
       //  slot store at the end of the launch instead of two 6-step 64-bit reductions per block on the critical path)
-      // geometry of the next block and the (cell, combination) pairs of this wave's first two tiles in it, requested now
+      // (geometry of the next block and the pairs of this wave's first two tiles in it: fetch_next, requested one block ahead)
       const bool more = jj + 1 < nbk;
-      int p0n = 0, ten = 0, tsn = ts; bool haveN = false;
-      int2 cN1 = make_int2(-1, -1), cNN1 = make_int2(-1, -1);
-      if (more) {
-        p0n = D.boff[jj + 1];
-        ten = (D.boff[jj + 2] - p0n) >> 4;
-        if constexpr (CHAIN_CONTIG) chain_range(ten, tsn, ten);      // (ten: from here on the end of THIS wave's range)
-        haveN = tsn < ten;
-        if (haveN) { cN1 = D.lpair[p0n + 16 * tsn + c]; if (tsn + tstep < ten) cNN1 = D.lpair[p0n + 16 * (tsn + tstep) + c]; }
-      }
+      // The R rows of a wave's LAST TWO tiles of the block leave BEHIND the arrival.  Nobody reads a block's R rows before the launch
+      // ends, but their stores -- 20 MB per block step from all workgroups at once, an HBM write burst the issuing waves sit behind --
+      // were 3.2 of the 6.7 us a two-tile wave needed between "table in LDS" and its arrival (tools/chain_probe.py).  The normalised
+      // rows stay in the two accumulator sets (epi_rows<DEFER>) through the contribution atomics, the barrier and the arrival, and are
+      // stored in the folder's shadow, interleaved with the next block's MFMAs (which overwrite the same registers).
+      bool two = false;                     // both hoisted tiles are the wave's last ones of this block: both epilogues deferred
       if (have) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the two-accumulator loop below
         int tile0 = ts + tstep;
-        if (have2) {                          // second hoisted tile: the first one's epilogue, then it becomes the pending tile
-          epilogue(cellC.x, tile_q(cellC), accC);
+        if (have2) {
+          two = ts + 2 * tstep >= te;
+          if (!two) {                         // more than two tiles: the first one's epilogue now, the second becomes the pending tile
+            epilogue(cellC.x, tile_q(cellC), accC);
 #pragma unroll
-          for (int ct = 0; ct < NCT; ct++) accC[ct] = accS[ct];
-          cellC = cellS;
-          tile0 = ts + 2 * tstep;
+            for (int ct = 0; ct < NCT; ct++) accC[ct] = accS[ct];
+            cellC = cellS;
+            tile0 = ts + 2 * tstep;
+          }
         }
-        for (int tile = tile0; tile < te; tile += tstep) {
-          const int2 cellT = cellN;
-          const RowRegs rowsA = rowsN;
-          cellN = cellNN;
-          cellNN = tile_cell(tile + 2 * tstep);
-          load_rows(next_rows(cellN, cellT), g, D.NT4, D.tail, rowsN);
-          f32x4 accT[NCT];
-          tile_dots_regs<NCT>(lds4, rowsA, cellT.x >= 0, lane, D.NS, D.NT4, D.tail, accT);   // MFMA pipe: tile i+1
-          epilogue(cellC.x, tile_q(cellC), accC);                                           // VALU pipe: tile i
+        if (!two) {
+          for (int tile = tile0; tile < te; tile += tstep) {
+            const int2 cellT = cellN;
+            const RowRegs rowsA = rowsN;
+            cellN = cellNN;
+            cellNN = tile_cell(tile + 2 * tstep);
+            ld_rows(next_rows(cellN, cellT), rowsN);
+            f32x4 accT[NCT];
+            dots_regs(rowsA, cellT.x >= 0, accT);   // MFMA pipe: tile i+1
+            epilogue(cellC.x, tile_q(cellC), accC);                                           // VALU pipe: tile i
 #pragma unroll
-          for (int ct = 0; ct < NCT; ct++) accC[ct] = accT[ct];
-          cellC = cellT;
+            for (int ct = 0; ct < NCT; ct++) accC[ct] = accT[ct];
+            cellC = cellT;
+          }
         }
-        // last tile of the block: next block's first rows requested first (older than everything below), then the
-        // epilogue with DEFERRED stores, the objective slot, the contribution atomics, and only then the tile's R stores
+        // next block's first rows requested first (older than everything below), then the epilogue(s) with DEFERRED stores and the
+        // contribution atomics
         lap(w1);
-        if (haveN) load_rows(D.Zc + (size_t)(cN1.x >= 0 ? cN1.x : 0) * zs, g, D.NT4, D.tail, rowsN);
+        if (haveN) ld_rows(D.Zc + (size_t)(cN1.x >= 0 ? cN1.x : 0) * zs, rowsN);
         epi_begin(tile_q(cellC));
         epi_rows(cellC.x, accC, std::true_type{});
+        if (two) {
+          epi_begin(tile_q(cellS));
+          epi_rows(cellS.x, accS, std::true_type{});
+        }
         lap(w2);
         if (curq >= 0) flush_run();
-        store_rows(cellC.x, accC);
         lap(w3);
-        // in-order retirement: at most the youngest NCT*4 - 4 operations (all of them R stores) may still be in flight
-        __builtin_amdgcn_s_waitcnt(0x0F70 | ((NCT * 4 - 4) & 15) | ((((NCT * 4 - 4) >> 4) & 3) << 14));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's atomics have been performed (no stores queued behind them)
       } else {
-        if (haveN) load_rows(D.Zc + (size_t)(cN1.x >= 0 ? cN1.x : 0) * zs, g, D.NT4, D.tail, rowsN);
+        if (haveN) ld_rows(D.Zc + (size_t)(cN1.x >= 0 ? cN1.x : 0) * zs, rowsN);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       lap(ww);
       wv_busy += w_prev - t_tab; wv_tiles += have ? (unsigned long long)((te - ts + tstep - 1) / tstep) : 0ull;
-      // a BARE s_barrier: __syncthreads() is also a workgroup-scope fence, i.e. an s_waitcnt vmcnt(0) that would wait for the
-      // R stores after all.  Nothing another wave of this workgroup reads is published here -- the barrier only says "every
-      // wave's contribution atomics have been performed" (each wave waited for its own above).
+      // a BARE s_barrier (not __syncthreads(): nothing another wave of this workgroup reads is published here -- the barrier only
+      // says "every wave's contribution atomics have been performed", each wave waited for its own above).
       __builtin_amdgcn_s_barrier();
       if (tid == 0) atomicAdd(&ctl[8 + 8 * jj + ((int)blockIdx.x & 7)], 1);          // arrival of this workgroup
+      const bool st1 = have, st2 = have && two;
+      const int sc1 = cellC.x, sc2 = cellS.x;
       if (more) { p0 = p0n; ts = tsn; te = ten; cellN = cN1; cellNN = cNN1; }
       lap(wd);
       have = haveN;
-      if (have) first_tile();                           // off the critical path: overlaps the folder's work
+      // off the critical path, in the folder's shadow: rows of the finished tiles out, MFMAs of the next block's tiles in
+      if (st1) store_rows(sc1, accC);
+      if (have) first_tile_a();
+      if (st2) store_rows(sc2, accS);
+      if (have) first_tile_b(); else have2 = false;
+      fetch_next(jj + 2);
       if (D.chain_old && jj + 2 < nbk) old_block(jj + 2);
       lap(wm);
     }
@@ -2190,9 +2353,9 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       const RowRegs rowsA = rowsN;
       cellN = cellNN;
       cellNN = tile_cell(tile + 2 * tstep);
-      load_rows(next_rows(cellN, cellA), g, D.NT4, D.tail, rowsN);
+      ld_rows(next_rows(cellN, cellA), rowsN);
       f32x4 acc[NCT];
-      tile_dots_regs<NCT>(lds4, rowsA, cellA.x >= 0, lane, D.NS, D.NT4, D.tail, acc);
+      dots_regs(rowsA, cellA.x >= 0, acc);
       if constexpr (MODE == 2) erows = &rowsA;
       epilogue(cellA.x, tile_q(cellA), acc);
     }
@@ -2202,6 +2365,27 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     // registers of the tile -- the four lanes that hold a cell's row (k-slots 0..3) add up their squares, scale, and write the
     // normalised pieces back where they came from: no separate pass over Z_corr (it was 67 us of 256 per head at 1M cells).
     auto norm_rows = [&](RowRegs& r, const int cell) __attribute__((always_inline)) {
+      if constexpr (BF) {     // split-bf16 row layout: the groups beyond the row were loaded clamped -- zero them, then as below
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        float ss = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          r.v[t] = (rowmask >> t) & 1 ? r.v[t] : zero4;
+          ss += r.v[t][0] * r.v[t][0] + r.v[t][1] * r.v[t][1] + r.v[t][2] * r.v[t][2] + r.v[t][3] * r.v[t][3];
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        float nrm = sqrtf(ss);
+        nrm = (nrm == 0.0f) ? 1.0f : nrm;
+        const float inv = 1.0f / nrm;
+        float* zrow = D.Zc + (size_t)(cell >= 0 ? cell : 0) * zs;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          r.v[t] = r.v[t] * inv;
+          if (cell >= 0 && ((rowmask >> t) & 1)) *reinterpret_cast<f32x4*>(zrow + 32 * (t >> 1) + 8 * g + 4 * (t & 1)) = r.v[t];
+        }
+        return;
+      }
       float ss = 0.0f;
 #pragma unroll
       for (int t = 0; t < 4; t++) if (t < D.NT4) ss += r.v[t][0] * r.v[t][0] + r.v[t][1] * r.v[t][1] + r.v[t][2] * r.v[t][2] + r.v[t][3] * r.v[t][3];
@@ -2231,9 +2415,9 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         RowRegs rowsA = rowsN;
         cellN = cellNN;
         cellNN = tile_cell(ts + 2 * tstep);
-        load_rows(next_rows(cellN, cellC), g, D.NT4, D.tail, rowsN);
+        ld_rows(next_rows(cellN, cellC), rowsN);
         if constexpr (MODE == 1) { if (D.head_norm) norm_rows(rowsA, cellC.x); }
-        tile_dots_regs<NCT>(lds4, rowsA, cellC.x >= 0, lane, D.NS, D.NT4, D.tail, accC);
+        dots_regs(rowsA, cellC.x >= 0, accC);
       }
       stamp(3);
       // every load of the prologue has landed before the loop is entered: hipcc merges the wait state of the two loop
@@ -2246,7 +2430,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         RowRegs rowsA = rowsN;
         cellN = cellNN;
         cellNN = tile_cell(tile + 2 * tstep);
-        load_rows(next_rows(cellN, cellT), g, D.NT4, D.tail, rowsN);
+        ld_rows(next_rows(cellN, cellT), rowsN);
         if constexpr (MODE == 1) { if (D.head_norm) norm_rows(rowsA, cellT.x); }
         stamp(9);
         f32x4 accT[NCT];
@@ -2255,7 +2439,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         if (dbg & 2) {
 #pragma unroll
           for (int ct = 0; ct < NCT; ct++) accT[ct] = rowsA.v[0];
-        } else tile_dots_regs<NCT>(lds4, rowsA, cellT.x >= 0, lane, D.NS, D.NT4, D.tail, accT);
+        } else dots_regs(rowsA, cellT.x >= 0, accT);
         stamp(10);
         if (!(dbg & 1)) epilogue(cellC.x, tile_q(cellC), accC);
         else {
@@ -2264,7 +2448,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         }
         stamp(11);
 #else
-        tile_dots_regs<NCT>(lds4, rowsA, cellT.x >= 0, lane, D.NS, D.NT4, D.tail, accT);   // MFMA pipe: tile i+1
+        dots_regs(rowsA, cellT.x >= 0, accT);   // MFMA pipe: tile i+1
         epilogue(cellC.x, tile_q(cellC), accC);                                           // VALU pipe: tile i
 #endif
 #pragma unroll
@@ -2281,7 +2465,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       cellN = cellNN;
       cellNN = tile_cell(tile + 2 * tstep);
       f32x4 acc[NCT];
-      tile_dots<NCT>(lds4, D.Zc + (size_t)(cellA.x >= 0 ? cellA.x : 0) * zs, cellA.x >= 0, g, lane, D.NS, D.NT4, D.tail, acc);
+      dots_stream(D.Zc + (size_t)(cellA.x >= 0 ? cellA.x : 0) * zs, cellA.x >= 0, acc);
       epilogue(cellA.x, tile_q(cellA), acc);
     }
   }
@@ -2316,6 +2500,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 
 
 
+#if !HMX_TILE_BF
 // cross-entropy term of the objective from the K x B tables alone (src/harmony.cpp:162):
 //   sum_k sigma_k sum_b theta_b log((O+E+1)/(2E+1)) * O[k,b]     (O[k,b] = sum_{i in b} R_ki)
 // single workgroup; obj[2..4] = {dist, entropy, cross} snapshot, obj[0..1] reset.
@@ -2759,6 +2944,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
     D.Ycur[(size_t)k * d + j] = y;
     D.Yt[(size_t)j * K + k] = y;
     D.Yimg[yimg_index(D, j, k)] = y;
+    bfimg_store(D.Yimg3, D.NCT, D.NS2, j, k, y);
   }
 }
 
@@ -3243,6 +3429,7 @@ __global__ __launch_bounds__(64) void k_lloyd_finish(Dev D) {
     D.Ycur[(size_t)k * d + j] = y;
     D.Yt[(size_t)j * K + k] = y;
     D.Yimg[yimg_index(D, j, k)] = y;
+    bfimg_store(D.Yimg3, D.NCT, D.NS2, j, k, y);
     s2 += y * y;
   }
   // ||y_k||^2 as the host computes it: sequential fp32 sum over j (d <= 128: lane-serial is fine for K blocks)
@@ -3253,11 +3440,27 @@ __global__ __launch_bounds__(64) void k_lloyd_finish(Dev D) {
   (void)s2;
 }
 
+#endif  // !HMX_TILE_BF
 // --------------------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------------------
+#if HMX_TILE_BF
+#define HMX_LNAME(x) x##_bf
+#else
+#define HMX_LNAME(x) x
 size_t lds_bytes_y(const Dev& D) { return (size_t)D.d * D.KP * sizeof(float); }
+#endif
+// bytes of the centroid image the tile kernels of THIS translation unit stage in LDS, and of the split-bf16 one
+static inline size_t bf_image_bytes(const Dev& D) { return (size_t)D.NCT * D.NS2 * 3 * 1024; }
+static inline size_t tile_image_bytes(const Dev& D) { return HMX_TILE_BF ? bf_image_bytes(D) : (size_t)D.NQ * D.NS * 64 * sizeof(f32x4); }
+constexpr size_t LDS_PER_CU = 160 * 1024;
+// the split-bf16 build of a launch is taken when the workgroups that are to share a CU still fit its LDS with the larger image
+static inline bool bf_fits(const Dev& D, size_t rest, long long blocks) {
+  const long long per_cu = (blocks + 255) / 256;
+  return D.dot_bf && D.Yimg3 && (bf_image_bytes(D) + rest) * (size_t)(per_cu < 1 ? 1 : per_cu) <= LDS_PER_CU;
+}
 
+#if !HMX_TILE_BF
 #define HMX_DISPATCH_KD(KERNEL, EXTRA, GRID, LDS, ...)                                         \
   do {                                                                                         \
     const int kpl_ = D.KP / 64, dpl_ = D.d > 64 ? 2 : 1;                                       \
@@ -3310,22 +3513,31 @@ void l_normalize_from(const Launch& L, const float* src, float* dst, int n, int 
   else if (nq <= 32) hipLaunchKernelGGL(k_normalize4<2>, dim3(stream_grid(L, (n + 15) / 16)), dim3(TPB), 0, L.stream, src, dst, n, nq);
   else { l_copy(L, src, dst, (size_t)n * zs); hipLaunchKernelGGL(k_normalize, dim3(stream_grid(L, n)), dim3(TPB), 0, L.stream, dst, n, d, zs); }
 }
+#endif  // !HMX_TILE_BF
 // MFMA tile passes over the static 16-cell tiles: mode 1 = head, mode 2 = Lloyd, mode 3 = seeding race
-void l_tile_static(const Launch& L, const Dev& D, int mode) {
+void HMX_LNAME(l_tile_static)(const Launch& L, const Dev& D, int mode) {
   const int wpb = tile_threads(D.NCT) / 64;
   long long blocks = (((long long)D.ntitems + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
   if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
   if (D.static_maxblocks > 0 && blocks > D.static_maxblocks) blocks = D.static_maxblocks;
-  size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4);
-  if (mode == 2) { lds += ((size_t)D.K * D.d + D.K) * sizeof(long long); if (blocks > 512) blocks = 512; }
+  const size_t rest = mode == 2 ? ((size_t)D.K * D.d + D.K) * sizeof(long long) : 0;
+  if (mode == 2 && blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
+  int thr = tile_threads(D.NCT);
+#if !HMX_TILE_BF
+  if (bf_fits(D, rest, blocks) || (mode == 2 && bf_fits(D, rest, 256))) { l_tile_static_bf(L, D, mode); return; }
+#else
+  // Lloyd with the larger image: two 256-thread workgroups per CU no longer fit next to their K x d sum tables -> one of 512 threads
+  if (mode == 2 && !bf_fits(D, rest, blocks)) { thr = 512; blocks = (blocks + 1) / 2; if (blocks > 256) blocks = 256; }
+#endif
+  const size_t lds = tile_image_bytes(D) + rest;
   const dim3 grid((unsigned)blocks);
   // head / Lloyd.  Head variants: general sigma | uniform sigma (D.usig) | uniform sigma at 4 waves per SIMD (K <= 64)
-#define HMX_TS(N) case N: if (mode == 3) hipLaunchKernelGGL((k_tile<N, 3>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
-                          else if (mode == 2) hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
-                          else if (D.usig) hipLaunchKernelGGL((k_tile<N, 1, 2, true>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); \
-                          else hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); break;
-#define HMX_TSL(N) case N: hipLaunchKernelGGL((k_tile<N, 1, 4, true>), grid, dim3(tile_threads(N)), lds, L.stream, D, 0); break;
+#define HMX_TS(N) case N: if (mode == 3) hipLaunchKernelGGL((k_tile<N, 3>), grid, dim3(thr), lds, L.stream, D, 0); \
+                          else if (mode == 2) hipLaunchKernelGGL((k_tile<N, 2>), grid, dim3(thr), lds, L.stream, D, 0); \
+                          else if (D.usig) hipLaunchKernelGGL((k_tile<N, 1, 2, true>), grid, dim3(thr), lds, L.stream, D, 0); \
+                          else hipLaunchKernelGGL((k_tile<N, 1>), grid, dim3(thr), lds, L.stream, D, 0); break;
+#define HMX_TSL(N) case N: hipLaunchKernelGGL((k_tile<N, 1, 4, true>), grid, dim3(thr), lds, L.stream, D, 0); break;
   if (mode == 1 && D.upd_wps == 4) {
     switch (D.NCT) {
       HMX_TSL(1) HMX_TSL(2) HMX_TSL(3) HMX_TSL(4)
@@ -3341,6 +3553,7 @@ void l_tile_static(const Launch& L, const Dev& D, int mode) {
 #undef HMX_TS
 #undef HMX_TSL
 }
+#if !HMX_TILE_BF
 void l_head(const Launch& L, const Dev& D, int mode) {
   const dim3 grid(stream_grid(L, D.nitems));
   const size_t lds = lds_bytes_y(D);
@@ -3496,7 +3709,9 @@ void l_obj_reduce(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_obj_reduce, dim3(D.objslots), dim3(1024), 0, L.stream, D);
   hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(1), 0, L.stream, D);
 }
-void l_update(const Launch& L, const Dev& D, int j) {
+#endif  // !HMX_TILE_BF
+void HMX_LNAME(l_update)(const Launch& L, const Dev& D, int j) {
+#if !HMX_TILE_BF
   if (D.upd_impl == 1) {
     // a block holds ~n/nb cells; D.upd_cpw cells per wave (tunable: HMX_UPD_CPW)
     const long long waves = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + D.upd_cpw - 1) / D.upd_cpw + 1;
@@ -3504,6 +3719,7 @@ void l_update(const Launch& L, const Dev& D, int j) {
     HMX_DISPATCH_KD(k_update, , grid, lds_bytes_y(D), D, j);
     return;
   }
+#endif
   const long long tiles = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + 15) / 16 + (long long)D.Q + 1;
   const int wpb = D.upd_threads / 64;
   long long blocks = ((tiles + D.upd_tpw - 1) / D.upd_tpw + wpb - 1) / wpb;
@@ -3511,8 +3727,12 @@ void l_update(const Launch& L, const Dev& D, int j) {
   if (blocks > D.nwmax / wpb) blocks = D.nwmax / wpb;
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks);
-  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + (D.fused_fold ? (size_t)D.B * D.K * 8 : 0) +
-                     ((D.pen_lds || D.fused_fold) ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
+  const size_t rest = (D.fused_fold ? (size_t)D.B * D.K * 8 : 0) +
+                      ((D.pen_lds || D.fused_fold) ? ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4 : 0);
+#if !HMX_TILE_BF
+  if (bf_fits(D, rest, blocks)) { l_update_bf(L, D, j); return; }
+#endif
+  const size_t lds = tile_image_bytes(D) + rest;
 #define HMX_UPDL(N) case N: hipLaunchKernelGGL((k_tile<N, 0, 4, true>), grid, dim3(1024), lds, L.stream, D, j); break;
   if (D.upd_wps == 4) {   // hmx_setup: upd_threads == 1024, uniform sigma, K <= 64
     switch (D.NCT) {
@@ -3531,21 +3751,30 @@ void l_update(const Launch& L, const Dev& D, int j) {
   }
 #undef HMX_UPD
 }
-void l_chain(const Launch& L, const Dev& D, int workgroups) {
-  size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4) + (size_t)D.B * D.K * 8 +
-               ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4;
+void HMX_LNAME(l_chain)(const Launch& L, const Dev& D, int workgroups) {
+  const size_t rest = (size_t)D.B * D.K * 8 + ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4;
+#if !HMX_TILE_BF
+  if (D.chain_wps == 2 && bf_image_bytes(D) + rest + 64 <= 150 * 1024 && bf_fits(D, rest, 1)) { l_chain_bf(L, D, workgroups); return; }
+#endif
+  size_t lds = tile_image_bytes(D) + rest;
   if (D.chain_wps >= 3) lds = ((lds + 15) & ~(size_t)15) + (size_t)(4 * D.chain_wps) * ((D.NT4 + D.tail) * 1024 + 1024);   // per wave: glds row image + pair images
   const dim3 grid((unsigned)workgroups);
+#if HMX_TILE_BF
+#define HMX_CH(N) case N: if (D.usig) hipLaunchKernelGGL((k_tile<N, 4, 2, true>), grid, dim3(512), lds, L.stream, D, 0); \
+                          else hipLaunchKernelGGL((k_tile<N, 4>), grid, dim3(512), lds, L.stream, D, 0); break;
+#else
 #define HMX_CH(N) case N: if (D.chain_wps == 4 && D.usig) hipLaunchKernelGGL((k_tile<N, 4, 4, true>), grid, dim3(1024), lds, L.stream, D, 0); \
                           else if (D.chain_wps == 3 && D.usig) hipLaunchKernelGGL((k_tile<N, 4, 3, true>), grid, dim3(768), lds, L.stream, D, 0); \
                           else if (D.usig) hipLaunchKernelGGL((k_tile<N, 4, 2, true>), grid, dim3(512), lds, L.stream, D, 0); \
                           else hipLaunchKernelGGL((k_tile<N, 4>), grid, dim3(512), lds, L.stream, D, 0); break;
+#endif
   switch (D.NCT) {
     HMX_CH(1) HMX_CH(2) HMX_CH(3) HMX_CH(4) HMX_CH(5) HMX_CH(6) HMX_CH(7)
     default: break;
   }
 #undef HMX_CH
 }
+#if !HMX_TILE_BF
 // Self-test of the peer-to-peer inboxes, run by every rank at the same time before the chain may use them: P2P_TEST_STEPS exchanges of
 // a 2048-entry table with known contents through exactly the chain's code path (p2p_send, the same slots, parities and polls),
 // every received value checked.  result[0] = wrong or missing values (0 = pass), result[1] = 100 MHz ticks of the steps after the
@@ -3698,4 +3927,5 @@ void l_lloyd(const Launch& L, const Dev& D) {
   HMX_DISPATCH_KD(k_lloyd, , grid, lds, D);
 }
 
+#endif  // !HMX_TILE_BF
 }  // namespace hmx
