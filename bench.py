@@ -403,11 +403,13 @@ def main():
     run_gbs = run_bytes / (ms_per_step * 1e-3) / 1e9
     nct = (K + 15) // 16
     on_chain = bool(obj._scalar("chain")) and (world == 1 or bool(obj._scalar("p2p")))
-    kname = ("k_tile<%d,4,2,%s> -- the persistent block chain: ONE launch = one round of update_R (%d block steps, every cell once)"
-             % (nct, "true" if obj._scalar("usig") else "false", int(obj._scalar("n_blocks")))) if on_chain else \
-            ("k_tile<%d,0,%d,%s> -- one launch = the block update of one block of update_R" % (nct, int(obj._scalar("upd_wps")), "true" if obj._scalar("usig") else "false"))
+    bf = "true" if obj._scalar("dot_bf") else "false"        # the build of the tile kernels' distance GEMM: split bf16 | fp32 MFMA
+    kname = ("k_tile<%d,4,2,%s,%s> -- the persistent block chain: ONE launch = one round of update_R (%d block steps, every cell once)"
+             % (nct, "true" if obj._scalar("usig") else "false", bf, int(obj._scalar("n_blocks")))) if on_chain else \
+            ("k_tile<%d,0,%d,%s,%s> -- one launch = the block update of one block of update_R" % (nct, int(obj._scalar("upd_wps")), "true" if obj._scalar("usig") else "false", bf))
     roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "mfma_busy_frac": mfma_util,
+                "distance_gemm": "split bf16: 6 x v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block on three exact bf16 parts per fp32 operand" if bf == "true" else "v_mfma_f32_16x16x4_f32",
                 "traffic_and_mfma_busy_are": ("replayed from profiles/pmc_traffic_update_kernel.json (separate rocprofv3 --pmc passes over this kernel, "
                                               "%s); not collected in this run" % pm_note) if traffic is not None else None,
                 "avg_launch_us": 1e3 * upd_ms / max(upd_launches, 1), "launches": int(upd_launches),

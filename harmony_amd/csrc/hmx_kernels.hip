@@ -2257,10 +2257,12 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       // stored in the folder's shadow, interleaved with the next block's MFMAs (which overwrite the same registers).
       bool two = false;                     // both hoisted tiles are the wave's last ones of this block: both epilogues deferred
       if (have) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the two-accumulator loop below
         int tile0 = ts + tstep;
+        if (have2) two = ts + 2 * tstep >= te;
+        // (waves that enter the tile loop: every load has landed before it, see the two-accumulator loop below; the others must not wait
+        //  here -- the oldest operations in flight are the R stores they issued behind the previous arrival)
+        if (!two) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         if (have2) {
-          two = ts + 2 * tstep >= te;
           if (!two) {                         // more than two tiles: the first one's epilogue now, the second becomes the pending tile
             epilogue(cellC.x, tile_q(cellC), accC);
 #pragma unroll

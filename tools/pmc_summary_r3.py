@@ -14,8 +14,8 @@ stats = {r["Name"].split("(")[0].replace("void ", "").strip(): float(r["AverageN
 summ = {"source": "rocprofv3 --pmc <counters> --kernel-trace -- python tools/prof_update.py 1000000 (separate passes per counter group, tools/final_profiles_r3.sh); durations from rocprofv3 --kernel-trace --stats of bench.py (profiles/r3_kernel_stats.csv)",
         "notes": ["FETCH_SIZE / WRITE_SIZE are KB per dispatch (mean)",
                   "gfx950: FETCH_SIZE reports 1/2 of the bytes of coalesced reads (MI355X_MICROARCH.md, HBM section): x2, calibrated on k_copy in the same pass (reads 208.0 MB, FETCH_SIZE 101.6 MB)",
-                  "SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_16x16x4_f32); mfma_busy_frac = MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)",
-                  "k_tile<7,4,2,true> is the persistent block chain: one dispatch = one clustering round = 20 block steps"], "kernels": {}}
+                  "SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_16x16x4_f32, ~16 per v_mfma_f32_16x16x32_bf16); mfma_busy_frac = MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)",
+                  "k_tile<7,4,2,true,true> is the persistent block chain (split-bf16 build): one dispatch = one clustering round = 20 block steps"], "kernels": {}}
 for k in sorted(set(fe) | set(wr) | set(sq)):
     name = k.replace("void ", "").strip(); e = {}
     if k in fe: e["FETCH_SIZE_KB"] = fe[k][0]["FETCH_SIZE"]; e["hbm_read_bytes_corrected"] = 2 * 1000 * fe[k][0]["FETCH_SIZE"]
@@ -30,9 +30,9 @@ for k in sorted(set(fe) | set(wr) | set(sq)):
         if e.get("SQ_VALU_MFMA_BUSY_CYCLES"): e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur * 1e-6 * 2.4e9 * 1024)
     summ["kernels"][name] = e
 json.dump(summ, open(os.path.join(P, "r3_pmc_summary.json"), "w"), indent=1)
-c = summ["kernels"]["hmx::k_tile<7, 4, 2, true>"]
+c = summ["kernels"].get("hmx::k_tile<7, 4, 2, true, true>") or summ["kernels"]["hmx::k_tile<7, 4, 2, true, false>"]
 json.dump({"workload": {"cells_per_gpu": 1000000, "pcs": 50, "clusters": 100, "batches": 10},
-           "kernel": "k_tile<7,4,2,true> (persistent block chain, one launch = 20 block steps)",
+           "kernel": "k_tile<7,4,2,true,true> (persistent block chain, split-bf16 build, one launch = 20 block steps)",
            "hbm_bytes_per_launch": c["hbm_total_bytes"], "mfma_busy_frac": c["mfma_busy_frac"], "collected": "round 3, on the final code (tools/final_profiles_r3.sh)",
            "source": "profiles/r3_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs); separate --pmc passes)"},
           open(os.path.join(P, "pmc_traffic_update_kernel.json"), "w"), indent=1)
