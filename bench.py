@@ -331,7 +331,7 @@ def main():
     obj.setup(**skw)
     t_setup = time.perf_counter() - t_setup
     ingest_ms = obj.timer("ingest_Z")     # H2D of Z (N*d*8 B from pageable host memory) + fp32 conversion, inside setup
-    del Z
+    del Z                                 # (skw keeps the d x N matrix the library was given)
 
     def sync():
         torch.cuda.synchronize()
@@ -445,11 +445,22 @@ def main():
         zc32 = obj.get_matrix("Z_corr", np.float32)
         egress32_ms = 1e3 * (time.perf_counter() - t1)
         del zc, zc32
-        e2e = {"T_conv_ms": ms_per_step, "ingest_Z_f64_ms": ingest_ms, "egress_Zcorr_f64_ms": egress_ms,
+        ingest_first_ms = ingest_ms
+        if world == 1:
+            # the ingest again, into a second object: the first setup of a process also carries the HIP runtime's first-use costs
+            # (~20 ms: measured as `ingest_Z_f64_first_call_in_process_ms`), which are not a property of the seam
+            o2 = Harmony(device=local_rank, seed=1)
+            o2.set_stream(torch.cuda.current_stream().cuda_stream)
+            o2.setup(**skw)
+            ingest_ms = o2.timer("ingest_Z")
+            del o2
+        e2e = {"T_conv_ms": ms_per_step, "ingest_Z_f64_ms": ingest_ms, "ingest_Z_f64_first_call_in_process_ms": ingest_first_ms,
+               "egress_Zcorr_f64_ms": egress_ms,
                "egress_Zcorr_f32_ms": egress32_ms, "T_e2e_ms": ms_per_step + ingest_ms + egress_ms,
                "cells_per_sec_e2e": n / ((ms_per_step + ingest_ms + egress_ms) * 1e-3), "setup_total_ms": 1e3 * t_setup,
-               "note": "per GPU; the caller's (pageable) buffers are page-locked for the transfer (HMX_PIN=0: left pageable); the fp64 egress is mostly the "
-                       "first touch of the fresh host array; setup_total also holds Phi -> level codes and the combination sort on the host"}
+               "note": "per GPU; pageable fp64 matrices on the host side (the R seam), moved through a ring of page-locked slots by 8 host threads while the DMA "
+                       "engine works (HMX_XFER=pin: register the caller's matrix instead; HMX_PIN=0: plain pageable copies); the process' one-time "
+                       "costs (ring allocation, code-object load) are in setup_total, which also holds Phi -> level codes and the combination sort on the host"}
     out = {
         "metric": "cells_per_sec_to_convergence", "value": N / (ms_per_step * 1e-3), "unit": "cells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,

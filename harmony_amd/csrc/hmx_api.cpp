@@ -10,6 +10,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -91,6 +93,96 @@ bool host_pin_enabled() { const char* e = getenv("HMX_PIN"); return !(e && atoi(
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// ---- host side of the R seam (R/ui.R:178-183, 292-295: a pageable fp64 matrix in, a fresh pageable fp64 matrix out) ---------------------
+// Page-locking the caller's 400 MB matrix for one transfer costs more than the transfer (every page is faulted in and pinned by ONE thread
+// before the first byte moves).  Default path instead: a small ring of page-locked buffers, allocated once per process, and a few host
+// threads that move the bytes between the caller's matrix and the ring slot by slot while the DMA engine moves the previous slots --
+// on egress the threads are also the ones that first touch the fresh destination pages, in parallel.  HMX_XFER=pin: register the caller's
+// buffer (the earlier path); HMX_PIN=0: plain pageable copies; HMX_XFER_THREADS: threads (default 8).
+struct XferPool {
+  // (the workers SPIN between the slots of one transfer -- a transfer lasts ~10-20 ms and hands out a slot every ~0.5 ms; waking sleeping
+  //  threads through a condition variable for every slot cost more than the copies)
+  std::vector<std::thread> th;
+  const char* src = nullptr; char* dst = nullptr; size_t bytes = 0;
+  std::atomic<size_t> next{0};
+  std::atomic<int> gen{0}, running{0};
+  std::atomic<bool> stop{false};
+  static constexpr size_t CHUNK = 1 << 20;
+  void work() {
+    for (;;) {
+      const size_t off = next.fetch_add(CHUNK);
+      if (off >= bytes) break;
+      memcpy(dst + off, src + off, std::min(CHUNK, bytes - off));
+    }
+  }
+  void loop() {
+    int seen = 0;
+    for (;;) {
+      int g;
+      while ((g = gen.load(std::memory_order_acquire)) == seen) {
+        if (stop.load(std::memory_order_relaxed)) return;
+        __builtin_ia32_pause();
+      }
+      seen = g;
+      work();
+      running.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void start(int T) { for (int i = 0; i < T; i++) th.emplace_back([this] { loop(); }); }
+  void copy(void* d, const void* s_, size_t n) {           // blocking; the caller works too
+    if (th.empty() || n < 4 * CHUNK) { memcpy(d, s_, n); return; }
+    src = (const char*)s_; dst = (char*)d; bytes = n; next.store(0);
+    running.store((int)th.size(), std::memory_order_relaxed);
+    gen.fetch_add(1, std::memory_order_release);
+    work();
+    while (running.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  }
+  ~XferPool() {
+    stop.store(true);
+    for (auto& t : th) t.join();
+  }
+};
+struct XferRing {     // page-locked staging slots + the copy stream, HBM staging slabs and events of a transfer: one set per device and
+                      // process, built (and run through once) on first use, shared by all handles (guarded: one transfer at a time)
+  static constexpr int NB = 4;
+  static constexpr size_t SLOT = (size_t)16 << 20;
+  std::mutex mu, init_mu;
+  void* slot[NB] = {nullptr, nullptr, nullptr, nullptr};
+  void* stage[2] = {nullptr, nullptr};                       // HBM staging slabs (SLOT bytes each)
+  hipStream_t cs = nullptr;
+  hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr}, ev_slot[NB] = {nullptr, nullptr, nullptr, nullptr};
+  bool ok = false, tried = false;
+  bool ensure() {
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (tried) return ok;
+    tried = true;
+    bool good = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < NB && good; i++) good = hipHostMalloc(&slot[i], SLOT, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev_slot[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && good; i++) good = hipMalloc(&stage[i], SLOT) == hipSuccess && hipEventCreateWithFlags(&ev_a[i], hipEventDisableTiming) == hipSuccess &&
+                                               hipEventCreateWithFlags(&ev_b[i], hipEventDisableTiming) == hipSuccess;
+    // first touch from both sides and one pass through exactly the calls a transfer makes (the CPU faults the slots' pages in on its
+    // first write, the device maps them and sets up its copy queues on the first asynchronous copy): once per process instead of inside
+    // the first matrix's transfer
+    for (int i = 0; i < NB && good; i++) {
+      memset(slot[i], 0, SLOT);
+      good = hipMemcpyAsync(stage[i & 1], slot[i], SLOT, hipMemcpyHostToDevice, cs) == hipSuccess && hipEventRecord(ev_slot[i], cs) == hipSuccess &&
+             hipMemcpyAsync(slot[i], stage[i & 1], SLOT, hipMemcpyDeviceToHost, cs) == hipSuccess && hipEventRecord(ev_a[i & 1], cs) == hipSuccess &&
+             hipEventSynchronize(ev_slot[i]) == hipSuccess;
+    }
+    if (good) good = hipStreamSynchronize(cs) == hipSuccess;
+    if (!good) (void)hipGetLastError();
+    return ok = good;
+  }
+};
+XferRing& xfer_ring(int device) { static std::mutex m; static std::map<int, XferRing> rings; std::lock_guard<std::mutex> lk(m); return rings[device]; }
+int xfer_mode() {     // 0 pageable copies, 1 register the caller's buffer, 2 ring of page-locked slots + host threads (default)
+  if (!host_pin_enabled()) return 0;
+  const char* e = getenv("HMX_XFER");
+  if (e && std::string(e) == "pin") return 1;
+  return 2;
+}
+int xfer_threads() { const char* e = getenv("HMX_XFER_THREADS"); const int t = e ? atoi(e) : 8; return std::max(0, std::min(t, 64)) ; }
 
 }  // namespace
 
@@ -1758,6 +1850,11 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   HIPCHK(hipMemsetAsync(D.Wq, 0, sizeof(float) * (size_t)Q * K * d, ctx->L.stream));
   // Z: d x N (cell-major), double (the R seam, conv_to :41) or float, on the host or already in HBM -> fp32 rows in internal
   // order.  Host input goes through two HBM staging slabs: the copy of slab s+1 (copy stream) overlaps the conversion of slab s.
+  if (z_location != HMX_DEVICE && xfer_mode() == 2) (void)xfer_ring(ctx->device).ensure();    // (once per process: not part of a matrix's transfer time)
+  // (the buffers' first touch by the clears above is allocate_buffers' time, and the first launch of a library kernel in a process loads the
+  //  code object -- tens of ms once per process --: neither is the ingest's)
+  l_copy(ctx->L, D.Zo, D.Zo, 0); KCHK();
+  HIPCHK(hipStreamSynchronize(ctx->L.stream));
   {
     const double t_in = now_ms();
     const int f32 = z_dtype == HMX_F32;
@@ -1765,13 +1862,43 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     if (z_location == HMX_DEVICE) {
       l_convert_in(ctx->L, Z, f32, D.Zo, D.invperm, (int)N, d, D.zs); KCHK();
       HIPCHK(hipStreamSynchronize(ctx->L.stream));
+    } else if (xfer_mode() == 2 && xfer_ring(ctx->device).ensure()) {
+      // ring of page-locked slots: host threads fill slot b while the DMA engine drains the earlier ones and the conversion kernel
+      // consumes what has landed (two HBM staging slabs)
+      XferRing& ring = xfer_ring(ctx->device);
+      std::lock_guard<std::mutex> ring_lock(ring.mu);
+      XferPool pool; pool.start(xfer_threads());
+      const int64_t slab = std::max<int64_t>(1, (int64_t)XferRing::SLOT / ((int64_t)esz * d));
+      hipStream_t cs = ring.cs;
+      hipEvent_t* copied = ring.ev_a; hipEvent_t* used = ring.ev_b; hipEvent_t* left = ring.ev_slot;   // left[b]: slot b's bytes have left for the device
+      ctx->timers["ingest_pinned"] = 2.0;
+      hipError_t e = hipSuccess;
+      int it = 0;
+      for (int64_t s0 = 0; s0 < N && e == hipSuccess; s0 += slab, it++) {
+        const int64_t cnt = std::min<int64_t>(slab, N - s0);
+        const size_t nbytes = (size_t)cnt * d * esz;
+        const int b = it & 1, rb = it % XferRing::NB;
+        if (it >= XferRing::NB) e = hipEventSynchronize(left[rb]);
+        if (e != hipSuccess) break;
+        pool.copy(ring.slot[rb], (const char*)Z + (size_t)s0 * d * esz, nbytes);
+        if (it >= 2) e = hipStreamWaitEvent(cs, used[b], 0);           // the slab's previous conversion has read it
+        if (e == hipSuccess) e = hipMemcpyAsync(ring.stage[b], ring.slot[rb], nbytes, hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipEventRecord(left[rb], cs);
+        if (e == hipSuccess) e = hipEventRecord(copied[b], cs);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->L.stream, copied[b], 0);
+        if (e == hipSuccess) { l_convert_in(ctx->L, ring.stage[b], f32, D.Zo, D.invperm + s0, (int)cnt, d, D.zs); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipEventRecord(used[b], ctx->L.stream);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
+      (void)hipStreamSynchronize(cs);
+      if (e != hipSuccess) return fail(ctx, HMX_ERR_DEVICE, hipGetErrorString(e));
     } else {
       const int64_t slab = std::max<int64_t>(1, (int64_t)(128ll << 20) / ((int64_t)esz * d));
       const int64_t scnt = std::min<int64_t>(slab, N);
       void* stage[2] = {nullptr, nullptr}; hipStream_t cs = nullptr; hipEvent_t copied[2] = {nullptr, nullptr}, used[2] = {nullptr, nullptr};
       // The caller's matrix is pageable (R's heap): page-lock it for the duration of the ingest, so that the slab copies are real DMA
       // at PCIe speed instead of the runtime's staged pageable path (HMX_PIN=0 leaves it pageable; a failed registration is not an error).
-      const bool pinned = host_pin_enabled() && hipHostRegister(const_cast<void*>(Z), (size_t)N * d * esz, hipHostRegisterDefault) == hipSuccess;
+      const bool pinned = xfer_mode() >= 1 && hipHostRegister(const_cast<void*>(Z), (size_t)N * d * esz, hipHostRegisterDefault) == hipSuccess;
       if (!pinned) (void)hipGetLastError();
       ctx->timers["ingest_pinned"] = pinned ? 1.0 : 0.0;
       hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
@@ -2263,11 +2390,44 @@ int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype
     l_convert_out(ctx->L, src, out, f32, ctx->D.invperm, ctx->D.n, w, ws);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
+  } else if (xfer_mode() == 2 && xfer_ring(ctx->device).ensure()) {
+    // conversion -> HBM staging slab -> DMA into a page-locked ring slot -> host threads copy the slot into the caller's (fresh, pageable)
+    // matrix, touching its pages in parallel, while the next slots are on their way
+    XferRing& ring = xfer_ring(ctx->device);
+    std::lock_guard<std::mutex> ring_lock(ring.mu);
+    XferPool pool; pool.start(xfer_threads());
+    const int64_t slab = std::max<int64_t>(1, (int64_t)XferRing::SLOT / ((int64_t)esz * w));
+    constexpr int NB = XferRing::NB, LAG = NB - 1;
+    hipStream_t cs = ring.cs;
+    hipEvent_t* conv = ring.ev_a; hipEvent_t* copied = ring.ev_b; hipEvent_t* arrived = ring.ev_slot;
+    const int nslabs = (int)((ctx->N + slab - 1) / slab);
+    auto drain = [&](int j) {          // slab j has arrived in its ring slot: out of the ring, into the caller's matrix
+      const int64_t s0 = (int64_t)j * slab, c = std::min<int64_t>(slab, ctx->N - s0);
+      hipError_t ee = hipEventSynchronize(arrived[j % NB]);
+      if (ee == hipSuccess) pool.copy((char*)out + (size_t)s0 * w * esz, ring.slot[j % NB], (size_t)c * w * esz);
+      return ee;
+    };
+    for (int it = 0; it < nslabs && e == hipSuccess; it++) {
+      const int64_t s0 = (int64_t)it * slab, c = std::min<int64_t>(slab, ctx->N - s0);
+      const int b = it & 1;
+      if (it >= 2) e = hipStreamWaitEvent(ctx->L.stream, copied[b], 0);   // the slab's previous contents have left for the host
+      if (e == hipSuccess) { l_convert_out(ctx->L, src, ring.stage[b], f32, ctx->D.invperm + s0, (int)c, w, ws); e = hipGetLastError(); }
+      if (e == hipSuccess) e = hipEventRecord(conv[b], ctx->L.stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs, conv[b], 0);
+      // (ring slot it % NB was drained by the host in iteration it - NB + LAG, i.e. before this point)
+      if (e == hipSuccess) e = hipMemcpyAsync(ring.slot[it % NB], ring.stage[b], (size_t)c * w * esz, hipMemcpyDeviceToHost, cs);
+      if (e == hipSuccess) e = hipEventRecord(copied[b], cs);
+      if (e == hipSuccess) e = hipEventRecord(arrived[it % NB], cs);
+      if (e == hipSuccess && it >= LAG) e = drain(it - LAG);
+    }
+    for (int j = std::max(0, nslabs - LAG); j < nslabs && e == hipSuccess; j++) e = drain(j);
+    (void)hipStreamSynchronize(cs);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
   } else {
     const int64_t slab = std::max<int64_t>(1, (int64_t)(128ll << 20) / ((int64_t)esz * w));
     const int64_t scnt = std::min<int64_t>(slab, ctx->N);
     void* stage[2] = {nullptr, nullptr}; hipStream_t cs = nullptr; hipEvent_t conv[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
-    const bool pinned = host_pin_enabled() && hipHostRegister(out, (size_t)cnt * esz, hipHostRegisterDefault) == hipSuccess;     // (see hmx_setup_ex)
+    const bool pinned = xfer_mode() >= 1 && hipHostRegister(out, (size_t)cnt * esz, hipHostRegisterDefault) == hipSuccess;     // (see hmx_setup_ex)
     if (!pinned) (void)hipGetLastError();
     e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
