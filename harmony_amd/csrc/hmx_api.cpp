@@ -1702,7 +1702,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   D.KP = (K + 63) / 64 * 64; D.nb = ctx->nb;
   D.zs = (d + 3) / 4 * 4;
   { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 8; if (want > 8) want = 8; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
-  { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
+  { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 14, 16};     // (13: K = 200, BASELINE configs[4])
     const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
   D.lloyd_lds = ((size_t)d * D.KP * 4 + ((size_t)K * d + K) * 8 <= 98304) ? 1 : 0;
   { const char* e = getenv("HMX_MOE_IMPL");

@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void flush_tile_fx(long long* __restrict__ tab, long 
   for (int ct = 0; ct < NCT; ct++) oacc[ct] = 0ull;
 }
 
-// Instantiated cluster-tile counts are {1..8,10,12,14,16} (hmx_setup picks the smallest >= ceil(K/16)): cluster tiles
+// Instantiated cluster-tile counts are {1..8,10,12,13,14,16} (hmx_setup picks the smallest >= ceil(K/16)): cluster tiles
 // below this index are always completely inside K, only the ones from it on can hold k >= K.
 // (cluster tiles are grouped in quads by kcol: the tiles of the last group can hold k >= K)
 constexpr int first_partial_ct(int nct) { return (nct & 3) ? 4 * (nct >> 2) : 4 * ((nct >> 2) - 1); }
@@ -3549,7 +3549,7 @@ void HMX_LNAME(l_tile_static)(const Launch& L, const Dev& D, int mode) {
   }
   switch (D.NCT) {
     HMX_TS(1) HMX_TS(2) HMX_TS(3) HMX_TS(4) HMX_TS(5) HMX_TS(6) HMX_TS(7) HMX_TS(8)
-    HMX_TS(10) HMX_TS(12) HMX_TS(14) HMX_TS(16)
+    HMX_TS(10) HMX_TS(12) HMX_TS(13) HMX_TS(14) HMX_TS(16)
     default: break;
   }
 #undef HMX_TS
@@ -3748,7 +3748,7 @@ void HMX_LNAME(l_update)(const Launch& L, const Dev& D, int j) {
                            else hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(D.upd_threads), lds, L.stream, D, j); break;
   switch (D.NCT) {
     HMX_UPD(1) HMX_UPD(2) HMX_UPD(3) HMX_UPD(4) HMX_UPD(5) HMX_UPD(6) HMX_UPD(7) HMX_UPD(8)
-    HMX_UPD(10) HMX_UPD(12) HMX_UPD(14) HMX_UPD(16)
+    HMX_UPD(10) HMX_UPD(12) HMX_UPD(13) HMX_UPD(14) HMX_UPD(16)
     default: break;
   }
 #undef HMX_UPD
@@ -3885,7 +3885,7 @@ void l_moe_stats_mfma(const Launch& L, const Dev& D) {
 #define HMX_MS2(N) case N: hipLaunchKernelGGL((k_moe_stats_mfma<N, 2>), grid, block, 0, L.stream, D, tpw, npt); break;
   switch (D.NCT) {
     HMX_MS(1) HMX_MS(2) HMX_MS(3) HMX_MS(4) HMX_MS(5) HMX_MS(6) HMX_MS(7) HMX_MS(8)
-    HMX_MS2(10) HMX_MS2(12) HMX_MS2(14) HMX_MS2(16)
+    HMX_MS2(10) HMX_MS2(12) HMX_MS2(13) HMX_MS2(14) HMX_MS2(16)
     default: break;
   }
 #undef HMX_MS

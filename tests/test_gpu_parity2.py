@@ -165,7 +165,7 @@ def test_carried_old_contributions_equal_a_fresh_pass(monkeypatch, shape, chain)
     np.testing.assert_allclose(Oa[:, :L0], Odirect, rtol=2e-6, atol=1e-3)
 
 
-@pytest.mark.parametrize("K", [12, 60, 64, 104, 116, 128, 148, 192, 256])
+@pytest.mark.parametrize("K", [12, 60, 64, 104, 116, 128, 148, 192, 200, 256])
 def test_every_cluster_tile_shape(K):
     """The tile kernels deal clusters to MFMA columns in quads (a lane's columns are consecutive clusters: 16 / 12 / 8 / 4-byte R
     stores, 16-byte penalty reads, one contribution atomic per 64 clusters).  Cluster counts that end inside a full quad, inside
