@@ -170,6 +170,8 @@ struct SolveArgs {
   const float* Of; const float* Ef;   // oe_arith: the fp32 O / E tables that replace the exact fixed-point O (keep rule, lambda = alpha E); else nullptr
   int solve_f32;                      // solve_arith: one covariate -> the reference's closed-form fp32 arrowhead inverse (src/harmony.cpp:575-586)
   size_t lds_b_bytes;              // LDS bytes available for the right-hand sides during the substitution (0: leave them in HBM)
+  size_t lds_body_bytes;           // LDS bytes behind the index arrays (panel / right-hand sides; the combination-row table during the assembly)
+  size_t lds_mask_off;             // byte offset of the coupling masks behind them (0: none -- dense Schur complement)
 };
 
 struct Launch {

@@ -2730,7 +2730,71 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
   const bool full = misc[2] != 0, skipped = !full && misc[1] == 0;
   // correction rows of this cluster start from zero (also the result for a skipped cluster, :449-452)
   for (int i = tid; i < Q * d; i += nt) { const int q = i / d, j = i - q * d; D.Wq[((size_t)q * K + k) * d + j] = 0.0f; }
+  // Combination -> design rows table in LDS (the panel space, free until the Cholesky): with it every entry of the system is summed by ONE
+  // thread over the combinations in ascending order -- the same order as the combination-by-combination loop below (bit-identical
+  // results), without its Q workgroup barriers and read-modify-write round trips (0.26 ms of a 1.2 ms solve at configs[4]).
+  const int nd_ = sch_nd, ms_ = m - nd_;
+  const bool qtab = !skipped && ((size_t)2 * Q * (C + 1) + M + 1) * sizeof(int) <= A.lds_body_bytes;
+  unsigned long long* const dmask = (A.lds_mask_off && qtab && nd_ > 0) ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sm_) + A.lds_mask_off) : nullptr;
+  const int mw = (nd_ + 63) >> 6;         // mask words per row: bit (r - ms) of dmask[a] <=> B[r][a] != 0 (level r meets row a in some combination)
+  if (qtab) {
+    int* const qr = sm_ + PAN_OFF;          // [Q][C + 1]: qr[q][0] = 0 (intercept) if any level of q is kept, else -1; qr[q][1 + c] = row of covariate c's level or -1
+    if (dmask) for (int i = tid; i < ms_ * mw; i += nt) dmask[i] = 0ull;
+    __syncthreads();
+    for (int q = tid; q < Q; q += nt) {
+      int any = -1, rD = -1;
+      for (int c = 0; c < C; c++) {
+        const int ro = row_of[D.qlev[q * C + c]];
+        const int r = ro >= 0 ? prow[ro] : -1;
+        qr[q * (C + 1) + 1 + c] = r;
+        if (r >= 0) any = 0;
+        if (r >= ms_) rD = r;
+      }
+      qr[q * (C + 1)] = any;
+      if (dmask && rD >= 0) {
+        atomicOr(&dmask[0 * mw + ((rD - ms_) >> 6)], 1ull << ((rD - ms_) & 63));
+        for (int c = 0; c < C; c++) { const int r = qr[q * (C + 1) + 1 + c]; if (r >= 0 && r < ms_) atomicOr(&dmask[(size_t)r * mw + ((rD - ms_) >> 6)], 1ull << ((rD - ms_) & 63)); }
+      }
+    }
+    __syncthreads();
+    auto in_q = [&](const int* r, const int a) { bool in = (a == 0); for (int c = 0; c < C; c++) in |= (r[1 + c] == a); return in; };
+    // per design row: the combinations that contain it, ascending (row 0: every combination with a kept level)
+    int* const qoff = qr + Q * (C + 1);     // [m + 1]
+    int* const qlst = qoff + M + 1;         // [<= Q (C + 1)]
+    for (int a = tid; a < m; a += nt) {
+      int cnt = 0;
+      for (int q = 0; q < Q; q++) { const int* r = qr + q * (C + 1); if (r[0] == 0 && in_q(r, a)) cnt++; }
+      qoff[a + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) { qoff[0] = 0; for (int a = 0; a < m; a++) qoff[a + 1] += qoff[a]; }
+    __syncthreads();
+    for (int a = tid; a < m; a += nt) {
+      int o = qoff[a];
+      for (int q = 0; q < Q; q++) { const int* r = qr + q * (C + 1); if (r[0] == 0 && in_q(r, a)) qlst[o++] = q; }
+    }
+    __syncthreads();
+    for (int i = tid; i < m * d; i += nt) {
+      const int j = i / m, a = i - j * m;
+      double sacc = 0.0;
+      for (int x = qoff[a]; x < qoff[a + 1]; x++) sacc += D.Sq[((size_t)qlst[x] * K + k) * d + j];
+      rhs[i] = sacc;
+    }
+    for (int i = tid; i < m * m; i += nt) {
+      const int cb = i / m, ra = i - cb * m;
+      if (ra < cb) continue;                              // lower triangle, mirrored below
+      double sacc = 0.0;
+      if (!(cb >= ms_ && ra != cb)) {                    // (the eliminated covariate's own block is diagonal)
+        // (the lists of the rows ra > 0 are short -- a level's combinations --; every one of them contains row 0)
+        for (int x = qoff[ra]; x < qoff[ra + 1]; x++) { const int q = qlst[x]; if (cb == 0 || cb == ra || in_q(qr + q * (C + 1), cb)) sacc += D.nq[(size_t)q * K + k]; }
+      }
+      cov[(size_t)cb * m + ra] = sacc;
+      cov[(size_t)ra * m + cb] = sacc;
+    }
+    __syncthreads();
+  }
   if (!skipped) {
+    if (!qtab) {
     for (int i = tid; i < m * m; i += nt) cov[i] = 0.0;
     for (int i = tid; i < m * d; i += nt) rhs[i] = 0.0;
     __syncthreads();
@@ -2745,6 +2809,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       }
       __syncthreads();
     }
+    }   // (!qtab)
     if (A.use_s0) {   // ridge_arith = 1: the intercept row's own sequential fp32 totals (k_moe_stats_seq)
       if (tid == 0) cov[0] = D.n0[k];
       for (int j = tid; j < d; j += nt) rhs[(size_t)j * m] = D.S0[(size_t)k * d + j];
@@ -2807,19 +2872,35 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       // S = A - B^T D^-1 B, rhs_A -= B^T D^-1 rhs_D   (cov = [[A, B^T], [B, D]], B = rows >= ms of the first ms columns)
       for (int r = ms + tid; r < m; r += nt) { const double dv = cov[(size_t)r * m + r]; if (!(dv > 0.0)) misc[3] = 1; cov[(size_t)r * m + r] = 1.0 / dv; }
       __syncthreads();
+      // (with the coupling masks only the levels that really meet a row are visited -- the skipped terms are exact zeros, the sums
+      //  keep their order: B is sparse, at configs[4]'s nested covariates a level of the eliminated one meets 3 of the 73 other rows)
       for (int i = tid; i < ms * ms; i += nt) {
         const int cb = i / ms, ra = i - cb * ms;
         if (ra < cb) continue;                      // the Cholesky reads the lower triangle only
         const double* ca = cov + (size_t)ra * m; const double* cc = cov + (size_t)cb * m;
         double sacc = 0.0;
-        for (int r = ms; r < m; r++) sacc += ca[r] * cov[(size_t)r * m + r] * cc[r];
+        if (dmask) {
+          for (int w2 = 0; w2 < mw; w2++) {
+            unsigned long long bits = dmask[(size_t)ra * mw + w2] & dmask[(size_t)cb * mw + w2];
+            while (bits) { const int r = ms + 64 * w2 + __builtin_ctzll(bits); bits &= bits - 1; sacc += ca[r] * cov[(size_t)r * m + r] * cc[r]; }
+          }
+        } else {
+          for (int r = ms; r < m; r++) sacc += ca[r] * cov[(size_t)r * m + r] * cc[r];
+        }
         cov[(size_t)cb * m + ra] -= sacc;
       }
       for (int i = tid; i < ms * d; i += nt) {
         const int j = i / ms, ra = i - j * ms;
         const double* ca = cov + (size_t)ra * m;
         double sacc = 0.0;
-        for (int r = ms; r < m; r++) sacc += ca[r] * cov[(size_t)r * m + r] * rhs[(size_t)j * m + r];
+        if (dmask) {
+          for (int w2 = 0; w2 < mw; w2++) {
+            unsigned long long bits = dmask[(size_t)ra * mw + w2];
+            while (bits) { const int r = ms + 64 * w2 + __builtin_ctzll(bits); bits &= bits - 1; sacc += ca[r] * cov[(size_t)r * m + r] * rhs[(size_t)j * m + r]; }
+          }
+        } else {
+          for (int r = ms; r < m; r++) sacc += ca[r] * cov[(size_t)r * m + r] * rhs[(size_t)j * m + r];
+        }
         rhs[(size_t)j * m + ra] -= sacc;
       }
       __syncthreads();
@@ -2894,7 +2975,8 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
         for (int i = tid; i < nd * d; i += nt) {
           const int j = i / nd, r = ms + (i - j * nd);
           double sacc = rhs[(size_t)j * m + r];
-          for (int a = 0; a < ms; a++) sacc -= cov[(size_t)a * m + r] * rhs[(size_t)j * m + a];
+          if (dmask) { for (int a = 0; a < ms; a++) if ((dmask[(size_t)a * mw + ((r - ms) >> 6)] >> ((r - ms) & 63)) & 1ull) sacc -= cov[(size_t)a * m + r] * rhs[(size_t)j * m + a]; }
+          else for (int a = 0; a < ms; a++) sacc -= cov[(size_t)a * m + r] * rhs[(size_t)j * m + a];
           rhs[(size_t)j * m + r] = sacc * cov[(size_t)r * m + r];
         }
       }
@@ -3863,8 +3945,13 @@ void l_moe_solve(const Launch& L, const Dev& D, const SolveArgs& A0) {
   if (ints + ball <= 150 * 1024) body = std::max(panel, ball);     // the d right-hand sides live in LDS during the substitution
   if (ints + body > 158 * 1024) body = 0;                           // (B + 1 > ~1200 levels: outside the device-solve envelope, see hmx_setup)
   A.lds_b_bytes = (body >= ball) ? ball : 0;
+  A.lds_body_bytes = body;
+  // coupling masks of the Schur complement: one bit per (row, eliminated level) -- only while they are small
+  const size_t maskb = M * ((M + 63) / 64) * sizeof(unsigned long long);
+  const size_t moff = (ints + body + 7) & ~(size_t)7;
+  A.lds_mask_off = (D.C > 1 && body > 0 && moff + maskb <= 159 * 1024) ? moff : 0;
   const int threads = M > 48 ? 1024 : 256;
-  hipLaunchKernelGGL(k_moe_solve, dim3(D.K), dim3(threads), ints + body, L.stream, D, A);
+  hipLaunchKernelGGL(k_moe_solve, dim3(D.K), dim3(threads), A.lds_mask_off ? moff + maskb : ints + body, L.stream, D, A);
 }
 void l_moe_stats_mfma(const Launch& L, const Dev& D) {
   const int npt = (D.d + 15) / 16;
