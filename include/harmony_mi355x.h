@@ -123,7 +123,9 @@ int hmx_compute_objective(hmx_ctx* ctx);
 int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap);
 /* getZcorr / getZorig / getR (src/harmony.cpp:640-655) with a choice of element type (HMX_F64 = the R seam, HMX_F32) and
  * destination (HMX_HOST or HMX_DEVICE pointer); `cap` counts elements.  Host destinations are filled slab by slab
- * through two HBM staging buffers -- no N x w fp64 device copy.  hmx_get(ctx, "Z_corr", ...) is this with (F64, HOST). */
+ * through two HBM staging buffers -- no N x w fp64 device copy -- and a ring of page-locked slots that a few host threads drain
+ * into `out` (pageable, possibly never touched: R's allocMatrix) while the next slabs are on their way.
+ * hmx_get(ctx, "Z_corr", ...) is this with (F64, HOST). */
 int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype, int32_t location, int64_t cap);
 /* writable fields: "max_iter_kmeans" (vignettes/detailedWalkthrough.Rmd:364), "seed",
  * "device" (before setup), "profile" (HIP-event timing of the update kernel, see below),
@@ -134,7 +136,12 @@ int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype
  *   fields "grid", "upd_wps" (before setup), "upd_tpw", "upd_cpw", "upd_impl", "comm_force";
  *   environment, read by hmx_setup: HMX_GRID, HMX_NREP, HMX_UPD_WPS (2|4), HMX_USIG=0 (general-sigma kernels),
  *   HMX_UPD_THREADS, HMX_UPD_MAXBLOCKS, HMX_STATIC_MAXBLOCKS, HMX_UPD_TPW, HMX_UPD_CPW, HMX_FUSED_FOLD=0, HMX_FOLD_IMPL=split,
- *   HMX_OLDSUM_IMPL=gather|stream1, HMX_UPDATE_IMPL=v1, HMX_TILE_IMPL=v1, HMX_MOE_IMPL=v1 (first-generation kernels). */
+ *   HMX_OLDSUM_IMPL=gather|stream1, HMX_UPDATE_IMPL=v1, HMX_TILE_IMPL=v1, HMX_MOE_IMPL=v1 (first-generation kernels),
+ *   HMX_DOT=f32 (tile kernels: fp32-MFMA distance GEMM only; default: the split-bf16 build wherever its LDS image fits -- same
+ *   fp32 accuracy);
+ *   host matrices (hmx_setup / hmx_get_matrix with HMX_HOST): HMX_XFER=pin (register the caller's buffer instead of moving it
+ *   through the process-wide ring of page-locked slots), HMX_XFER_THREADS (host threads that fill / drain the ring, default 8),
+ *   HMX_PIN=0 (plain pageable copies). */
 int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t value);
 
 /* ---- randomness ------------------------------------------------------------------------
