@@ -182,7 +182,11 @@ int xfer_mode() {     // 0 pageable copies, 1 register the caller's buffer, 2 ri
   if (e && std::string(e) == "pin") return 1;
   return 2;
 }
-int xfer_threads() { const char* e = getenv("HMX_XFER_THREADS"); const int t = e ? atoi(e) : 8; return std::max(0, std::min(t, 64)) ; }
+int xfer_threads() {      // (the workers spin while a transfer runs: never more of them than spare cores)
+  const char* e = getenv("HMX_XFER_THREADS");
+  const int t = e ? atoi(e) : 8, spare = (int)std::thread::hardware_concurrency() - 1;
+  return std::max(0, std::min(std::min(t, 64), std::max(spare, 0)));
+}
 
 }  // namespace
 
