@@ -218,7 +218,8 @@ __host__ __device__ inline void kcol_inv(int nct, int k, int& qd, int& i, int& c
 }
 // fp32 -> three bf16 parts by truncation: x = hi + mid + lo EXACTLY (8 + 8 + 8 mantissa bits; both differences are exact in fp32),
 // so a product of two fp32 numbers is the sum of nine exact bf16 x bf16 products; the tile kernels keep the six largest
-// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi: what is dropped is below 2^-25 of |x||y|) and add them in fp32 on the matrix cores.
+// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi: what is dropped -- mid lo + lo mid + lo lo -- is below 2^-21 |x||y| at worst with this
+// truncating split, |mid| < 2^-7 |x|, |lo| < 2^-15 |x|, and ~2^-24 typically: tests/test_abi_cpu.py) and add them in fp32 on the matrix cores.
 __host__ __device__ inline void bf3_split(float x, unsigned short (&p)[3]) {
   union { float f; unsigned u; } a, b;
   a.f = x;

@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void tile_dots_regs(const f32x4* __restrict__ ldsY4, 
 // ---- split-bf16 form of the distance GEMM ---------------------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate on gfx950 (32 cycles per SIMD, on the datapath the epilogue's VALU work needs);
 // v_mfma_f32_16x16x32_bf16 takes ~17 cycles for 8x the products on the matrix cores proper.  With x = hi + mid + lo (three bf16 parts,
-// exact: bf3_split) the 16 x 16 x 32 product of fp32 operands is six bf16 MFMAs (the three dropped cross terms are < 2^-25 |x||y|),
+// exact: bf3_split) the 16 x 16 x 32 product of fp32 operands is six bf16 MFMAs (the three dropped cross terms are < 2^-21 |x||y| at worst, ~2^-24 typically: hmx_internal.h),
 // fp32 accumulation: 12 NCT MFMAs per 64 PCs instead of 16 NCT per 64, at half the cycles each, and VALU work of the SIMD's other
 // wave overlaps them.  A operand (cells): lane (c, g) holds PCs 32 s + 8 g + {0..7} of cell c in step s -- two 16-byte loads -- and
 // splits them in registers (5.5 VALU per value); B operand (centroids): the three parts from the LDS image D.Yimg3, one ds_read_b128 each.

@@ -167,3 +167,49 @@ def test_cluster_to_column_mapping_is_a_bijection():
             seen.update(ks)
         assert seen == set(range(16 * nct))
     assert lib.hmx_cluster_of_column(7, 7, 0) == -1 and lib.hmx_cluster_of_column(0, 0, 0) == -1
+
+
+def test_split_bf16_helpers(tmp_path):
+    """the three-way bf16 split the tile kernels and the host image builder share (hmx_internal.h: bf3_split, bfimg_index):
+    hi + mid + lo reproduces every fp32 number EXACTLY, every part is a bf16 number, the six products the kernels keep reproduce a product
+    to 2^-21 of |x||y| at worst (2^-24 in the median), and the image index is a bijection of (PC, cluster, part) onto the 16-byte-per-lane B-operand layout."""
+    import ctypes as C
+    import subprocess
+    so = tmp_path / "bf3_probe.so"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
+                           os.path.join(ROOT, "tests", "cpp", "bf3_probe.cpp"), "-o", str(so)])
+    lib = C.CDLL(str(so))
+    lib.probe_bf3_split.argtypes = [C.c_float, C.POINTER(C.c_uint16)]
+    lib.probe_bfimg_index.restype = C.c_longlong
+    lib.probe_bfimg_index.argtypes = [C.c_int] * 5
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.normal(size=2000).astype(np.float32), (rng.normal(size=2000) * np.exp(rng.normal(size=2000) * 8)).astype(np.float32),
+                         np.array([0.0, -0.0, 1.0, -1.0, 1 - 2.0**-24, 2.0**-24, 3.4e38, -3.4e38, 1.17549435e-38, 0.1, 1.0 / 3], np.float32)])
+
+    def parts(x):
+        p = (C.c_uint16 * 3)()
+        lib.probe_bf3_split(C.c_float(float(x)), p)
+        return [np.array([int(v) << 16], np.uint32).view(np.float32)[0] for v in p]       # a bf16 number IS the upper half of an fp32 one
+    split = np.array([parts(x) for x in xs], np.float64)                                  # (fp64 holds sums of three fp32 numbers exactly)
+    assert np.array_equal(split.sum(axis=1), xs.astype(np.float64))
+    assert np.all(np.abs(split[:, 1]) <= np.abs(xs) * 2.0**-7 + 1e-45) and np.all(np.abs(split[:, 2]) <= np.abs(xs) * 2.0**-15 + 1e-45)
+    a, b = split[:2000], split[2000:4000]
+    six = a[:, 0] * b[:, 0] + a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0] + a[:, 1] * b[:, 1] + a[:, 0] * b[:, 2] + a[:, 2] * b[:, 0]
+    exact = xs[:2000].astype(np.float64) * xs[2000:4000].astype(np.float64)
+    # dropped: mid lo + lo mid + lo lo < 2 * 2^-7 * 2^-15 |x||y| = 2^-21 |x||y| in the worst case of the truncating split (typically 2^-23):
+    # the size of the rounding error a 50-term fp32 fmaf chain accumulates anyway (test_gpu_dots.py measures both against fp64)
+    rel = np.abs(six - exact) / np.maximum(np.abs(exact), 1e-300)
+    assert rel.max() <= 2.0**-21 and np.median(rel) <= 2.0**-24, (rel.max(), np.median(rel))
+    for nct, ns2, K, d in ((7, 2, 100, 50), (13, 2, 200, 50), (4, 4, 60, 100), (1, 1, 12, 20)):
+        seen = set()
+        for k in range(K):
+            for j in range(d):
+                for part in range(3):
+                    i = lib.probe_bfimg_index(nct, ns2, j, k, part)
+                    assert 0 <= i < nct * ns2 * 3 * 512 and i not in seen
+                    seen.add(i)
+                    lane, slot = (i // 8) % 64, i % 8
+                    assert slot == j % 8 and lane // 16 == (j % 32) // 8 and ((i // 8) // 64) % 3 == part
+                    ct = (i // 8) // 64 // 3 // ns2
+                    assert lib.probe_kcol(nct, ct, lane % 16) == k and ((i // 8) // 64 // 3) % ns2 == j // 32
