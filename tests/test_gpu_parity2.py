@@ -126,6 +126,31 @@ def test_config5_shape_200k():
     print("config5 200k:", s, "subset clusters", c.subset_clusters)
 
 
+def test_chain_with_three_and_more_tiles_per_wave_equals_launch_per_step(monkeypatch):
+    """3M cells: the persistent chain's waves own three and more tiles of a block -- the tile loop in front of the deferred epilogues, rows
+    of the LAST tile stored behind the arrival (the suite's other chain cases stop at two tiles per wave) -- against the launch-per-step
+    kernels on the same data: same kernels' arithmetic, integer O sums => bit-identical (tools/gpu_runs/r3_chain3m.sh is the same check)."""
+    Z, meta, _ = synth(3000000, d=50, levels=(10,), seed=11)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
+    out, Y0 = [], None
+    for chain in ("1", "0"):
+        monkeypatch.setenv("HMX_CHAIN", chain)
+        g = Harmony(seed=3)
+        g.setup(**skw)
+        if Y0 is None:
+            Y0 = g.kmeans_centers()
+        g.init_cluster_cpp(Y0)
+        for _ in range(2):
+            assert g.cluster_cpp() == 0
+            g.moe_correct_ridge_cpp()
+        out.append((int(g._scalar("chain")), g.getZcorr().copy(), np.array(g.objective_kmeans), np.array(g.O)))
+        del g
+    (c1, Z1, o1, O1), (c0, Z0, o0, O0) = out
+    assert c1 == 1 and c0 == 0
+    assert np.array_equal(O1, O0) and len(o1) == len(o0)
+    assert relfro(Z1, Z0) < 1e-6 and float(np.max(np.abs(o1 - o0) / np.abs(o0))) < 1e-6
+
+
 @pytest.mark.parametrize("shape", [dict(N=30000, K=100, levels=(10,)), dict(N=20000, K=60, levels=(3, 4)), dict(N=9000, K=24, levels=(5,))])
 @pytest.mark.parametrize("chain", ["1", "0"])
 def test_carried_old_contributions_equal_a_fresh_pass(monkeypatch, shape, chain):
