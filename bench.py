@@ -12,8 +12,9 @@ Other driver-reproducible modes:
     --cells-per-gpu 10000000 --batches 20          north_star target: 10M x 50 x K=100 on ONE GPU (configs[3]'s size)
     --workload c5 [--cells-per-gpu N]              configs[4] shape: K=200, 3 nested covariates 8 > 64 > 128 (200 levels)
     --total-cells 10000000 --batches 20 --gpus N   STRONG scaling: configs[3] = 10M cells in total, sharded over the N GPUs
-    --also ref,10M,c5 (default at N=1; "none")     extra legs of the same invocation, reported under "also": the reference-arithmetic
-                                                   mode on the main workload, 10M cells on this one GPU, the configs[4] shape at 1M
+    --also ref,10M,c5,pbmc (default at N=1; "none")  extra legs of the same invocation, reported under "also": the reference-arithmetic
+                                                   mode on the main workload, 10M cells on this one GPU, the configs[4] shape at 1M,
+                                                   configs[1] (pbmc, 30k cells) with its own CPU-oracle timing and parity check
 
 A "step" = one full run from HBM-resident inputs: hmx_restart -> init_cluster_cpp (k-means seeding + 10 Lloyd)
 -> {cluster_cpp, moe_correct_ridge_cpp, check_convergence}* until converged.  Prints ONE JSON line (rank 0).
@@ -116,18 +117,23 @@ def cpu_baseline(cells, d, K, levels, nested, seed):
 def _full_size_cpu():
     """the same oracle at the FULL configs[2] size, from the committed parity table (profiles/, a builder run: ~1 minute of CPU)"""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r3_parity_table_1000000.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", "r4_parity_table_1000000.json" if os.path.exists(os.path.join(ROOT, "profiles", "r4_parity_table_1000000.json")) else "r3_parity_table_1000000.json")))
         s = j["seconds"]["oracle_faithful"]
         return {"cells": j["workload"]["cells"], "seconds": s, "value": j["workload"]["cells"] / s, "unit": "cells/s",
-                "source": "profiles/r3_parity_table_1000000.json (tests/test_gpu_parity2.py::test_arithmetic_gap_table[1000000]; 4 BLAS threads, "
+                "source": "profiles/r*_parity_table_1000000.json of the latest round (tests/test_gpu_parity2.py::test_arithmetic_gap_table[1000000]; 4 BLAS threads, "
                           "shared k-means centres: the init is not in this figure)"}
     except Exception:
         return None
 
 
-def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps, warmup, sync, **hkw):
-    """one extra workload / mode on this GPU: time to convergence from HBM-resident inputs, same step definition as the main line"""
-    Z, meta, _ = synth(n, d=d, levels=levels, seed=seed, nested=nested)
+def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps, warmup, sync, data=None, **hkw):
+    """one extra workload / mode on this GPU: time to convergence from HBM-resident inputs, same step definition as the main line;
+    `data` = (Z, meta, label) replaces the synthetic generator (the pbmc 30k leg)"""
+    if data is None:
+        Z, meta, _ = synth(n, d=d, levels=levels, seed=seed, nested=nested)
+        label = "synthetic %d cells x %d PCs, K=%d, levels %s%s" % (n, d, K, "x".join(map(str, levels)), " nested" if nested else "")
+    else:
+        Z, meta, label = data
     skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
     o = Harmony(seed=1, **hkw)
     o.setup(**skw)
@@ -143,11 +149,19 @@ def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps,
     ph = {k: round(o._scalar("gputimer:" + k) / steps, 3) for k in ("kmeans_centers", "cluster_head", "randomize", "EO_update", "Rcells_update",
                                                                      "objective", "ridge_statistics", "arma_inv", "update_Zcorr")}
     upd_ms, upd_steps = o._scalar("prof:update_ms"), max(o._scalar("prof:update_steps"), 1)
+    upd_cells = o._scalar("prof:update_cells")
     kr = np.asarray(o.kmeans_rounds, dtype=np.int64)
     run_bytes = float(n) * float(np.sum(4.0 * d * (4 + kr) + 4.0 * K * (3 + 2 * kr)))
-    out = {"workload": "synthetic %d cells x %d PCs, K=%d, levels %s%s" % (n, d, K, "x".join(map(str, levels)), " nested" if nested else ""),
+    chain = bool(o._scalar("chain"))
+    ach = upd_cells * (4.0 * d + 4.0 * K) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    out = {"workload": label,
            "ms_per_step": ms, "cells_per_s": n / (ms * 1e-3), "harmony_iterations": its, "steps": steps, "gpu_phase_ms_per_step": ph,
-           "block_chain": bool(o._scalar("chain")), "avg_block_step_us": 1e3 * upd_ms / upd_steps,
+           "block_chain": chain, "avg_block_step_us": 1e3 * upd_ms / upd_steps,
+           # the leg's own dominant kernel (the E-step update of update_R, as on the main line): algorithmic bytes (4d + 4K per cell and
+           # round) over its HIP-event time on the library's stream
+           "roofline": {"kernel": ("k_tile<%d,4,...> persistent block chain" if chain else "k_tile<%d,0,...> one launch per block step") % ((K + 15) // 16),
+                        "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                        "kernel_time_share": upd_ms / (ms * steps) if ms > 0 else None},
            "roofline_run_frac": run_bytes / (ms * 1e-3) / 8e12}
     if hkw:
         out["mode"] = hkw
@@ -155,6 +169,72 @@ def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps,
     del o
     return out
 
+
+def pbmc30k_leg(Harmony, prepare_setup_args, sync):
+    """BASELINE configs[1] at its stated size: ~30k cells x 50 PCs, K = 50, stim / ctrl (bench_data.pbmc30k: the shipped 2 000-cell sample
+    resampled to 30k), GPU vs the CPU oracle on the same box -- timed, and compared (the GPU run is checked against this very oracle run)"""
+    from bench_data import pbmc30k
+    from oracle.oracle import OracleHarmony, use_openblas
+    Z, meta = pbmc30k()
+    n, d, K = Z.shape[0], Z.shape[1], 50
+    leg = bench_leg(Harmony, prepare_setup_args, n, d, K, (2,), False, 0, 5, 2, sync,
+                    data=(Z, meta, "pbmc_stim stand-in: %d cells x %d PCs, K=%d, stim/ctrl (BASELINE configs[1])" % (n, d, K)))
+    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
+    g = Harmony(seed=1)
+    g.setup(**skw)
+    Y0 = g.kmeans_centers()
+    g.init_cluster_cpp(Y0)
+    cpu = {}
+    for tag, threads, mask in (("oracle_faithful_1_thread", 1, 0), ("oracle_accurate_4_threads", 4, 15)):
+        use_openblas(threads)
+        o = OracleHarmony(mask=mask, seed=1)
+        o.setup(**skw)
+        t0 = time.time()
+        o.init_cluster_cpp(Y0)
+        it = 0
+        for it in range(1, 11):
+            o.cluster_cpp(); o.moe_correct_ridge_cpp()
+            if o.check_convergence(1):
+                break
+        dt = time.time() - t0
+        cpu[tag] = {"seconds": dt, "cells_per_s": n / dt, "iterations": it, "Z": o.getZcorr()}
+    ig = 0
+    for ig in range(1, 11):
+        g.cluster_cpp(); g.moe_correct_ridge_cpp()
+        if g.check_convergence(1):
+            break
+    Zg = g.getZcorr()
+    leg["cpu_oracle"] = {k: {kk: vv for kk, vv in v.items() if kk != "Z"} for k, v in cpu.items()}
+    leg["parity_this_run"] = {"Z_rel_vs_oracle_accurate": float(np.linalg.norm(Zg - cpu["oracle_accurate_4_threads"]["Z"]) / np.linalg.norm(cpu["oracle_accurate_4_threads"]["Z"])),
+                              "Z_rel_vs_oracle_faithful": float(np.linalg.norm(Zg - cpu["oracle_faithful_1_thread"]["Z"]) / np.linalg.norm(cpu["oracle_faithful_1_thread"]["Z"])),
+                              "iterations_gpu": ig, "shared": "k-means centres and block partitions"}
+    leg["gpu_vs_cpu_1_thread"] = leg["cells_per_s"] / cpu["oracle_faithful_1_thread"]["cells_per_s"]
+    return leg
+
+
+def headline_parity(n, d, K, levels):
+    """where the HEADLINE mode (exact accumulators) stands against both oracle arithmetics at this exact workload, replayed from the committed
+    parity table of the round (tests/test_gpu_parity2.py::test_arithmetic_gap_table, a driver-run GPU test) -- so that nobody reads `value` as
+    a faithful-arithmetic number: the mode that follows the reference's fp32 arithmetic is `also.reference_arith`"""
+    for tag in ("r4", "r3"):
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", "%s_parity_table_%d.json" % (tag, n))))
+        except Exception:
+            continue
+        w = j["workload"]
+        if (w["cells"], w["pcs"], w["clusters"], w["batches"]) != (n, d, K, levels[0]) or len(levels) != 1:
+            continue
+        pr = j["pairs"]
+        return {"parity_mode": "default: exact accumulators (64-bit fixed point / fp64 in a fixed order); parity target = the oracle with fp64 accumulators",
+                "Z_rel_vs_accurate": pr["gpu_vs_oracle_accurate"]["Z_rel"], "Z_rel_vs_faithful": pr["gpu_vs_oracle_faithful"]["Z_rel"],
+                "clear_flips_vs_accurate": pr["gpu_vs_oracle_accurate"]["argmax_diff_margin_ge_1e-5"],
+                "clear_flips_vs_faithful": pr["gpu_vs_oracle_faithful"]["argmax_diff_margin_ge_1e-5"],
+                "reference_arith_mode": {"Z_rel_vs_faithful": pr["gpu_ref_arith_vs_oracle_faithful"]["Z_rel"],
+                                         "clear_flips_vs_faithful": pr["gpu_ref_arith_vs_oracle_faithful"]["argmax_diff_margin_ge_1e-5"],
+                                         "timed_as": "also.reference_arith"},
+                "the_reference_itself_faithful_vs_accurate": pr["oracle_faithful_vs_oracle_accurate"]["Z_rel"],
+                "replayed_from": "profiles/%s_parity_table_%d.json (not measured in this run; cpu_baseline.gpu_reference_arith_vs_this_run is a live check on a sample)" % (tag, n)}
+    return None
 
 
 def _free_port():
@@ -174,8 +254,8 @@ def main():
                     "c5: configs[4] shape, K=200, nested covariates 8 > 64 > 128")
     ap.add_argument("--cells-per-gpu", type=int, default=1000000)
     ap.add_argument("--total-cells", type=int, default=0, help="strong scaling: this many cells in TOTAL, sharded over --gpus (overrides --cells-per-gpu)")
-    ap.add_argument("--also", default=None, help="extra legs at N=1, comma separated: ref (reference arithmetic on the main workload), 10M, c5; "
-                    "default 'ref,10M,c5' for the default workload on one GPU, 'none' otherwise")
+    ap.add_argument("--also", default=None, help="extra legs at N=1, comma separated: ref (reference arithmetic on the main workload), 10M, c5, pbmc "
+                    "(configs[1] at its stated size, with its own CPU oracle timing); default 'ref,10M,c5,pbmc' for the default workload on one GPU, 'none' otherwise")
     ap.add_argument("--pcs", type=int, default=50)
     ap.add_argument("--clusters", type=int, default=None)
     ap.add_argument("--batches", type=int, default=10)
@@ -475,8 +555,11 @@ def main():
                    "gpu_phase_ms_per_step": gpu_phase, "chain_us_per_block_step": chain, "e2e": e2e},
         "roofline": roofline,
     }
+    hp = headline_parity(n, d, K, levels) if world == 1 else None
+    if hp:
+        out.update({"parity_mode": hp["parity_mode"], "Z_rel_vs_accurate": hp["Z_rel_vs_accurate"], "Z_rel_vs_faithful": hp["Z_rel_vs_faithful"], "parity": hp})
     default_main = world == 1 and a.workload == "c3" and n == 1000000 and levels == (10,) and K == 100 and d == 50
-    also = a.also if a.also is not None else ("ref,10M,c5" if default_main else "none")
+    also = a.also if a.also is not None else ("ref,10M,c5,pbmc" if default_main else "none")
     if world == 1 and also != "none":
         # extra legs of this invocation (never part of `value`): each one is a full run to convergence from HBM-resident inputs
         del obj
@@ -490,6 +573,8 @@ def main():
                     legs["10M_one_gpu"] = bench_leg(Harmony, prepare_setup_args, 10000000, 50, 100, (20,), False, a.seed, 2, 1, sync)
                 elif leg == "c5":      # configs[4] shape at 1M cells
                     legs["c5_shape_1M"] = bench_leg(Harmony, prepare_setup_args, 1000000, 50, 200, (8, 64, 128), True, a.seed, 2, 1, sync)
+                elif leg == "pbmc":    # configs[1] at its stated size, GPU vs CPU oracle
+                    legs["pbmc30k"] = pbmc30k_leg(Harmony, prepare_setup_args, sync)
             except Exception as e:     # pragma: no cover  (an extra leg never costs the main line)
                 legs[leg] = {"error": repr(e)}
         out["also"] = legs

@@ -47,3 +47,24 @@ def synth(N, d=50, n_types=30, levels=(10,), seed=0, nested=False, shard=0):
         Z += deltas[ci][covs[ci]] + epss[ci][types, covs[ci]]
     meta = {"cov%d" % i: c for i, c in enumerate(covs)}
     return Z, meta, types
+
+
+def pbmc30k(n=30000, seed=0):
+    """BASELINE configs[1] at its stated size: pbmc_stim, ~30k cells x 50 PCs, stim / ctrl.  The full Kang et al. data set is a download
+    (vignettes/Seurat.Rmd:54-75); the repository ships a 2 000-cell sample (data/pbmc_stim.RData -> tests/golden/pbmc_stim_pcs.npz: its
+    own 50 PCs).  Stand-in of the stated size: the sample's cells resampled with replacement inside each condition (the conditions keep
+    their 1:1 split) plus Gaussian jitter of 10 % of every PC's spread -- the sample's cluster and batch structure at 30k cells.
+    Returns (Z [n x 50] float64, {"stim": labels})."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "pbmc_stim_pcs.npz"), allow_pickle=False)
+    pcs, stim = fx["pcs"].astype(np.float64), fx["stim"]
+    rng = np.random.Generator(np.random.Philox(key=[seed, 30000]))
+    idx = []
+    levels = np.unique(stim)
+    for li, lv in enumerate(levels):
+        pool = np.where(stim == lv)[0]
+        cnt = n // len(levels) + (1 if li < n % len(levels) else 0)
+        idx.append(rng.choice(pool, size=cnt, replace=True))
+    idx = rng.permutation(np.concatenate(idx))
+    Z = pcs[idx] + rng.normal(size=(n, pcs.shape[1])) * (0.1 * pcs.std(axis=0))
+    return Z, {"stim": fx["stim_levels"][stim[idx]]}

@@ -243,7 +243,12 @@ struct hmx_ctx {
   // restarted sequential sums (hmx_seq.hip): plans (segments + chains on the device), shared workspace, cell lists
   struct SeqPlan { SeqSeg* d_segs = nullptr; SeqChain* d_chains = nullptr; size_t cap_segs = 0, cap_chains = 0; int nsegs = 0, nchains = 0;
                    std::vector<int> seg0;   /* [nchains + 1] first segment of every chain */ int seg_cells = 0; };
-  SeqPlan plan_head, plan_ridge, plan_round;
+  SeqPlan plan_head, plan_ridge, plan_round, plan_pair;
+  // ridge_arith with several covariates: Phi_Rk * Phi_moe_t has one entry per PAIR of levels that meet in a cell (src/harmony.cpp:561-568):
+  // a sequential sum of R_k over the cells that carry both levels, in original order.  pairlist = those cells pair by pair, pair_idx[b][b2]
+  // (b < b2) = the pair's chain or -1; rg_tot / rp_tot = the chain totals the device solve assembles its systems from.
+  int* pairlist = nullptr; int* pair_idx = nullptr; int npairs = 0;
+  float* rg_tot = nullptr; float* rp_tot = nullptr; float* rp_start = nullptr; bool rp_warm = false;
   float* sq_start = nullptr; float* sq_end = nullptr; size_t sq_cap = 0;
   float* sq_total = nullptr; size_t sq_total_cap = 0;
   unsigned* sq_mismatch = nullptr; int seq_passes = 3; int64_t seq_runs = 0;
@@ -328,13 +333,14 @@ void free_all(hmx_ctx* ctx) {
   }
   {   // reference-arithmetic buffers (grown on demand, not in `allocs`)
     void* ps[] = {ctx->sq_start, ctx->sq_end, ctx->sq_total, ctx->sq_mismatch, ctx->headlist, ctx->roundlist, ctx->Of, ctx->Ef, ctx->Mtab, ctx->objT,
-                  ctx->inset, ctx->obj_start, ctx->rg_start, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
+                  ctx->inset, ctx->obj_start, ctx->rg_start, ctx->pairlist, ctx->pair_idx, ctx->rg_tot, ctx->rp_tot, ctx->rp_start, ctx->plan_pair.d_segs, ctx->plan_pair.d_chains, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
                   ctx->plan_round.d_segs, ctx->plan_round.d_chains};
     for (void* q : ps) if (q) (void)hipFree(q);
     ctx->sq_start = ctx->sq_end = ctx->sq_total = nullptr; ctx->sq_mismatch = nullptr; ctx->sq_conv = nullptr; ctx->headlist = ctx->roundlist = nullptr;
     ctx->Of = ctx->Ef = ctx->Mtab = ctx->objT = nullptr; ctx->inset = nullptr; ctx->sq_cap = ctx->sq_total_cap = ctx->objT_cap = 0;
     ctx->obj_start = ctx->rg_start = nullptr; ctx->obj_start_cap = ctx->rg_start_cap = 0; ctx->obj_warm = ctx->rg_warm = false;
-    ctx->plan_head = hmx_ctx::SeqPlan(); ctx->plan_ridge = hmx_ctx::SeqPlan(); ctx->plan_round = hmx_ctx::SeqPlan();
+    ctx->plan_head = hmx_ctx::SeqPlan(); ctx->plan_ridge = hmx_ctx::SeqPlan(); ctx->plan_round = hmx_ctx::SeqPlan(); ctx->plan_pair = hmx_ctx::SeqPlan();
+    ctx->pairlist = ctx->pair_idx = nullptr; ctx->rg_tot = ctx->rp_tot = ctx->rp_start = nullptr; ctx->npairs = 0; ctx->rp_warm = false;
   }
   if (ctx->h_obj) { (void)hipHostFree(ctx->h_obj); ctx->h_obj = nullptr; ctx->obj_cap = 0; }
   if (ctx->obj_event) { (void)hipEventDestroy(ctx->obj_event); ctx->obj_event = nullptr; }
@@ -483,7 +489,7 @@ int push_objective(hmx_ctx* ctx) {
 // R, O, E from scratch (src/harmony.cpp:141-150, :221-227); leaves objective partials in obj[0..1]
 int prepare_round(hmx_ctx* ctx, uint64_t round);
 int oe_head(hmx_ctx* ctx);
-int objective_snapshot(hmx_ctx* ctx);
+int objective_snapshot(hmx_ctx* ctx, const Dev* Dterms = nullptr);
 int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- normalise(Z_corr) first (:220)
   // With the round-to-round carry (update_R) the head of cluster_cpp runs over the padded order of the round that FOLLOWS it and
   // files its R sums as that round's old contributions: no pass over R between the head and the first round either.
@@ -871,17 +877,36 @@ int seq_setup_static(hmx_ctx* ctx) {
       const int hi = (j == ctx->nb - 1) ? n : (int)std::min<uint64_t>((uint64_t)n, (uint64_t)(j + 1) * ctx->cells_per_block);
       ch.push_back({lo, hi - lo});
     }
-    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 128));
+    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 64));
     size_t cap = 0; CHK(seq_grow(ctx, ctx->roundlist, cap, (size_t)n));
   }
   if (ctx->ridge_arith) {
-    if (C != 1) return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 (the reference's summation order) supports one covariate");
     if (ctx->d > 62) return fail(ctx, HMX_ERR_LIMIT, "ridge_arith = 1 supports d <= 62");
     if (!ctx->solve_on_device) return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 needs the device-side ridge solve");
     std::vector<std::pair<int, int>> ch; ch.push_back({0, n});      // the intercept row's chain: all (kept) cells in original order
-    for (int q = 0; q < Q; q++) { const int b = ctx->qlev[q]; ch.push_back({ctx->lev_off[b], ctx->lev_cnt[b]}); }    // a level's cells, ascending
-    CHK(seq_plan_build(ctx, ctx->plan_ridge, ch, 256));
+    if (C == 1) { for (int q = 0; q < Q; q++) { const int b = ctx->qlev[q]; ch.push_back({ctx->lev_off[b], ctx->lev_cnt[b]}); } }    // a level's cells, ascending
+    else for (int b = 0; b < B; b++) ch.push_back({ctx->lev_off[b], ctx->lev_cnt[b]});      // several covariates: one chain per LEVEL (chain 1 + b)
+    CHK(seq_plan_build(ctx, ctx->plan_ridge, ch, 1024));
     size_t cap = 0; CHK(seq_grow(ctx, ctx->inset, cap, (size_t)Q * ((K + 7) / 8 * 8) + 8));
+    if (C > 1) {
+      // level pairs across covariates: cells stably sorted by (level of c, level of c2), original order inside a pair
+      std::vector<int> pl; std::vector<int> pidx((size_t)B * B, -1); std::vector<std::pair<int, int>> pch;
+      for (int c = 0; c < C; c++) for (int c2 = c + 1; c2 < C; c2++) {
+        std::map<std::pair<int, int>, std::vector<int>> by;
+        for (int i = 0; i < n; i++) { const int cell = ctx->invperm_h[i]; const int* lv = &ctx->qlev[(size_t)ctx->combo_h[cell] * C]; by[{lv[c], lv[c2]}].push_back(cell); }
+        for (auto& kv : by) {
+          pidx[(size_t)kv.first.first * B + kv.first.second] = (int)pch.size();
+          pch.push_back({(int)pl.size(), (int)kv.second.size()});
+          pl.insert(pl.end(), kv.second.begin(), kv.second.end());
+        }
+      }
+      ctx->npairs = (int)pch.size();
+      { size_t c1 = 0, c2 = 0; CHK(seq_grow(ctx, ctx->pairlist, c1, pl.size())); CHK(seq_grow(ctx, ctx->pair_idx, c2, pidx.size()));
+        CHK(h2d(ctx, ctx->pairlist, pl.data(), pl.size())); CHK(h2d(ctx, ctx->pair_idx, pidx.data(), pidx.size())); }
+      CHK(seq_plan_build(ctx, ctx->plan_pair, pch, 256));
+      { size_t c1 = 0, c2 = 0, c3 = 0; CHK(seq_grow(ctx, ctx->rg_tot, c1, (size_t)(1 + B) * K * 64)); CHK(seq_grow(ctx, ctx->rp_tot, c2, (size_t)std::max(ctx->npairs, 1) * K));
+        CHK(seq_grow(ctx, ctx->rp_start, c3, (size_t)std::max(ctx->plan_pair.nsegs, 1) * K)); }
+    }
   }
   if ((ctx->solve_arith || ctx->oe_arith) && !ctx->solve_on_device) return fail(ctx, HMX_ERR_ARG, "solve_arith / oe_arith need the device-side ridge solve");
   return 0;
@@ -889,14 +914,15 @@ int seq_setup_static(hmx_ctx* ctx) {
 // E, O of the head in the reference's arithmetic: R has just been rewritten
 int oe_head(hmx_ctx* ctx) {
   CHK(seq_run_oe(ctx, ctx->plan_head, ctx->headlist, 0, 1));
-  l_oe_fold(ctx->L, ctx->D, ctx->Of, ctx->Ef, ctx->sq_total, nullptr, 0); KCHK();
+  l_oe_fold(ctx->L, ctx->D, ctx->Of, ctx->Ef, nullptr, ctx->sq_total, nullptr, 1); KCHK();
   return 0;
 }
 // compute_objective's three my_accu sums (src/harmony.cpp:160-162) as sequential fp32 chains over K*N terms each -> obj[2..4]
-int seq_objective(hmx_ctx* ctx) {
-  const Dev& D = ctx->D;
+// Dterms: the state the k-means term's distances are taken from (default: the current Z_corr / Y; stale_dist: the snapshot of the last head,
+// i.e. the reference's stored dist_mat, src/harmony.cpp:160)
+int seq_objective(hmx_ctx* ctx, const Dev& D) {
   const long long nt = (long long)ctx->N * ctx->K;
-  constexpr int LSEG = 4096;
+  constexpr int LSEG = 2048;
   const int nsegs = (int)((nt + LSEG - 1) / LSEG);
   CHK(seq_grow(ctx, ctx->objT, ctx->objT_cap, (size_t)3 * (size_t)nt));
   CHK(seq_workspace(ctx, (size_t)3 * nsegs, 3));
@@ -911,9 +937,9 @@ int seq_objective(hmx_ctx* ctx) {
   return 0;
 }
 // the objective snapshot obj[2..4] from what the last pass over the cells left behind (obj[0..1]: exact per-cell sums)
-int objective_snapshot(hmx_ctx* ctx) {
+int objective_snapshot(hmx_ctx* ctx, const Dev* Dterms) {
   l_objective_tables(ctx->L, ctx->D); KCHK();      // (also resets the block chain's control words)
-  if (ctx->obj_arith) return seq_objective(ctx);
+  if (ctx->obj_arith) return seq_objective(ctx, Dterms ? *Dterms : ctx->D);
   if (ctx->oe_arith) { l_obj_cross_f32(ctx->L, ctx->D, ctx->Of, ctx->Ef, ctx->Mtab); KCHK(); }
   return 0;
 }
@@ -924,15 +950,29 @@ int seq_ridge_stats(hmx_ctx* ctx) {
   const Dev& D = ctx->D;
   const hmx_ctx::SeqPlan& P = ctx->plan_ridge;
   const int W = ctx->K * 64;
+  const bool multi = ctx->C > 1;
+  float* const tot = multi ? ctx->rg_tot : ctx->sq_total;
   CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
   if ((size_t)P.nsegs * W > ctx->rg_start_cap) { CHK(seq_grow(ctx, ctx->rg_start, ctx->rg_start_cap, (size_t)P.nsegs * W)); ctx->rg_warm = false; }
   l_seq_inset(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->sv_cov_bounds, ctx->cutoff, ctx->inset); KCHK();
   CHK(seq_iterate(ctx, ctx->rg_warm, ctx->N >= ctx->seq_adaptive_cells,
                   [&](bool zero) -> int { l_seq_ridge_pass(ctx->L, D, ctx->headlist, P.d_segs, 0, P.nsegs, ctx->inset, ctx->rg_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
-                  [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->rg_start, ctx->sq_end, ctx->rg_start, ctx->sq_total, conv, zero ? 1 : 0); KCHK(); return 0; }));
+                  [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->rg_start, ctx->sq_end, ctx->rg_start, tot, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->rg_warm = true;
-  l_seq_ridge_store(ctx->L, D, ctx->sq_total); KCHK();
   ctx->seq_runs++;
+  if (!multi) { l_seq_ridge_store(ctx->L, D, ctx->sq_total); KCHK(); return 0; }
+  // several covariates: the level-pair entries of Phi_Rk * Phi_moe_t (:561-568): plain sequential sums of R_k over each pair's cells
+  const hmx_ctx::SeqPlan& PP = ctx->plan_pair;
+  if (PP.nchains > 0) {
+    CHK(seq_workspace(ctx, (size_t)PP.nsegs * ctx->K, 1));
+    int longest = 0;
+    for (int c = 0; c < PP.nchains; c++) longest = std::max(longest, PP.seg0[c + 1] - PP.seg0[c]);
+    CHK(seq_iterate(ctx, ctx->rp_warm, (int64_t)longest * PP.seg_cells >= ctx->seq_adaptive_cells,
+                    [&](bool zero) -> int { l_seq_sum_pass(ctx->L, D, ctx->pairlist, PP.d_segs, 0, PP.nsegs, ctx->rp_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
+                    [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, PP.d_chains, 0, PP.nchains, ctx->K, ctx->rp_start, ctx->sq_end, ctx->rp_start, ctx->rp_tot, conv, zero ? 1 : 0); KCHK(); return 0; }));
+    ctx->rp_warm = true;
+    ctx->seq_runs++;
+  }
   return 0;
 }
 
@@ -960,10 +1000,12 @@ int update_R_ref(hmx_ctx* ctx) {
   { PhaseScope ph(ctx, "EO_update");     // every block's cells are still untouched at this point: the sums each block will remove (:312-313), all at once
     CHK(seq_run_oe(ctx, P, ctx->roundlist, 0, nb)); }
   D.fused_fold = 0; D.Sold_next = nullptr;
+  const float* put_back = nullptr;                                   // the sums of the block updated last, still to be added back (:329-330)
   for (int j = 0; j < nb; j++) {
     if (P.seg0[j + 1] == P.seg0[j]) continue;                      // N * block_size rounding can leave trailing empty blocks
     float* tot = ctx->sq_total + (size_t)j * W;
-    { PhaseScope ph(ctx, "EO_update"); l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, tot, D.pen, -1); KCHK(); }
+    // one launch: the previous block goes back in, this block comes out, this block's penalty table (:329-330, :312-313, :322)
+    { PhaseScope ph(ctx, "EO_update"); l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, put_back, tot, D.pen, 0); KCHK(); }
     if (ctx->profile) {
       if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); ctx->ev_pool.emplace_back(a, b); }
       HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
@@ -972,9 +1014,10 @@ int update_R_ref(hmx_ctx* ctx) {
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
     { PhaseScope ph(ctx, "EO_update");
       // the same cells in the same order as the sums removed above, their R rows updated: that run's segment starts are this run's first guess
-      CHK(seq_run_oe(ctx, P, ctx->roundlist, j, 1, true));
-      l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, tot, nullptr, +1); KCHK(); }
+      CHK(seq_run_oe(ctx, P, ctx->roundlist, j, 1, true)); }
+    put_back = tot;
   }
+  if (put_back) { PhaseScope ph(ctx, "EO_update"); l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, put_back, nullptr, nullptr, 0); KCHK(); }
   { PhaseScope ph(ctx, "objective");
     l_obj_reduce(ctx->L, D); KCHK();
     CHK(objective_snapshot(ctx)); }
@@ -1599,6 +1642,8 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   if (N <= 0 || d <= 0 || K <= 0 || B <= 0 || C <= 0) return fail(ctx, HMX_ERR_ARG, "non-positive dimension");
   if (d > 128 || K > 256 || C > 15) return fail(ctx, HMX_ERR_LIMIT, "supported envelope: d <= 128, K <= 256, covariates <= 15");
   if (N > 2000000000ll) return fail(ctx, HMX_ERR_LIMIT, "at most 2e9 cells per GPU shard");
+  if ((ctx->ridge_arith || ctx->oe_arith || ctx->obj_arith || ctx->solve_arith) && (ctx->world > 1 || ctx->comm_force))
+    return fail(ctx, HMX_ERR_ARG, "the reference-arithmetic modes (ridge_arith / oe_arith / obj_arith / solve_arith) run on one GPU");
   if (ctx->world <= 1) { ctx->N_global = N; ctx->goff = 0; }
   if (ctx->N_global > 4000000000ll) return fail(ctx, HMX_ERR_LIMIT, "at most 4e9 cells in total");
   if (ctx->N_global < 6) return fail(ctx, HMX_ERR_TOO_FEW, "Refusing to run with less than 6 cells");
@@ -1705,6 +1750,12 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   D.n = (int)N; D.d = d; D.K = K; D.B = B; D.C = C; D.Q = Q; D.B0 = ctx->B_vec[0];
   D.KP = (K + 63) / 64 * 64; D.nb = ctx->nb;
   D.zs = (d + 3) / 4 * 4;
+  { // Rows of whole 128-byte lines where that costs at most 30 % more bytes (d = 50: 208 -> 256 B): the block chain GATHERS the rows of a
+    // block's cells, and a 208-byte row at 16-byte alignment touches 2.6 lines on average -- 404 B of HBM reads per cell for 200 B of
+    // payload (rocprof FETCH_SIZE, profiles/r3_pmc_summary.json).  The pad floats are zero and stay zero.  HMX_ZS_PAD=0: tight rows.
+    const char* e = getenv("HMX_ZS_PAD");
+    const int zp = (D.zs + 31) / 32 * 32;
+    if (!(e && atoi(e) == 0) && zp != D.zs && zp * 10 <= D.zs * 13) D.zs = zp; }
   { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 8; if (want > 8) want = 8; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
   { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 14, 16};     // (13: K = 200, BASELINE configs[4])
     const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
@@ -1999,7 +2050,7 @@ int hmx_restart(hmx_ctx* ctx) {
   ctx->obj_kmeans.clear(); ctx->obj_dist.clear(); ctx->obj_entropy.clear(); ctx->obj_cross.clear(); ctx->obj_harmony.clear();
   ctx->kmeans_rounds.clear(); ctx->round_counter = 0; ctx->ran_init = false; ctx->injected.clear(); ctx->rrng_seeded = false;
   ctx->y_on_device = false; ctx->solve_pending = false;
-  ctx->obj_warm = ctx->rg_warm = false;            // (a run never depends on what the handle computed before it)
+  ctx->obj_warm = ctx->rg_warm = ctx->rp_warm = false;            // (a run never depends on what the handle computed before it)
   ctx->head_is_stale = false;
   HIPCHK(hipMemsetAsync(ctx->D.solve_err, 0, sizeof(int), ctx->L.stream));
   if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
@@ -2038,11 +2089,13 @@ int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the cur
   if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemsetAsync(ctx->D.objpart, 0, sizeof(double) * 2 * (size_t)ctx->D.objslots * ctx->D.nwmax, ctx->L.stream));
-  if (ctx->stale_dist && ctx->head_is_stale) { Dev Ds = ctx->D; Ds.Zc = ctx->Zc_head; Ds.Yt = ctx->Yt_head; l_head(ctx->L, Ds, 1); KCHK(); }   // the reference's stored dist_mat
-  else { l_head(ctx->L, ctx->D, 1); KCHK(); }
+  Dev Ds = ctx->D;
+  const bool stale = ctx->stale_dist && ctx->head_is_stale;
+  if (stale) { Ds.Zc = ctx->Zc_head; Ds.Yt = ctx->Yt_head; }          // the reference's stored dist_mat (:160)
+  l_head(ctx->L, Ds, 1); KCHK();
   l_obj_reduce(ctx->L, ctx->D); KCHK();
   CHK(allreduce(ctx, ctx->D.obj, 2, 1));
-  CHK(objective_snapshot(ctx));
+  CHK(objective_snapshot(ctx, stale ? &Ds : nullptr));     // (obj_arith re-derives the terms: from the same snapshot)
   CHK(push_objective(ctx));
   return flush_objectives(ctx);
 }
@@ -2114,6 +2167,7 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
     A.lambda = ctx->lambda_estimation ? nullptr : ctx->sv_lambda; A.cov_bounds = ctx->sv_cov_bounds;
     A.alpha = ctx->alpha; A.cutoff = ctx->cutoff; A.use_s0 = seq ? 1 : 0; A.err = ctx->D.solve_err;
     A.Of = ctx->oe_arith ? ctx->Of : nullptr; A.Ef = ctx->oe_arith ? ctx->Ef : nullptr; A.solve_f32 = ctx->solve_arith;
+    A.ref_tot = (seq && ctx->C > 1) ? ctx->rg_tot : nullptr; A.pair_tot = ctx->rp_tot; A.pair_idx = ctx->pair_idx;
     { PhaseScope ph(ctx, "arma_inv"); l_moe_solve(ctx->L, D, A); KCHK(); }
     { PhaseScope ph(ctx, "update_Zcorr");
       if (D.moe_mfma) { l_moe_apply_mfma(ctx->L, D); KCHK(); } else { l_moe_apply(ctx->L, D); KCHK(); } }

@@ -168,6 +168,9 @@ struct SolveArgs {
   const int* cov_bounds;           // [C] cumulative level counts
   float alpha, cutoff; int use_s0;
   const float* Of; const float* Ef;   // oe_arith: the fp32 O / E tables that replace the exact fixed-point O (keep rule, lambda = alpha E); else nullptr
+  // ridge_arith with several covariates: the systems come straight from the sequential fp32 chain totals -- ref_tot [1 + B][K][64] (chain 0: all
+  // kept cells, chain 1 + b: level b; lane j < d: sum fl(z_j R_k), lane 63: sum R_k), pair_tot [pairs][K], pair_idx [B][B] (b < b2) -> pair or -1
+  const float* ref_tot; const float* pair_tot; const int* pair_idx;
   int solve_f32;                      // solve_arith: one covariate -> the reference's closed-form fp32 arrowhead inverse (src/harmony.cpp:575-586)
   size_t lds_b_bytes;              // LDS bytes available for the right-hand sides during the substitution (0: leave them in HBM)
   size_t lds_body_bytes;           // LDS bytes behind the index arrays (panel / right-hand sides; the combination-row table during the assembly)
@@ -243,7 +246,7 @@ __host__ __device__ inline void bfimg_store(unsigned short* img, int nct, int ns
   bf3_split(y, p);
   for (int part = 0; part < 3; part++) img[bfimg_index(nct, ns2, j, k, part)] = p[part];
 }
-constexpr int P2P_CAP = 16384;                       // K x B entries an inbox holds per (parity, source)
+constexpr int P2P_CAP = 65536;                       // K x B entries an inbox holds per (parity, source): 200 clusters x 200 levels (BASELINE configs[4]) fit; 16 MB per inbox
 constexpr size_t P2P_TEST_BASE = (size_t)2 * 8 * P2P_CAP * 2;   // 64 granules behind the tables: the connection self-test
 constexpr size_t P2P_INBOX_GRANULES = P2P_TEST_BASE + 64;
 void l_p2p_selftest(const Launch& L, const Dev& D, unsigned tag, int* result);   // the whole block chain of a round: one persistent launch
@@ -266,6 +269,8 @@ struct SeqSeg { int off; int cnt; };       // a segment of a chain: cells list[o
 struct SeqChain { int seg0; int nseg; };   // the segments of one chain, in chain order
 void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
                    int zero_start);
+void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
+                    int zero_start);
 void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord);
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start);
@@ -275,9 +280,10 @@ void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains
                 float* total, unsigned* mismatch, int zero_start);
 void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, const float* end, float* start_out, float* total,
                  unsigned* mismatch, int zero_start);
-void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot, float* pen, int mode);
+void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot_add, const float* tot_sub, float* pen, int head);
 void l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
 void l_obj_store(const Launch& L, const float* total, double* obj);
+bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride);
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M);
 void l_seq_inset(const Launch& L, const Dev& D, const float* Of, const int* cov_bounds, float cutoff, unsigned char* inset);
 void l_seq_ridge_store(const Launch& L, const Dev& D, const float* total);

@@ -2541,6 +2541,76 @@ __global__ __launch_bounds__(TPB) void k_objective_tables(Dev D) {
   if (D.chain_ctl) for (int i = threadIdx.x; i < 8 * D.nb + 24; i += blockDim.x) D.chain_ctl[i] = 0;
 }
 
+// obj_arith: the objective's three K x N term matrices (src/harmony.cpp:160-162, see hmx_seq.hip k_obj_terms) with the distances from the
+// matrix cores: static 16-cell tiles like the head, the R row and the term rows as 16-byte accesses (a lane's clusters are consecutive,
+// kcol).  Round 3's cluster-lane VALU version took 1.44 ms per evaluation at 1M cells, a quarter of the reference-arithmetic run.
+// T[0] = R % dist, T[1] = (R % log R) % sigma, T[2] = (R % sigma) % (M Phi); rows at the cells' ORIGINAL positions, k fastest.
+template <int NCT>
+__global__ __launch_bounds__(256) void k_obj_terms_mfma(Dev D, const float* __restrict__ M, float* __restrict__ T, long long stride) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 ldsI[];
+  constexpr int NFULL = NCT >> 2, RT = NCT & 3;
+  const int K = D.K, C = D.C, zs = D.zs;
+  const int nY4 = D.NQ * D.NS * 64;
+  { const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
+    for (int i = threadIdx.x; i < nY4; i += blockDim.x) ldsI[i] = src[i]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nw = (int)((gridDim.x * blockDim.x) >> 6);
+  auto one = [&](const float r, const float dot, const float sg, const float m, float& t0, float& t1, float& t2) __attribute__((always_inline)) {
+    const float dist = __fmul_rn(2.0f, __fsub_rn(1.0f, dot));
+    const float lg = (r > 0.0f) ? logf(r) : logf(FLT_MIN);      // arma::trunc_log
+    t0 = __fmul_rn(r, dist);
+    t1 = __fmul_rn(__fmul_rn(r, lg), sg);
+    t2 = __fmul_rn(__fmul_rn(r, sg), m);
+  };
+  for (int tile = wave; tile < D.ntitems; tile += nw) {
+    const Item it = D.titems[tile];
+    const bool av = c < it.cnt;
+    f32x4 acc[NCT];
+    tile_dots<NCT>(ldsI, D.Zc + (size_t)(it.start + (av ? c : 0)) * zs, av, g, lane, D.NS, D.NT4, D.tail, acc);
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int cl = 4 * g + reg;
+      const bool cv = cl < it.cnt;
+      const int cell = it.start + (cv ? cl : 0);
+      const size_t orow = (size_t)D.perm[cell] * K;
+      const float* __restrict__ rrow = D.R + (size_t)cell * K;
+#pragma unroll
+      for (int q = 0; q < NFULL; q++) {
+        const int k0 = 64 * q + 4 * c;
+        if (4 * q < first_partial_ct(NCT) || k0 < K) {
+          const f32x4 r4 = *reinterpret_cast<const f32x4*>(rrow + k0), sg4 = *reinterpret_cast<const f32x4*>(D.sigma + k0);
+          f32x4 m4 = {0.f, 0.f, 0.f, 0.f};
+          for (int cc = 0; cc < C; cc++) {
+            const f32x4 mm = *reinterpret_cast<const f32x4*>(M + (size_t)D.qlev[it.q * C + cc] * K + k0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) m4[i] = __fadd_rn(m4[i], mm[i]);
+          }
+          f32x4 t0, t1, t2;
+#pragma unroll
+          for (int i = 0; i < 4; i++) { float a0, a1, a2; one(r4[i], acc[4 * q + i][reg], sg4[i], m4[i], a0, a1, a2); t0[i] = a0; t1[i] = a1; t2[i] = a2; }
+          if (cv) {
+            *reinterpret_cast<f32x4*>(T + orow + k0) = t0;
+            *reinterpret_cast<f32x4*>(T + (size_t)stride + orow + k0) = t1;
+            *reinterpret_cast<f32x4*>(T + 2 * (size_t)stride + orow + k0) = t2;
+          }
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < RT; jj++) {
+        const int k = 64 * NFULL + RT * c + jj;
+        if (k < K) {
+          float m = 0.0f;
+          for (int cc = 0; cc < C; cc++) m = __fadd_rn(m, M[(size_t)D.qlev[it.q * C + cc] * K + k]);
+          float t0, t1, t2;
+          one(rrow[k], acc[4 * NFULL + jj][reg], D.sigma[k], m, t0, t1, t2);
+          if (cv) { T[orow + k] = t0; T[(size_t)stride + orow + k] = t1; T[2 * (size_t)stride + orow + k] = t2; }
+        }
+      }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------
 // MoE ridge correction (src/harmony.cpp:345-638)
 //   k_moe_stats : per combination q and cluster k:  nq = sum_i R_ki,  Sq = sum_i R_ki z_i
@@ -2774,6 +2844,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       for (int q = 0; q < Q; q++) { const int* r = qr + q * (C + 1); if (r[0] == 0 && in_q(r, a)) qlst[o++] = q; }
     }
     __syncthreads();
+    if (!A.ref_tot) {
     for (int i = tid; i < m * d; i += nt) {
       const int j = i / m, a = i - j * m;
       double sacc = 0.0;
@@ -2791,10 +2862,37 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       cov[(size_t)cb * m + ra] = sacc;
       cov[(size_t)ra * m + cb] = sacc;
     }
+    }   // (!A.ref_tot)
     __syncthreads();
   }
   if (!skipped) {
-    if (!qtab) {
+    if (A.ref_tot) {
+      // ridge_arith with several covariates: every entry of the system IS one of the reference's sequential fp32 accumulators
+      // (hmx_seq.hip): Phi_Rk * Phi_moe_t entry (a, a2) = the sum of R_k over the kept cells that carry both design rows, in original order
+      // (src/harmony.cpp:561-568; the intercept row is in every cell, a level row in its level's cells, two levels of different covariates
+      // in their pair's cells, two levels of one covariate never meet); the right-hand sides = the same chains over fl(z_j R_k) (:592-608).
+      auto chain_of = [&](const int a) { return a == 0 ? 0 : 1 + keepl[a - 1]; };
+      for (int i = tid; i < m * d; i += nt) {
+        const int j = i / m, a = i - j * m;
+        rhs[(size_t)j * m + prow[a]] = (double)A.ref_tot[((size_t)chain_of(a) * K + k) * 64 + j];
+      }
+      for (int i = tid; i < m * m; i += nt) {
+        const int a2 = i / m, a = i - a2 * m;
+        float v;
+        if (a == 0 || a2 == 0 || a == a2) v = A.ref_tot[((size_t)chain_of(a == 0 ? a2 : a) * K + k) * 64 + 63];
+        else {
+          const int b = keepl[a - 1], b2 = keepl[a2 - 1];
+          int cv = 0, cv2 = 0;
+          while (cv < C - 1 && !(b < A.cov_bounds[cv])) cv++;
+          while (cv2 < C - 1 && !(b2 < A.cov_bounds[cv2])) cv2++;
+          const int pi = (cv == cv2) ? -1 : A.pair_idx[(size_t)min(b, b2) * B + max(b, b2)];
+          v = pi >= 0 ? A.pair_tot[(size_t)pi * K + k] : 0.0f;
+        }
+        cov[(size_t)prow[a2] * m + prow[a]] = (double)v;
+      }
+      __syncthreads();
+    }
+    if (!qtab && !A.ref_tot) {
     for (int i = tid; i < m * m; i += nt) cov[i] = 0.0;
     for (int i = tid; i < m * d; i += nt) rhs[i] = 0.0;
     __syncthreads();
@@ -2822,7 +2920,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       const int b = keepl[a - 1];
       const float lam = A.lambda ? A.lambda[b + 1] : (A.Ef ? A.Ef[(size_t)b * K + k] : (float)(rsd * (double)D.Pr_b[b])) * A.alpha;
       const int pa = prow[a];
-      if (A.solve_f32) cov[(size_t)pa * m + pa] = (double)__fadd_rn((float)cov[(size_t)pa * m + pa], lam);     // an fp32 matrix in the reference
+      if (A.solve_f32 || A.use_s0) cov[(size_t)pa * m + pa] = (double)__fadd_rn((float)cov[(size_t)pa * m + pa], lam);     // an fp32 matrix in the reference
       else cov[(size_t)pa * m + pa] += (double)lam;
     }
     __syncthreads();
@@ -2859,6 +2957,88 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       }
       __syncthreads();
       for (int i = tid; i < m * d; i += nt) rhs[i] = (double)Wtmp[i];
+      __syncthreads();
+    } else if (A.solve_f32 && C > 1) {
+      // Several covariates: the reference calls arma::inv (src/harmony.cpp:573), i.e. LAPACK's LU of the fp32 matrix.  LAPACK's blocked
+      // rounding order cannot be pinned without the reference's BLAS; what is reproduced bit for bit is the oracle's restatement: unblocked
+      // fp32 LU with partial pivoting (first largest pivot) applied to the identity, back substitution column by column, then
+      // W = inv_cov * rhs with sequential fp32 accumulation.  One workgroup per cluster; the m x m fp32 matrix and its inverse live in the
+      // cluster's fp64 scratch (2 m^2 floats = m^2 doubles).
+      float* const ac = reinterpret_cast<float*>(sm_ + PAN_OFF);      // [m] multipliers of the current column (the panel space)
+      __shared__ unsigned long long pivkey;
+      // the fp64 scratch holds the assembled fp32 values: repack them as floats (through registers: the two layouts overlap)
+      {
+        const int per = (m * m + nt - 1) / nt;
+        float* const Af = reinterpret_cast<float*>(cov);
+        for (int base = 0; base < per; base += 16) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) { const int i = (base + u) * nt + tid; v[u] = (base + u < per && i < m * m) ? (float)cov[i] : 0.0f; }
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 16; u++) { const int i = (base + u) * nt + tid; if (base + u < per && i < m * m) Af[i] = v[u]; }
+          __syncthreads();
+        }
+      }
+      float* const Af = reinterpret_cast<float*>(cov);
+      float* const If = Af + (size_t)m * m;
+      for (int i = tid; i < m * m; i += nt) If[i] = (i / m == i % m) ? 1.0f : 0.0f;
+      __syncthreads();
+      for (int cc = 0; cc < m && !misc[3]; cc++) {
+        if (tid == 0) pivkey = 0ull;
+        __syncthreads();
+        unsigned long long best = 0ull;
+        for (int r = cc + tid; r < m; r += nt) {
+          const unsigned long long key = ((unsigned long long)(__float_as_uint(fabsf(Af[(size_t)cc * m + r]))) << 32) | (unsigned)(0x7fffffff - r);   // largest |a|, then the smallest row
+          best = key > best ? key : best;
+        }
+        if (best) atomicMax(&pivkey, best);
+        __syncthreads();
+        const unsigned long long pk = pivkey;
+        if ((pk >> 32) == 0ull) { if (tid == 0) misc[3] = 1; __syncthreads(); break; }
+        const int pr = 0x7fffffff - (int)(pk & 0xffffffffull);
+        if (pr != cc) {
+          for (int j = tid; j < 2 * m; j += nt) {
+            float* M2 = j < m ? Af + (size_t)j * m : If + (size_t)(j - m) * m;
+            const float t = M2[cc]; M2[cc] = M2[pr]; M2[pr] = t;
+          }
+        }
+        __syncthreads();
+        const float inv = 1.0f / Af[(size_t)cc * m + cc];
+        for (int r = cc + 1 + tid; r < m; r += nt) { const float f = __fmul_rn(Af[(size_t)cc * m + r], inv); ac[r] = f; }
+        __syncthreads();
+        for (int r = cc + 1 + tid; r < m; r += nt) if (ac[r] != 0.0f) Af[(size_t)cc * m + r] = ac[r];
+        const int h = m - cc - 1;              // rows below the pivot
+        // A[j][r] -= f_r A[j][cc] (j > cc), I[j][r] -= f_r I[j][cc] (all j): element-wise, one rounding for the product, one for the difference
+        for (int i = tid; i < (h + m) * h; i += nt) {
+          const int jj = i / h, r = cc + 1 + (i - jj * h);
+          float* col = jj < h ? Af + (size_t)(cc + 1 + jj) * m : If + (size_t)(jj - h) * m;
+          const float f = ac[r];
+          if (f != 0.0f) col[r] = __fsub_rn(col[r], __fmul_rn(f, col[cc]));
+        }
+        __syncthreads();
+      }
+      if (!misc[3]) {
+        // back substitution of every column of the identity: s -= A[c][r] * x[c], c ascending, then / A[r][r]
+        for (int j = tid; j < m; j += nt) {
+          float* x = If + (size_t)j * m;
+          for (int r = m - 1; r >= 0; r--) {
+            float sacc = x[r];
+            for (int c2 = r + 1; c2 < m; c2++) sacc = __fsub_rn(sacc, __fmul_rn(Af[(size_t)c2 * m + r], x[c2]));
+            x[r] = sacc / Af[(size_t)r * m + r];
+          }
+        }
+        __syncthreads();
+        float* const Wtmp = A.Wall + (size_t)k * d * M;
+        for (int i = tid; i < m * d; i += nt) {
+          const int j = i / m, r2 = i - j * m;
+          float sacc = 0.0f;
+          for (int c2 = 0; c2 < m; c2++) sacc = __fadd_rn(sacc, __fmul_rn(If[(size_t)c2 * m + r2], (float)rhs[(size_t)j * m + c2]));
+          Wtmp[i] = sacc;
+        }
+        __syncthreads();
+        for (int i = tid; i < m * d; i += nt) rhs[i] = (double)Wtmp[i];
+      }
       __syncthreads();
     } else {
     // ---- blocked right-looking Cholesky (lower, column-major, in place in the L2-resident scratch).  Panels of NBW columns
@@ -3911,6 +4091,19 @@ void l_p2p_selftest(const Launch& L, const Dev& D, unsigned tag, int* result) {
 }
 void l_objective_tables(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);
+}
+// false: shape outside this kernel's envelope (the caller falls back to the cluster-lane version)
+bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride) {
+  const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4);
+  if (!D.tile_impl || D.K % 4 != 0 || lds > 64 * 1024 || !D.Yimg) return false;
+  int blocks = (D.ntitems + 3) / 4; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+#define HMX_OT(N) case N: hipLaunchKernelGGL((k_obj_terms_mfma<N>), dim3(blocks), dim3(256), lds, L.stream, D, M, T, stride); break;
+  switch (D.NCT) {
+    HMX_OT(1) HMX_OT(2) HMX_OT(3) HMX_OT(4) HMX_OT(5) HMX_OT(6) HMX_OT(7) HMX_OT(8) HMX_OT(10) HMX_OT(12) HMX_OT(13) HMX_OT(14) HMX_OT(16)
+    default: return false;
+  }
+#undef HMX_OT
+  return true;
 }
 void l_moe_stats(const Launch& L, const Dev& D) {
   const int zch = (D.d + 31) / 32;

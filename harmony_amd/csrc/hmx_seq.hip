@@ -36,6 +36,10 @@ namespace hmx {
 //     cluster: row 0 lives in a register, the level rows in LDS (one column per lane: no cross-lane traffic, the read-modify-write of
 //     a lane's own slot is its sequential chain).  The 64 cell ids / level codes of a batch are fetched with one load each, the R rows
 //     32 at a time (a segment is latency-bound: what counts is the number of memory round trips).
+// ROWS = false: row 0 only -- a plain sequential sum of R_k over a list of cells, W = K lane-chains per segment (the level-pair sums of
+// Phi_Rk * Phi_moe_t for several covariates, src/harmony.cpp:561-568).
+// Round 4: all 64 R loads of a batch are in flight together (a segment is latency-bound: one memory round trip per 64 cells instead of two).
+template <bool ROWS>
 __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R, int K, int B, int C, const int* __restrict__ list,
                                                      const int* __restrict__ combo, const int* __restrict__ qlev,
                                                      const SeqSeg* __restrict__ segs, int seg0, int nsegs,
@@ -48,37 +52,40 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   const int k = blockIdx.y * 64 + lane, ks = min(k, K - 1);
   const SeqSeg sg = segs[seg];
   float* const acc = acc_ + (size_t)wib * B * 64 + lane;
-  const size_t so = (size_t)seg * (1 + B) * K + ks;
+  const int NR = ROWS ? 1 + B : 1;
+  const size_t so = (size_t)seg * NR * K + ks;
   float s0 = (zero_start || k >= K) ? 0.0f : start[so];
-  for (int b = 0; b < B; b++) acc[b * 64] = (zero_start || k >= K) ? 0.0f : start[so + (size_t)(1 + b) * K];
+  if constexpr (ROWS) for (int b = 0; b < B; b++) acc[b * 64] = (zero_start || k >= K) ? 0.0f : start[so + (size_t)(1 + b) * K];
   for (int base = 0; base < sg.cnt; base += 64) {
     const int nc = min(64, sg.cnt - base);
     const int ci = sg.off + min(base + lane, sg.cnt - 1);
     const int myc = list ? list[ci] : ci;
-    const int myq = combo[myc];
-    int mylev[4];
+    int myq = 0, mylev[4] = {0, 0, 0, 0};
+    if constexpr (ROWS) {
+      myq = combo[myc];
 #pragma unroll
-    for (int c = 0; c < 4; c++) mylev[c] = qlev[myq * C + min(c, C - 1)];
-    for (int c0 = 0; c0 < nc; c0 += 32) {
-      float r[32];
+      for (int c = 0; c < 4; c++) mylev[c] = qlev[myq * C + min(c, C - 1)];
+    }
+    float r[64];
 #pragma unroll
-      for (int u = 0; u < 32; u++) {
-        const int cell = __builtin_amdgcn_readlane(myc, min(c0 + u, nc - 1));
-        r[u] = R[(size_t)cell * K + ks];
-      }
+    for (int u = 0; u < 64; u++) {
+      const int cell = __builtin_amdgcn_readlane(myc, u);       // (lanes past the end hold the segment's last cell: a valid row)
+      r[u] = R[(size_t)cell * K + ks];
+    }
 #pragma unroll
-      for (int u = 0; u < 32; u++) {
-        if (c0 + u < nc) {
-          s0 = __fadd_rn(s0, r[u]);
+    for (int u = 0; u < 64; u++) {
+      if (u < nc) {
+        s0 = __fadd_rn(s0, r[u]);
+        if constexpr (ROWS) {
 #pragma unroll
           for (int c = 0; c < 4; c++) {
             if (c < C) {
-              const int b = __builtin_amdgcn_readlane(mylev[c], c0 + u);
+              const int b = __builtin_amdgcn_readlane(mylev[c], u);
               acc[b * 64] = __fadd_rn(acc[b * 64], r[u]);
             }
           }
           for (int c = 4; c < C; c++) {       // (more than four covariates: level codes straight from the table)
-            const int b = qlev[__builtin_amdgcn_readlane(myq, c0 + u) * C + c];
+            const int b = qlev[__builtin_amdgcn_readlane(myq, u) * C + c];
             acc[b * 64] = __fadd_rn(acc[b * 64], r[u]);
           }
         }
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   }
   if (k < K) {
     end[so] = s0;
-    for (int b = 0; b < B; b++) end[so + (size_t)(1 + b) * K] = acc[b * 64];
+    if constexpr (ROWS) for (int b = 0; b < B; b++) end[so + (size_t)(1 + b) * K] = acc[b * 64];
   }
 }
 
@@ -95,22 +102,30 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
 //     (Z_tmp = Z_orig % R_k is rounded to fp32 first, src/harmony.cpp:592); lane 63: sum_i R_ki (the matching entry of
 //     Phi* diag(R_k) Phi*^T, :567).  A cell enters cluster k's regression only if one of its levels is kept for k (:400,456-460):
 //     inset[combination][k] (bytes, row stride KP8); a cell outside contributes the term +0, which leaves an fp32 accumulator untouched.
-//     Per batch of 64 cells every lane fetches its own cell's id and 8 flags; per cell one row load of Z, one of R (lanes 0..7 hold the
-//     wave's 8 clusters, zeroed where the cell is outside), then 8 x (broadcast, multiply, add).
+//     Round 4: ONE workgroup per segment, one wave per 8 clusters -- all waves of a workgroup walk the same cells, so a cell's embedding
+//     row comes from HBM once (round 3: one single-wave workgroup per (segment, 8 clusters): 13 x the Z traffic at K = 100, 3.4 ms per
+//     pass at 1M cells).  The cell's 8 R values are wave-uniform: they travel through the SCALAR cache (s_load_dwordx8) and feed
+//     v_pk_mul_f32 / v_pk_add_f32 straight from SGPR pairs -- two clusters per VALU instruction, each component rounded on its own
+//     (no contraction: the reference multiplies, rounds, then adds).  10 VALU instructions per (cell, 8 clusters) instead of ~30.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int KPW>
-__global__ __launch_bounds__(64) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
-                                                       int K, int d, int zs, int KP8, const int* __restrict__ list,
-                                                       const SeqSeg* __restrict__ segs, int seg0, const unsigned char* __restrict__ inset,
-                                                       const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+__global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
+                                                         int K, int d, int zs, int KP8, const int* __restrict__ list,
+                                                         const SeqSeg* __restrict__ segs, int seg0, const unsigned char* __restrict__ inset,
+                                                         const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+#pragma clang fp contract(off)
   static_assert(KPW == 8, "one flag byte per cluster, eight per load");
-  const int lane = threadIdx.x;
-  const int seg = seg0 + blockIdx.x, k0 = blockIdx.y * KPW;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int seg = seg0 + blockIdx.x, k0 = (blockIdx.y * (int)(blockDim.x >> 6) + wv) * KPW;
+  if (k0 >= K) return;
   const SeqSeg sg = segs[seg];
-  float s[KPW];
+  f32x2 s[KPW / 2];
 #pragma unroll
-  for (int kk = 0; kk < KPW; kk++) s[kk] = (zero_start || k0 + kk >= K) ? 0.0f : start[((size_t)seg * K + k0 + kk) * 64 + lane];
+  for (int kk = 0; kk < KPW; kk++) s[kk >> 1][kk & 1] = (zero_start || k0 + kk >= K) ? 0.0f : start[((size_t)seg * K + k0 + kk) * 64 + lane];
   const int js = min(lane, d - 1);
-  const int kl = min(k0 + (lane & (KPW - 1)), K - 1);
+  const bool zl_ok = lane < d;
+  constexpr int U = 4;
   for (int base = 0; base < sg.cnt; base += 64) {
     const int nc = min(64, sg.cnt - base);
     const int ci = sg.off + min(base + lane, sg.cnt - 1);
@@ -119,36 +134,62 @@ __global__ __launch_bounds__(64) void k_seq_ridge_pass(const float* __restrict__
     unsigned mym = 0;
 #pragma unroll
     for (int kk = 0; kk < KPW; kk++) mym |= ((fl >> (8 * kk)) & 0xffull) ? (1u << kk) : 0u;
-    for (int c0 = 0; c0 < nc; c0 += 4) {
-      float z[4], rv[4];
+    // (R rows are read 8 floats at a time from k0: the last group of a row runs into the next row -- R has a dummy row behind the
+    //  last cell -- and those clusters >= K are never stored)
+    const bool allin = (nc == 64) && __builtin_amdgcn_readfirstlane((int)(__ballot(mym != 0xffu) == 0ull)) != 0;
+    if (allin) {        // every cell of the batch enters all 8 regressions (the common case: no masks)
+      for (int c0 = 0; c0 < 64; c0 += U) {
+        float z[U]; f32x2 rv[U][KPW / 2];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int c = min(c0 + u, nc - 1);
-        const int cell = __builtin_amdgcn_readlane(myc, c);
-        const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mym, c);
-        const float zl = Zo[(size_t)cell * zs + js];
-        z[u] = (lane == 63) ? 1.0f : (lane < d ? zl : 0.0f);
-        const float rl = R[(size_t)cell * K + kl];
-        rv[u] = (c0 + u < nc && ((m >> (lane & (KPW - 1))) & 1u)) ? rl : 0.0f;      // outside the regression (or past the end): the term is +0
+        for (int u = 0; u < U; u++) {
+          const int cell = __builtin_amdgcn_readlane(myc, c0 + u);
+          const float zl = Zo[(size_t)cell * zs + js];
+          z[u] = (lane == 63) ? 1.0f : (zl_ok ? zl : 0.0f);
+          const f32x2* rr = reinterpret_cast<const f32x2*>(R + (size_t)cell * K + k0);
+#pragma unroll
+          for (int h = 0; h < KPW / 2; h++) rv[u][h] = rr[h];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const f32x2 zz = {z[u], z[u]};
+#pragma unroll
+          for (int h = 0; h < KPW / 2; h++) s[h] = s[h] + zz * rv[u][h];
+        }
       }
+    } else {
+      for (int c0 = 0; c0 < nc; c0 += U) {
+        float z[U], rv[U][KPW];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
+          const int c = min(c0 + u, nc - 1);
+          const int cell = __builtin_amdgcn_readlane(myc, c);
+          const unsigned m = (c0 + u < nc) ? (unsigned)__builtin_amdgcn_readlane((int)mym, c) : 0u;      // outside the regression (or past the end): the term is +0
+          const float zl = Zo[(size_t)cell * zs + js];
+          z[u] = (lane == 63) ? 1.0f : (zl_ok ? zl : 0.0f);
+          const float* rr = R + (size_t)cell * K + k0;
 #pragma unroll
-        for (int kk = 0; kk < KPW; kk++) {
-          const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv[u]), kk));
-          s[kk] = __fadd_rn(s[kk], __fmul_rn(z[u], r));
+          for (int kk = 0; kk < KPW; kk++) { const float r = rr[kk]; rv[u][kk] = ((m >> kk) & 1u) ? r : 0.0f; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const f32x2 zz = {z[u], z[u]};
+#pragma unroll
+          for (int h = 0; h < KPW / 2; h++) { const f32x2 r2 = {rv[u][2 * h], rv[u][2 * h + 1]}; s[h] = s[h] + zz * r2; }
         }
       }
     }
   }
 #pragma unroll
   for (int kk = 0; kk < KPW; kk++)
-    if (k0 + kk < K) end[((size_t)seg * K + k0 + kk) * 64 + lane] = s[kk];
+    if (k0 + kk < K) end[((size_t)seg * K + k0 + kk) * 64 + lane] = s[kk >> 1][kk & 1];
 }
 
-// (c) a contiguous array of terms (the objective's three K*N-term chains, one array each): thread = segment of L terms
+// (c) a contiguous array of terms (the objective's three K*N-term chains, one array each): thread = segment of L terms.
+//     Round 4: a thread reads one whole 128-byte line (32 terms) per step, the next line already in flight while the 32 dependent adds of
+//     this one run (round 3: 64 bytes per step and no prefetch -- with one wave per SIMD every step exposed a full memory latency).
 __global__ __launch_bounds__(256) void k_seq_arr_pass(const float* __restrict__ T, long long n, long long stride, int L, int nsegs,
                                                       const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= nsegs) return;
   const float* __restrict__ t = T + (size_t)blockIdx.y * (size_t)stride;
@@ -157,16 +198,22 @@ __global__ __launch_bounds__(256) void k_seq_arr_pass(const float* __restrict__ 
   const int cnt = (int)min((long long)L, n - off);
   float s = zero_start ? 0.0f : start[so];
   int i = 0;
-  if ((((uintptr_t)(t + off)) & 15) == 0) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
+  if ((((uintptr_t)(t + off)) & 15) == 0 && cnt >= 32) {
     const f4* __restrict__ t4 = reinterpret_cast<const f4*>(t + off);
-    for (; i + 16 <= cnt; i += 16) {
-      const f4 a = t4[i / 4], b = t4[i / 4 + 1], c = t4[i / 4 + 2], e = t4[i / 4 + 3];
-      s = __fadd_rn(s, a[0]); s = __fadd_rn(s, a[1]); s = __fadd_rn(s, a[2]); s = __fadd_rn(s, a[3]);
-      s = __fadd_rn(s, b[0]); s = __fadd_rn(s, b[1]); s = __fadd_rn(s, b[2]); s = __fadd_rn(s, b[3]);
-      s = __fadd_rn(s, c[0]); s = __fadd_rn(s, c[1]); s = __fadd_rn(s, c[2]); s = __fadd_rn(s, c[3]);
-      s = __fadd_rn(s, e[0]); s = __fadd_rn(s, e[1]); s = __fadd_rn(s, e[2]); s = __fadd_rn(s, e[3]);
+    const int nl = cnt >> 5;                          // whole lines
+    f4 c[8], nx[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) c[q] = t4[q];
+    for (int l = 0; l < nl; l++) {
+      const int ln = min(l + 1, nl - 1);              // (the last step re-reads its own line: no branch around the loads)
+#pragma unroll
+      for (int q = 0; q < 8; q++) nx[q] = t4[8 * ln + q];
+#pragma unroll
+      for (int q = 0; q < 8; q++) { s = __fadd_rn(s, c[q][0]); s = __fadd_rn(s, c[q][1]); s = __fadd_rn(s, c[q][2]); s = __fadd_rn(s, c[q][3]); }
+#pragma unroll
+      for (int q = 0; q < 8; q++) c[q] = nx[q];
     }
+    i = nl << 5;
   }
   for (; i < cnt; i++) s = __fadd_rn(s, t[off + i]);
   end[so] = s;
@@ -185,33 +232,33 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
   const SeqChain c = chains[chain];
   const int per = (c.nseg + 15) / 16;
   const int s0 = c.seg0 + min(v * per, c.nseg), s1 = c.seg0 + min((v + 1) * per, c.nseg);
-  // (eight segments per step: the loads of a step are independent of each other and in flight together -- a step costs one memory
-  //  latency, not eight)
+  // (sixteen segments per step: the loads of a step are independent of each other and in flight together -- a step costs one memory
+  //  latency, not sixteen)
   double acc = 0.0;
-  for (int sb = s0; sb < s1; sb += 8) {
-    float e8[8], o8[8];
+  for (int sb = s0; sb < s1; sb += 16) {
+    float e8[16], o8[16];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 16; u++) {
       const size_t i = (size_t)min(sb + u, s1 - 1) * W + ws;
       e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i];
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) if (sb + u < s1) acc += (double)e8[u] - (double)o8[u];
+    for (int u = 0; u < 16; u++) if (sb + u < s1) acc += (double)e8[u] - (double)o8[u];
   }
   tot[v][lane] = acc;
   __syncthreads();
   double run = 0.0;
   for (int u = 0; u < v; u++) run += tot[u][lane];
   unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;       // how far this lane-chain's starts moved, against the largest start of the chain
-  for (int sb = s0; sb < s1; sb += 8) {
-    float e8[8], o8[8];
+  for (int sb = s0; sb < s1; sb += 16) {
+    float e8[16], o8[16];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 16; u++) {
       const size_t i = (size_t)min(sb + u, s1 - 1) * W + ws;
       e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i];
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 16; u++) {
       if (sb + u < s1) {
         const float ns = (float)run;
         if (w < W) {
@@ -235,6 +282,55 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
     for (int m = 32; m >= 1; m >>= 1) { mm += __shfl_xor(mm, m, 64); dd = fmaxf(dd, __shfl_xor(dd, m, 64)); ss = fmaxf(ss, __shfl_xor(ss, m, 64)); }
     if (lane == 0 && mm) atomicAdd(mismatch, mm);
     if (lane == 0 && v == 0 && ss > 0.0f && dd > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dd / ss));
+  }
+}
+// Small scans (a block's O / E sums, the level-pair sums: ~10^3 lane-chains x <= a few 10^3 segments): ONE WAVE per (chain, lane-chain), lanes
+// along the segments -- every load of a lane-chain is in flight at once and the prefix is a wave scan: one memory round trip per 256
+// segments instead of two per 8 (k_seq_scan took 18 us for a block's 390 segments, as long as the pass it follows).  Same arithmetic:
+// fp64 sums of fp32-representable differences, exact.
+__global__ __launch_bounds__(256) void k_seq_scan_t(const SeqChain* __restrict__ chains, int chain0, int nchains, int W, const float* start_in,
+                                                    const float* __restrict__ end, float* start_out, float* __restrict__ total,
+                                                    unsigned* __restrict__ mismatch, int zero_start) {
+  constexpr int NBK = 4;
+  const int lane = threadIdx.x & 63;
+  const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wid >= (long long)nchains * W) return;
+  const int chain = chain0 + (int)(wid / W), w = (int)(wid % W);
+  const SeqChain c = chains[chain];
+  double run = 0.0;
+  unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;
+  for (int base = 0; base < c.nseg; base += 64 * NBK) {
+    float e[NBK], o[NBK];
+#pragma unroll
+    for (int u = 0; u < NBK; u++) {
+      const int sidx = base + u * 64 + lane;
+      const size_t i = (size_t)(c.seg0 + min(sidx, c.nseg - 1)) * W + w;
+      e[u] = end[i]; o[u] = zero_start ? 0.0f : start_in[i];
+    }
+#pragma unroll
+    for (int u = 0; u < NBK; u++) {
+      const int sidx = base + u * 64 + lane;
+      const bool valid = sidx < c.nseg;
+      const double dlt = valid ? (double)e[u] - (double)o[u] : 0.0;
+      double inc = dlt;
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) { const double t = __shfl_up(inc, m, 64); if (lane >= m) inc += t; }
+      const float ns = (float)(run + (inc - dlt));
+      if (valid) {
+        if (!zero_start && __float_as_uint(ns) != __float_as_uint(o[u])) { mm++; dmax = fmaxf(dmax, fabsf(ns - o[u])); }
+        smax = fmaxf(smax, fabsf(ns));
+        start_out[(size_t)(c.seg0 + sidx) * W + w] = ns;
+      }
+      run += __shfl(inc, 63, 64);
+    }
+  }
+  if (lane == 0) total[(size_t)chain * W + w] = (float)run;
+  if (mismatch && !zero_start) {       // [0] starts that moved, [1] the largest move relative to this lane-chain's own largest start (float bits)
+    smax = fmaxf(smax, fabsf((float)run));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { mm += __shfl_xor(mm, m, 64); dmax = fmaxf(dmax, __shfl_xor(dmax, m, 64)); smax = fmaxf(smax, __shfl_xor(smax, m, 64)); }
+    if (lane == 0 && mm) atomicAdd(mismatch, mm);
+    if (lane == 0 && smax > 1e-30f && dmax > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dmax / smax));
   }
 }
 // one lane-chain per chain (the objective's arrays): threads along the segments, one workgroup per chain
@@ -280,22 +376,26 @@ __global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* star
 }
 
 // ---- O / E tables in the reference's fp32 arithmetic (oe_arith) ----------------------------------------------------------------
-// tot: [(1 + B)][K] chain totals of one block (or of the head): row 0 = sum(Rcells, 1), row 1 + b = Rcells * Phi_tcells column b.
-//   mode  0: head      E = rs Pr_b^T, O = tmp                                  (src/harmony.cpp:149-150, 226-227)
-//   mode -1: remove    E -= rs Pr_b^T, O -= tmp, then the block's penalty table (:312-313, :322)
-//   mode +1: put back  E += rs Pr_b^T, O += tmp                                 (:329-330)
-__global__ void k_oe_fold(float* __restrict__ Of, float* __restrict__ Ef, const float* __restrict__ tot, const float* __restrict__ Pr_b,
-                          const float* __restrict__ theta, float* __restrict__ pen, int B, int K, int mode) {
+// tot_*: [(1 + B)][K] chain totals of one block (or of the head): row 0 = sum(Rcells, 1), row 1 + b = Rcells * Phi_tcells column b.
+//   head      E = rs Pr_b^T, O = tmp                                              (src/harmony.cpp:149-150, 226-227; tot_sub holds the sums)
+//   tot_add   put back: E += rs Pr_b^T, O += tmp   (the block just updated)         (:329-330)
+//   tot_sub   remove:   E -= rs Pr_b^T, O -= tmp, then this block's penalty table   (:312-313, :322)
+// One launch does "put block j-1 back, take block j out" (round 3: two launches per block step) -- the same two roundings per entry in the
+// same order.
+__global__ void k_oe_fold(float* __restrict__ Of, float* __restrict__ Ef, const float* __restrict__ tot_add, const float* __restrict__ tot_sub,
+                          const float* __restrict__ Pr_b, const float* __restrict__ theta, float* __restrict__ pen, int B, int K, int head) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * K) return;
   const int b = i / K, k = i - b * K;
-  const float de = __fmul_rn(tot[k], Pr_b[b]), dO = tot[(size_t)(1 + b) * K + k];
   float e, o;
-  if (mode == 0) { e = de; o = dO; }
-  else if (mode < 0) { e = __fsub_rn(Ef[i], de); o = __fsub_rn(Of[i], dO); }
-  else { e = __fadd_rn(Ef[i], de); o = __fadd_rn(Of[i], dO); }
+  if (head) { e = __fmul_rn(tot_sub[k], Pr_b[b]); o = tot_sub[(size_t)(1 + b) * K + k]; }
+  else {
+    e = Ef[i]; o = Of[i];
+    if (tot_add) { e = __fadd_rn(e, __fmul_rn(tot_add[k], Pr_b[b])); o = __fadd_rn(o, tot_add[(size_t)(1 + b) * K + k]); }
+    if (tot_sub) { e = __fsub_rn(e, __fmul_rn(tot_sub[k], Pr_b[b])); o = __fsub_rn(o, tot_sub[(size_t)(1 + b) * K + k]); }
+  }
   Ef[i] = e; Of[i] = o;
-  if (mode < 0 && pen) {
+  if (!head && tot_sub && pen) {
     const float num = __fadd_rn(__fmul_rn(2.0f, e), 1.0f), den = __fadd_rn(__fadd_rn(o, e), 1.0f);
     pen[i] = powf(num / den, theta[b]);      // harmony_pow(((2E+1)/(O+E+1)), theta) :322 (not on any critical path here: the accurate powf)
   }
@@ -413,13 +513,21 @@ void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg*
   if (nsegs <= 0) return;
   int wpb = 4;                                           // waves per workgroup, limited by the level rows in LDS
   while (wpb > 1 && (size_t)wpb * D.B * 256 > 60 * 1024) wpb >>= 1;
-  hipLaunchKernelGGL(k_seq_oe_pass, dim3((nsegs + wpb - 1) / wpb, (D.K + 63) / 64), dim3(64 * wpb), (size_t)wpb * D.B * 256, L.stream, D.R, D.K, D.B,
+  hipLaunchKernelGGL(k_seq_oe_pass<true>, dim3((nsegs + wpb - 1) / wpb, (D.K + 63) / 64), dim3(64 * wpb), (size_t)wpb * D.B * 256, L.stream, D.R, D.K, D.B,
                      D.C, list, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start);
+}
+// plain list sums: W = K lane-chains per segment (row 0 of the kernel above only)
+void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
+                    int zero_start) {
+  if (nsegs <= 0) return;
+  hipLaunchKernelGGL(k_seq_oe_pass<false>, dim3((nsegs + 3) / 4, (D.K + 63) / 64), dim3(256), 0, L.stream, D.R, D.K, 0, 0, list, D.combo, D.qlev, segs, seg0,
+                     nsegs, start, end, zero_start);
 }
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start) {
   if (nsegs <= 0) return;
-  hipLaunchKernelGGL(k_seq_ridge_pass<8>, dim3(nsegs, (D.K + 7) / 8), dim3(64), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, D.zs, (D.K + 7) / 8 * 8, list, segs,
+  const int kg = (D.K + 7) / 8, wpg = kg < 16 ? kg : 16;       // one wave per 8 clusters, up to 16 waves (128 clusters) per workgroup
+  hipLaunchKernelGGL(k_seq_ridge_pass<8>, dim3(nsegs, (kg + wpg - 1) / wpg), dim3(64 * wpg), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, D.zs, (D.K + 7) / 8 * 8, list, segs,
                      seg0, inset, start, end, zero_start);
 }
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
@@ -429,6 +537,12 @@ void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stri
 void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains, int W, const float* start_in, const float* end, float* start_out,
                 float* total, unsigned* mismatch, int zero_start) {
   if (nchains <= 0) return;
+  if ((long long)nchains * W <= 65536) {      // few lane-chains: one wave each, lanes along the segments
+    const long long waves = (long long)nchains * W;
+    hipLaunchKernelGGL(k_seq_scan_t, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, L.stream, chains, chain0, nchains, W, start_in, end, start_out, total,
+                       mismatch, zero_start);
+    return;
+  }
   hipLaunchKernelGGL(k_seq_scan, dim3(nchains, (W + 63) / 64), dim3(1024), 0, L.stream, chains, chain0, W, start_in, end, start_out, total, mismatch,
                      zero_start);
 }
@@ -436,13 +550,14 @@ void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, co
                  unsigned* mismatch, int zero_start) {
   hipLaunchKernelGGL(k_seq_scan1, dim3(narr), dim3(1024), 0, L.stream, nsegs, start_in, end, start_out, total, mismatch, zero_start);
 }
-void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot, float* pen, int mode) {
+void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot_add, const float* tot_sub, float* pen, int head) {
   const int n = D.B * D.K;
-  hipLaunchKernelGGL(k_oe_fold, dim3((n + 255) / 256), dim3(256), 0, L.stream, Of, Ef, tot, D.Pr_b, D.theta, pen, D.B, D.K, mode);
+  hipLaunchKernelGGL(k_oe_fold, dim3((n + 255) / 256), dim3(256), 0, L.stream, Of, Ef, tot_add, tot_sub, D.Pr_b, D.theta, pen, D.B, D.K, head);
 }
 void l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride) {
   const int n = D.B * D.K;
   hipLaunchKernelGGL(k_obj_mtable, dim3((n + 255) / 256), dim3(256), 0, L.stream, D, Of, Ef, M);
+  if (l_obj_terms_mfma(L, D, M, T, stride)) return;          // distances on the matrix cores, 16-byte rows (hmx_kernels.hip)
   int blocks = (D.n + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_obj_terms, dim3(blocks), dim3(256), (size_t)D.d * D.KP * sizeof(float), L.stream, D, M, T, stride);
 }

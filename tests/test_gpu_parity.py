@@ -98,6 +98,16 @@ def test_pbmc_default_run(pbmc):
     assert_parity(g, c, ig, ic)
 
 
+def test_pbmc_30k_default_run():
+    """BASELINE configs[1] at its stated size (~30k cells x 50 PCs, K = 50, stim / ctrl): the shipped 2 000-cell sample resampled to 30k
+    cells (bench_data.pbmc30k), reference defaults, to convergence, against the oracle; bench.py times the same workload (`also.pbmc30k`)"""
+    from bench_data import pbmc30k
+    Z, meta = pbmc30k()
+    g, c, ig, ic = run_both(Z, meta, "stim", nclust=50)
+    s = assert_parity(g, c, ig, ic)
+    print("pbmc 30k:", s, "iterations", ig)
+
+
 def test_fixed_lambda_tau_vector_sigma(cell_lines):
     K = 12
     g, c, ig, ic = run_both(cell_lines["pcs"], _meta(cell_lines), ["dataset", "cell_type"], max_iter=3, nclust=K,
@@ -146,6 +156,24 @@ def test_stand_alone_compute_objective_after_a_correction(cell_lines):
     assert len(vals["stale"]) == len(vals["oracle"])
     np.testing.assert_allclose(vals["stale"], vals["oracle"], rtol=1e-5)
     assert abs(vals["fresh"][-1] - vals["oracle"][-1]) > 1e-3 * abs(vals["oracle"][-1])      # (the documented deviation is real)
+
+
+def test_stand_alone_compute_objective_in_reference_arithmetic(cell_lines):
+    """the same stand-alone call with ref_arith = 1: obj_arith re-derives the three term matrices -- they must come from
+    the stale snapshot too, not from the corrected Z_corr / new Y -- and is compared with the FAITHFUL oracle"""
+    skw, _ = prepare_setup_args(cell_lines["pcs"], _meta(cell_lines), "dataset", nclust=20)
+    Y0 = np.asfortranarray(cell_lines["pcs"][:20].T)
+    vals = {}
+    for name, obj in (("stale", Harmony(seed=1, stale_dist=1, ref_arith=1)), ("oracle", OracleHarmony(accurate=False, seed=1))):
+        obj.setup(**skw)
+        obj.init_cluster_cpp(Y0)
+        assert obj.cluster_cpp() == 0
+        obj.moe_correct_ridge_cpp()
+        obj.compute_objective()
+        vals[name] = [np.array(getattr(obj, nm)) for nm in ("objective_kmeans", "objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross")]
+    for a, b in zip(vals["stale"], vals["oracle"]):
+        assert len(a) == len(b)
+        np.testing.assert_allclose(a, b, rtol=2e-5)
 
 
 def test_tiny_N_block_size_warning():

@@ -42,13 +42,13 @@ def _flips(Ra, Rb, margin):
 
 # ---------------------------------------------------------------- VERDICT r1 item 1 + 2a: the arithmetic-gap table
 @pytest.mark.timeout(1500, method="thread")
-@pytest.mark.parametrize("N", [20000, 100000, 1000000])
+@pytest.mark.parametrize("N", [20000, 100000, 1000000, 2000000])
 def test_arithmetic_gap_table(N):
     """GPU (default: exact accumulators) and GPU (ref_arith = 1: every accumulator group in the reference's fp32 operation order --
     ridge statistics, O / E tables, objective sums, closed-form inverse) against the oracle in accurate (fp64 accumulators) AND
     faithful (the reference's fp32 arithmetic) mode: N x 50, K = 100, 10 batches, reference defaults, to convergence -- N = 1M is
-    BASELINE configs[2] exactly.  Shared random choices: the GPU's k-means centres, the documented Feistel block partitions (same
-    seed).  The numbers go to gpurun_out/r3_parity_table_<N>.json (copied to profiles/ and quoted in DESIGN.md section 2)."""
+    BASELINE configs[2] exactly, N = 2M pins a faithful comparison beyond it in the regular suite.  Shared random choices: the GPU's k-means centres, the documented Feistel block partitions (same
+    seed).  The numbers go to gpurun_out/r4_parity_table_<N>.json (copied to profiles/ and quoted in DESIGN.md section 2)."""
     K, B, seed = 100, 10, 3
     Z, meta, _ = synth(N, d=50, levels=(B,), seed=7)
     skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
@@ -99,7 +99,7 @@ def test_arithmetic_gap_table(N):
     out = {"workload": {"cells": N, "pcs": 50, "clusters": K, "batches": B}, "seconds": timing, "pairs": rows,
            "seq_residual": res["gpu_ref_arith"]["seq_residual"]}
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "r3_parity_table_%d.json" % N), "w") as fh:
+    with open(os.path.join(OUT, "r4_parity_table_%d.json" % N), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
     ga, gf, rf = rows["gpu_vs_oracle_accurate"], rows["gpu_vs_oracle_faithful"], rows["gpu_ref_arith_vs_oracle_faithful"]
@@ -384,23 +384,31 @@ def _pair_row(ra, rb):
 @pytest.mark.timeout(1500, method="thread")
 def test_config5_shape_1M_to_convergence():
     """BASELINE configs[4]'s shape at 1M cells: K = 200, three nested covariates 8 > 64 > 128 = 200 levels, reference defaults, to convergence
-    (7 harmony iterations): GPU (default arithmetic) against the oracle with exact accumulators AND against the faithful oracle (fp32
-    accumulators, arma::inv as fp32 LU, src/harmony.cpp:572-574), the batch-subset ridge path counted per iteration (:440-547).
-    Table -> gpurun_out/r3_parity_c5_1M.json (profiles/)."""
+    (7 harmony iterations): GPU (default arithmetic) against the oracle with exact accumulators, and GPU REFERENCE ARITHMETIC (round 4:
+    ridge statistics of several covariates as sequential fp32 chains incl. the level-pair sums of Phi_Rk * Phi_moe_t, arma::inv as the
+    oracle's unblocked fp32 LU, src/harmony.cpp:561-574) against the faithful oracle; the batch-subset ridge path counted per iteration
+    (:440-547).  Table -> gpurun_out/r4_parity_c5_1M.json (profiles/)."""
     Z, meta, _ = synth(1_000_000, d=50, levels=(8, 64, 128), seed=11, nested=True)
-    res, timing = _run_pair_to_convergence(Z, meta, 200, 5, {"gpu": {}}, {"oracle_accurate": 15, "oracle_faithful": 0})
+    res, timing = _run_pair_to_convergence(Z, meta, 200, 5, {"gpu": {}, "gpu_ref_arith": {"ref_arith": 1}}, {"oracle_accurate": 15, "oracle_faithful": 0})
     rows = {"gpu_vs_oracle_accurate": _pair_row(res["gpu"], res["oracle_accurate"]), "gpu_vs_oracle_faithful": _pair_row(res["gpu"], res["oracle_faithful"]),
+            "gpu_ref_arith_vs_oracle_faithful": _pair_row(res["gpu_ref_arith"], res["oracle_faithful"]),
             "oracle_faithful_vs_oracle_accurate": _pair_row(res["oracle_faithful"], res["oracle_accurate"])}
     out = {"workload": {"cells": 1000000, "pcs": 50, "clusters": 200, "levels": [8, 64, 128], "nested": True}, "seconds": timing, "pairs": rows}
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "r3_parity_c5_1M.json"), "w") as fh:
+    with open(os.path.join(OUT, "r4_parity_c5_1M.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
     ga = rows["gpu_vs_oracle_accurate"]
     assert ga["Z_rel"] <= 2e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1] and ga["kmeans_rounds_equal"], ga
     assert ga["objective_rel_max"] <= 1e-4, ga
     assert ga["subset_clusters_per_iteration"][0] == ga["subset_clusters_per_iteration"][1] and max(ga["subset_clusters_per_iteration"][0]) > 0, ga
-    gf = rows["gpu_vs_oracle_faithful"]      # reported: the reference's fp32 drift at this shape (multi-covariate reference arithmetic is not reproduced)
+    # the reference's own arithmetic at this shape: north_star's 1e-4 (the fp32 LU amplifies the ~1e-7 differences between the two
+    # implementations' R by the systems' condition number, 5e3 .. 1.6e4: the bar here is the contract's, not the one-covariate 1e-5)
+    rf = rows["gpu_ref_arith_vs_oracle_faithful"]
+    assert rf["Z_rel"] <= 1e-4 and rf["iterations"][0] == rf["iterations"][1] and rf["kmeans_rounds_equal"], rf
+    assert rf["objective_rel_max"] <= 1e-4, rf
+    assert rf["subset_clusters_per_iteration"][0] == rf["subset_clusters_per_iteration"][1], rf
+    gf = rows["gpu_vs_oracle_faithful"]      # reported: the default mode against the reference's fp32 drift at this shape
     assert gf["iterations"][0] == gf["iterations"][1], gf
 
 
@@ -408,7 +416,7 @@ def test_config5_shape_1M_to_convergence():
 @pytest.mark.skipif(os.environ.get("HMX_SLOW", "0") != "1", reason="builder run (HMX_SLOW=1): ~15 minutes of CPU for the oracle at 10M cells; table in profiles/")
 def test_config4_10M_against_the_oracle():
     """BASELINE configs[3] at FULL size on one GPU -- 10M x 50, K = 100, 20 batches, to convergence: GPU default vs the oracle with exact
-    accumulators, and GPU reference arithmetic vs the faithful oracle.  Table -> gpurun_out/r3_parity_c4_10M.json (profiles/)."""
+    accumulators, and GPU reference arithmetic vs the faithful oracle.  Table -> gpurun_out/r4_parity_c4_10M.json (profiles/)."""
     with open("/proc/meminfo") as fh:
         avail_gb = [int(l.split()[1]) for l in fh if l.startswith("MemAvailable")][0] / 1048576.0
     if avail_gb < 120:
@@ -420,7 +428,7 @@ def test_config4_10M_against_the_oracle():
             "gpu_vs_oracle_faithful": _pair_row(res["gpu"], res["oracle_faithful"]), "oracle_faithful_vs_oracle_accurate": _pair_row(res["oracle_faithful"], res["oracle_accurate"])}
     out = {"workload": {"cells": 10000000, "pcs": 50, "clusters": 100, "batches": 20}, "seconds": timing, "pairs": rows}
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "r3_parity_c4_10M.json"), "w") as fh:
+    with open(os.path.join(OUT, "r4_parity_c4_10M.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
     ga, rf = rows["gpu_vs_oracle_accurate"], rows["gpu_ref_arith_vs_oracle_faithful"]

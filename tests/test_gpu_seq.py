@@ -191,20 +191,46 @@ def test_reference_arithmetic_groups_can_be_switched_one_by_one(cell_lines_small
         assert ig == ic and s["Z_rel"] <= 1e-5 and s["obj_rel"] <= 2e-5 and s["clear_flips"] == 0, (kw, s)
 
 
-def test_reference_arithmetic_needs_one_gpu_and_one_covariate(cell_lines):
+def test_reference_arithmetic_several_covariates(cell_lines):
+    """two crossed covariates (dataset x cell_type) on the reference's 2370-cell fixture and three nested ones on a synthetic: the ridge
+    statistics are the level and level-PAIR chains of Phi_Rk * Phi_moe_t (src/harmony.cpp:561-568), the inverse the oracle's unblocked
+    fp32 LU (arma::inv, :573) -- against the faithful oracle (mask 0)"""
+    orc.use_openblas(1)
     meta = {"dataset": cell_lines["dataset_levels"][cell_lines["dataset"]], "cell_type": cell_lines["cell_type_levels"][cell_lines["cell_type"]]}
-    skw, _ = prepare_setup_args(cell_lines["pcs"], meta, ["dataset", "cell_type"], nclust=20)
-    g = Harmony(seed=1, ridge_arith=1)
-    with pytest.raises(Exception, match="one covariate"):
-        g.setup(**skw)
-    # the tables and the objective follow the reference for any number of covariates
-    g = Harmony(seed=1, oe_arith=1, obj_arith=1); g.setup(**skw)
-    c = OracleHarmony(mask=12, seed=1); c.setup(**skw)
-    Y0 = g.kmeans_centers()
-    g.init_cluster_cpp(Y0); c.init_cluster_cpp(Y0)
-    ig, ic = _iterate(g, 3), _iterate(c, 3)
+    g, c, ig, ic = _pair(cell_lines["pcs"], meta, ["dataset", "cell_type"], seed=1, max_iter=4, nclust=20)
     s = _report(g, c)
-    assert ig == ic and s["Z_rel"] <= 1e-5 and s["obj_rel"] <= 2e-5 and s["clear_flips"] == 0, s
+    print("ref_arith, two crossed covariates:", s)
+    assert ig == ic and s["obj_len"][0] == s["obj_len"][1] and np.array_equal(g.kmeans_rounds, c.kmeans_rounds), (ig, ic, s)
+    assert s["Z_rel"] <= 1e-4 and s["clear_flips"] == 0 and s["obj_rel"] <= 1e-4, s
+    Z, meta3, _ = synth(40000, d=50, levels=(4, 12, 24), seed=5, nested=True)
+    orc.use_openblas(4)
+    g, c, ig, ic = _pair(Z, meta3, list(meta3), seed=2, max_iter=4, nclust=60)
+    s = _report(g, c)
+    print("ref_arith, three nested covariates:", s, "subset clusters", int(g._scalar("subset_clusters")), c.subset_clusters)
+    assert ig == ic and s["obj_len"][0] == s["obj_len"][1], (ig, ic, s)
+    assert int(g._scalar("subset_clusters")) == c.subset_clusters
+    assert s["Z_rel"] <= 1e-4 and s["clear_flips"] == 0 and s["obj_rel"] <= 1e-4, s
+    # each group alone still follows its own oracle mask (the statistics alone: fp64 solve on both sides)
+    skw, _ = prepare_setup_args(cell_lines["pcs"], meta, ["dataset", "cell_type"], nclust=20)
+    for kw, mask in ((dict(ridge_arith=1), 11), (dict(oe_arith=1, obj_arith=1), 12)):
+        g = Harmony(seed=1, **kw); g.setup(**skw)
+        c = OracleHarmony(mask=mask, seed=1); c.setup(**skw)
+        Y0 = g.kmeans_centers()
+        g.init_cluster_cpp(Y0); c.init_cluster_cpp(Y0)
+        ig, ic = _iterate(g, 3), _iterate(c, 3)
+        s = _report(g, c)
+        assert ig == ic and s["Z_rel"] <= 1e-5 and s["obj_rel"] <= 2e-5 and s["clear_flips"] == 0, (kw, s)
+
+
+def test_reference_arithmetic_needs_one_gpu(cell_lines_small):
+    """a sharded handle refuses the reference-arithmetic switches: a block's shuffled order interleaves the shards cell by cell, the
+    reference's sequential sums cannot be followed from contiguous shards"""
+    meta = {"dataset": cell_lines_small["dataset_levels"][cell_lines_small["dataset"]]}
+    skw, _ = prepare_setup_args(cell_lines_small["pcs"], meta, "dataset", nclust=10)
+    g = Harmony(seed=1, ref_arith=1)
+    g._set("comm_force", 1)
+    with pytest.raises(Exception, match="one GPU"):
+        g.setup(**skw)
 
 
 def test_reference_arithmetic_with_the_hosts_shuffles(cell_lines):
