@@ -256,6 +256,7 @@ struct hmx_ctx {
   unsigned* sq_conv = nullptr; int seq_max_passes = 24; int64_t seq_adaptive_cells = 200000, seq_extra_passes = 0; double seq_resid_max = 0.0; uint64_t seq_mismatch_sum = 0;
   int* headlist = nullptr;                 // [(1 + C) n] cells in original order | cells by (level of covariate c, original order)
   std::vector<int> lev_off, lev_cnt;       // [B] a level's range inside its covariate's part of headlist
+  int* headlev = nullptr; int* roundlev = nullptr;     // [min(C, 4)][n] level codes of the positions of headlist's first part / of roundlist
   int* roundlist = nullptr;                // [(1 + C) n] this round's cells in shuffled order | by (block, level of covariate c), shuffled order
   std::vector<int> invperm_h, combo_h;     // host copies (internal order)
   float* Of = nullptr; float* Ef = nullptr; float* Mtab = nullptr;    // [B][K] fp32 O / E (oe_arith), theta log((O+E+1)/(2E+1))
@@ -333,14 +334,14 @@ void free_all(hmx_ctx* ctx) {
   }
   {   // reference-arithmetic buffers (grown on demand, not in `allocs`)
     void* ps[] = {ctx->sq_start, ctx->sq_end, ctx->sq_total, ctx->sq_mismatch, ctx->headlist, ctx->roundlist, ctx->Of, ctx->Ef, ctx->Mtab, ctx->objT,
-                  ctx->inset, ctx->obj_start, ctx->rg_start, ctx->pairlist, ctx->pair_idx, ctx->rg_tot, ctx->rp_tot, ctx->rp_start, ctx->plan_pair.d_segs, ctx->plan_pair.d_chains, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
+                  ctx->inset, ctx->obj_start, ctx->rg_start, ctx->headlev, ctx->roundlev, ctx->pairlist, ctx->pair_idx, ctx->rg_tot, ctx->rp_tot, ctx->rp_start, ctx->plan_pair.d_segs, ctx->plan_pair.d_chains, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
                   ctx->plan_round.d_segs, ctx->plan_round.d_chains};
     for (void* q : ps) if (q) (void)hipFree(q);
     ctx->sq_start = ctx->sq_end = ctx->sq_total = nullptr; ctx->sq_mismatch = nullptr; ctx->sq_conv = nullptr; ctx->headlist = ctx->roundlist = nullptr;
     ctx->Of = ctx->Ef = ctx->Mtab = ctx->objT = nullptr; ctx->inset = nullptr; ctx->sq_cap = ctx->sq_total_cap = ctx->objT_cap = 0;
     ctx->obj_start = ctx->rg_start = nullptr; ctx->obj_start_cap = ctx->rg_start_cap = 0; ctx->obj_warm = ctx->rg_warm = false;
     ctx->plan_head = hmx_ctx::SeqPlan(); ctx->plan_ridge = hmx_ctx::SeqPlan(); ctx->plan_round = hmx_ctx::SeqPlan(); ctx->plan_pair = hmx_ctx::SeqPlan();
-    ctx->pairlist = ctx->pair_idx = nullptr; ctx->rg_tot = ctx->rp_tot = ctx->rp_start = nullptr; ctx->npairs = 0; ctx->rp_warm = false;
+    ctx->headlev = ctx->roundlev = nullptr; ctx->pairlist = ctx->pair_idx = nullptr; ctx->rg_tot = ctx->rp_tot = ctx->rp_start = nullptr; ctx->npairs = 0; ctx->rp_warm = false;
   }
   if (ctx->h_obj) { (void)hipHostFree(ctx->h_obj); ctx->h_obj = nullptr; ctx->obj_cap = 0; }
   if (ctx->obj_event) { (void)hipEventDestroy(ctx->obj_event); ctx->obj_event = nullptr; }
@@ -834,14 +835,14 @@ template <class PASS, class SCAN> int seq_iterate(hmx_ctx* ctx, bool warm, bool 
 // scan that hands every segment its start).
 // warm: the workspace still holds these segments' starts from a run over (nearly) the same terms -- the first pass starts from them
 // instead of from zero, which is worth one pass.
-int seq_run_oe(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, int chain0, int nchains, bool warm = false) {
+int seq_run_oe(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, const int* poslev, int chain0, int nchains, bool warm = false) {
   const int W = (1 + ctx->B) * ctx->K, lo = P.seg0[chain0], n = P.seg0[chain0 + nchains] - lo;
   CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
   int longest = 0;
   for (int c = chain0; c < chain0 + nchains; c++) longest = std::max(longest, P.seg0[c + 1] - P.seg0[c]);
   const bool adaptive = (int64_t)longest * P.seg_cells >= ctx->seq_adaptive_cells;
   CHK(seq_iterate(ctx, warm, adaptive,
-                  [&](bool zero) -> int { l_seq_oe_pass(ctx->L, ctx->D, list, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
+                  [&](bool zero) -> int { l_seq_oe_pass(ctx->L, ctx->D, list, poslev, (int)ctx->N, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
                   [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, chain0, nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->seq_runs++;
   return 0;
@@ -877,8 +878,12 @@ int seq_setup_static(hmx_ctx* ctx) {
       const int hi = (j == ctx->nb - 1) ? n : (int)std::min<uint64_t>((uint64_t)n, (uint64_t)(j + 1) * ctx->cells_per_block);
       ch.push_back({lo, hi - lo});
     }
-    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 64));
+    CHK(seq_plan_build(ctx, ctx->plan_round, ch, 128));
     size_t cap = 0; CHK(seq_grow(ctx, ctx->roundlist, cap, (size_t)n));
+    { const int Cl = std::min(C, 4); size_t c1 = 0, c2 = 0; CHK(seq_grow(ctx, ctx->roundlev, c1, (size_t)Cl * n)); CHK(seq_grow(ctx, ctx->headlev, c2, (size_t)Cl * n));
+      std::vector<int> hv((size_t)Cl * n);
+      for (int i = 0; i < n; i++) for (int c = 0; c < Cl; c++) hv[(size_t)c * n + i] = ctx->qlev[(size_t)ctx->combo_h[ctx->invperm_h[i]] * C + c];
+      CHK(h2d(ctx, ctx->headlev, hv.data(), hv.size())); }
   }
   if (ctx->ridge_arith) {
     if (ctx->d > 62) return fail(ctx, HMX_ERR_LIMIT, "ridge_arith = 1 supports d <= 62");
@@ -913,7 +918,7 @@ int seq_setup_static(hmx_ctx* ctx) {
 }
 // E, O of the head in the reference's arithmetic: R has just been rewritten
 int oe_head(hmx_ctx* ctx) {
-  CHK(seq_run_oe(ctx, ctx->plan_head, ctx->headlist, 0, 1));
+  CHK(seq_run_oe(ctx, ctx->plan_head, ctx->headlist, ctx->headlev, 0, 1));
   l_oe_fold(ctx->L, ctx->D, ctx->Of, ctx->Ef, nullptr, ctx->sq_total, nullptr, 1); KCHK();
   return 0;
 }
@@ -951,8 +956,8 @@ int seq_ridge_stats(hmx_ctx* ctx) {
   const hmx_ctx::SeqPlan& P = ctx->plan_ridge;
   const int W = ctx->K * 64;
   const bool multi = ctx->C > 1;
-  float* const tot = multi ? ctx->rg_tot : ctx->sq_total;
   CHK(seq_workspace(ctx, (size_t)P.nsegs * W, (size_t)P.nchains * W));
+  float* const tot = multi ? ctx->rg_tot : ctx->sq_total;          // (after the workspace call: it may have re-allocated sq_total)
   if ((size_t)P.nsegs * W > ctx->rg_start_cap) { CHK(seq_grow(ctx, ctx->rg_start, ctx->rg_start_cap, (size_t)P.nsegs * W)); ctx->rg_warm = false; }
   l_seq_inset(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->sv_cov_bounds, ctx->cutoff, ctx->inset); KCHK();
   CHK(seq_iterate(ctx, ctx->rg_warm, ctx->N >= ctx->seq_adaptive_cells,
@@ -992,13 +997,16 @@ int update_R_ref(hmx_ctx* ctx) {
       std::vector<int> po((size_t)n);
       for (int p = 0; p < n; p++) po[p] = ctx->invperm_h[(size_t)order[p]];
       CHK(h2d(ctx, ctx->roundlist, po.data(), po.size()));
-    } else { l_ref_posord(ctx->L, D, ctx->seed, ctx->round_counter, (uint64_t)ctx->N_global, ctx->roundlist); KCHK(); }
+      { const int Cl = std::min(ctx->C, 4); std::vector<int> lv((size_t)Cl * n);
+        for (int p = 0; p < n; p++) for (int c = 0; c < Cl; c++) lv[(size_t)c * n + p] = ctx->qlev[(size_t)ctx->combo_h[po[p]] * ctx->C + c];
+        CHK(h2d(ctx, ctx->roundlev, lv.data(), lv.size())); }
+    } else { l_ref_posord(ctx->L, D, ctx->seed, ctx->round_counter, (uint64_t)ctx->N_global, ctx->roundlist, ctx->roundlev); KCHK(); }
     CHK(prepare_round(ctx, ctx->round_counter)); }             // the tile kernels' padded block order, from the same shuffle
   ctx->round_counter++;
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * B * K, ctx->L.stream));   // (the kernel's fixed-point sums are not used here)
   const int W = (1 + B) * K;
   { PhaseScope ph(ctx, "EO_update");     // every block's cells are still untouched at this point: the sums each block will remove (:312-313), all at once
-    CHK(seq_run_oe(ctx, P, ctx->roundlist, 0, nb)); }
+    CHK(seq_run_oe(ctx, P, ctx->roundlist, ctx->roundlev, 0, nb)); }
   D.fused_fold = 0; D.Sold_next = nullptr;
   const float* put_back = nullptr;                                   // the sums of the block updated last, still to be added back (:329-330)
   for (int j = 0; j < nb; j++) {
@@ -1014,7 +1022,7 @@ int update_R_ref(hmx_ctx* ctx) {
     if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
     { PhaseScope ph(ctx, "EO_update");
       // the same cells in the same order as the sums removed above, their R rows updated: that run's segment starts are this run's first guess
-      CHK(seq_run_oe(ctx, P, ctx->roundlist, j, 1, true)); }
+      CHK(seq_run_oe(ctx, P, ctx->roundlist, ctx->roundlev, j, 1, true)); }
     put_back = tot;
   }
   if (put_back) { PhaseScope ph(ctx, "EO_update"); l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, put_back, nullptr, nullptr, 0); KCHK(); }
@@ -1750,12 +1758,14 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   D.n = (int)N; D.d = d; D.K = K; D.B = B; D.C = C; D.Q = Q; D.B0 = ctx->B_vec[0];
   D.KP = (K + 63) / 64 * 64; D.nb = ctx->nb;
   D.zs = (d + 3) / 4 * 4;
-  { // Rows of whole 128-byte lines where that costs at most 30 % more bytes (d = 50: 208 -> 256 B): the block chain GATHERS the rows of a
-    // block's cells, and a 208-byte row at 16-byte alignment touches 2.6 lines on average -- 404 B of HBM reads per cell for 200 B of
-    // payload (rocprof FETCH_SIZE, profiles/r3_pmc_summary.json).  The pad floats are zero and stay zero.  HMX_ZS_PAD=0: tight rows.
+  { // HMX_ZS_PAD=1: rows of whole 128-byte lines where that costs at most 30 % more bytes (d = 50: 208 -> 256 B).  The block chain GATHERS
+    // the rows of a block's cells, and a 208-byte row at 16-byte alignment touches 2.6 lines on average (404 B of HBM reads per cell for
+    // 200 B of payload, rocprof FETCH_SIZE) -- but the chain is not bound by those reads: measured back to back on one box (round 4) the
+    // padded layout shortened the phase behind an arrival by 0.5 us and left the block step where it was (17.7 vs 17.4 us), for 23 % more
+    // memory.  Off by default.
     const char* e = getenv("HMX_ZS_PAD");
     const int zp = (D.zs + 31) / 32 * 32;
-    if (!(e && atoi(e) == 0) && zp != D.zs && zp * 10 <= D.zs * 13) D.zs = zp; }
+    if (e && atoi(e) == 1 && zp != D.zs && zp * 10 <= D.zs * 13) D.zs = zp; }
   { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 8; if (want > 8) want = 8; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
   { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 14, 16};     // (13: K = 200, BASELINE configs[4])
     const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
@@ -2091,7 +2101,7 @@ int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the cur
   HIPCHK(hipMemsetAsync(ctx->D.objpart, 0, sizeof(double) * 2 * (size_t)ctx->D.objslots * ctx->D.nwmax, ctx->L.stream));
   Dev Ds = ctx->D;
   const bool stale = ctx->stale_dist && ctx->head_is_stale;
-  if (stale) { Ds.Zc = ctx->Zc_head; Ds.Yt = ctx->Yt_head; }          // the reference's stored dist_mat (:160)
+  if (stale) { Ds.Zc = ctx->Zc_head; Ds.Yt = ctx->Yt_head; Ds.obj_stale = 1; }          // the reference's stored dist_mat (:160)
   l_head(ctx->L, Ds, 1); KCHK();
   l_obj_reduce(ctx->L, ctx->D); KCHK();
   CHK(allreduce(ctx, ctx->D.obj, 2, 1));
@@ -2247,7 +2257,7 @@ int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level,
     std::vector<std::pair<int, int>> ch;
     for (int c = 0; c < nchains; c++) ch.push_back({chain_off[c], chain_cnt[c]});
     CHK(seq_plan_build(ctx, ctx->plan_round, ch, seg_cells));
-    CHK(seq_run_oe(ctx, ctx->plan_round, dl, 0, nchains));
+    CHK(seq_run_oe(ctx, ctx->plan_round, dl, nullptr, 0, nchains));
     CHK(d2h(ctx, totals, ctx->sq_total, (size_t)nchains * (1 + B) * K));
     unsigned mm[2] = {0, 0}; CHK(d2h(ctx, mm, ctx->sq_conv, 2));
     if (mismatch) *mismatch = (int64_t)mm[0];

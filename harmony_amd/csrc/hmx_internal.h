@@ -93,6 +93,7 @@ struct Dev {
   int head_gather;             // k_tile MODE 1 runs over the padded order of the upcoming round (lpair) instead of the static tiles
   long long* Sold_head;        // [nb][B][K] the head files its R sums here as the old contributions of that round's blocks (or nullptr)
   int head_norm;               // k_tile MODE 1: normalise the tile's Z_corr rows in registers and write them back (fused head of cluster_cpp)
+  int obj_stale;               // compute_objective on the stale snapshot (stale_dist): Yt / Zc are not the ones the MFMA images were built from
   int rvec;                    // K % 4 == 0: R rows are 16-byte aligned, the tile kernels store them with vector stores
   int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)
   // peer-to-peer block chain (sharded runs, one process per GPU on a node): p2p_inbox[g] = rank g's inbox as mapped into THIS
@@ -267,11 +268,11 @@ size_t lds_bytes_y(const Dev& D);
 // ---- reference arithmetic: restarted sequential fp32 sums (hmx_seq.hip) ------------------------------------------------------------
 struct SeqSeg { int off; int cnt; };       // a segment of a chain: cells list[off .. off + cnt) (or the cells off .. off + cnt - 1 themselves)
 struct SeqChain { int seg0; int nseg; };   // the segments of one chain, in chain order
-void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
-                   int zero_start);
+void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* poslev, int nlist, const SeqSeg* segs, int seg0, int nsegs, const float* start,
+                   float* end, int zero_start);
 void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
                     int zero_start);
-void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord);
+void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord, int* poslev);
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start);
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,

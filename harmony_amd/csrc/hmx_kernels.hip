@@ -2908,7 +2908,7 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       __syncthreads();
     }
     }   // (!qtab)
-    if (A.use_s0) {   // ridge_arith = 1: the intercept row's own sequential fp32 totals (k_moe_stats_seq)
+    if (A.use_s0 && !A.ref_tot) {   // ridge_arith = 1, one covariate: the intercept row's own sequential fp32 totals (k_seq_ridge_store)
       if (tid == 0) cov[0] = D.n0[k];
       for (int j = tid; j < d; j += nt) rhs[(size_t)j * m] = D.S0[(size_t)k * d + j];
     }
@@ -3841,12 +3841,19 @@ void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uin
 }
 // oe_arith: the round's shuffled order itself, posord[position] = internal cell id (arma::shuffle's update_order, src/harmony.cpp:272-273,
 // for the documented generator: cell g sits at position feistel(seed, round, g))
-__global__ void k_ref_posord(Dev D, FeistelKeys fk, uint64_t Nglob, int* __restrict__ posord) {
-  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < D.n; g += gridDim.x * blockDim.x)
-    posord[feistel_apply(fk, Nglob, (uint64_t)g)] = D.invperm[g];
+__global__ void k_ref_posord(Dev D, FeistelKeys fk, uint64_t Nglob, int* __restrict__ posord, int* __restrict__ poslev) {
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < D.n; g += gridDim.x * blockDim.x) {
+    const int cell = D.invperm[g];
+    const size_t pos = (size_t)feistel_apply(fk, Nglob, (uint64_t)g);
+    posord[pos] = cell;
+    if (poslev) {       // the position's level codes, [c][n]: the sequential-sum kernels then need no combo / qlev lookups
+      const int q = D.combo[cell];
+      for (int c = 0; c < D.C && c < 4; c++) poslev[(size_t)c * D.n + pos] = D.qlev[q * D.C + c];
+    }
+  }
 }
-void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord) {
-  hipLaunchKernelGGL(k_ref_posord, dim3(1024), dim3(256), 0, L.stream, D, make_keys(seed, round, Nglob), Nglob, posord);
+void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord, int* poslev) {
+  hipLaunchKernelGGL(k_ref_posord, dim3(1024), dim3(256), 0, L.stream, D, make_keys(seed, round, Nglob), Nglob, posord, poslev);
 }
 void l_oldsum(const Launch& L, const Dev& D) {
   const size_t tab = (size_t)D.nb * D.K * sizeof(unsigned long long);
@@ -4095,7 +4102,7 @@ void l_objective_tables(const Launch& L, const Dev& D) {
 // false: shape outside this kernel's envelope (the caller falls back to the cluster-lane version)
 bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride) {
   const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4);
-  if (!D.tile_impl || D.K % 4 != 0 || lds > 64 * 1024 || !D.Yimg) return false;
+  if (!D.tile_impl || D.K % 4 != 0 || lds > 64 * 1024 || !D.Yimg || D.obj_stale) return false;
   int blocks = (D.ntitems + 3) / 4; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
 #define HMX_OT(N) case N: hipLaunchKernelGGL((k_obj_terms_mfma<N>), dim3(blocks), dim3(256), lds, L.stream, D, M, T, stride); break;
   switch (D.NCT) {

@@ -39,8 +39,11 @@ namespace hmx {
 // ROWS = false: row 0 only -- a plain sequential sum of R_k over a list of cells, W = K lane-chains per segment (the level-pair sums of
 // Phi_Rk * Phi_moe_t for several covariates, src/harmony.cpp:561-568).
 // Round 4: all 64 R loads of a batch are in flight together (a segment is latency-bound: one memory round trip per 64 cells instead of two).
+// poslev (or nullptr): the level codes of the list's positions, [c][nlist] -- without them a wave walks list -> combo -> qlev -> R, four
+// dependent memory round trips before the first add of a 64-cell batch; with them two.
 template <bool ROWS>
 __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R, int K, int B, int C, const int* __restrict__ list,
+                                                     const int* __restrict__ poslev, int nlist,
                                                      const int* __restrict__ combo, const int* __restrict__ qlev,
                                                      const SeqSeg* __restrict__ segs, int seg0, int nsegs,
                                                      const float* __restrict__ start, float* __restrict__ end, int zero_start) {
@@ -56,41 +59,62 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   const size_t so = (size_t)seg * NR * K + ks;
   float s0 = (zero_start || k >= K) ? 0.0f : start[so];
   if constexpr (ROWS) for (int b = 0; b < B; b++) acc[b * 64] = (zero_start || k >= K) ? 0.0f : start[so + (size_t)(1 + b) * K];
-  for (int base = 0; base < sg.cnt; base += 64) {
-    const int nc = min(64, sg.cnt - base);
+  // software pipeline over the batches of 64 cells: the ids (cell, level codes) of batch b + 2 and the 64 R loads of batch b + 1 are in
+  // flight while batch b is added up -- a segment of 128 cells costs two memory round trips instead of four
+  struct Ids { int myc, myq, lev[4]; };
+  auto fetch_ids = [&](const int base) __attribute__((always_inline)) {
+    Ids I; I.myq = 0; I.lev[0] = I.lev[1] = I.lev[2] = I.lev[3] = 0;
     const int ci = sg.off + min(base + lane, sg.cnt - 1);
-    const int myc = list ? list[ci] : ci;
-    int myq = 0, mylev[4] = {0, 0, 0, 0};
+    I.myc = list ? list[min(ci, sg.off + sg.cnt - 1)] : ci;
     if constexpr (ROWS) {
-      myq = combo[myc];
+      if (poslev && C <= 4) {
 #pragma unroll
-      for (int c = 0; c < 4; c++) mylev[c] = qlev[myq * C + min(c, C - 1)];
+        for (int c = 0; c < 4; c++) I.lev[c] = poslev[(size_t)min(c, C - 1) * nlist + ci];
+      } else {
+        I.myq = combo[I.myc];
+#pragma unroll
+        for (int c = 0; c < 4; c++) I.lev[c] = qlev[I.myq * C + min(c, C - 1)];
+      }
     }
-    float r[64];
+    return I;
+  };
+  auto fetch_r = [&](const Ids& I, float (&r)[64]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < 64; u++) {
-      const int cell = __builtin_amdgcn_readlane(myc, u);       // (lanes past the end hold the segment's last cell: a valid row)
+      const int cell = __builtin_amdgcn_readlane(I.myc, u);       // (lanes past the end hold the segment's last cell: a valid row)
       r[u] = R[(size_t)cell * K + ks];
     }
+  };
+  Ids idc = fetch_ids(0), idn = fetch_ids(64);
+  float rc[64], rn[64];
+  fetch_r(idc, rc);
+  for (int base = 0; base < sg.cnt; base += 64) {
+    const int nc = min(64, sg.cnt - base);
+    const bool more = base + 64 < sg.cnt;
+    if (more) fetch_r(idn, rn);
+    const Ids idnn = fetch_ids(base + 128);                     // (clamped into the segment: harmless when there is no such batch)
 #pragma unroll
     for (int u = 0; u < 64; u++) {
       if (u < nc) {
-        s0 = __fadd_rn(s0, r[u]);
+        s0 = __fadd_rn(s0, rc[u]);
         if constexpr (ROWS) {
 #pragma unroll
           for (int c = 0; c < 4; c++) {
             if (c < C) {
-              const int b = __builtin_amdgcn_readlane(mylev[c], u);
-              acc[b * 64] = __fadd_rn(acc[b * 64], r[u]);
+              const int b = __builtin_amdgcn_readlane(idc.lev[c], u);
+              acc[b * 64] = __fadd_rn(acc[b * 64], rc[u]);
             }
           }
           for (int c = 4; c < C; c++) {       // (more than four covariates: level codes straight from the table)
-            const int b = qlev[__builtin_amdgcn_readlane(myq, u) * C + c];
-            acc[b * 64] = __fadd_rn(acc[b * 64], r[u]);
+            const int b = qlev[__builtin_amdgcn_readlane(idc.myq, u) * C + c];
+            acc[b * 64] = __fadd_rn(acc[b * 64], rc[u]);
           }
         }
       }
     }
+    idc = idn; idn = idnn;
+#pragma unroll
+    for (int u = 0; u < 64; u++) rc[u] = rn[u];
   }
   if (k < K) {
     end[so] = s0;
@@ -124,8 +148,9 @@ __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict
 #pragma unroll
   for (int kk = 0; kk < KPW; kk++) s[kk >> 1][kk & 1] = (zero_start || k0 + kk >= K) ? 0.0f : start[((size_t)seg * K + k0 + kk) * 64 + lane];
   const int js = min(lane, d - 1);
-  const bool zl_ok = lane < d;
-  constexpr int U = 4;
+  // lane j < d: z_j; lane 63: 1 (the mass chain); the others 0 -- as z * zmask + one63 (exact: x * 1 + 0), NOT as a select around the load:
+  // hipcc sinks the load into the select's branch and waits for it on the spot (one exposed memory latency per cell)
+  const float zmask = lane < d ? 1.0f : 0.0f, one63 = lane == 63 ? 1.0f : 0.0f;
   for (int base = 0; base < sg.cnt; base += 64) {
     const int nc = min(64, sg.cnt - base);
     const int ci = sg.off + min(base + lane, sg.cnt - 1);
@@ -134,47 +159,38 @@ __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict
     unsigned mym = 0;
 #pragma unroll
     for (int kk = 0; kk < KPW; kk++) mym |= ((fl >> (8 * kk)) & 0xffull) ? (1u << kk) : 0u;
-    // (R rows are read 8 floats at a time from k0: the last group of a row runs into the next row -- R has a dummy row behind the
-    //  last cell -- and those clusters >= K are never stored)
-    const bool allin = (nc == 64) && __builtin_amdgcn_readfirstlane((int)(__ballot(mym != 0xffu) == 0ull)) != 0;
-    if (allin) {        // every cell of the batch enters all 8 regressions (the common case: no masks)
-      for (int c0 = 0; c0 < 64; c0 += U) {
-        float z[U]; f32x2 rv[U][KPW / 2];
+    // R of the whole batch with EIGHT vector loads -- lane l of load i holds cluster k0 + (l & 7) of cell 8 i + (l >> 3) -- all in flight
+    // together (vector loads retire in order: counted waits, unlike scalar loads); a cell's 8 values then reach the SGPRs by v_readlane and
+    // feed the packed multiplies from there.  The in-set flags (and the end of a partial batch) are applied to the loaded value, lane by
+    // lane: a masked term is +0 and the inner loop has no branches.  (Clusters >= K of the last group read into the next row -- R has a
+    // dummy row behind the last cell -- and are never stored.)  Z rows 16 cells at a time.
+    float rq[8];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int cell = __builtin_amdgcn_readlane(myc, c0 + u);
-          const float zl = Zo[(size_t)cell * zs + js];
-          z[u] = (lane == 63) ? 1.0f : (zl_ok ? zl : 0.0f);
-          const f32x2* rr = reinterpret_cast<const f32x2*>(R + (size_t)cell * K + k0);
+    for (int i = 0; i < 8; i++) {
+      const int src = 8 * i + (lane >> 3);
+      const int cellv = __shfl(myc, src, 64);
+      const unsigned mv = (unsigned)__shfl((int)mym, src, 64);
+      const float rl = R[(size_t)cellv * K + k0 + (lane & 7)];
+      rq[i] = rl * ((src < nc && ((mv >> (lane & 7)) & 1u)) ? 1.0f : 0.0f);       // (a product, not a select around the load: see zmask)
+    }
 #pragma unroll
-          for (int h = 0; h < KPW / 2; h++) rv[u][h] = rr[h];
-        }
+    for (int i = 0; i < 4; i++) {
+      if (16 * i >= nc) break;
+      float z[16];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const f32x2 zz = {z[u], z[u]};
-#pragma unroll
-          for (int h = 0; h < KPW / 2; h++) s[h] = s[h] + zz * rv[u][h];
-        }
+      for (int u = 0; u < 16; u++) {
+        const int cell = __builtin_amdgcn_readlane(myc, 16 * i + u);       // (lanes past the end hold the segment's last cell: a valid row)
+        z[u] = __builtin_fmaf(Zo[(size_t)cell * zs + js], zmask, one63);
       }
-    } else {
-      for (int c0 = 0; c0 < nc; c0 += U) {
-        float z[U], rv[U][KPW];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int c = min(c0 + u, nc - 1);
-          const int cell = __builtin_amdgcn_readlane(myc, c);
-          const unsigned m = (c0 + u < nc) ? (unsigned)__builtin_amdgcn_readlane((int)mym, c) : 0u;      // outside the regression (or past the end): the term is +0
-          const float zl = Zo[(size_t)cell * zs + js];
-          z[u] = (lane == 63) ? 1.0f : (zl_ok ? zl : 0.0f);
-          const float* rr = R + (size_t)cell * K + k0;
+      for (int u = 0; u < 16; u++) {
+        const f32x2 zz = {z[u], z[u]};
+        const float rsrc = rq[2 * i + (u >> 3)];
 #pragma unroll
-          for (int kk = 0; kk < KPW; kk++) { const float r = rr[kk]; rv[u][kk] = ((m >> kk) & 1u) ? r : 0.0f; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const f32x2 zz = {z[u], z[u]};
-#pragma unroll
-          for (int h = 0; h < KPW / 2; h++) { const f32x2 r2 = {rv[u][2 * h], rv[u][2 * h + 1]}; s[h] = s[h] + zz * r2; }
+        for (int h = 0; h < KPW / 2; h++) {
+          const f32x2 r2 = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsrc), 8 * (u & 7) + 2 * h)),
+                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsrc), 8 * (u & 7) + 2 * h + 1))};
+          s[h] = s[h] + zz * r2;
         }
       }
     }
@@ -230,8 +246,41 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
   const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
   const int chain = chain0 + blockIdx.x, w = blockIdx.y * 64 + lane, ws = min(w, W - 1);
   const SeqChain c = chains[chain];
+  if (c.nseg == 0) { if (v == 15 && w < W) total[(size_t)chain * W + w] = 0.0f; return; }      // (an empty chain: a level without cells in this block)
   const int per = (c.nseg + 15) / 16;
   const int s0 = c.seg0 + min(v * per, c.nseg), s1 = c.seg0 + min((v + 1) * per, c.nseg);
+  unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;       // how far this lane-chain's starts moved, against the largest start of the chain
+  double run = 0.0;
+  constexpr int PC = 28;
+  if (per <= PC) {
+    // short chains (a block's O / E sums: 391 segments): a wave's whole share of the chain is loaded at once and stays in registers -- ONE
+    // memory round trip per scan (round 3: two sweeps of eight loads each: 18 us for a block, as long as the pass it followed)
+    float e8[PC], o8[PC];
+    const int slast = c.seg0 + c.nseg - 1;              // (unconditional loads from clamped, always valid segments; masked by s0 + u < s1 below)
+#pragma unroll
+    for (int u = 0; u < PC; u++) {
+      const size_t i = (size_t)min(s0 + u, slast) * W + ws;
+      e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < PC; u++) if (s0 + u < s1) acc += (double)e8[u] - (double)o8[u];
+    tot[v][lane] = acc;
+    __syncthreads();
+    for (int u = 0; u < v; u++) run += tot[u][lane];
+#pragma unroll
+    for (int u = 0; u < PC; u++) {
+      if (s0 + u < s1) {
+        const float ns = (float)run;
+        if (w < W) {
+          if (!zero_start && __float_as_uint(ns) != __float_as_uint(o8[u])) { mm++; dmax = fmaxf(dmax, fabsf(ns - o8[u])); }
+          smax = fmaxf(smax, fabsf(ns));
+          start_out[(size_t)(s0 + u) * W + w] = ns;
+        }
+        run += (double)e8[u] - (double)o8[u];
+      }
+    }
+  } else {
   // (sixteen segments per step: the loads of a step are independent of each other and in flight together -- a step costs one memory
   //  latency, not sixteen)
   double acc = 0.0;
@@ -247,9 +296,7 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
   }
   tot[v][lane] = acc;
   __syncthreads();
-  double run = 0.0;
   for (int u = 0; u < v; u++) run += tot[u][lane];
-  unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;       // how far this lane-chain's starts moved, against the largest start of the chain
   for (int sb = s0; sb < s1; sb += 16) {
     float e8[16], o8[16];
 #pragma unroll
@@ -270,6 +317,7 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
       }
     }
   }
+  }
   if (v == 15 && w < W) total[(size_t)chain * W + w] = (float)run;     // (empty chunks: run = the sum of all chunks before)
   if (mismatch && !zero_start) {      // [0] segments whose start moved in this scan, [1] the largest move of a start relative to its chain's largest start (float bits)
     dmx[v][lane] = dmax; smx[v][lane] = fmaxf(smax, fabsf((float)run));
@@ -284,55 +332,6 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
     if (lane == 0 && v == 0 && ss > 0.0f && dd > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dd / ss));
   }
 }
-// Small scans (a block's O / E sums, the level-pair sums: ~10^3 lane-chains x <= a few 10^3 segments): ONE WAVE per (chain, lane-chain), lanes
-// along the segments -- every load of a lane-chain is in flight at once and the prefix is a wave scan: one memory round trip per 256
-// segments instead of two per 8 (k_seq_scan took 18 us for a block's 390 segments, as long as the pass it follows).  Same arithmetic:
-// fp64 sums of fp32-representable differences, exact.
-__global__ __launch_bounds__(256) void k_seq_scan_t(const SeqChain* __restrict__ chains, int chain0, int nchains, int W, const float* start_in,
-                                                    const float* __restrict__ end, float* start_out, float* __restrict__ total,
-                                                    unsigned* __restrict__ mismatch, int zero_start) {
-  constexpr int NBK = 4;
-  const int lane = threadIdx.x & 63;
-  const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (wid >= (long long)nchains * W) return;
-  const int chain = chain0 + (int)(wid / W), w = (int)(wid % W);
-  const SeqChain c = chains[chain];
-  double run = 0.0;
-  unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;
-  for (int base = 0; base < c.nseg; base += 64 * NBK) {
-    float e[NBK], o[NBK];
-#pragma unroll
-    for (int u = 0; u < NBK; u++) {
-      const int sidx = base + u * 64 + lane;
-      const size_t i = (size_t)(c.seg0 + min(sidx, c.nseg - 1)) * W + w;
-      e[u] = end[i]; o[u] = zero_start ? 0.0f : start_in[i];
-    }
-#pragma unroll
-    for (int u = 0; u < NBK; u++) {
-      const int sidx = base + u * 64 + lane;
-      const bool valid = sidx < c.nseg;
-      const double dlt = valid ? (double)e[u] - (double)o[u] : 0.0;
-      double inc = dlt;
-#pragma unroll
-      for (int m = 1; m < 64; m <<= 1) { const double t = __shfl_up(inc, m, 64); if (lane >= m) inc += t; }
-      const float ns = (float)(run + (inc - dlt));
-      if (valid) {
-        if (!zero_start && __float_as_uint(ns) != __float_as_uint(o[u])) { mm++; dmax = fmaxf(dmax, fabsf(ns - o[u])); }
-        smax = fmaxf(smax, fabsf(ns));
-        start_out[(size_t)(c.seg0 + sidx) * W + w] = ns;
-      }
-      run += __shfl(inc, 63, 64);
-    }
-  }
-  if (lane == 0) total[(size_t)chain * W + w] = (float)run;
-  if (mismatch && !zero_start) {       // [0] starts that moved, [1] the largest move relative to this lane-chain's own largest start (float bits)
-    smax = fmaxf(smax, fabsf((float)run));
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { mm += __shfl_xor(mm, m, 64); dmax = fmaxf(dmax, __shfl_xor(dmax, m, 64)); smax = fmaxf(smax, __shfl_xor(smax, m, 64)); }
-    if (lane == 0 && mm) atomicAdd(mismatch, mm);
-    if (lane == 0 && smax > 1e-30f && dmax > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dmax / smax));
-  }
-}
 // one lane-chain per chain (the objective's arrays): threads along the segments, one workgroup per chain
 __global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* start_in, const float* __restrict__ end, float* start_out,
                                                     float* __restrict__ total, unsigned* __restrict__ mismatch, int zero_start) {
@@ -343,7 +342,13 @@ __global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* star
   const int per = (nsegs + 1023) / 1024;
   const int s0 = min(t * per, nsegs), s1 = min((t + 1) * per, nsegs);
   double acc = 0.0;
-  for (int s = s0; s < s1; s++) acc += (double)end[base + s] - (zero_start ? 0.0 : (double)start_in[base + s]);
+  for (int sb = s0; sb < s1; sb += 16) {      // (sixteen independent loads in flight per step)
+    float e8[16], o8[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const size_t i = base + min(sb + u, s1 - 1); e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i]; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) if (sb + u < s1) acc += (double)e8[u] - (double)o8[u];
+  }
   part[t] = acc;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -354,13 +359,20 @@ __global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* star
   }
   double run = part[t] - acc;
   unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;
-  for (int s = s0; s < s1; s++) {
-    const float ns = (float)run;
-    const float old = zero_start ? 0.0f : start_in[base + s];
-    if (!zero_start && __float_as_uint(ns) != __float_as_uint(old)) { mm++; dmax = fmaxf(dmax, fabsf(ns - old)); }
-    smax = fmaxf(smax, fabsf(ns));
-    start_out[base + s] = ns;
-    run += (double)end[base + s] - (double)old;
+  for (int sb = s0; sb < s1; sb += 16) {
+    float e8[16], o8[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const size_t i = base + min(sb + u, s1 - 1); e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i]; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      if (sb + u < s1) {
+        const float ns = (float)run;
+        if (!zero_start && __float_as_uint(ns) != __float_as_uint(o8[u])) { mm++; dmax = fmaxf(dmax, fabsf(ns - o8[u])); }
+        smax = fmaxf(smax, fabsf(ns));
+        start_out[base + sb + u] = ns;
+        run += (double)e8[u] - (double)o8[u];
+      }
+    }
   }
   if (t == 1023) total[blockIdx.x] = (float)part[1023];
   if (mismatch && !zero_start) {
@@ -494,6 +506,7 @@ __global__ __launch_bounds__(256) void k_seq_inset(Dev D, const float* __restric
     int in = 0;
     for (int c = 0; c < C; c++) in |= keep[D.qlev[q * C + c]];
     inset[(size_t)q * KP8 + k] = (unsigned char)in;
+    if (k == K - 1) for (int kp = K; kp < KP8; kp++) inset[(size_t)q * KP8 + kp] = 1;      // (the pad columns of the last 8-cluster group: defined, never used)
   }
 }
 // chain totals [1 + Q][K][64] -> S0 / n0 (chain 0: the intercept row) and Sq / nq (chain 1 + q: combination = level q's row)
@@ -508,20 +521,20 @@ __global__ void k_seq_ridge_store(Dev D, const float* __restrict__ total) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------
-void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
-                   int zero_start) {
+void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* poslev, int nlist, const SeqSeg* segs, int seg0, int nsegs, const float* start,
+                   float* end, int zero_start) {
   if (nsegs <= 0) return;
   int wpb = 4;                                           // waves per workgroup, limited by the level rows in LDS
   while (wpb > 1 && (size_t)wpb * D.B * 256 > 60 * 1024) wpb >>= 1;
   hipLaunchKernelGGL(k_seq_oe_pass<true>, dim3((nsegs + wpb - 1) / wpb, (D.K + 63) / 64), dim3(64 * wpb), (size_t)wpb * D.B * 256, L.stream, D.R, D.K, D.B,
-                     D.C, list, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start);
+                     D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start);
 }
 // plain list sums: W = K lane-chains per segment (row 0 of the kernel above only)
 void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
                     int zero_start) {
   if (nsegs <= 0) return;
-  hipLaunchKernelGGL(k_seq_oe_pass<false>, dim3((nsegs + 3) / 4, (D.K + 63) / 64), dim3(256), 0, L.stream, D.R, D.K, 0, 0, list, D.combo, D.qlev, segs, seg0,
-                     nsegs, start, end, zero_start);
+  hipLaunchKernelGGL(k_seq_oe_pass<false>, dim3((nsegs + 3) / 4, (D.K + 63) / 64), dim3(256), 0, L.stream, D.R, D.K, 0, 0, list, nullptr, 0, D.combo, D.qlev, segs,
+                     seg0, nsegs, start, end, zero_start);
 }
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start) {
@@ -537,12 +550,6 @@ void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stri
 void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains, int W, const float* start_in, const float* end, float* start_out,
                 float* total, unsigned* mismatch, int zero_start) {
   if (nchains <= 0) return;
-  if ((long long)nchains * W <= 65536) {      // few lane-chains: one wave each, lanes along the segments
-    const long long waves = (long long)nchains * W;
-    hipLaunchKernelGGL(k_seq_scan_t, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, L.stream, chains, chain0, nchains, W, start_in, end, start_out, total,
-                       mismatch, zero_start);
-    return;
-  }
   hipLaunchKernelGGL(k_seq_scan, dim3(nchains, (W + 63) / 64), dim3(1024), 0, L.stream, chains, chain0, W, start_in, end, start_out, total, mismatch,
                      zero_start);
 }
