@@ -280,7 +280,8 @@ struct hmx_ctx {
   // next block) -- then the next round needs no pass over R (k_oldsum).  state: 0 all zero, 1 unknown contents, 2 carried for round sold_round.
   long long* sold_buf[2] = {nullptr, nullptr}; int sold_cur = 0, sold_state[2] = {1, 1}; int64_t sold_round[2] = {-1, -1}; uint64_t sold_seed[2] = {0, 0};
   bool sets_clean = false;     // the three Snew replica sets are all zero
-  bool carry_ok = false, last_round_hint = false; bool sorted_nxt[2] = {false, false};
+  bool carry_ok = false, last_round_hint = false, round_may_be_last = true; bool sorted_nxt[2] = {false, false};
+  int64_t rounds_without_R = 0;
   int64_t carried_rounds = 0;
   bool chain_ok = false; int chain_wgs = 0; uint64_t chain_rounds = 0;   // persistent block chain (one launch per round)
   int tun_impl = -1, tun_tpw = -1, tun_cpw = -1, tun_wps = -1;  // tunables set through hmx_set_int before setup
@@ -518,6 +519,11 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
       HIPCHK(hipMemsetAsync(ctx->sold_buf[cur], 0, sizeof(long long) * (size_t)D.nb * D.B * D.K, ctx->L.stream));
     D.head_gather = 1; D.Sold_head = ctx->sold_buf[cur];
     ctx->sold_state[cur] = 2; ctx->sold_round[cur] = (int64_t)ctx->round_counter; ctx->sold_seed[cur] = ctx->seed;
+    // the head of cluster_cpp is followed, inside the same call, by a round that rewrites every R row and takes its old contributions from
+    // the sums filed here: the head's own rows are never read (Dev::r_store) -- 4K bytes per cell less.  (init_cluster_cpp's head is followed
+    // by the caller, who may read R: it stores.)
+    { const char* rs = getenv("HMX_R_STORE");
+      if (normalise && ctx->max_iter_kmeans >= 1 && !ctx->poll && !(rs && atoi(rs) == 1)) D.r_store = 0; }
   }
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
@@ -1058,6 +1064,7 @@ int update_R(hmx_ctx* ctx) {
   for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g];
   const bool chain_old = chain_path && !p2p && D.chain_old && D.chain_wps == 2 && D.K % 4 == 0;   // (16-byte row loads)
   { PhaseScope ph(ctx, "EO_update");      // removal of every block's old contribution (:312-313)
+    D.r_store = 1;
     if (chain_old) {   // gathered inside the persistent chain, two blocks ahead of their use: only the replica tables are reset here
       HIPCHK(hipMemsetAsync(D.Sold_rep, 0, sizeof(long long) * (size_t)D.nrep * D.nb * D.B * D.K, ctx->L.stream));
       HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
@@ -1085,6 +1092,13 @@ int update_R(hmx_ctx* ctx) {
         ctx->sold_state[oth] = 2; ctx->sold_round[oth] = rnd + 1; ctx->sold_seed[oth] = ctx->seed;
       }
       ctx->sets_clean = false;
+      // R rows nobody reads are not written: this round's rows are dead if the NEXT round takes its old contributions from the carried sums
+      // (write_next) and this round cannot be the call's last (round_may_be_last, set by hmx_cluster) -- moe_correct_ridge_cpp, the getters
+      // and a stand-alone compute_objective only ever see the last round's R.  (A host with an abort poll may leave the call early: it
+      // always gets its rows.  HMX_R_STORE=1: always store.)
+      { const char* rs = getenv("HMX_R_STORE");
+        D.r_store = (write_next && !ctx->round_may_be_last && !ctx->poll && !(rs && atoi(rs) == 1)) ? 0 : 1;
+        if (!D.r_store) ctx->rounds_without_R++; }
     } }
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
@@ -1773,6 +1787,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   { const char* e = getenv("HMX_MOE_IMPL");
     D.moe_mfma = (K % 4 == 0 && d <= 64 && K <= 256 && !(e && std::string(e) == "v1")) ? 1 : 0;   // K > 128: split statistics kernel
     D.wNT4 = K / 16; D.wtail = (K - 16 * D.wNT4) / 4; D.wNS = 4 * D.wNT4 + D.wtail; D.wNQ = ((d + 15) / 16 + 3) / 4; }
+  D.r_store = 1;
   D.nwmax = 4 * ctx->L.grid; D.objslots = std::min(D.nb, 64);
   D.pen_lds = ((size_t)D.NQ * 0 + (size_t)B * K * 4 + (size_t)Q * C * 4 <= 24576) ? 1 : 0;
   D.rvec = (K % 4 == 0) ? 1 : 0;
@@ -2135,6 +2150,7 @@ int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
   for (iter = 0; iter < ctx->max_iter_kmeans; iter++) {
     if (ctx->poll && ctx->poll(ctx->poll_user)) return HMX_ABORTED;  // :233-234
     ctx->last_round_hint = (iter == ctx->max_iter_kmeans - 1);         // (nothing follows the last round that could use its R sums)
+    ctx->round_may_be_last = ctx->last_round_hint || iter > ctx->window_size;      // (the windowed convergence check below can end the call after this round)
     CHK(update_R(ctx));                                                 // :241 (objective fused, :248)
     if (iter > ctx->window_size) {                                      // :250-256 (the only place a round's value is needed at once)
       CHK(flush_objectives(ctx));
@@ -2369,6 +2385,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "dot_bf") return scalar(ctx->D.dot_bf ? 1.0 : 0.0);     // split-bf16 tile kernels offered (each launch still checks its LDS budget)
   if (f == "sold_carry") return scalar(ctx->carry_ok ? 1.0 : 0.0);
   if (f == "carried_rounds") return scalar((double)ctx->carried_rounds);
+  if (f == "rounds_without_R") return scalar((double)ctx->rounds_without_R);
   if (f == "p2p:exchange_us") return scalar(ctx->p2p_exchange_us);
   if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);
   if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them

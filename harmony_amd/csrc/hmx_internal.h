@@ -93,6 +93,11 @@ struct Dev {
   int head_gather;             // k_tile MODE 1 runs over the padded order of the upcoming round (lpair) instead of the static tiles
   long long* Sold_head;        // [nb][B][K] the head files its R sums here as the old contributions of that round's blocks (or nullptr)
   int head_norm;               // k_tile MODE 1: normalise the tile's Z_corr rows in registers and write them back (fused head of cluster_cpp)
+  // 0: the block updates of this round do NOT write their R rows.  Inside a cluster_cpp call every round rewrites every cell's row, the
+  // distances are recomputed from Z, and with the round-to-round carry (Sold_next) the next round takes its old contributions from the
+  // sums this round files -- so the rows of every round but the call's last are never read by anything (src/harmony.cpp:285-339 shuffles
+  // and un-shuffles R every round because its update reads R; ours does not).  20 MB per block step that never leave the registers.
+  int r_store;
   int obj_stale;               // compute_objective on the stale snapshot (stale_dist): Yt / Zc are not the ones the MFMA images were built from
   int rvec;                    // K % 4 == 0: R rows are 16-byte aligned, the tile kernels store them with vector stores
   int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)

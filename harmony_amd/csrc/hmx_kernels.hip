@@ -1635,8 +1635,10 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #ifdef HMX_TRACE
         if (!(D.upd_debug & 4))   // timing experiment: no R stores
 #endif
+        if (D.r_store) {    // (a pass whose R rows nobody will read leaves them in the registers: see Dev::r_store)
 #pragma unroll
-        for (int i = 0; i < RB; i++) put_row(Rrow[i], acc, r0 + i);
+          for (int i = 0; i < RB; i++) put_row(Rrow[i], acc, r0 + i);
+        }
       }
     }
   };
@@ -1645,6 +1647,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #ifdef HMX_TRACE
     if (D.upd_debug & 4) return;
 #endif
+    if (!D.r_store) return;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int cell = __shfl(cellA, 4 * g + i, 64);
