@@ -140,22 +140,26 @@ def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps,
     del Z
     for _ in range(warmup):
         run_to_convergence(o)
-    o.set_profile(True)
+    o.set_profile(1)
     sync()
     t0 = time.perf_counter()
     its = [run_to_convergence(o) for _ in range(steps)]
     sync()
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    ph = {k: round(o._scalar("gputimer:" + k) / steps, 3) for k in ("kmeans_centers", "cluster_head", "randomize", "EO_update", "Rcells_update",
-                                                                     "objective", "ridge_statistics", "arma_inv", "update_Zcorr")}
     upd_ms, upd_steps = o._scalar("prof:update_ms"), max(o._scalar("prof:update_steps"), 1)
     upd_cells = o._scalar("prof:update_cells")
     kr = np.asarray(o.kmeans_rounds, dtype=np.int64)
+    o.set_profile(2)          # the phase table comes from ONE more, untimed run (its ~200 event records would cost the timed ones up to 1 ms each)
+    run_to_convergence(o)
+    sync()
+    ph = {k: round(o._scalar("gputimer:" + k), 3) for k in ("kmeans_centers", "cluster_head", "randomize", "EO_update", "Rcells_update",
+                                                             "objective", "ridge_statistics", "arma_inv", "update_Zcorr")}
+    ph["Rcells_update"] = round(upd_ms / steps, 3)
     run_bytes = float(n) * float(np.sum(4.0 * d * (4 + kr) + 4.0 * K * (3 + 2 * kr)))
     chain = bool(o._scalar("chain"))
     ach = upd_cells * (4.0 * d + 4.0 * K) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     out = {"workload": label,
-           "ms_per_step": ms, "cells_per_s": n / (ms * 1e-3), "harmony_iterations": its, "steps": steps, "gpu_phase_ms_per_step": ph,
+           "ms_per_step": ms, "cells_per_s": n / (ms * 1e-3), "harmony_iterations": its, "steps": steps, "gpu_phase_ms_per_step": ph, "gpu_phase_from": "one extra untimed run with per-phase events",
            "block_chain": chain, "avg_block_step_us": 1e3 * upd_ms / upd_steps,
            # the leg's own dominant kernel (the E-step update of update_R, as on the main line): algorithmic bytes (4d + 4K per cell and
            # round) over its HIP-event time on the library's stream
@@ -435,7 +439,10 @@ def main():
             comm_kind += " -- SWITCHED OFF after a failed trial run: one launch + one all-reduce per block"
     for _ in range(a.warmup):
         run_to_convergence(obj)
-    obj.set_profile(True)  # HIP events around every launch of the dominant kernel, on the library's stream
+    # start / stop HIP events attached to every launch of the dominant kernel, on the library's stream (profile level 1; the per-phase event
+    # brackets -- level 2, ~200 extra packets per run -- are taken in ONE extra untimed run behind the timed region: HMX_BENCH_NOPROF=1 shows
+    # what the events themselves cost)
+    obj.set_profile(0 if os.environ.get("HMX_BENCH_NOPROF", "0") == "1" else 1)
     sync()
     t0 = time.perf_counter()
     iters = []
@@ -448,6 +455,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / a.steps
+    prof = {k: obj._scalar("prof:" + k) for k in ("update_ms", "update_launches", "update_cells", "update_steps")}
+    kr_timed = np.asarray(obj.kmeans_rounds, dtype=np.int64)
+    obj.set_profile(2)
+    run_to_convergence(obj)
+    sync()
+    gpu_phase = {k: round(obj._scalar("gputimer:" + k), 3) for k in
+                 ("kmeans_centers", "cluster_head", "randomize", "EO_update", "correct_ridge_loop", "ridge_statistics", "arma_inv", "update_Zcorr")}
+    gpu_phase["Rcells_update"] = round(prof["update_ms"] / a.steps, 3)
+    gpu_phase["from"] = "one extra untimed run with per-phase event brackets (Rcells_update: the timed runs' own launch events)"
     shard_check = None
     if world > 1:
         # sharded sanity: every rank holds the same global O (integer sums) and it accounts for every cell
@@ -458,14 +474,14 @@ def main():
                        "sum_O_over_N": float(O.sum().item()) / float(N)}
         if not shard_check["O_identical_on_all_ranks"] or abs(shard_check["sum_O_over_N"] - 1.0) > 1e-4:
             raise SystemExit("sharded run inconsistent: %r" % (shard_check,))
-    kr = np.asarray(obj.kmeans_rounds, dtype=np.int64)      # rounds of every harmony iteration of the LAST step
+    kr = kr_timed                                           # rounds of every harmony iteration of the LAST timed step
     rounds = int(kr.sum())
 
     # roofline of the dominant kernel (k_tile<NCT,0>: E-step of one block of cells).  Algorithmic bytes per cell
     # per launch: read the cell's normalised embedding row (4d) + write its R row (4K)  [DESIGN.md]
-    upd_ms = obj._scalar("prof:update_ms")
-    upd_launches = obj._scalar("prof:update_launches")
-    upd_cells = obj._scalar("prof:update_cells")  # cells summed over rounds (every round touches every cell once)
+    upd_ms = prof["update_ms"]
+    upd_launches = prof["update_launches"]
+    upd_cells = prof["update_cells"]  # cells summed over rounds (every round touches every cell once)
     alg_bytes = upd_cells * (4.0 * d + 4.0 * K)
     achieved = alg_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     traffic = mfma_util = None  # HBM bytes / MFMA busy per launch from the PMC passes (collected separately, profiles/)
@@ -493,14 +509,11 @@ def main():
                 "traffic_and_mfma_busy_are": ("replayed from profiles/pmc_traffic_update_kernel.json (separate rocprofv3 --pmc passes over this kernel, "
                                               "%s); not collected in this run" % pm_note) if traffic is not None else None,
                 "avg_launch_us": 1e3 * upd_ms / max(upd_launches, 1), "launches": int(upd_launches),
-                "avg_block_step_us": 1e3 * upd_ms / max(obj._scalar("prof:update_steps"), 1),
+                "avg_block_step_us": 1e3 * upd_ms / max(prof["update_steps"], 1),
                 "alg_bytes_per_launch": alg_bytes / max(upd_launches, 1),
                 "kernel_time_share": upd_ms / (1e3 * dt) if dt > 0 else None,
                 "run": {"alg_bytes_per_step_per_gpu": run_bytes, "achieved": run_gbs, "frac": run_gbs / 8000.0,
                         "note": "SURVEY 8(d): N * sum_iters(4d(4+I_k) + 4K(3+2 I_k)) / T_conv, per GPU, vs 8 TB/s"}}
-    gpu_phase = {k: round(obj._scalar("gputimer:" + k) / a.steps, 3) for k in
-                 ("kmeans_centers", "cluster_head", "randomize", "EO_update", "Rcells_update", "correct_ridge_loop",
-                  "ridge_statistics", "arma_inv", "update_Zcorr")}
     chain = None
     if obj._scalar("chain"):   # persistent block chain: where its workgroups spent their time (100 MHz ticks -> us per block step)
         dbg = obj._get("chain_dbg")

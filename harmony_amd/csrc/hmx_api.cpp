@@ -273,7 +273,7 @@ struct hmx_ctx {
   bool own_stream = false, ran_setup = false, ran_init = false;
   std::vector<void*> allocs;
   // profiling of the dominant kernel
-  bool profile = false;
+  int profile = 0;             // 0 off | 1 the dominant kernel's launches carry a start / stop event pair | 2 and every phase is bracketed by events (PhaseScope)
   bool fused_ok = false;       // k_tile prologue fold usable (LDS budget) and not disabled
   // Old-contribution tables: two buffers.  `cur` is what this round's block steps subtract; the other one collects, inside this
   // round's tile kernels, the old contributions of the NEXT round's blocks (carry_ok: the shuffle keys every tile by its cells'
@@ -298,6 +298,14 @@ struct hmx_ctx {
   struct SortSet { int* blk; int* lorder; int2* lpair; int* lcombo; int* boff; int* binoff; int* counts; int* offs; int* blkv; int* bincnt; };
   SortSet sets[2] = {}; hipStream_t side = nullptr; hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   int64_t sorted_round[2] = {-1, -1}; uint64_t sorted_seed[2] = {0, 0}; bool sorted_on_side[2] = {false, false}; bool sort_overlap = true;
+  // Round-4 schedule of the shuffle (sort_sched = 2, default): its HISTOGRAM half depends on (seed, round) only and runs rounds ahead on the side
+  // stream, into one of four slots (round & 3: block ids, composite keys, per-chunk counts); its dependent TAIL (bin scan, bin offsets,
+  // scatter) is enqueued on the MAIN stream right behind the block chain of the round before -- in queue order, no cross-stream event between
+  // a chain launch and the next one (round 3: the whole sort of round r + 1 sat on the side stream behind chain r: 30 us of sort tail, a
+  // 27 us event hand-over and the next histogram in front of every chain launch, profiles/r3_round_timeline.txt).
+  struct HistSet { int* blk; int* blkv; int* counts; };
+  HistSet hset[4] = {}; int64_t hist_round[4] = {-1, -1, -1, -1}; uint64_t hist_seed[4] = {0, 0, 0, 0}; bool hist_on_side[4] = {false, false, false, false}, hist_nxt[4] = {false, false, false, false};
+  hipEvent_t ev_hist[4] = {nullptr, nullptr, nullptr, nullptr}; int sort_sched = 2;
   std::string err, warn, warn_ret;
 };
 
@@ -333,6 +341,7 @@ void free_all(hmx_ctx* ctx) {
     if (ctx->ev_free[i]) { (void)hipEventDestroy(ctx->ev_free[i]); ctx->ev_free[i] = nullptr; }
     ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false;
   }
+  for (int i = 0; i < 4; i++) { if (ctx->ev_hist[i]) { (void)hipEventDestroy(ctx->ev_hist[i]); ctx->ev_hist[i] = nullptr; } ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; }
   {   // reference-arithmetic buffers (grown on demand, not in `allocs`)
     void* ps[] = {ctx->sq_start, ctx->sq_end, ctx->sq_total, ctx->sq_mismatch, ctx->headlist, ctx->roundlist, ctx->Of, ctx->Ef, ctx->Mtab, ctx->objT,
                   ctx->inset, ctx->obj_start, ctx->rg_start, ctx->headlev, ctx->roundlev, ctx->pairlist, ctx->pair_idx, ctx->rg_tot, ctx->rp_tot, ctx->rp_start, ctx->plan_pair.d_segs, ctx->plan_pair.d_chains, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
@@ -380,7 +389,7 @@ int allreduce(hmx_ctx* ctx, void* buf, int64_t count, int dtype) {
 struct PhaseScope {
   hmx_ctx* c; int idx = -1;
   PhaseScope(hmx_ctx* ctx, const char* name) : c(ctx) {
-    if (!c->profile) return;
+    if (c->profile < 2) return;      // (an event record is a barrier packet of its own: ~2-5 us each between dependent kernels -- 200 of them per run were 0.4-1 ms of a 15 ms run)
     int id = -1;
     for (size_t i = 0; i < c->ph_names.size(); i++) if (c->ph_names[i] == name) { id = (int)i; break; }
     if (id < 0) { id = (int)c->ph_names.size(); c->ph_names.push_back(name); }
@@ -395,6 +404,16 @@ struct PhaseScope {
   }
   ~PhaseScope() { if (idx >= 0) (void)hipEventRecord(c->ph_pool[idx].b, c->L.stream); }
 };
+// profile mode: the dominant kernel's launches carry their own start / stop events (hipExtLaunchKernelGGL: the timestamps of the dispatch
+// packet itself, no barrier packets around it)
+int launch_with_events(hmx_ctx* ctx, Launch& L) {
+  L = ctx->L;
+  if (!ctx->profile) return 0;
+  if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); ctx->ev_pool.emplace_back(a, b); }
+  L.ev0 = ctx->ev_pool[ctx->ev_used].first; L.ev1 = ctx->ev_pool[ctx->ev_used].second;
+  ctx->ev_used++;
+  return 0;
+}
 void resolve_phases(hmx_ctx* c) {
   if (!c->ph_used) return;
   (void)hipStreamSynchronize(c->L.stream);
@@ -719,10 +738,65 @@ int kmeans_centers(hmx_ctx* ctx) {
 void apply_set(Dev& D, const hmx_ctx::SortSet& s) {
   D.blk = s.blk; D.lorder = s.lorder; D.lpair = s.lpair; D.lcombo = s.lcombo; D.boff = s.boff; D.binoff = s.binoff; D.counts = s.counts; D.offs = s.offs; D.blkv = s.blkv; D.bincnt = s.bincnt;
 }
+// ---- sort_sched = 2 -----------------------------------------------------------------------------------------------------------
+void apply_hist(Dev& D, const hmx_ctx::HistSet& hs) { D.blk = hs.blk; D.blkv = hs.blkv; D.counts = hs.counts; }
+// the histogram half of round `round` into slot round & 3 (no-op if it is there already)
+int enqueue_hist(hmx_ctx* ctx, uint64_t round, bool on_side) {
+  const int hs = (int)(round & 3);
+  if (ctx->hist_round[hs] == (int64_t)round && ctx->hist_seed[hs] == ctx->seed) return 0;
+  Dev Dt = ctx->D; apply_hist(Dt, ctx->hset[hs]);
+  Dt.nxt = ctx->carry_ok ? 1 : 0;
+  Launch L2 = ctx->L;
+  if (on_side && ctx->side) {
+    // behind everything the main stream has queued so far: the slot's last readers (tail / old-sum pass of round - 4) are among it
+    HIPCHK(hipEventRecord(ctx->ev_free[hs & 1], ctx->L.stream));
+    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_free[hs & 1], 0));
+    L2.stream = ctx->side;
+  } else if (ctx->hist_on_side[hs]) {        // (an older prefetch into this slot may still be running on the side stream)
+    HIPCHK(hipStreamWaitEvent(ctx->L.stream, ctx->ev_hist[hs], 0));
+  }
+  l_sort_hist(L2, Dt, true, ctx->seed, round, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
+  ctx->hist_on_side[hs] = on_side && ctx->side;
+  if (ctx->hist_on_side[hs]) HIPCHK(hipEventRecord(ctx->ev_hist[hs], ctx->side));
+  ctx->hist_round[hs] = (int64_t)round; ctx->hist_seed[hs] = ctx->seed; ctx->hist_nxt[hs] = Dt.nxt != 0;
+  return 0;
+}
+// the dependent half of round `round` on the MAIN stream, into order set round & 1 (no-op if it is there already)
+int enqueue_tail(hmx_ctx* ctx, uint64_t round) {
+  const int os = (int)(round & 1), hs = (int)(round & 3);
+  if (ctx->sorted_round[os] == (int64_t)round && ctx->sorted_seed[os] == ctx->seed) return 0;
+  CHK(enqueue_hist(ctx, round, false));                       // (in line if nobody prefetched it)
+  if (ctx->hist_on_side[hs]) { HIPCHK(hipStreamWaitEvent(ctx->L.stream, ctx->ev_hist[hs], 0)); ctx->hist_on_side[hs] = false; }
+  Dev Dt = ctx->D; apply_set(Dt, ctx->sets[os]); apply_hist(Dt, ctx->hset[hs]);
+  Dt.nxt = ctx->hist_nxt[hs] ? 1 : 0;
+  l_sort_tail(ctx->L, Dt); KCHK();
+  ctx->sorted_round[os] = (int64_t)round; ctx->sorted_seed[os] = ctx->seed; ctx->sorted_nxt[os] = Dt.nxt != 0; ctx->sorted_on_side[os] = false;
+  return 0;
+}
+// after the block steps of round `round` have been queued: the next round's tail right behind them, the histograms of the rounds after that
+int sort_after_round(hmx_ctx* ctx, uint64_t round) {
+  if (ctx->sort_sched != 2 || !ctx->injected.empty() || ctx->rng_mode == 1) return 0;
+  CHK(enqueue_hist(ctx, round + 1, false));
+  CHK(enqueue_tail(ctx, round + 1));
+  for (int k = 2; k <= 3; k++) CHK(enqueue_hist(ctx, round + k, true));
+  return 0;
+}
 int prepare_round(hmx_ctx* ctx, uint64_t round) {
   Dev& D = ctx->D;
   const int sset = (int)(round & 1);
   const bool host_order = !ctx->injected.empty() || ctx->rng_mode == 1;
+  if (ctx->sort_sched == 2 && !host_order) {
+    CHK(enqueue_tail(ctx, round));
+    apply_set(D, ctx->sets[sset]); apply_hist(D, ctx->hset[round & 3]);
+    D.nxt = ctx->sorted_nxt[sset] ? 1 : 0;
+    for (int k = 1; k <= 3; k++) CHK(enqueue_hist(ctx, round + k, true));       // (usually there already)
+    return 0;
+  }
+  if (ctx->sort_sched == 2) {       // host-provided order: the in-line path below, on set `sset` and its own histogram arrays; prefetched slots are void
+    for (int i = 0; i < 4; i++) ctx->hist_round[i] = -1;
+    if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
+    for (int i = 0; i < 4; i++) ctx->hist_on_side[i] = false;
+  }
   if (ctx->sorted_on_side[sset]) {   // a prefetch into this set is (or was) in flight on the side stream: order the main stream behind it
     HIPCHK(hipStreamWaitEvent(ctx->L.stream, ctx->ev_sorted[sset], 0));
     ctx->sorted_on_side[sset] = false;
@@ -1020,12 +1094,7 @@ int update_R_ref(hmx_ctx* ctx) {
     float* tot = ctx->sq_total + (size_t)j * W;
     // one launch: the previous block goes back in, this block comes out, this block's penalty table (:329-330, :312-313, :322)
     { PhaseScope ph(ctx, "EO_update"); l_oe_fold(ctx->L, D, ctx->Of, ctx->Ef, put_back, tot, D.pen, 0); KCHK(); }
-    if (ctx->profile) {
-      if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); ctx->ev_pool.emplace_back(a, b); }
-      HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
-    }
-    l_update(ctx->L, D, j); KCHK();
-    if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
+    { Launch Le; CHK(launch_with_events(ctx, Le)); l_update(Le, D, j); KCHK(); if (ctx->profile) ctx->prof_update_steps++; }
     { PhaseScope ph(ctx, "EO_update");
       // the same cells in the same order as the sums removed above, their R rows updated: that run's segment starts are this run's first guess
       CHK(seq_run_oe(ctx, P, ctx->roundlist, ctx->roundlev, j, 1, true)); }
@@ -1111,10 +1180,6 @@ int update_R(hmx_ctx* ctx) {
     D.chain_tag = (unsigned)(1 + (ctx->chain_rounds++ % (1u << 24)) * 64);
     long long* const keep_snew = D.Snew_fx;
     D.Snew_fx = D.Snew_set[0];     // one replica set: the folder resets it by exchange (zeroed by the round's memset)
-    if (ctx->profile) {
-      if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t x, y; HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y)); ctx->ev_pool.emplace_back(x, y); }
-      HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
-    }
     const int keep_old = D.chain_old; D.chain_old = chain_old ? 1 : 0;
     // one GPU: the chain's folder also closes the round (objective snapshot, table clears, control reset): no k_round_tail launch
     chain_tail = !sharded && !ctx->obj_arith && D.chain_wps == 2 && !getenv("HMX_CHAIN_TAIL_OFF");
@@ -1133,12 +1198,12 @@ int update_R(hmx_ctx* ctx) {
       const void*& owner = gate.owner[ctx->device];
       if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       else if (owner != (const void*)ctx->L.stream) HIPCHK(hipStreamWaitEvent(ctx->L.stream, ev, 0));   // (the same stream orders its own launches: no event, ~20 us of barrier packet less per round)
-      l_chain(ctx->L, D, ctx->chain_wgs); KCHK();
+      { Launch Le; CHK(launch_with_events(ctx, Le)); l_chain(Le, D, ctx->chain_wgs); KCHK(); }
       HIPCHK(hipEventRecord(ev, ctx->L.stream));
       owner = (const void*)ctx->L.stream;
     }
     D.chain_old = keep_old; D.chain_tail = 0;
-    if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps += D.nb; }
+    if (ctx->profile) ctx->prof_update_steps += D.nb;
     D.Snew_fx = keep_snew;
     ctx->chain_check = true;
     round_done = true;
@@ -1151,12 +1216,7 @@ int update_R(hmx_ctx* ctx) {
     D.fused_fold = 1;
     for (int j = 0; j < D.nb; j++) {
       D.fold_prev = D.Snew_set[(j + 2) % 3]; D.Snew_fx = D.Snew_set[j % 3]; D.fold_zero = D.Snew_set[(j + 1) % 3];
-      if (ctx->profile) {
-        if (ctx->ev_used == ctx->ev_pool.size()) { hipEvent_t x, y; HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y)); ctx->ev_pool.emplace_back(x, y); }
-        HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
-      }
-      l_update(ctx->L, D, j); KCHK();
-      if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; }
+      { Launch Le; CHK(launch_with_events(ctx, Le)); l_update(Le, D, j); KCHK(); }
       if (ctx->profile) ctx->prof_update_steps++;
       if (sharded) CHK(allreduce(ctx, D.Snew_fx, (int64_t)D.nrep * D.B * D.K, 0));   // this block's new contribution, all ranks
       std::swap(D.O_fx, D.O_alt);   // workgroup 0 published O' into O_alt
@@ -1183,16 +1243,9 @@ int update_R(hmx_ctx* ctx) {
       if (j < D.nb) { l_penalty(ctx->L, D); KCHK(); }
     }
     if (j == D.nb) break;
-    if (ctx->profile) {
-      if (ctx->ev_used == ctx->ev_pool.size()) {
-        hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-        ctx->ev_pool.emplace_back(a, b);
-      }
-      HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].first, ctx->L.stream));
-    }
-    l_update(ctx->L, D, j); KCHK();
-    if (ctx->profile) { HIPCHK(hipEventRecord(ctx->ev_pool[ctx->ev_used].second, ctx->L.stream)); ctx->ev_used++; ctx->prof_update_steps++; }
+    { Launch Le; CHK(launch_with_events(ctx, Le)); l_update(Le, D, j); KCHK(); if (ctx->profile) ctx->prof_update_steps++; }
   }
+  CHK(sort_after_round(ctx, ctx->round_counter - 1));      // (sort_sched = 2) the next round's sort tail right behind this round's block steps
   if (chain_tail) {
     if (!chain_old) ctx->sold_state[ctx->sold_cur] = 0;
     ctx->sets_clean = true;
@@ -1628,13 +1681,13 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "seq_passes") { if (v < 2 || v > 64) return fail(ctx, HMX_ERR_ARG, "seq_passes: 2..64"); ctx->seq_passes = (int)v; if (ctx->seq_max_passes < (int)v) ctx->seq_max_passes = (int)v; }
   else if (f == "seq_max_passes") { if (v < 2 || v > 256) return fail(ctx, HMX_ERR_ARG, "seq_max_passes: 2..256"); ctx->seq_max_passes = (int)v; }
   else if (f == "device") ctx->device = (int)v;
-  else if (f == "profile") { ctx->profile = v != 0; ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->prof_update_steps = 0; ctx->ev_used = 0;
+  else if (f == "profile") { ctx->profile = (int)(v < 0 ? 0 : v > 2 ? 2 : v); ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->prof_update_steps = 0; ctx->ev_used = 0;
                              ctx->ph_used = 0; ctx->gpu_timers.clear(); }
   else if (f == "grid") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "grid must be set before setup"); ctx->L.grid = (int)v; }
   else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
   else if (f == "comm_force") ctx->comm_force = v != 0;
   else if (f == "upd_impl") { ctx->tun_impl = (int)v; if (ctx->ran_setup) { ctx->D.upd_impl = (int)v;
-                                if (v == 1 && !ctx->D.need_lorder) { ctx->D.need_lorder = 1; for (int i = 0; i < 2; i++) ctx->sorted_round[i] = -1; } } }   // (the v1 kernel reads lorder: re-sort with it)
+                                if (v == 1 && !ctx->D.need_lorder) { ctx->D.need_lorder = 1; for (int i = 0; i < 2; i++) ctx->sorted_round[i] = -1; } } }   // (the v1 kernel reads lorder: re-sort with it; the histogram slots stay valid)
   else if (f == "upd_wps") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "upd_wps must be set before setup"); ctx->tun_wps = (int)v; }
   else if (f == "upd_debug") { if (ctx->ran_setup) ctx->D.upd_debug = (int)v; }
   else if (f == "upd_tpw") { ctx->tun_tpw = (int)v; if (ctx->ran_setup) ctx->D.upd_tpw = (int)(v < 1 ? 1 : v); }
@@ -1866,7 +1919,14 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     const char* e = getenv("HMX_SORT_OVERLAP"); ctx->sort_overlap = !(e && atoi(e) == 0);
     { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lowest priority: the shuffle only fills gaps
       HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, lo)); }
-    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); } }
+    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); }
+    { const char* sc = getenv("HMX_SORT_SCHED"); ctx->sort_sched = (sc && atoi(sc) == 1) ? 1 : 2; if (!ctx->sort_overlap) ctx->sort_sched = 1; }
+    ctx->hset[0] = {ctx->sets[0].blk, ctx->sets[0].blkv, ctx->sets[0].counts}; ctx->hset[1] = {ctx->sets[1].blk, ctx->sets[1].blkv, ctx->sets[1].counts};
+    for (int i = 2; i < 4; i++) {
+      if (ctx->sort_sched == 2) { CHK(dalloc(ctx, &ctx->hset[i].blk, (size_t)N)); CHK(dalloc(ctx, &ctx->hset[i].blkv, (size_t)N)); CHK(dalloc(ctx, &ctx->hset[i].counts, (size_t)nV * D.nchunks)); }
+      else ctx->hset[i] = ctx->hset[i & 1];
+    }
+    for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_hist[i], hipEventDisableTiming)); ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; } }
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K));
   { const char* e = getenv("HMX_MOE_SOLVE"); ctx->solve_on_device = !(e && std::string(e) == "host") && (size_t)(B + 1) * 16 * 8 + (size_t)(4 * B + 8 + C) * 4 <= 158 * 1024; }   // (LDS panel of the device Cholesky)
@@ -2080,6 +2140,7 @@ int hmx_restart(hmx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->D.solve_err, 0, sizeof(int), ctx->L.stream));
   if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
   for (int i = 0; i < 2; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
+  for (int i = 0; i < 4; i++) { ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; }
   return 0;
 }
 

@@ -186,6 +186,7 @@ struct SolveArgs {
 struct Launch {
   hipStream_t stream;
   int grid;  // workgroups for streaming kernels
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // l_update / l_chain: start / stop events attached to the launch itself (profile mode)
 };
 
 // ---- launchers (hmx_kernels.hip) -----------------------------------------------------
@@ -199,6 +200,8 @@ void l_head(const Launch& L, const Dev& D, int mode);
 void l_tile_static(const Launch& L, const Dev& D, int mode);
 void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                    uint64_t cells_per_block);
+void l_sort_hist(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff, uint64_t cells_per_block);
+void l_sort_tail(const Launch& L, const Dev& D);
 void l_oldsum(const Launch& L, const Dev& D);
 void l_fold(const Launch& L, const Dev& D, int j, int mode);
 void l_penalty(const Launch& L, const Dev& D);

@@ -12,6 +12,7 @@
 // fp64 for the rest.
 #include "hmx_internal.h"
 #include <float.h>
+#include <hip/hip_ext.h>
 
 #ifndef HMX_USE_DPP
 #define HMX_USE_DPP 1
@@ -3828,19 +3829,28 @@ void l_head(const Launch& L, const Dev& D, int mode) {
   else HMX_DISPATCH_KD(k_head, HMX_COMMA 1, grid, lds, D);
 }
 // fused = true: D.blk is produced by the histogram kernel from (seed, round); false: the host uploaded D.blk (injected shuffle)
-void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
-                   uint64_t cells_per_block) {
+// the histogram half (block ids from the Feistel bijection + per-chunk counts): depends on nothing but (seed, round)
+void l_sort_hist(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff, uint64_t cells_per_block) {
   const int nV = D.nxt ? D.nb * D.nb : D.nb;
   const size_t lds = (size_t)nV * sizeof(int);
-  // (padding slots = -1: written by k_sort_scatter, bin by bin)
   BlockIdArgs A;
   A.fk = make_keys(seed, round, Nglob); A.fk2 = make_keys(seed, round + 1, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
   A.inv_cpb = 1.0f / (float)cells_per_block;
   if (fused) hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
   else hipLaunchKernelGGL(k_sort_hist<false>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
+}
+// the dependent half: bin offsets from the counts, then the placement (padding slots = -1: written by k_sort_scatter, bin by bin)
+void l_sort_tail(const Launch& L, const Dev& D) {
+  const int nV = D.nxt ? D.nb * D.nb : D.nb;
+  const size_t lds = (size_t)nV * sizeof(int);
   hipLaunchKernelGGL(k_sort_binscan, dim3(nV * D.Q), dim3(WAVE), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D);
   hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
+}
+void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+                   uint64_t cells_per_block) {
+  l_sort_hist(L, D, fused, seed, round, Nglob, goff, cells_per_block);
+  l_sort_tail(L, D);
 }
 // oe_arith: the round's shuffled order itself, posord[position] = internal cell id (arma::shuffle's update_order, src/harmony.cpp:272-273,
 // for the documented generator: cell g sits at position feistel(seed, round, g))
@@ -3984,6 +3994,12 @@ void l_obj_reduce(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(1), 0, L.stream, D);
 }
 #endif  // !HMX_TILE_BF
+// launch with the start / stop events of profile mode attached to the dispatch (no barrier packets around the launch), or plainly
+#define HMX_LAUNCH_EV(KERNEL, GRID, BLOCK, LDS, ...)                                                                      \
+  do {                                                                                                                     \
+    if (L.ev0) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, (std::uint32_t)(LDS), L.stream, L.ev0, L.ev1, 0, __VA_ARGS__);   \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, L.stream, __VA_ARGS__);                                              \
+  } while (0)
 void HMX_LNAME(l_update)(const Launch& L, const Dev& D, int j) {
 #if !HMX_TILE_BF
   if (D.upd_impl == 1) {
@@ -4007,7 +4023,7 @@ void HMX_LNAME(l_update)(const Launch& L, const Dev& D, int j) {
   if (bf_fits(D, rest, blocks)) { l_update_bf(L, D, j); return; }
 #endif
   const size_t lds = tile_image_bytes(D) + rest;
-#define HMX_UPDL(N) case N: hipLaunchKernelGGL((k_tile<N, 0, 4, true>), grid, dim3(1024), lds, L.stream, D, j); break;
+#define HMX_UPDL(N) case N: HMX_LAUNCH_EV((k_tile<N, 0, 4, true>), grid, dim3(1024), lds, D, j); break;
   if (D.upd_wps == 4) {   // hmx_setup: upd_threads == 1024, uniform sigma, K <= 64
     switch (D.NCT) {
       HMX_UPDL(1) HMX_UPDL(2) HMX_UPDL(3) HMX_UPDL(4)
@@ -4016,8 +4032,8 @@ void HMX_LNAME(l_update)(const Launch& L, const Dev& D, int j) {
     return;
   }
 #undef HMX_UPDL
-#define HMX_UPD(N) case N: if (D.usig) hipLaunchKernelGGL((k_tile<N, 0, 2, true>), grid, dim3(D.upd_threads), lds, L.stream, D, j); \
-                           else hipLaunchKernelGGL((k_tile<N, 0>), grid, dim3(D.upd_threads), lds, L.stream, D, j); break;
+#define HMX_UPD(N) case N: if (D.usig) HMX_LAUNCH_EV((k_tile<N, 0, 2, true>), grid, dim3(D.upd_threads), lds, D, j); \
+                           else HMX_LAUNCH_EV((k_tile<N, 0>), grid, dim3(D.upd_threads), lds, D, j); break;
   switch (D.NCT) {
     HMX_UPD(1) HMX_UPD(2) HMX_UPD(3) HMX_UPD(4) HMX_UPD(5) HMX_UPD(6) HMX_UPD(7) HMX_UPD(8)
     HMX_UPD(10) HMX_UPD(12) HMX_UPD(13) HMX_UPD(14) HMX_UPD(16)
@@ -4034,13 +4050,13 @@ void HMX_LNAME(l_chain)(const Launch& L, const Dev& D, int workgroups) {
   if (D.chain_wps >= 3) lds = ((lds + 15) & ~(size_t)15) + (size_t)(4 * D.chain_wps) * ((D.NT4 + D.tail) * 1024 + 1024);   // per wave: glds row image + pair images
   const dim3 grid((unsigned)workgroups);
 #if HMX_TILE_BF
-#define HMX_CH(N) case N: if (D.usig) hipLaunchKernelGGL((k_tile<N, 4, 2, true>), grid, dim3(512), lds, L.stream, D, 0); \
-                          else hipLaunchKernelGGL((k_tile<N, 4>), grid, dim3(512), lds, L.stream, D, 0); break;
+#define HMX_CH(N) case N: if (D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 2, true>), grid, dim3(512), lds, D, 0); \
+                          else HMX_LAUNCH_EV((k_tile<N, 4>), grid, dim3(512), lds, D, 0); break;
 #else
-#define HMX_CH(N) case N: if (D.chain_wps == 4 && D.usig) hipLaunchKernelGGL((k_tile<N, 4, 4, true>), grid, dim3(1024), lds, L.stream, D, 0); \
-                          else if (D.chain_wps == 3 && D.usig) hipLaunchKernelGGL((k_tile<N, 4, 3, true>), grid, dim3(768), lds, L.stream, D, 0); \
-                          else if (D.usig) hipLaunchKernelGGL((k_tile<N, 4, 2, true>), grid, dim3(512), lds, L.stream, D, 0); \
-                          else hipLaunchKernelGGL((k_tile<N, 4>), grid, dim3(512), lds, L.stream, D, 0); break;
+#define HMX_CH(N) case N: if (D.chain_wps == 4 && D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 4, true>), grid, dim3(1024), lds, D, 0); \
+                          else if (D.chain_wps == 3 && D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 3, true>), grid, dim3(768), lds, D, 0); \
+                          else if (D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 2, true>), grid, dim3(512), lds, D, 0); \
+                          else HMX_LAUNCH_EV((k_tile<N, 4>), grid, dim3(512), lds, D, 0); break;
 #endif
   switch (D.NCT) {
     HMX_CH(1) HMX_CH(2) HMX_CH(3) HMX_CH(4) HMX_CH(5) HMX_CH(6) HMX_CH(7)

@@ -146,7 +146,9 @@ class Harmony(object):
         self._check(self._lib.hmx_restart(self._h), "restart")
 
     def set_profile(self, on=True):
-        self._set("profile", 1 if on else 0)
+        """0 / False: off; 1 / True: the dominant kernel's launches carry start / stop events ("prof:*"); 2: every phase is bracketed by events
+        as well ("gputimer:*" -- an event record is a packet of its own in the queue: ~200 of them per run cost 0.4-1 ms of a 15 ms run)"""
+        self._set("profile", int(on))
 
     def timer(self, name):
         return self._scalar("timer:" + name)
