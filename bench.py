@@ -241,6 +241,119 @@ def headline_parity(n, d, K, levels):
     return None
 
 
+def comm_stats(obj):
+    """what travelled how in a sharded run (per rank, since setup): collectives left on the communicator / hook, small all-reduces through the
+    peers' inboxes, the state of the in-launch exchange"""
+    return {"communicator_or_hook_calls": int(obj._scalar("comm:calls")), "communicator_or_hook_bytes": int(obj._scalar("comm:bytes")),
+            "inbox_allreduce_calls": int(obj._scalar("p2p:allreduce_calls")), "p2p_chain": bool(obj._scalar("p2p")),
+            "p2p_status": obj.p2p_status, "p2p_selftest_us_per_exchange": obj._scalar("p2p:exchange_us")}
+
+
+def main_file_bootstrap(a):
+    """--bootstrap file: the whole N-rank run WITHOUT torch in the process -- the path a plain C / R host takes.  Ranks are separate processes
+    (spawned here if no launcher did: RANK / LOCAL_RANK / WORLD_SIZE in the environment), rank 0 creates the RCCL unique id
+    (hmx_comm_unique_id) and passes it through a file, hmx_comm_init builds the communicator and connects + self-tests the peers' inboxes,
+    barriers / max-over-ranks / the sanity sums go through hmx_comm_allreduce_host.  Same step, same JSON contract as the default path; the
+    single-GPU extras (e2e, `also` legs, CPU baseline) stay with the default invocation."""
+    import tempfile
+    world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
+    if a.gpus > 1 and "RANK" not in os.environ:
+        uid_file = os.path.join(tempfile.gettempdir(), "hmx_bench_uid_%d" % os.getpid())
+        procs = []
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), HMX_BENCH_UID_FILE=uid_file)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = max(p.wait() for p in procs)
+        for f in (uid_file, uid_file + ".tmp"):
+            if os.path.exists(f):
+                os.remove(f)
+        raise SystemExit(rc)
+    from harmony_amd import Harmony, prepare_setup_args
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to print a line whose n_gpus differs from --gpus" % (a.gpus, world))
+    ndev = int(os.environ.get("HMX_BENCH_NDEV", "0"))          # (smoke tests: several ranks on one GPU)
+    obj = Harmony(device=(local_rank % ndev) if ndev else local_rank, seed=1)
+    if a.workload == "c5":
+        levels, nested, K = (8, 64, 128), True, (a.clusters or 200)
+    else:
+        levels, nested, K = (a.batches,), False, (a.clusters or 100)
+    strong = a.total_cells > 0
+    n, d = (a.total_cells // world if strong else a.cells_per_gpu), a.pcs
+    N = n * world
+    if world > 1:
+        uid_file = os.environ.get("HMX_BENCH_UID_FILE") or os.path.join(tempfile.gettempdir(), "hmx_bench_uid_%s" % os.environ.get("MASTER_PORT", "0"))
+        if rank == 0:
+            with open(uid_file + ".tmp", "wb") as fh:
+                fh.write(Harmony.comm_unique_id())
+            os.replace(uid_file + ".tmp", uid_file)
+        t0 = time.time()
+        while not os.path.exists(uid_file):
+            if time.time() - t0 > 120:
+                raise SystemExit("rank %d: no unique id file after 120 s" % rank)
+            time.sleep(0.01)
+        with open(uid_file, "rb") as fh:
+            uid = fh.read()
+        obj.comm_init(rank, world, uid)              # communicator + inboxes + transport self-test
+        obj.set_shard(rank, world, rank * n, N, None)
+    Z, meta, _ = synth(n, d=d, levels=levels, seed=a.seed, shard=rank, nested=nested)
+    vars_use = list(meta)
+    N_b = None
+    if world > 1:
+        N_b = np.concatenate([obj.comm_allreduce_host(np.bincount(meta[v], minlength=L).astype(float)) for v, L in zip(vars_use, levels)])
+    skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=K, N_b=N_b, levels={v: np.arange(L) for v, L in zip(vars_use, levels)})
+    obj.setup(**skw)
+    del Z
+
+    def sync():
+        if world > 1:
+            obj.comm_allreduce_host([0.0])           # device synchronisation + barrier
+        else:
+            obj._scalar("sync")
+
+    for _ in range(a.warmup + (1 if world > 1 else 0)):
+        run_to_convergence(obj)
+    obj.set_profile(1)
+    sync()
+    t0 = time.perf_counter()
+    iters = [run_to_convergence(obj) for _ in range(a.steps)]
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = float(obj.comm_allreduce_host([dt], "max")[0])
+    ms_per_step = 1e3 * dt / a.steps
+    shard_check = None
+    if world > 1:
+        O = np.ascontiguousarray(obj.O, dtype=np.float64).ravel()
+        lo_, hi_ = obj.comm_allreduce_host(O, "min"), obj.comm_allreduce_host(O, "max")
+        shard_check = {"O_identical_on_all_ranks": bool((lo_ == hi_).all()), "sum_O_over_N": float(O.sum()) / float(N)}
+        if not shard_check["O_identical_on_all_ranks"] or abs(shard_check["sum_O_over_N"] - 1.0) > 1e-4:
+            raise SystemExit("sharded run inconsistent: %r" % (shard_check,))
+    upd_ms, upd_launches = obj._scalar("prof:update_ms"), obj._scalar("prof:update_launches")
+    upd_cells, upd_steps = obj._scalar("prof:update_cells"), obj._scalar("prof:update_steps")
+    kr = np.asarray(obj.kmeans_rounds, dtype=np.int64)
+    alg_bytes = upd_cells * (4.0 * d + 4.0 * K)
+    achieved = alg_bytes / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    run_bytes = float(n) * float(np.sum(4.0 * d * (4 + kr) + 4.0 * K * (3 + 2 * kr)))
+    on_chain = bool(obj._scalar("chain")) and (world == 1 or bool(obj._scalar("p2p")))
+    out = {"metric": "cells_per_sec_to_convergence", "value": N / (ms_per_step * 1e-3), "unit": "cells/s", "n_gpus": world, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "synthetic %d cells x %d PCs, K=%d, levels %s%s%s" % (N, d, K, "x".join(map(str, levels)), " nested" if nested else "",
+                                                                                          "" if world == 1 else ", %d cells/GPU cell-sharded" % n),
+                      "parallelism": "single GPU" if world == 1 else "cells sharded x%d, RCCL over xGMI from the C library" % world,
+                      "bootstrap": "file: hmx_comm_unique_id -> file -> hmx_comm_init (communicator, inboxes, self-test); no torch in the process",
+                      "comm": comm_stats(obj) if world > 1 else None, "shard_check": shard_check, "harmony_iterations": iters,
+                      "kmeans_rounds_last_step": int(kr.sum())},
+           "roofline": {"kernel": "k_tile<%d,%s,...>: %s" % ((K + 15) // 16, "4" if on_chain else "0", "persistent block chain, one launch per round" if on_chain else "one launch per block step"),
+                        "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                        "avg_launch_us": 1e3 * upd_ms / max(upd_launches, 1), "avg_block_step_us": 1e3 * upd_ms / max(upd_steps, 1),
+                        "run": {"achieved": run_bytes / (ms_per_step * 1e-3) / 1e9, "frac": run_bytes / (ms_per_step * 1e-3) / 8e12}},
+           "cpu_baseline": None}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -267,8 +380,12 @@ def main():
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--no-e2e", action="store_true", help="skip the T_e2e measurement (ingest + egress over PCIe)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for smoke tests on one GPU)")
+    ap.add_argument("--bootstrap", default="torch", choices=["torch", "file"], help="torch: torch.distributed bootstraps the communicator (default); "
+                    "file: no torch in the process -- unique id through a file, hmx_comm_init, host reductions through the library")
     a = ap.parse_args()
 
+    if a.bootstrap == "file":
+        return main_file_bootstrap(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: become one (one process per GPU over RCCL), and make sure the line really is an N-GPU line
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
@@ -563,6 +680,7 @@ def main():
                                   "" if world == 1 else ", %d cells/GPU cell-sharded" % n,
                                   "configs[4] shape" if a.workload == "c5" else ("configs[2]" if n == 1000000 and levels == (10,) else "configs[2]/[3] family")),
                    "parallelism": ("cells sharded x%d, all-reduce of O/E/statistics: %s" % (world, comm_kind)) if world > 1 else "single GPU",
+                   "comm": comm_stats(obj) if world > 1 else None,
                    "shard_check": shard_check, "harmony_iterations": iters, "kmeans_rounds_last_step": rounds,
                    "s_per_iter": 1e-3 * ms_per_step / max(float(np.mean(iters)), 1.0),
                    "gpu_phase_ms_per_step": gpu_phase, "chain_us_per_block_step": chain, "e2e": e2e},

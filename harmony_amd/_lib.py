@@ -48,6 +48,7 @@ SIGNATURES = {
     "hmx_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "hmx_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "hmx_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    "hmx_comm_allreduce_host": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32]),
     "hmx_p2p_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
     "hmx_p2p_connect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     "hmx_p2p_selftest": (C.c_int, [C.c_void_p]),

@@ -201,6 +201,7 @@ struct hmx_ctx {
   // peer-to-peer block chain (hmx_p2p_*): inboxes shared through HIP IPC; on only after the connection self-test passed everywhere
   unsigned long long* p2p_self = nullptr; unsigned long long* p2p_peer[8] = {}; int p2p_rank = 0, p2p_world = 0; bool p2p_on = false;
   unsigned p2p_tests = 0; int* p2p_result = nullptr; double p2p_exchange_us = 0.0; std::string p2p_note = "not connected";
+  unsigned p2p_ar_seq = 0, p2p_xseq = 0; int64_t p2p_ar_calls = 0;     // generic inbox all-reduces issued (same on every rank) / chain exchanges issued
   int (*poll)(void*) = nullptr; void* poll_user = nullptr;
   // ---- problem --------------------------------------------------------------------
   int64_t N = 0;  // local cells
@@ -369,13 +370,26 @@ template <class T> int d2h(hmx_ctx* ctx, T* dst, const T* src, size_t count) {
 }
 int allreduce(hmx_ctx* ctx, void* buf, int64_t count, int dtype) {
   if (ctx->world <= 1 && !ctx->comm_force) return 0;
+  // small buffers go through the peers' inboxes when they are connected and tested (k_p2p_allreduce: one launch, one trip over xGMI, no ring):
+  // everything but the big ridge statistics of many-level designs.  HMX_P2P_AR=0: always the communicator / hook.
+  if (ctx->p2p_on && ctx->p2p_world == ctx->world && !ctx->comm_force && count <= (int64_t)P2P_CAP && ctx->ran_setup && ctx->D.chain_ctl) {
+    static const bool off = [] { const char* e = getenv("HMX_P2P_AR"); return e && atoi(e) == 0; }();
+    if (!off) {
+      Dev T = ctx->D; T.p2p_world = ctx->p2p_world; T.p2p_rank = ctx->p2p_rank;
+      for (int g = 0; g < 8; g++) T.p2p_inbox[g] = ctx->p2p_peer[g];
+      l_p2p_allreduce(ctx->L, T, buf, (int)count, dtype, ctx->p2p_ar_seq++, ctx->D.chain_ctl + 1);
+      if (hipGetLastError() != hipSuccess) return fail(ctx, HMX_ERR_COMM, "inbox all-reduce launch failed");
+      ctx->p2p_ar_calls++;
+      return 0;
+    }
+  }
   ctx->comm_calls++; ctx->comm_bytes += count * 8;
   if (ctx->ar) {
     int st = ctx->ar(ctx->ar_user, buf, count, dtype, (void*)ctx->L.stream);
     if (st) return fail(ctx, HMX_ERR_COMM, "all-reduce callback failed");
     return 0;
   }
-  if (!ctx->comm) return fail(ctx, HMX_ERR_COMM, "sharded handle without hmx_comm_init or an all-reduce hook");
+  if (!ctx->comm && !(ctx->p2p_on && ctx->p2p_world == ctx->world)) return fail(ctx, HMX_ERR_COMM, "sharded handle without hmx_comm_init or an all-reduce hook");
   RcclApi* api = rccl_api(nullptr);
   ncclResult_t r = api->AllReduce(buf, buf, (size_t)count, dtype == 1 ? ncclFloat64 : ncclInt64,
                                   dtype == 2 ? ncclMin : ncclSum, ctx->comm, ctx->L.stream);
@@ -1151,7 +1165,7 @@ int update_R(hmx_ctx* ctx) {
         l_oldsum(ctx->L, D); KCHK();
       }
       ctx->sold_state[cur] = 1;
-      CHK(allreduce(ctx, D.Sold_fx, (int64_t)nSold, 0));
+      if (!(chain_path && p2p)) CHK(allreduce(ctx, D.Sold_fx, (int64_t)nSold, 0));      // (p2p chain: the folder exchanges new(j - 1) - old_local(j), the ranks' old sums meet there)
       // this round's tile kernels collect the next round's old contributions if this round's tiles are keyed by the next block
       const bool write_next = ctx->carry_ok && ctx->sorted_nxt[(rnd & 1)] && !ctx->last_round_hint && !chain_old && D.upd_impl == 0;
       D.Sold_next = nullptr;
@@ -1178,6 +1192,7 @@ int update_R(hmx_ctx* ctx) {
     // (chain_ctl was reset by the launch that closed the previous round: k_round_tail / k_objective_tables.  The shuffle kernels must
     //  not touch chain_ctl, pen_g or the Sold buffers: prefetch_next() runs them on the side stream while a chain may be in flight)
     D.chain_tag = (unsigned)(1 + (ctx->chain_rounds++ % (1u << 24)) * 64);
+    D.chain_xseq = ctx->p2p_xseq; if (p2p) ctx->p2p_xseq += (unsigned)D.nb + 1u;
     long long* const keep_snew = D.Snew_fx;
     D.Snew_fx = D.Snew_set[0];     // one replica set: the folder resets it by exchange (zeroed by the round's memset)
     const int keep_old = D.chain_old; D.chain_old = chain_old ? 1 : 0;
@@ -1521,6 +1536,25 @@ int hmx_comm_init(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* uniq
   ncclResult_t r = api->CommInitRank(&ctx->comm, world, id, rank);
   if (r != ncclSuccess) { ctx->comm = nullptr; return fail(ctx, HMX_ERR_COMM, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "error")); }
   p2p_auto(ctx, api, rank, world);     // in-launch exchange of the block chain over the peers' inboxes, if the node allows it
+  return 0;
+}
+int hmx_comm_allreduce_host(hmx_ctx* ctx, double* inout, int32_t count, int32_t op) {
+  if (!ctx || !inout || count <= 0 || op < 0 || op > 2) return ctx ? fail(ctx, HMX_ERR_ARG, "bad arguments") : HMX_ERR_ARG;
+  if (!ctx->comm) return fail(ctx, HMX_ERR_STATE, "hmx_comm_init first");
+  RcclApi* api = rccl_api(nullptr);
+  if (ctx->device >= 0) HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->L.stream) { HIPCHK(hipStreamCreateWithFlags(&ctx->L.stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+  if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
+  double* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, sizeof(double) * (size_t)count));
+  hipError_t e = hipMemcpyAsync(d, inout, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->L.stream);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) r = api->AllReduce(d, d, (size_t)count, ncclFloat64, op == 0 ? ncclSum : op == 1 ? ncclMax : ncclMin, ctx->comm, ctx->L.stream);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(inout, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->L.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->L.stream);
+  (void)hipFree(d);
+  if (r != ncclSuccess) return fail(ctx, HMX_ERR_COMM, "ncclAllReduce failed");
+  if (e != hipSuccess) return fail(ctx, HMX_ERR_DEVICE, hipGetErrorString(e));
   return 0;
 }
 // ---- peer-to-peer block chain ------------------------------------------------------------------------------------------
@@ -2442,12 +2476,18 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "prof:update_launches") return scalar((double)ctx->prof_update_launches);
   if (f == "prof:update_cells") return scalar((double)ctx->prof_update_cells);
   if (f == "prof:update_steps") return scalar((double)ctx->prof_update_steps);
+  if (f == "sync") {        // everything queued on the handle's streams has completed (hosts without a HIP runtime of their own: bench.py --bootstrap file)
+    if (ctx->L.stream && hipStreamSynchronize(ctx->L.stream) != hipSuccess) return -1;
+    if (ctx->side && hipStreamSynchronize(ctx->side) != hipSuccess) return -1;
+    return scalar(1.0);
+  }
   if (f == "chain") return scalar(ctx->chain_ok ? 1.0 : 0.0);
   if (f == "dot_bf") return scalar(ctx->D.dot_bf ? 1.0 : 0.0);     // split-bf16 tile kernels offered (each launch still checks its LDS budget)
   if (f == "sold_carry") return scalar(ctx->carry_ok ? 1.0 : 0.0);
   if (f == "carried_rounds") return scalar((double)ctx->carried_rounds);
   if (f == "rounds_without_R") return scalar((double)ctx->rounds_without_R);
   if (f == "p2p:exchange_us") return scalar(ctx->p2p_exchange_us);
+  if (f == "p2p:allreduce_calls") return scalar((double)ctx->p2p_ar_calls);
   if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);
   if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them
     if (!ctx->ran_setup) return -1;

@@ -76,6 +76,7 @@ struct Dev {
   unsigned long long* pen_g;   // [B][K] { tag << 32 | penalty bits }
   int* chain_ctl;              // [0] block flag (tag), [1] error, [2 + j] arrivals of block j
   unsigned chain_tag;
+  unsigned chain_xseq;         // sharded chain: number of this round's first inbox exchange (plane = exchange number & 1, carried across rounds)
   int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
   long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int* tail_ticket;            // k_round_tail: workgroups done (the last one finishes the round's objective)
@@ -255,9 +256,15 @@ __host__ __device__ inline void bfimg_store(unsigned short* img, int nct, int ns
   bf3_split(y, p);
   for (int part = 0; part < 3; part++) img[bfimg_index(nct, ns2, j, k, part)] = p[part];
 }
-constexpr int P2P_CAP = 65536;                       // K x B entries an inbox holds per (parity, source): 200 clusters x 200 levels (BASELINE configs[4]) fit; 16 MB per inbox
-constexpr size_t P2P_TEST_BASE = (size_t)2 * 8 * P2P_CAP * 2;   // 64 granules behind the tables: the connection self-test
+constexpr int P2P_CAP = 65536;                       // K x B entries an inbox holds per (plane, source): 200 clusters x 200 levels (BASELINE configs[4]) fit
+// an inbox = [4 planes][8 sources][P2P_CAP entries][2 granules]: planes 0 / 1 = the block chain's exchanges (alternating by exchange
+// number), planes 2 / 3 = the generic small all-reduces (alternating by call number); 64 granules behind them: the connection self-test
+constexpr int P2P_PLANES = 4;
+constexpr size_t P2P_TEST_BASE = (size_t)P2P_PLANES * 8 * P2P_CAP * 2;
 constexpr size_t P2P_INBOX_GRANULES = P2P_TEST_BASE + 64;
+// generic all-reduce of a small buffer through the inboxes (k_p2p_allreduce): dtype 0 int64 sum | 1 float64 sum (rank order: identical on
+// every rank) | 2 int64 min; `seq` = the call's number (same on every rank: plane 2 + (seq & 1), tag 0x40000000 + seq)
+void l_p2p_allreduce(const Launch& L, const Dev& D, void* buf, int n, int dtype, unsigned seq, int* err);
 void l_p2p_selftest(const Launch& L, const Dev& D, unsigned tag, int* result);   // the whole block chain of a round: one persistent launch
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
 void l_moe_stats(const Launch& L, const Dev& D);

@@ -79,6 +79,7 @@ __device__ __forceinline__ unsigned long long fx_of(float r) {  // R in [0,1] ->
 // 26-cycle dependent-issue latency).  ONE definition for the fused and the stand-alone fold kernels: the sharded and the
 // single-GPU paths must produce bit-identical penalty tables.
 // one int64 of a K x B table into every peer's inbox: two self-validating granules {tag, half}, written through at system scope
+// (par = plane * 8: the plane's first source slot)
 __device__ __forceinline__ void p2p_send(const Dev& D, size_t par, int i, unsigned tag, long long v) {
   const unsigned long long tb = (unsigned long long)tag << 32;
   const unsigned long long lo = tb | ((unsigned long long)v & 0xffffffffull), hi = tb | ((unsigned long long)v >> 32);
@@ -1879,31 +1880,37 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           // of a peer (it needs that peer's contribution of step jj to finish step jj).
           const int G = D.p2p_world, me = D.p2p_rank;
           const unsigned tagx = tag0 + (unsigned)jj;
-          const size_t par = (size_t)(jj & 1) * 8;
+          // (round 4) EVERY step exchanges, jj = 0 included, and what travels is  new(jj - 1) - old_local(jj): the old contributions are filed
+          // rank-locally by the previous round's tile kernels and are summed over the ranks right here -- the per-round all-reduce of the
+          // nb x K x B table (24 host-launched collectives per run) is gone.  The plane alternates with the exchange NUMBER, carried across
+          // rounds (nb + 1 exchanges per round: with jj & 1 two consecutive exchanges of neighbouring rounds would share a plane).
+          const size_t par = (size_t)((D.chain_xseq + (unsigned)jj) & 1u) * 8;
           for (int base = 0; base < nBK; base += FE * bd) {
-            long long dl[FE], so[FE];
+            long long dl[FE];
 #pragma unroll
             for (int e = 0; e < FE; e++) {
               const int i = base + tid + e * bd;
-              dl[e] = 0; so[e] = 0;
+              dl[e] = 0;
               if (i < nBK) {
-                if (jj < nbk) so[e] = D.Sold_fx[(size_t)jj * nBK + i];
+                long long so = 0;
+                if (jj < nbk) so = D.Sold_fx[(size_t)jj * nBK + i];
                 if (jj > 0) {
                   unsigned long long a[8];
 #pragma unroll
                   for (int r = 0; r < 8; r++) a[r] = (r < D.nrep) ? atomicExch((unsigned long long*)&D.Snew_fx[(size_t)r * nBK + i], 0ull) : 0ull;
 #pragma unroll
                   for (int r = 0; r < 8; r++) dl[e] += (long long)a[r];
-                  p2p_send(D, par, i, tagx, dl[e]);
                 }
+                dl[e] -= so;
+                p2p_send(D, par, i, tagx, dl[e]);
               }
             }
 #pragma unroll
             for (int e = 0; e < FE; e++) {
               const int i = base + tid + e * bd;
               if (i < nBK) {
-                long long o = ldsO[i] + dl[e] - so[e];
-                if (jj > 0) {
+                long long o = ldsO[i] + dl[e];
+                {
                   unsigned long long lo[8], hi[8];
 #pragma unroll
                   for (int gq = 0; gq < 8; gq++) if (gq < G && gq != me) {
@@ -4084,7 +4091,7 @@ __global__ void __launch_bounds__(512) k_p2p_selftest(Dev D, unsigned tag, int* 
   for (int step = 0; step < P2P_TEST_STEPS; step++) {
     if (step == 1) t1 = wall_clock64();
     const unsigned tagx = tag + (unsigned)step;
-    const size_t par = (size_t)(step & 1) * 8;
+    const size_t par = (size_t)(step & 1) * 8;      // (the chain's two planes)
 #pragma unroll
     for (int e = 0; e < 4; e++) p2p_send(D, par, tid + e * 512, tagx, p2p_test_value(me, step, tid + e * 512));
 #pragma unroll
@@ -4114,6 +4121,59 @@ __global__ void __launch_bounds__(512) k_p2p_selftest(Dev D, unsigned tag, int* 
 }
 void l_p2p_selftest(const Launch& L, const Dev& D, unsigned tag, int* result) {
   hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(512), 0, L.stream, D, tag, result);
+}
+// Generic all-reduce of a small buffer through the peers' inboxes (planes 2 / 3): the collectives of a run that are NOT block steps --
+// O after a head, the objective's two sums, the Lloyd sums and counts, the seeding minima, small ridge statistics -- are a few KB each
+// and latency-bound: as host-launched ncclAllReduce calls they cost a launch + a ring each (~50 per run).  Here: one workgroup, every
+// rank writes its values straight into every peer's inbox (self-validating {tag, half} granules, as the chain does) and adds up what
+// arrived in its own, in RANK ORDER (fp64 sums are then identical on every rank).  A rank can be at most one call ahead of a peer (it
+// needs the peer's values of call n to finish call n), so two planes alternate.  Every spin is bounded; a timeout raises *err (the
+// chain's error word: it reaches the host with the next objective snapshot).
+__global__ void __launch_bounds__(1024) k_p2p_allreduce(Dev D, unsigned long long* __restrict__ buf, int n, int dtype, unsigned seq, int* err) {
+  const int tid = threadIdx.x, G = D.p2p_world, me = D.p2p_rank;
+  const unsigned tag = 0x40000000u + (seq & 0x3fffffffu);
+  const size_t par = (size_t)(2 + (seq & 1u)) * 8;
+  for (int base = 0; base < n; base += 1024 * 4) {
+    unsigned long long mine[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = base + tid + e * 1024;
+      mine[e] = (i < n) ? buf[i] : 0ull;
+      if (i < n) p2p_send(D, par, i, tag, (long long)mine[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = base + tid + e * 1024;
+      if (i >= n) continue;
+      unsigned long long val[8];
+#pragma unroll
+      for (int gq = 0; gq < 8; gq++) {
+        val[gq] = mine[e];
+        if (gq < G && gq != me) {
+          const unsigned long long* src = D.p2p_inbox_self() + ((par + gq) * P2P_CAP + i) * 2;
+          unsigned long long lo = 0, hi = 0;
+          bool got = false;
+          for (int spins = 0; spins < (1 << 20); spins++) {
+            lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) { got = true; break; }
+            if ((spins & 255) == 255 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+          if (!got && err) atomicExch(err, 7);
+          val[gq] = (hi << 32) | (lo & 0xffffffffull);
+        }
+      }
+      unsigned long long out;
+      if (dtype == 1) { double a = 0.0; for (int gq = 0; gq < G; gq++) a += __longlong_as_double((long long)val[gq]); out = (unsigned long long)__double_as_longlong(a); }
+      else if (dtype == 2) { long long a = (long long)val[0]; for (int gq = 1; gq < G; gq++) a = min(a, (long long)val[gq]); out = (unsigned long long)a; }
+      else { long long a = 0; for (int gq = 0; gq < G; gq++) a += (long long)val[gq]; out = (unsigned long long)a; }
+      buf[i] = out;
+    }
+  }
+}
+void l_p2p_allreduce(const Launch& L, const Dev& D, void* buf, int n, int dtype, unsigned seq, int* err) {
+  hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(1024), 0, L.stream, D, (unsigned long long*)buf, n, dtype, seq, err);
 }
 void l_objective_tables(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);

@@ -100,6 +100,13 @@ class Harmony(object):
         self._check(self._lib.hmx_comm_init(self._h, int(rank), int(world), buf), "comm_init")
 
     # peer-to-peer block chain for hosts that bring their own all-reduce hook (comm_init does all of this by itself)
+    def comm_allreduce_host(self, values, op="sum"):
+        """all-reduce a few host doubles over the handle's communicator (also a barrier + device synchronisation): for hosts without a
+        collective library of their own (bench.py --bootstrap file)"""
+        a = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self._check(self._lib.hmx_comm_allreduce_host(self._h, _dptr(a), a.size, {"sum": 0, "max": 1, "min": 2}[op]), "comm_allreduce_host")
+        return a
+
     def p2p_export(self):
         buf = (C.c_uint8 * 64)()
         self._check(self._lib.hmx_p2p_export(self._h, buf), "p2p_export")

@@ -187,10 +187,18 @@ typedef int (*hmx_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dt
  * communicator, hmx_set_shard may pass fn == NULL. */
 int hmx_comm_unique_id(uint8_t* out128);
 int hmx_comm_init(hmx_ctx* ctx, int32_t rank, int32_t world, const uint8_t* unique_id128);
+/* Host-side helper for hosts that bring no collective library of their own (a plain C / R host, bench.py --bootstrap file): all-reduce
+ * `count` doubles in place over the ranks of the handle's communicator -- op 0 sum, 1 max, 2 min -- after everything queued on the handle's
+ * stream has completed: a barrier and a device synchronisation in one call (count = 1 works as a plain barrier).  Needs hmx_comm_init. */
+int hmx_comm_allreduce_host(hmx_ctx* ctx, double* inout, int32_t count, int32_t op);
 /* Peer-to-peer block chain (sharded runs, up to 8 ranks of one node).  The update_R block chain (src/harmony.cpp:296-331) needs
  * the K x B contribution table of every block summed over all ranks before the next block starts: 20 dependent all-reduces per
  * round.  With the peers' inboxes connected, the persistent chain kernel does that sum INSIDE the launch (each GPU writes its
  * table straight into every peer's inbox over xGMI and adds up what arrived in its own): no collective call, no launch per block.
+ * With the inboxes connected the library also sends every SMALL collective of a run through them (O after a head, the objective's sums, the
+ * Lloyd sums, the seeding minima, ridge statistics up to 65 536 values: one launch and one trip over xGMI each instead of a ring; the old
+ * contributions of a round's blocks travel with the chain's own exchange) -- hmx_get "p2p:allreduce_calls" counts them, "comm:calls" what is
+ * left on the communicator / hook.  HMX_P2P_AR=0 keeps them on the communicator.
  * hmx_comm_init sets all of this up by itself (HMX_P2P=0 disables it).  A host that brings its own all-reduce hook can do it by
  * hand: every rank exports a handle (a hipIpcMemHandle_t, HMX_P2P_HANDLE_BYTES bytes), the host all-gathers them (rank order),
  * every rank connects, then -- after a host barrier -- every rank runs the self-test AT THE SAME TIME, and only if it passed on

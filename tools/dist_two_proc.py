@@ -109,7 +109,8 @@ if rank == 0:
     assert rel < 1e-6, rel
     if a.p2p and not a.chain_max_tpw:
         assert g._scalar("p2p") == 1 and g._scalar("chain") == 1, (g.p2p_status, g._scalar("chain"))
-    print("DIST2_OK world=%d backend=%s p2p=%d chain=%d iterations=%d collectives/rank=%d Z_rel=%.1e run=%.1f ms (%s)"
-          % (world, a.backend, int(a.p2p), int(g._scalar("chain")), it, hook.calls, rel, 1e3 * t_run, g.p2p_status), flush=True)
+    print("DIST2_OK world=%d backend=%s p2p=%d chain=%d iterations=%d collectives/rank=%d inbox_allreduces/rank=%d Z_rel=%.1e run=%.1f ms (%s)"
+          % (world, a.backend, int(a.p2p), int(g._scalar("chain")), it, hook.calls, int(g._scalar("p2p:allreduce_calls")), rel, 1e3 * t_run, g.p2p_status),
+          flush=True)
 dist.barrier()
 dist.destroy_process_group()
