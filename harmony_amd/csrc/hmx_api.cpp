@@ -1192,13 +1192,15 @@ int update_R(hmx_ctx* ctx) {
     // (chain_ctl was reset by the launch that closed the previous round: k_round_tail / k_objective_tables.  The shuffle kernels must
     //  not touch chain_ctl, pen_g or the Sold buffers: prefetch_next() runs them on the side stream while a chain may be in flight)
     D.chain_tag = (unsigned)(1 + (ctx->chain_rounds++ % (1u << 24)) * 64);
-    D.chain_xseq = ctx->p2p_xseq; if (p2p) ctx->p2p_xseq += (unsigned)D.nb + 1u;
+    D.chain_xseq = ctx->p2p_xseq;
     long long* const keep_snew = D.Snew_fx;
     D.Snew_fx = D.Snew_set[0];     // one replica set: the folder resets it by exchange (zeroed by the round's memset)
     const int keep_old = D.chain_old; D.chain_old = chain_old ? 1 : 0;
     // one GPU: the chain's folder also closes the round (objective snapshot, table clears, control reset): no k_round_tail launch
-    chain_tail = !sharded && !ctx->obj_arith && D.chain_wps == 2 && !getenv("HMX_CHAIN_TAIL_OFF");
+    // (sharded runs with the in-launch exchange too: the ranks' objective sums travel through the inboxes, entries nBK and nBK + 1)
+    chain_tail = (!sharded || (p2p && (size_t)D.B * D.K + 2 <= (size_t)P2P_CAP && D.nb <= 62)) && !ctx->obj_arith && D.chain_wps == 2 && !getenv("HMX_CHAIN_TAIL_OFF");
     D.chain_tail = chain_tail ? 1 : 0;
+    if (p2p) ctx->p2p_xseq += (unsigned)D.nb + 1u + (chain_tail ? 1u : 0u);      // exchanges of this round: nb + 1 block steps (+ the objective's)
     if (chain_tail) {
       double* slot = nullptr;
       CHK(objective_slot(ctx, &slot));

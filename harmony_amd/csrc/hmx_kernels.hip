@@ -2021,6 +2021,40 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         if (tid == 0) {
           double sa = 0.0, sb = 0.0, sc = 0.0;
           for (int w2 = 0; w2 < (bd >> 6); w2++) { sa += red[3 * w2]; sb += red[3 * w2 + 1]; sc += red[3 * w2 + 2]; }
+          if (D.p2p_world > 1) {
+            // sharded: the two per-cell sums of every rank meet in the inboxes as well (one more exchange of the round, entries behind the
+            // K x B table) and are added in RANK ORDER -- identical objective values on every rank, no host-launched collective per round
+            // (the cross-entropy term comes from the global O / E tables: the same on every rank already)
+            const int G = D.p2p_world, me = D.p2p_rank;
+            const unsigned tagt = tag0 + (unsigned)nbk + 1u;
+            const size_t part = (size_t)((D.chain_xseq + (unsigned)nbk + 1u) & 1u) * 8;
+            p2p_send(D, part, nBK, tagt, __double_as_longlong(sa));
+            p2p_send(D, part, nBK + 1, tagt, __double_as_longlong(sb));
+            double va[8], vb[8];
+#pragma unroll
+            for (int gq = 0; gq < 8; gq++) {
+              va[gq] = sa; vb[gq] = sb;
+              if (gq < G && gq != me) {
+                for (int which = 0; which < 2; which++) {
+                  const unsigned long long* src = D.p2p_inbox_self() + ((part + gq) * P2P_CAP + nBK + which) * 2;
+                  unsigned long long lo = 0, hi = 0;
+                  int spins = 0;
+                  for (;;) {
+                    lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((unsigned)(lo >> 32) == tagt && (unsigned)(hi >> 32) == tagt) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 5); break; }
+                    if (dead(spins)) break;
+                  }
+                  const double x = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                  if (which == 0) va[gq] = x; else vb[gq] = x;
+                }
+              }
+            }
+            sa = 0.0; sb = 0.0;
+            for (int gq = 0; gq < G; gq++) { sa += va[gq]; sb += vb[gq]; }
+          }
           const double err = (double)__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((D.solve_err && *D.solve_err) ? 16.0 : 0.0);
           D.obj[0] = sa; D.obj[1] = sb; D.obj[2] = sa; D.obj[3] = sb; D.obj[4] = sc; D.obj[5] = err;
           if (D.tail_host_slot) {     // pinned host memory, mapped into the device: visible to the host once the event behind this launch completed
