@@ -129,7 +129,11 @@ struct XferPool {
       running.fetch_sub(1, std::memory_order_release);
     }
   }
-  void start(int T) { for (int i = 0; i < T; i++) th.emplace_back([this] { loop(); }); }
+  void start(int T) {      // (a thread that cannot be created is simply missing: the caller works too, copy() falls back to a plain memcpy without helpers)
+    for (int i = 0; i < T; i++) {
+      try { th.emplace_back([this] { loop(); }); } catch (...) { break; }
+    }
+  }
   void copy(void* d, const void* s_, size_t n) {           // blocking; the caller works too
     if (th.empty() || n < 4 * CHUNK) { memcpy(d, s_, n); return; }
     src = (const char*)s_; dst = (char*)d; bytes = n; next.store(0);
@@ -143,6 +147,7 @@ struct XferPool {
     for (auto& t : th) t.join();
   }
 };
+int xfer_threads();
 struct XferRing {     // page-locked staging slots + the copy stream, HBM staging slabs and events of a transfer: one set per device and
                       // process, built (and run through once) on first use, shared by all handles (guarded: one transfer at a time)
   static constexpr int NB = 4;
@@ -171,6 +176,13 @@ struct XferRing {     // page-locked staging slots + the copy stream, HBM stagin
              hipEventSynchronize(ev_slot[i]) == hipSuccess;
     }
     if (good) good = hipStreamSynchronize(cs) == hipSuccess;
+    if (good) {
+      // ... and once through the helper threads (round 3 measured +16 ms on a process' FIRST threaded transfer and left it unexplained:
+      // thread stacks, first scheduling of eight spinning threads, the cores' clocks): a pool of the size a transfer uses moves 4 slots'
+      // worth of bytes between the slots here, once per process, instead of inside the first matrix's transfer
+      XferPool warm; warm.start(xfer_threads());
+      for (int r = 0; r < 2; r++) for (int i = 0; i + 1 < NB; i += 2) warm.copy(slot[i + 1], slot[i], SLOT);
+    }
     if (!good) (void)hipGetLastError();
     return ok = good;
   }
@@ -791,8 +803,10 @@ int enqueue_tail(hmx_ctx* ctx, uint64_t round) {
 int sort_after_round(hmx_ctx* ctx, uint64_t round) {
   if (ctx->sort_sched != 2 || !ctx->injected.empty() || ctx->rng_mode == 1) return 0;
   CHK(enqueue_hist(ctx, round + 1, false));
-  CHK(enqueue_tail(ctx, round + 1));
+  // the histograms first: their side-stream wait is then for the block steps just queued only, and they run NEXT TO the tail below (queued
+  // behind the tail they would start as it ends -- right in front of the next chain launch, whose workgroups need every CU empty)
   for (int k = 2; k <= 3; k++) CHK(enqueue_hist(ctx, round + k, true));
+  CHK(enqueue_tail(ctx, round + 1));
   return 0;
 }
 int prepare_round(hmx_ctx* ctx, uint64_t round) {
@@ -803,7 +817,9 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
     CHK(enqueue_tail(ctx, round));
     apply_set(D, ctx->sets[sset]); apply_hist(D, ctx->hset[round & 3]);
     D.nxt = ctx->sorted_nxt[sset] ? 1 : 0;
-    for (int k = 1; k <= 3; k++) CHK(enqueue_hist(ctx, round + k, true));       // (usually there already)
+    // (no histogram prefetch HERE: queued in front of a chain launch, the side stream's histogram grabs CUs a moment before the persistent
+    //  chain wants all of them -- its small waves then hold up the chain's workgroups, measured 19 us per round.  sort_after_round queues the
+    //  histograms BEHIND the chain: they run next to the sort tail of the following round, while the GPU is nearly idle.)
     return 0;
   }
   if (ctx->sort_sched == 2) {       // host-provided order: the in-line path below, on set `sset` and its own histogram arrays; prefetched slots are void
@@ -2355,6 +2371,12 @@ int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level,
                      const int32_t* chain_off, const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals,
                      int64_t* mismatch, double* residual) {
   if (!R || !list || !level || !chain_off || !chain_cnt || !totals || n <= 0 || K <= 0 || B <= 0 || nchains <= 0 || seg_cells <= 0 || passes < 2) return HMX_ERR_ARG;
+  // (a probe, but an exported one: every index the kernels will use is checked here -- cells inside R, levels inside the LDS rows, chains
+  //  inside the list, the level rows inside the LDS budget of a workgroup)
+  if (nlist <= 0 || n > 2000000000ll || nlist > 2000000000ll || (size_t)B * 256 > 60 * 1024) return HMX_ERR_ARG;
+  for (int64_t i = 0; i < nlist; i++) if (list[i] < 0 || list[i] >= n) return HMX_ERR_ARG;
+  for (int64_t i = 0; i < n; i++) if (level[i] < 0 || level[i] >= B) return HMX_ERR_ARG;
+  for (int c = 0; c < nchains; c++) if (chain_off[c] < 0 || chain_cnt[c] < 0 || (int64_t)chain_off[c] + chain_cnt[c] > nlist) return HMX_ERR_ARG;
   hmx_ctx* ctx = hmx_create();
   float* dR = nullptr; int* dl = nullptr; int* dlev = nullptr; int* dq = nullptr;
   auto run = [&]() -> int {

@@ -2980,8 +2980,16 @@ __global__ __launch_bounds__(1024) void k_moe_solve(Dev D, SolveArgs A) {
       }
       __syncthreads();
       if (tid == 0) {
-        float u = 0.0f;
-        for (int a = 0; a < m; a++) u = __fadd_rn(u, __fmul_rn(__fmul_rn(ac[a], ac[a]), bb[a]));
+        // accu(square(ac) % b) as Armadillo's linear accumulate walks it: two accumulators over the even / odd elements, added at the end
+        // (arma::accu on an expression, src/harmony.cpp:581; the oracle restates the same order)
+        float u1 = 0.0f, u2 = 0.0f;
+        int a = 0;
+        for (; a + 1 < m; a += 2) {
+          u1 = __fadd_rn(u1, __fmul_rn(__fmul_rn(ac[a], ac[a]), bb[a]));
+          u2 = __fadd_rn(u2, __fmul_rn(__fmul_rn(ac[a + 1], ac[a + 1]), bb[a + 1]));
+        }
+        if (a < m) u1 = __fadd_rn(u1, __fmul_rn(__fmul_rn(ac[a], ac[a]), bb[a]));
+        const float u = __fadd_rn(u1, u2);
         uu[0] = 1.0f / __fsub_rn((float)cov[0], u);
         if (!(__fsub_rn((float)cov[0], u) != 0.0f)) misc[3] = 1;
       }

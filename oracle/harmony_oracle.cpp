@@ -566,7 +566,11 @@ template <unsigned MASK> struct Oracle : OracleBase {
         std::vector<float> ac(m), bb(m), acb(m);
         for (int a = 0; a < m; a++) { ac[a] = -(float)cov[(size_t)a * m + 0]; bb[a] = 1.f / (float)cov[(size_t)a * m + a]; }
         ac[0] = 1.f; float b0 = (float)cov[0]; bb[0] = 0.f;
-        float u = 0.f; for (int a = 0; a < m; a++) u += (ac[a] * ac[a]) * bb[a];
+        // arma::accu(square(ac) % b) (:581): Armadillo's linear accumulate runs TWO accumulators over the even / odd elements and adds them at the end
+        float u1 = 0.f, u2 = 0.f; int a2 = 0;
+        for (; a2 + 1 < m; a2 += 2) { u1 += (ac[a2] * ac[a2]) * bb[a2]; u2 += (ac[a2 + 1] * ac[a2 + 1]) * bb[a2 + 1]; }
+        if (a2 < m) u1 += (ac[a2] * ac[a2]) * bb[a2];
+        float u = u1 + u2;
         u = b0 - u;
         for (int a = 0; a < m; a++) acb[a] = ac[a] * bb[a];
         acb[0] = 1.f;
