@@ -458,28 +458,10 @@ void normalise_cols(std::vector<float>& Y, int d, int K) {  // arma::normalise(Y
     for (int j = 0; j < d; j++) Y[(size_t)k * d + j] /= nrm;
   }
 }
-int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Yt[j*K+k] and the MFMA B-operand image
-  const Dev& D = ctx->D;
-  const int d = ctx->d, K = ctx->K;
-  std::vector<float> yt((size_t)d * K);
-  for (int k = 0; k < K; k++) for (int j = 0; j < d; j++) yt[(size_t)j * K + k] = ctx->Y[(size_t)k * d + j];
-  CHK(h2d(ctx, D.Yt, yt.data(), yt.size()));
-  CHK(h2d(ctx, D.Ycur, ctx->Y.data(), ctx->Y.size()));
-  // image[qd][s][p][c][i] = Y[pc(s,p)][kcol(4qd+i, c)]; pc(s,p) as the tile kernels assign PCs to MFMA k-slots
-  std::vector<float> img((size_t)D.NQ * D.NS * 256, 0.f);
-  for (int qd = 0; qd < D.NQ; qd++) for (int s = 0; s < D.NS; s++) for (int p = 0; p < 4; p++) {
-    const int j = (s < 4 * D.NT4) ? 16 * (s / 4) + 4 * p + (s % 4) : 16 * D.NT4 + 4 * (s - 4 * D.NT4) + p;
-    if (j >= d) continue;
-    for (int c = 0; c < 16; c++) for (int i = 0; i < 4; i++) {
-      if (4 * qd + i >= D.NCT) continue;
-      const int k = kcol(D.NCT, 4 * qd + i, c);
-      if (k < K) img[((((size_t)qd * D.NS + s) * 4 + p) * 16 + c) * 4 + i] = ctx->Y[(size_t)k * d + j];
-    }
-  }
-  CHK(h2d(ctx, D.Yimg, img.data(), img.size()));
-  std::vector<unsigned short> img3((size_t)D.NCT * D.NS2 * 3 * 512, 0);
-  for (int k = 0; k < K; k++) for (int j = 0; j < d; j++) bfimg_store(img3.data(), D.NCT, D.NS2, j, k, ctx->Y[(size_t)k * d + j]);
-  return h2d(ctx, D.Yimg3, img3.data(), img3.size());
+int upload_Y(hmx_ctx* ctx) {  // host Y[k*d+j] -> device Ycur, from it (k_y_images) Yt[j*K+k], the MFMA B-operand images and ||y||^2
+  CHK(h2d(ctx, ctx->D.Ycur, ctx->Y.data(), ctx->Y.size()));
+  l_y_images(ctx->L, ctx->D, nullptr, 0); KCHK();
+  return 0;
 }
 
 // objective snapshot obj[2..4] -> the four series (src/harmony.cpp:165-168).  The copy is enqueued into a pinned slot;
@@ -639,9 +621,8 @@ int gather_centres(hmx_ctx* ctx, const std::vector<long long>& gcells, long long
   CHK(h2d(ctx, d_gcells, gcells.data(), (size_t)K));
   l_gather_rows(ctx->L, ctx->D, d_gcells, (uint64_t)ctx->goff, d_rows); KCHK();
   CHK(allreduce(ctx, d_rows, (int64_t)K * d, 1));
-  std::vector<double> rows((size_t)K * d);
-  CHK(d2h(ctx, rows.data(), d_rows, rows.size()));
-  for (size_t i = 0; i < rows.size(); i++) ctx->Y[i] = (float)rows[i];
+  l_y_images(ctx->L, ctx->D, d_rows, 0); KCHK();       // rows -> Ycur, Yt, the MFMA images, ||y||^2: no trip to the host
+  ctx->y_on_device = true;                              // (the host copy is fetched when somebody asks for it)
   return 0;
 }
 
@@ -657,7 +638,6 @@ int kmeans_centers(hmx_ctx* ctx) {
   if (rmode) ensure_rrng(ctx);
   for (int i = 0; i < K; i++) gcells[i] = (long long)std::floor((rmode ? ctx->rrng.arma_randu() : hmx_u01(ctx->seed, 0, (uint64_t)i)) * Nm1);
   CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
-  CHK(upload_Y(ctx));
   std::vector<unsigned long long> win(K), sentinel(K, SEED_SENTINEL);
   std::set<unsigned> sup;
   if (rmode) {
@@ -740,12 +720,6 @@ int kmeans_centers(hmx_ctx* ctx) {
   ctx->seed_cells.assign(gcells.begin(), gcells.end());   // diagnostics: hmx_get("seed_cells")
   CHK(gather_centres(ctx, gcells, d_gcells, d_rows));
   // 10 x one Lloyd iteration (:53-64); the centre update runs on the device, no host round trip per iteration
-  {
-    std::vector<float> yn(K);
-    for (int k = 0; k < K; k++) { float s = 0.f; for (int j = 0; j < d; j++) s += ctx->Y[(size_t)k * d + j] * ctx->Y[(size_t)k * d + j]; yn[k] = s; }
-    CHK(upload_Y(ctx));
-    CHK(h2d(ctx, D.ynorm, yn.data(), (size_t)K));
-  }
   const bool tile_ok = D.tile_impl && (size_t)D.NQ * D.NS * 1024 + ((size_t)K * d + K) * 8 <= 160 * 1024;
   for (int it = 0; it < 10; it++) {
     HIPCHK(hipMemsetAsync(D.lsum, 0, sizeof(long long) * ((size_t)K * d + K), ctx->L.stream));   // sums + counts: one buffer
@@ -754,7 +728,7 @@ int kmeans_centers(hmx_ctx* ctx) {
     CHK(allreduce(ctx, D.lsum, (int64_t)K * d + K, 0));   // sums and counts in one collective
     l_lloyd_finish(ctx->L, D); KCHK();
   }
-  CHK(d2h(ctx, ctx->Y.data(), D.Ycur, ctx->Y.size()));
+  ctx->y_on_device = true;       // (Ycur holds the centres; the host copy follows on demand)
   return 0;
 }
 
@@ -1947,7 +1921,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   CHK(dalloc(ctx, &D.Zo, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.Zc, (size_t)N * D.zs)); CHK(dalloc(ctx, &D.R, ((size_t)N + 1) * K));   // + one dummy row (target of masked stores)
   CHK(dalloc(ctx, &D.perm, (size_t)N)); CHK(dalloc(ctx, &D.invperm, (size_t)N)); CHK(dalloc(ctx, &D.combo, (size_t)N));
   CHK(dalloc(ctx, &D.qlev, (size_t)Q * C));
-  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); CHK(dalloc(ctx, &D.Yimg3, (size_t)D.NCT * D.NS2 * 3 * 512)); HIPCHK(hipMemsetAsync(D.Yimg3, 0, (size_t)D.NCT * D.NS2 * 3 * 1024, ctx->L.stream)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
+  CHK(dalloc(ctx, &D.Yt, (size_t)d * K)); CHK(dalloc(ctx, &D.Ycur, (size_t)d * K)); CHK(dalloc(ctx, &D.Yimg, (size_t)D.NQ * D.NS * 256)); HIPCHK(hipMemsetAsync(D.Yimg, 0, (size_t)D.NQ * D.NS * 1024, ctx->L.stream)); CHK(dalloc(ctx, &D.Yimg3, (size_t)D.NCT * D.NS2 * 3 * 512)); HIPCHK(hipMemsetAsync(D.Yimg3, 0, (size_t)D.NCT * D.NS2 * 3 * 1024, ctx->L.stream)); CHK(dalloc(ctx, &D.sigma, (size_t)K)); CHK(dalloc(ctx, &D.theta, (size_t)B)); CHK(dalloc(ctx, &D.Pr_b, (size_t)B));
   CHK(dalloc(ctx, &D.O_fx, (size_t)B * K)); CHK(dalloc(ctx, &D.Snew_fx, (size_t)D.nrep * B * K));
   // Sold_fx [nb][B][K] and the three rotating replica sets of the fused path share one buffer: one memset per round
   { long long* s3; CHK(dalloc(ctx, &s3, (size_t)2 * D.nb * B * K + (size_t)3 * D.nrep * B * K)); D.Sold_fx = s3;
@@ -2200,6 +2174,7 @@ int hmx_kmeans_centers(hmx_ctx* ctx, double* Y_out) {
   if (!ctx || !ctx->ran_setup) return ctx ? fail(ctx, HMX_ERR_STATE, "setup first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   CHK(kmeans_centers(ctx));
+  CHK(sync_solve_results(ctx));       // (the centres live on the device: fetch the host copy)
   if (Y_out) for (size_t i = 0; i < ctx->Y.size(); i++) Y_out[i] = (double)ctx->Y[i];
   return 0;
 }
@@ -2209,10 +2184,15 @@ int hmx_init_cluster(hmx_ctx* ctx, const double* Y0) {  // src/harmony.cpp:131-1
   HIPCHK(hipSetDevice(ctx->device));
   const double t0 = now_ms();
   ctx->y_on_device = false;
-  if (Y0) { ctx->Y.resize((size_t)ctx->d * ctx->K); for (size_t i = 0; i < ctx->Y.size(); i++) ctx->Y[i] = (float)Y0[i]; }
-  else { PhaseScope ph(ctx, "kmeans_centers"); CHK(kmeans_centers(ctx)); }
-  normalise_cols(ctx->Y, ctx->d, ctx->K);  // :136
-  CHK(upload_Y(ctx));
+  if (Y0) {
+    ctx->Y.resize((size_t)ctx->d * ctx->K); for (size_t i = 0; i < ctx->Y.size(); i++) ctx->Y[i] = (float)Y0[i];
+    normalise_cols(ctx->Y, ctx->d, ctx->K);  // :136
+    CHK(upload_Y(ctx));
+  } else {
+    { PhaseScope ph(ctx, "kmeans_centers"); CHK(kmeans_centers(ctx)); }
+    l_y_images(ctx->L, ctx->D, nullptr, 1); KCHK();       // Y <- normalise(Y) (:136) and its images, on the device
+    ctx->y_on_device = true;
+  }
   CHK(head_pass(ctx));
   CHK(objective_snapshot(ctx));
   CHK(push_objective(ctx));
@@ -2322,6 +2302,7 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   if (seq) { S0.resize((size_t)K * d); n0.resize((size_t)K); CHK(d2h(ctx, S0.data(), D.S0, S0.size())); CHK(d2h(ctx, n0.data(), D.n0, n0.size())); }
   const double t1 = now_ms();
   const std::vector<float> O = table_O(ctx, ofx), E = table_E(ctx, ofx);
+  CHK(sync_solve_results(ctx));        // (host solve path: the centroids may still live on the device only)
   std::vector<float> Wq((size_t)Q * K * d), Ynew = ctx->Y;
   std::vector<SolveOut> outs(K);
   {

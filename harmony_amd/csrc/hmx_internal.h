@@ -278,6 +278,7 @@ void l_seed_race_u(const Launch& L, const Dev& D, const float* u, int a0, int na
 void l_gather_rows(const Launch& L, const Dev& D, const long long* gcells, uint64_t goff, double* rows);
 void l_lloyd(const Launch& L, const Dev& D);
 void l_lloyd_finish(const Launch& L, const Dev& D);
+void l_y_images(const Launch& L, const Dev& D, const double* rows, int normalise);
 size_t lds_bytes_y(const Dev& D);
 
 // ---- reference arithmetic: restarted sequential fp32 sums (hmx_seq.hip) ------------------------------------------------------------

@@ -3757,6 +3757,38 @@ __global__ __launch_bounds__(64) void k_lloyd_finish(Dev D) {
   (void)s2;
 }
 
+// Ycur [K][d] (or, rows != nullptr, the fp64 rows gathered from the seed cells) -> Ycur, Yt [d][K], the fp32 MFMA image, the split-bf16 image and
+// ||y_k||^2 -- on the device: the centroids never travel to the host and back between the stages of kmeans_centers / init_cluster_cpp
+// (round 3: four synchronous uploads per stage).  normalise: Y[:,k] <- Y[:,k] / ||Y[:,k]|| first (arma::normalise(Y, 2, 0),
+// src/harmony.cpp:136: sequential fp32 sum of squares, a zero column is left alone).  One workgroup per cluster.
+__global__ __launch_bounds__(64) void k_y_images(Dev D, const double* __restrict__ rows, int normalise) {
+  const int k = blockIdx.x, lane = threadIdx.x, d = D.d, K = D.K;
+  __shared__ float ys[128];
+  __shared__ float nrm_;
+  for (int j = lane; j < d; j += 64) ys[j] = rows ? (float)rows[(size_t)k * d + j] : D.Ycur[(size_t)k * d + j];
+  __syncthreads();
+  if (lane == 0) {
+    float s = 0.0f;
+    for (int j = 0; j < d; j++) s = __fadd_rn(s, __fmul_rn(ys[j], ys[j]));
+    float nn = sqrtf(s);
+    if (nn == 0.0f) nn = 1.0f;
+    nrm_ = normalise ? nn : 1.0f;
+  }
+  __syncthreads();
+  for (int j = lane; j < d; j += 64) {
+    const float y = normalise ? ys[j] / nrm_ : ys[j];
+    ys[j] = y;
+    D.Ycur[(size_t)k * d + j] = y;
+    D.Yt[(size_t)j * K + k] = y;
+    D.Yimg[yimg_index(D, j, k)] = y;
+    bfimg_store(D.Yimg3, D.NCT, D.NS2, j, k, y);
+  }
+  __syncthreads();
+  if (lane == 0) { float s = 0.0f; for (int j = 0; j < d; j++) s = __fadd_rn(s, __fmul_rn(ys[j], ys[j])); D.ynorm[k] = s; }
+}
+void l_y_images(const Launch& L, const Dev& D, const double* rows, int normalise) {
+  hipLaunchKernelGGL(k_y_images, dim3(D.K), dim3(64), 0, L.stream, D, rows, normalise);
+}
 #endif  // !HMX_TILE_BF
 // --------------------------------------------------------------------------------------
 // launchers
