@@ -293,7 +293,7 @@ struct hmx_ctx {
   // next block) -- then the next round needs no pass over R (k_oldsum).  state: 0 all zero, 1 unknown contents, 2 carried for round sold_round.
   long long* sold_buf[2] = {nullptr, nullptr}; int sold_cur = 0, sold_state[2] = {1, 1}; int64_t sold_round[2] = {-1, -1}; uint64_t sold_seed[2] = {0, 0};
   bool sets_clean = false;     // the three Snew replica sets are all zero
-  bool carry_ok = false, last_round_hint = false, round_may_be_last = true; bool sorted_nxt[2] = {false, false};
+  bool carry_ok = false, last_round_hint = false, round_may_be_last = true; bool sorted_nxt[4] = {false, false, false, false};
   int64_t rounds_without_R = 0;
   int64_t carried_rounds = 0;
   bool chain_ok = false; int chain_wgs = 0; uint64_t chain_rounds = 0;   // persistent block chain (one launch per round)
@@ -309,8 +309,9 @@ struct hmx_ctx {
   // on (seed, round) only: the sort of round r+1 runs on a SIDE stream while round r's old-sum pass streams on the main one,
   // into the second of two buffer sets.
   struct SortSet { int* blk; int* lorder; int2* lpair; int* lcombo; int* boff; int* binoff; int* counts; int* offs; int* blkv; int* bincnt; };
-  SortSet sets[2] = {}; hipStream_t side = nullptr; hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
-  int64_t sorted_round[2] = {-1, -1}; uint64_t sorted_seed[2] = {0, 0}; bool sorted_on_side[2] = {false, false}; bool sort_overlap = true;
+  SortSet sets[4] = {}; int oset_mask = 1;      // order sets: round & oset_mask (two; four with the batched shuffle, sort_sched = 3)
+  hipStream_t side = nullptr; hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  int64_t sorted_round[4] = {-1, -1, -1, -1}; uint64_t sorted_seed[4] = {0, 0, 0, 0}; bool sorted_on_side[4] = {false, false, false, false}; bool sort_overlap = true;
   // Round-4 schedule of the shuffle (sort_sched = 2, default): its HISTOGRAM half depends on (seed, round) only and runs rounds ahead on the side
   // stream, into one of four slots (round & 3: block ids, composite keys, per-chunk counts); its dependent TAIL (bin scan, bin offsets,
   // scatter) is enqueued on the MAIN stream right behind the block chain of the round before -- in queue order, no cross-stream event between
@@ -319,6 +320,9 @@ struct hmx_ctx {
   struct HistSet { int* blk; int* blkv; int* counts; };
   HistSet hset[4] = {}; int64_t hist_round[4] = {-1, -1, -1, -1}; uint64_t hist_seed[4] = {0, 0, 0, 0}; bool hist_on_side[4] = {false, false, false, false}, hist_nxt[4] = {false, false, false, false};
   hipEvent_t ev_hist[4] = {nullptr, nullptr, nullptr, nullptr}; int sort_sched = 2;
+  // sort_sched = 3: the shuffles of FOUR consecutive rounds in one set of four launches on the main stream (l_sort_batch), into four full order
+  // sets (round & 3) -- rounds keep their numbers across cluster_cpp calls, so a batch serves whichever calls its rounds fall into; between
+  // two block chains of a batch there is no sort kernel, no side stream and no event at all.
   std::string err, warn, warn_ret;
 };
 
@@ -540,7 +544,7 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   D.head_norm = fused_norm ? 1 : 0;
   for (int i = 0; i < 2; i++) if (ctx->sold_state[i] == 2) ctx->sold_state[i] = 1;     // R is rewritten: carried old contributions are void
   D.head_gather = 0; D.Sold_head = nullptr;
-  if (gather && ctx->sorted_nxt[ctx->round_counter & 1] && ctx->sorted_round[ctx->round_counter & 1] == (int64_t)ctx->round_counter) {
+  if (gather && ctx->sorted_nxt[ctx->round_counter & ctx->oset_mask] && ctx->sorted_round[ctx->round_counter & ctx->oset_mask] == (int64_t)ctx->round_counter) {
     const int cur = ctx->sold_cur;
     if (ctx->sold_state[cur] != 0)
       HIPCHK(hipMemsetAsync(ctx->sold_buf[cur], 0, sizeof(long long) * (size_t)D.nb * D.B * D.K, ctx->L.stream));
@@ -785,8 +789,29 @@ int sort_after_round(hmx_ctx* ctx, uint64_t round) {
 }
 int prepare_round(hmx_ctx* ctx, uint64_t round) {
   Dev& D = ctx->D;
-  const int sset = (int)(round & 1);
+  const int sset = (int)(round & (uint64_t)ctx->oset_mask);
   const bool host_order = !ctx->injected.empty() || ctx->rng_mode == 1;
+  if (ctx->sort_sched == 3 && !host_order) {
+    if (!(ctx->sorted_round[sset] == (int64_t)round && ctx->sorted_seed[sset] == ctx->seed)) {
+      // this round and the three after it, whichever of them is not sorted yet (a run of consecutive rounds starting here)
+      int nr = 0; SortBatch Sb{};
+      Dev Dt = D; Dt.nxt = ctx->carry_ok ? 1 : 0;
+      for (; nr < 4; nr++) {
+        const int os = (int)((round + (uint64_t)nr) & 3);
+        if (nr && ctx->sorted_round[os] == (int64_t)round + nr && ctx->sorted_seed[os] == ctx->seed) break;
+        const hmx_ctx::SortSet& t = ctx->sets[os];
+        Sb.p[nr] = SortPtrs{t.blk, t.blkv, t.counts, t.offs, t.binoff, t.bincnt, t.boff, t.lorder, t.lcombo, t.lpair};
+      }
+      l_sort_batch(ctx->L, Dt, Sb, nr, ctx->seed, round, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
+      for (int r = 0; r < nr; r++) {
+        const int os = (int)((round + (uint64_t)r) & 3);
+        ctx->sorted_round[os] = (int64_t)round + r; ctx->sorted_seed[os] = ctx->seed; ctx->sorted_nxt[os] = Dt.nxt != 0; ctx->sorted_on_side[os] = false;
+      }
+    }
+    apply_set(D, ctx->sets[sset]);
+    D.nxt = ctx->sorted_nxt[sset] ? 1 : 0;
+    return 0;
+  }
   if (ctx->sort_sched == 2 && !host_order) {
     CHK(enqueue_tail(ctx, round));
     apply_set(D, ctx->sets[sset]); apply_hist(D, ctx->hset[round & 3]);
@@ -1148,7 +1173,7 @@ int update_R(hmx_ctx* ctx) {
       D.Sold_fx = ctx->sold_buf[cur];
       if (!ctx->sets_clean) { HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * nSets, ctx->L.stream)); ctx->sets_clean = true; }
       const bool carried = ctx->sold_state[cur] == 2 && ctx->sold_round[cur] == rnd && ctx->sold_seed[cur] == ctx->seed &&
-                           ctx->sorted_round[rnd & 1] == rnd && ctx->sorted_seed[rnd & 1] == ctx->seed;   // (same Feistel permutation as the sort's)
+                           ctx->sorted_round[rnd & ctx->oset_mask] == rnd && ctx->sorted_seed[rnd & ctx->oset_mask] == ctx->seed;   // (same Feistel permutation as the sort's)
       if (carried) ctx->carried_rounds++;     // filled by the previous round's tile kernels: no pass over R
       else {             // all blocks in one pass over R
         if (ctx->sold_state[cur] != 0) HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * nSold, ctx->L.stream));
@@ -1157,7 +1182,7 @@ int update_R(hmx_ctx* ctx) {
       ctx->sold_state[cur] = 1;
       if (!(chain_path && p2p)) CHK(allreduce(ctx, D.Sold_fx, (int64_t)nSold, 0));      // (p2p chain: the folder exchanges new(j - 1) - old_local(j), the ranks' old sums meet there)
       // this round's tile kernels collect the next round's old contributions if this round's tiles are keyed by the next block
-      const bool write_next = ctx->carry_ok && ctx->sorted_nxt[(rnd & 1)] && !ctx->last_round_hint && !chain_old && D.upd_impl == 0;
+      const bool write_next = ctx->carry_ok && ctx->sorted_nxt[rnd & ctx->oset_mask] && !ctx->last_round_hint && !chain_old && D.upd_impl == 0;
       D.Sold_next = nullptr;
       if (write_next) {
         if (ctx->sold_state[oth] != 0) HIPCHK(hipMemsetAsync(ctx->sold_buf[oth], 0, sizeof(long long) * nSold, ctx->L.stream));
@@ -1713,7 +1738,7 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   else if (f == "upd_cpw") { ctx->tun_cpw = (int)v; if (ctx->ran_setup) ctx->D.upd_cpw = (int)(v < 4 ? 4 : v); }
   else if (f == "comm_force") ctx->comm_force = v != 0;
   else if (f == "upd_impl") { ctx->tun_impl = (int)v; if (ctx->ran_setup) { ctx->D.upd_impl = (int)v;
-                                if (v == 1 && !ctx->D.need_lorder) { ctx->D.need_lorder = 1; for (int i = 0; i < 2; i++) ctx->sorted_round[i] = -1; } } }   // (the v1 kernel reads lorder: re-sort with it; the histogram slots stay valid)
+                                if (v == 1 && !ctx->D.need_lorder) { ctx->D.need_lorder = 1; for (int i = 0; i < 4; i++) ctx->sorted_round[i] = -1; } } }   // (the v1 kernel reads lorder: re-sort with it; the histogram slots stay valid)
   else if (f == "upd_wps") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "upd_wps must be set before setup"); ctx->tun_wps = (int)v; }
   else if (f == "upd_debug") { if (ctx->ran_setup) ctx->D.upd_debug = (int)v; }
   else if (f == "upd_tpw") { ctx->tun_tpw = (int)v; if (ctx->ran_setup) ctx->D.upd_tpw = (int)(v < 1 ? 1 : v); }
@@ -1946,7 +1971,14 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lowest priority: the shuffle only fills gaps
       HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, lo)); }
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); }
-    { const char* sc = getenv("HMX_SORT_SCHED"); ctx->sort_sched = (sc && atoi(sc) == 1) ? 1 : 2; if (!ctx->sort_overlap) ctx->sort_sched = 1; }
+    { const char* sc = getenv("HMX_SORT_SCHED"); const int v = sc ? atoi(sc) : 3; ctx->sort_sched = (v >= 1 && v <= 3) ? v : 3; if (!ctx->sort_overlap) ctx->sort_sched = 1; }
+    ctx->oset_mask = ctx->sort_sched == 3 ? 3 : 1;
+    if (ctx->sort_sched == 3) for (int i = 2; i < 4; i++) {
+      hmx_ctx::SortSet& u = ctx->sets[i];
+      CHK(dalloc(ctx, &u.blk, (size_t)N)); CHK(dalloc(ctx, &u.lorder, (size_t)3 * D.npad + 2)); u.lpair = reinterpret_cast<int2*>(u.lorder + (((size_t)D.npad + 1) & ~(size_t)1));
+      CHK(dalloc(ctx, &u.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &u.binoff, (size_t)nV * Q + 1)); CHK(dalloc(ctx, &u.boff, (size_t)D.nb + 1));
+      CHK(dalloc(ctx, &u.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &u.offs, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &u.blkv, (size_t)N)); CHK(dalloc(ctx, &u.bincnt, (size_t)nV * Q));
+    }
     ctx->hset[0] = {ctx->sets[0].blk, ctx->sets[0].blkv, ctx->sets[0].counts}; ctx->hset[1] = {ctx->sets[1].blk, ctx->sets[1].blkv, ctx->sets[1].counts};
     for (int i = 2; i < 4; i++) {
       if (ctx->sort_sched == 2) { CHK(dalloc(ctx, &ctx->hset[i].blk, (size_t)N)); CHK(dalloc(ctx, &ctx->hset[i].blkv, (size_t)N)); CHK(dalloc(ctx, &ctx->hset[i].counts, (size_t)nV * D.nchunks)); }
@@ -2165,7 +2197,7 @@ int hmx_restart(hmx_ctx* ctx) {
   ctx->head_is_stale = false;
   HIPCHK(hipMemsetAsync(ctx->D.solve_err, 0, sizeof(int), ctx->L.stream));
   if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
-  for (int i = 0; i < 2; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
+  for (int i = 0; i < 4; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
   for (int i = 0; i < 4; i++) { ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; }
   return 0;
 }

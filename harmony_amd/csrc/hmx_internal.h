@@ -203,6 +203,10 @@ void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uin
                    uint64_t cells_per_block);
 void l_sort_hist(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff, uint64_t cells_per_block);
 void l_sort_tail(const Launch& L, const Dev& D);
+struct SortPtrs { int* blk; int* blkv; int* counts; int* offs; int* binoff; int* bincnt; int* boff; int* lorder; int* lcombo; int2* lpair; };
+struct SortBatch { SortPtrs p[4]; };
+void l_sort_batch(const Launch& L, const Dev& D, const SortBatch& S, int nr, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+                  uint64_t cells_per_block);
 void l_oldsum(const Launch& L, const Dev& D);
 void l_fold(const Launch& L, const Dev& D, int j, int mode);
 void l_penalty(const Launch& L, const Dev& D);

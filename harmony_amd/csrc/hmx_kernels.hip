@@ -337,6 +337,7 @@ __global__ __launch_bounds__(TPB) void k_head(Dev D) {
 // every 16-cell tile also has ONE next block and the tile kernels can file the tile's new R sums as that block's old contribution
 // (flush_tile_fx): 16 padding slots per (block, combination, next block) instead of per (block, combination).
 struct BlockIdArgs { FeistelKeys fk, fk2; uint64_t Nglob, goff, cpb; float inv_cpb; };
+struct BlockIdBatch { BlockIdArgs a[4]; };      // one entry per round of a batched sort (blockIdx.y)
 // block of a position: min(pos / cells_per_block, n_blocks - 1) (src/harmony.cpp:296-300) without the 64-bit division (~100 instructions
 // per cell, twice per cell and round): a float estimate, corrected exactly by two integer comparisons
 __device__ __forceinline__ int block_of(uint64_t pos, const BlockIdArgs& A, int nb) {
@@ -347,8 +348,9 @@ __device__ __forceinline__ int block_of(uint64_t pos, const BlockIdArgs& A, int 
   return (int)(b < (long long)(nb - 1) ? b : (long long)(nb - 1));
 }
 template <bool FUSED>
-__global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
+__global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdBatch AB, SortBatch S) {
   extern __shared__ int cnt[];
+  const BlockIdArgs& A = AB.a[blockIdx.y]; const SortPtrs& P = S.p[blockIdx.y];      // (blockIdx.y: the round of a batched sort)
   const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb, nV = D.nxt ? nb * nb : nb;
   for (int v = lane; v < nV; v += WAVE) cnt[v] = 0;
   __syncthreads();
@@ -368,27 +370,28 @@ __global__ __launch_bounds__(WAVE) void k_sort_hist(Dev D, BlockIdArgs A) {
       if constexpr (FUSED) {
         const uint64_t pos = feistel_apply(A.fk, A.Nglob, A.goff + (uint64_t)pm[u]);
         b = block_of(pos, A, nb);
-        D.blk[i] = b;
+        P.blk[i] = b;
         if (D.nxt) {
           const uint64_t pos2 = feistel_apply(A.fk2, A.Nglob, A.goff + (uint64_t)pm[u]);
           b = b * nb + block_of(pos2, A, nb);
-          D.blkv[i] = b;
+          P.blkv[i] = b;
         }
-      } else b = D.blk[i];
+      } else b = P.blk[i];
       atomicAdd(&cnt[b], 1);
     }
   }
   __syncthreads();
-  for (int v = lane; v < nV; v += WAVE) D.counts[(size_t)v * D.nchunks + chunk] = cnt[v];
+  for (int v = lane; v < nV; v += WAVE) P.counts[(size_t)v * D.nchunks + chunk] = cnt[v];
 }
 // one wave per (block, combination) bin: exclusive prefix of the bin's chunk counts -> offs (offset inside the bin),
 // padded bin size -> binoff[bin].  The chunks of a combination are contiguous, so the loads are coalesced.
-__global__ __launch_bounds__(WAVE) void k_sort_binscan(Dev D) {
+__global__ __launch_bounds__(WAVE) void k_sort_binscan(Dev D, SortBatch S) {
+  const SortPtrs& P = S.p[blockIdx.y];
   const int lane = threadIdx.x, bin = blockIdx.x, Q = D.Q, nch = D.nchunks, nV = D.nxt ? D.nb * D.nb : D.nb;
   const int v = bin / Q, q = bin - v * Q;
   const int lo = D.qchunk[q], hi = D.qchunk[q + 1];
-  const int* __restrict__ cin = D.counts + (size_t)v * nch;
-  int* __restrict__ cout = D.offs + v;      // offs[chunk][key]: the scatter kernel reads a chunk's nV offsets as one contiguous run
+  const int* __restrict__ cin = P.counts + (size_t)v * nch;
+  int* __restrict__ cout = P.offs + v;      // offs[chunk][key]: the scatter kernel reads a chunk's nV offsets as one contiguous run
   int run = 0;
   for (int base = lo; base < hi; base += WAVE) {
     const int i = base + lane;
@@ -399,13 +402,14 @@ __global__ __launch_bounds__(WAVE) void k_sort_binscan(Dev D) {
     if (i < hi) cout[(size_t)i * nV] = run + incl - c;
     run += __shfl(incl, 63, 64);
   }
-  if (lane == 0) { D.binoff[bin] = (run + 15) & ~15; D.bincnt[bin] = run; }
+  if (lane == 0) { P.binoff[bin] = (run + 15) & ~15; P.bincnt[bin] = run; }
 }
 // single workgroup: exclusive scan of the padded bin sizes (block-major) -> binoff; boff[v] = padded start of block v
-__global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
+__global__ __launch_bounds__(1024) void k_sort_binoff(Dev D, SortBatch S) {
+  const SortPtrs& P = S.p[blockIdx.x];
   __shared__ int part[1024];
   const int t = threadIdx.x, nb = D.nb, Q = D.Q, vpb = D.nxt ? nb : 1, nbins = nb * vpb * Q;   // vpb: sort keys per block
-  int* bins = D.binoff;
+  int* bins = P.binoff;
   const int per = (nbins + 1023) / 1024;
   const int s = t * per, e = min(nbins, s + per);
   int sum = 0;
@@ -422,15 +426,16 @@ __global__ __launch_bounds__(1024) void k_sort_binoff(Dev D) {
   for (int i = s; i < e; i++) { const int c = bins[i]; bins[i] = run; run += c; }
   if (t == 1023) bins[nbins] = part[1023];
   __syncthreads();
-  for (int v = t; v <= nb; v += 1024) D.boff[v] = bins[v < nb ? v * vpb * Q : nbins];
+  for (int v = t; v <= nb; v += 1024) P.boff[v] = bins[v < nb ? v * vpb * Q : nbins];
 }
 // Placement of a chunk's cells into their (key, combination) bins, 64 cells per step; the chunk's first slot in every bin comes from
 // k_sort_binscan / k_sort_binoff, the rank inside the chunk from an LDS atomic (see below).
-__global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
+__global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D, SortBatch S) {
   extern __shared__ int base_[];
+  const SortPtrs& P = S.p[blockIdx.y];
   const int lane = threadIdx.x, chunk = blockIdx.x, nb = D.nb, nV = D.nxt ? nb * nb : nb;
   const Item ch = D.schunks[chunk];
-  const int* __restrict__ key = D.nxt ? D.blkv : D.blk;
+  const int* __restrict__ key = D.nxt ? P.blkv : P.blk;
   const int s = ch.start, e = ch.start + ch.cnt;
   constexpr int NSTEP = SORT_CHUNK / WAVE;
   for (int v0 = 0; v0 < nV; v0 += 8 * WAVE) {     // (eight independent pairs of loads in flight per pass)
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int v = min(v0 + u * WAVE + lane, nV - 1);
-      t0[u] = D.binoff[v * D.Q + ch.q]; t1[u] = D.offs[(size_t)chunk * nV + v];
+      t0[u] = P.binoff[v * D.Q + ch.q]; t1[u] = P.offs[(size_t)chunk * nV + v];
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) if (v0 + u * WAVE + lane < nV) base_[v0 + u * WAVE + lane] = t0[u] + t1[u];
@@ -459,8 +464,8 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
     const int ks = kk[u];
     if (base + lane < e) {
       const int dst = atomicAdd(&base_[ks], 1), cell = base + lane;
-      if (D.need_lorder) { D.lorder[dst] = cell; D.lcombo[dst] = ch.q; }
-      D.lpair[dst] = make_int2(cell, D.nxt ? (ch.q | ((ks % nb) << 19) | ((ks / nb) << 25)) : ch.q);     // (combination, next block, block): see flush_run in k_tile
+      if (D.need_lorder) { P.lorder[dst] = cell; P.lcombo[dst] = ch.q; }
+      P.lpair[dst] = make_int2(cell, D.nxt ? (ch.q | ((ks % nb) << 19) | ((ks / nb) << 25)) : ch.q);     // (combination, next block, block): see flush_run in k_tile
     }
   }
   // the padding slots (< 16 per bin) of this combination's bins: "no cell" -- written here, so that no memset of the whole order
@@ -468,8 +473,8 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D) {
   // (the keys are dealt over the combination's chunks: a couple of bins per wave)
   const int ci = chunk - D.qchunk[ch.q], ncq = D.qchunk[ch.q + 1] - D.qchunk[ch.q];
   for (int v = ci + ncq * lane; v < nV; v += ncq * WAVE) {
-    const int bin = v * D.Q + ch.q, st = D.binoff[bin], cnt = D.bincnt[bin], pad = (cnt + 15) & ~15;
-    for (int k = cnt; k < pad; k++) { if (D.need_lorder) D.lorder[st + k] = -1; D.lpair[st + k] = make_int2(-1, -1); }
+    const int bin = v * D.Q + ch.q, st = P.binoff[bin], cnt = P.bincnt[bin], pad = (cnt + 15) & ~15;
+    for (int k = cnt; k < pad; k++) { if (D.need_lorder) P.lorder[st + k] = -1; P.lpair[st + k] = make_int2(-1, -1); }
   }
 }
 
@@ -3910,28 +3915,49 @@ void l_head(const Launch& L, const Dev& D, int mode) {
   else HMX_DISPATCH_KD(k_head, HMX_COMMA 1, grid, lds, D);
 }
 // fused = true: D.blk is produced by the histogram kernel from (seed, round); false: the host uploaded D.blk (injected shuffle)
+static SortPtrs sort_ptrs_of(const Dev& D) { return SortPtrs{D.blk, D.blkv, D.counts, D.offs, D.binoff, D.bincnt, D.boff, D.lorder, D.lcombo, D.lpair}; }
+static BlockIdArgs block_id_args(uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff, uint64_t cells_per_block) {
+  BlockIdArgs A;
+  A.fk = make_keys(seed, round, Nglob); A.fk2 = make_keys(seed, round + 1, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
+  A.inv_cpb = 1.0f / (float)cells_per_block;
+  return A;
+}
 // the histogram half (block ids from the Feistel bijection + per-chunk counts): depends on nothing but (seed, round)
 void l_sort_hist(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff, uint64_t cells_per_block) {
   const int nV = D.nxt ? D.nb * D.nb : D.nb;
   const size_t lds = (size_t)nV * sizeof(int);
-  BlockIdArgs A;
-  A.fk = make_keys(seed, round, Nglob); A.fk2 = make_keys(seed, round + 1, Nglob); A.Nglob = Nglob; A.goff = goff; A.cpb = cells_per_block;
-  A.inv_cpb = 1.0f / (float)cells_per_block;
-  if (fused) hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
-  else hipLaunchKernelGGL(k_sort_hist<false>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, A);
+  BlockIdBatch AB{}; AB.a[0] = block_id_args(seed, round, Nglob, goff, cells_per_block);
+  SortBatch S{}; S.p[0] = sort_ptrs_of(D);
+  if (fused) hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, AB, S);
+  else hipLaunchKernelGGL(k_sort_hist<false>, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, AB, S);
 }
 // the dependent half: bin offsets from the counts, then the placement (padding slots = -1: written by k_sort_scatter, bin by bin)
 void l_sort_tail(const Launch& L, const Dev& D) {
   const int nV = D.nxt ? D.nb * D.nb : D.nb;
   const size_t lds = (size_t)nV * sizeof(int);
-  hipLaunchKernelGGL(k_sort_binscan, dim3(nV * D.Q), dim3(WAVE), 0, L.stream, D);
-  hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D);
+  SortBatch S{}; S.p[0] = sort_ptrs_of(D);
+  hipLaunchKernelGGL(k_sort_binscan, dim3(nV * D.Q), dim3(WAVE), 0, L.stream, D, S);
+  hipLaunchKernelGGL(k_sort_binoff, dim3(1), dim3(1024), 0, L.stream, D, S);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks), dim3(WAVE), lds, L.stream, D, S);
 }
 void l_sort_blocks(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                    uint64_t cells_per_block) {
   l_sort_hist(L, D, fused, seed, round, Nglob, goff, cells_per_block);
   l_sort_tail(L, D);
+}
+// The shuffles of `nr` consecutive rounds (first: `round`) in ONE set of four launches, blockIdx.y = the round: the four kernels of a
+// sort are latency-bound chains of small dependent steps, so four rounds cost little more than one -- and inside a cluster_cpp call
+// no sort is left between two block chains (round 3: 4 x ~70 us of sort tail, event hand-over and dispatch per call).
+void l_sort_batch(const Launch& L, const Dev& D, const SortBatch& S, int nr, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+                  uint64_t cells_per_block) {
+  const int nV = D.nxt ? D.nb * D.nb : D.nb;
+  const size_t lds = (size_t)nV * sizeof(int);
+  BlockIdBatch AB{};
+  for (int r = 0; r < nr; r++) AB.a[r] = block_id_args(seed, round + (uint64_t)r, Nglob, goff, cells_per_block);
+  hipLaunchKernelGGL(k_sort_hist<true>, dim3(D.nchunks, nr), dim3(WAVE), lds, L.stream, D, AB, S);
+  hipLaunchKernelGGL(k_sort_binscan, dim3(nV * D.Q, nr), dim3(WAVE), 0, L.stream, D, S);
+  hipLaunchKernelGGL(k_sort_binoff, dim3(nr), dim3(1024), 0, L.stream, D, S);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks, nr), dim3(WAVE), lds, L.stream, D, S);
 }
 // oe_arith: the round's shuffled order itself, posord[position] = internal cell id (arma::shuffle's update_order, src/harmony.cpp:272-273,
 // for the documented generator: cell g sits at position feistel(seed, round, g))
