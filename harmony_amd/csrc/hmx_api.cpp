@@ -293,7 +293,7 @@ struct hmx_ctx {
   // next block) -- then the next round needs no pass over R (k_oldsum).  state: 0 all zero, 1 unknown contents, 2 carried for round sold_round.
   long long* sold_buf[2] = {nullptr, nullptr}; int sold_cur = 0, sold_state[2] = {1, 1}; int64_t sold_round[2] = {-1, -1}; uint64_t sold_seed[2] = {0, 0};
   bool sets_clean = false;     // the three Snew replica sets are all zero
-  bool carry_ok = false, last_round_hint = false, round_may_be_last = true; bool sorted_nxt[4] = {false, false, false, false};
+  bool carry_ok = false, last_round_hint = false, round_may_be_last = true; bool sorted_nxt[4] = {};
   int64_t rounds_without_R = 0;
   int64_t carried_rounds = 0;
   bool chain_ok = false; int chain_wgs = 0; uint64_t chain_rounds = 0;   // persistent block chain (one launch per round)
@@ -311,7 +311,7 @@ struct hmx_ctx {
   struct SortSet { int* blk; int* lorder; int2* lpair; int* lcombo; int* boff; int* binoff; int* counts; int* offs; int* blkv; int* bincnt; };
   SortSet sets[4] = {}; int oset_mask = 1;      // order sets: round & oset_mask (two; four with the batched shuffle, sort_sched = 3)
   hipStream_t side = nullptr; hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
-  int64_t sorted_round[4] = {-1, -1, -1, -1}; uint64_t sorted_seed[4] = {0, 0, 0, 0}; bool sorted_on_side[4] = {false, false, false, false}; bool sort_overlap = true;
+  int64_t sorted_round[4] = {-1, -1, -1, -1}; uint64_t sorted_seed[4] = {}; bool sorted_on_side[4] = {}; bool sort_overlap = true;
   // Round-4 schedule of the shuffle (sort_sched = 2, default): its HISTOGRAM half depends on (seed, round) only and runs rounds ahead on the side
   // stream, into one of four slots (round & 3: block ids, composite keys, per-chunk counts); its dependent TAIL (bin scan, bin offsets,
   // scatter) is enqueued on the MAIN stream right behind the block chain of the round before -- in queue order, no cross-stream event between
@@ -321,8 +321,11 @@ struct hmx_ctx {
   HistSet hset[4] = {}; int64_t hist_round[4] = {-1, -1, -1, -1}; uint64_t hist_seed[4] = {0, 0, 0, 0}; bool hist_on_side[4] = {false, false, false, false}, hist_nxt[4] = {false, false, false, false};
   hipEvent_t ev_hist[4] = {nullptr, nullptr, nullptr, nullptr}; int sort_sched = 2;
   // sort_sched = 3: the shuffles of FOUR consecutive rounds in one set of four launches on the main stream (l_sort_batch), into four full order
-  // sets (round & 3) -- rounds keep their numbers across cluster_cpp calls, so a batch serves whichever calls its rounds fall into; between
-  // two block chains of a batch there is no sort kernel, no side stream and no event at all.
+  // sets -- rounds keep their numbers across cluster_cpp calls, so a batch serves whichever calls its rounds fall into; between two block
+  // chains of a batch there is no sort kernel and no event at all.  The batches are aligned groups (round >> 2).
+  // the sort-free form of the batched shuffle (k_shuf_*): position -> (cell, rank) per order set, the blocks of the round behind a batch,
+  // the (block, bin, part) count matrix
+  bool shuf_inv = false; int2* posr[4] = {}; int* shuf_partcnt[4] = {}; int* shuf_binacc[4] = {}; int64_t injected_round = -1;   // (injected_round: the round whose order the host provided -- its D.blk came with it)
   std::string err, warn, warn_ret;
 };
 
@@ -356,8 +359,8 @@ void free_all(hmx_ctx* ctx) {
   for (int i = 0; i < 2; i++) {
     if (ctx->ev_sorted[i]) { (void)hipEventDestroy(ctx->ev_sorted[i]); ctx->ev_sorted[i] = nullptr; }
     if (ctx->ev_free[i]) { (void)hipEventDestroy(ctx->ev_free[i]); ctx->ev_free[i] = nullptr; }
-    ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false;
   }
+  for (int i = 0; i < 4; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
   for (int i = 0; i < 4; i++) { if (ctx->ev_hist[i]) { (void)hipEventDestroy(ctx->ev_hist[i]); ctx->ev_hist[i] = nullptr; } ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; }
   {   // reference-arithmetic buffers (grown on demand, not in `allocs`)
     void* ps[] = {ctx->sq_start, ctx->sq_end, ctx->sq_total, ctx->sq_mismatch, ctx->headlist, ctx->roundlist, ctx->Of, ctx->Ef, ctx->Mtab, ctx->objT,
@@ -777,7 +780,38 @@ int enqueue_tail(hmx_ctx* ctx, uint64_t round) {
   ctx->sorted_round[os] = (int64_t)round; ctx->sorted_seed[os] = ctx->seed; ctx->sorted_nxt[os] = Dt.nxt != 0; ctx->sorted_on_side[os] = false;
   return 0;
 }
+// ---- sort_sched = 3 -----------------------------------------------------------------------------------------------------------
+// rounds first..(first | 3) in one batch of launches on the main stream, into sets round & 3.
+// (Sorting a group AHEAD on the side stream was measured twice and lost twice: next to the persistent block chain every block step got
+//  1 us slower (14.2 vs 14.1 ms per run); in the shadow of the correction's statistics pass that pass went from 1.47 to 2.25 ms per run for
+//  0.5 ms of sort taken off the main stream.  The sort's thousands of one-wave workgroups get in the way of whatever runs beside them.)
+int sort_group(hmx_ctx* ctx, uint64_t first) {
+  const int nr = 4 - (int)(first & 3);
+  SortBatch Sb{};
+  Dev Dt = ctx->D; Dt.nxt = ctx->carry_ok ? 1 : 0;
+  if (ctx->shuf_inv) {
+    ShufSets T{};
+    for (int r = 0; r < nr; r++) {
+      const int os = (int)((first + (uint64_t)r) & 3);
+      const hmx_ctx::SortSet& t = ctx->sets[os];
+      T.posr[r] = ctx->posr[os]; T.lpair[r] = t.lpair; T.lorder[r] = t.lorder; T.lcombo[r] = t.lcombo; T.boff[r] = t.boff; T.partcnt[r] = ctx->shuf_partcnt[os]; T.binbase[r] = t.binoff; T.bincnt[r] = t.bincnt; T.binacc[r] = ctx->shuf_binacc[os];
+    }
+    l_shuffle_inv(ctx->L, Dt, T, nr, ctx->seed, first, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
+  } else {
+  for (int r = 0; r < nr; r++) {
+    const hmx_ctx::SortSet& t = ctx->sets[(first + (uint64_t)r) & 3];
+    Sb.p[r] = SortPtrs{t.blk, t.blkv, t.counts, t.offs, t.binoff, t.bincnt, t.boff, t.lorder, t.lcombo, t.lpair};
+  }
+  l_sort_batch(ctx->L, Dt, Sb, nr, ctx->seed, first, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
+  }
+  for (int r = 0; r < nr; r++) {
+    const int os = (int)((first + (uint64_t)r) & 3);
+    ctx->sorted_round[os] = (int64_t)first + r; ctx->sorted_seed[os] = ctx->seed; ctx->sorted_nxt[os] = Dt.nxt != 0; ctx->sorted_on_side[os] = false;
+  }
+  return 0;
+}
 // after the block steps of round `round` have been queued: the next round's tail right behind them, the histograms of the rounds after that
+// (sort_sched = 2)
 int sort_after_round(hmx_ctx* ctx, uint64_t round) {
   if (ctx->sort_sched != 2 || !ctx->injected.empty() || ctx->rng_mode == 1) return 0;
   CHK(enqueue_hist(ctx, round + 1, false));
@@ -792,22 +826,7 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
   const int sset = (int)(round & (uint64_t)ctx->oset_mask);
   const bool host_order = !ctx->injected.empty() || ctx->rng_mode == 1;
   if (ctx->sort_sched == 3 && !host_order) {
-    if (!(ctx->sorted_round[sset] == (int64_t)round && ctx->sorted_seed[sset] == ctx->seed)) {
-      // this round and the three after it, whichever of them is not sorted yet (a run of consecutive rounds starting here)
-      int nr = 0; SortBatch Sb{};
-      Dev Dt = D; Dt.nxt = ctx->carry_ok ? 1 : 0;
-      for (; nr < 4; nr++) {
-        const int os = (int)((round + (uint64_t)nr) & 3);
-        if (nr && ctx->sorted_round[os] == (int64_t)round + nr && ctx->sorted_seed[os] == ctx->seed) break;
-        const hmx_ctx::SortSet& t = ctx->sets[os];
-        Sb.p[nr] = SortPtrs{t.blk, t.blkv, t.counts, t.offs, t.binoff, t.bincnt, t.boff, t.lorder, t.lcombo, t.lpair};
-      }
-      l_sort_batch(ctx->L, Dt, Sb, nr, ctx->seed, round, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
-      for (int r = 0; r < nr; r++) {
-        const int os = (int)((round + (uint64_t)r) & 3);
-        ctx->sorted_round[os] = (int64_t)round + r; ctx->sorted_seed[os] = ctx->seed; ctx->sorted_nxt[os] = Dt.nxt != 0; ctx->sorted_on_side[os] = false;
-      }
-    }
+    if (!(ctx->sorted_round[sset] == (int64_t)round && ctx->sorted_seed[sset] == ctx->seed)) CHK(sort_group(ctx, round));    // this round and the rest of its group
     apply_set(D, ctx->sets[sset]);
     D.nxt = ctx->sorted_nxt[sset] ? 1 : 0;
     return 0;
@@ -866,6 +885,7 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
       pos_blk[i] = (int)std::min<uint64_t>(b, (uint64_t)(ctx->nb - 1));
     }
     CHK(h2d(ctx, D.blk, pos_blk.data(), pos_blk.size()));
+    ctx->injected_round = (int64_t)round;
   } else gen_blocks = true;   // block ids from the Feistel bijection, computed inside the sort's histogram kernel
   D.nxt = (gen_blocks && ctx->carry_ok) ? 1 : 0;
   l_sort_blocks(ctx->L, D, gen_blocks, ctx->seed, round, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
@@ -1177,6 +1197,8 @@ int update_R(hmx_ctx* ctx) {
       if (carried) ctx->carried_rounds++;     // filled by the previous round's tile kernels: no pass over R
       else {             // all blocks in one pass over R
         if (ctx->sold_state[cur] != 0) HIPCHK(hipMemsetAsync(D.Sold_fx, 0, sizeof(long long) * nSold, ctx->L.stream));
+        if (ctx->shuf_inv && ctx->injected_round != rnd) {      // (the sort-free shuffle leaves D.blk alone: block ids of this round's cells, on demand)
+          l_shuffle_blocks(ctx->L, D, ctx->seed, (uint64_t)rnd, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK(); }
         l_oldsum(ctx->L, D); KCHK();
       }
       ctx->sold_state[cur] = 1;
@@ -1973,6 +1995,14 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); }
     { const char* sc = getenv("HMX_SORT_SCHED"); const int v = sc ? atoi(sc) : 3; ctx->sort_sched = (v >= 1 && v <= 3) ? v : 3; if (!ctx->sort_overlap) ctx->sort_sched = 1; }
     ctx->oset_mask = ctx->sort_sched == 3 ? 3 : 1;
+    { const char* si = getenv("HMX_SHUFFLE_INV"); const int v = si ? atoi(si) : 1;      // 0: counting sort always; 2: sort-free form on sharded runs too
+      ctx->shuf_inv = ctx->sort_sched == 3 && v != 0 && (ctx->world == 1 || v == 2) && D.nb < 64 && Q < 2048 && ctx->N_global < ((int64_t)1 << 31) &&
+                      ((size_t)D.nb * Q + (size_t)Q + 1) * sizeof(int) <= 64 * 1024; }     // (lpair packs the combination in 19 bits and the blocks in 6; posr the combination in 11)
+    if (ctx->shuf_inv) {
+      const int P = shuffle_parts((uint64_t)ctx->N_global, D.nb, ctx->cells_per_block);
+      for (int i = 0; i < 4; i++) { CHK(dalloc(ctx, &ctx->posr[i], (size_t)ctx->N_global)); CHK(dalloc(ctx, &ctx->shuf_partcnt[i], (size_t)nV * Q * P));
+        CHK(dalloc(ctx, &ctx->shuf_binacc[i], (size_t)nV * Q)); HIPCHK(hipMemsetAsync(ctx->shuf_binacc[i], 0, sizeof(int) * (size_t)nV * Q, ctx->L.stream)); }
+    }
     if (ctx->sort_sched == 3) for (int i = 2; i < 4; i++) {
       hmx_ctx::SortSet& u = ctx->sets[i];
       CHK(dalloc(ctx, &u.blk, (size_t)N)); CHK(dalloc(ctx, &u.lorder, (size_t)3 * D.npad + 2)); u.lpair = reinterpret_cast<int2*>(u.lorder + (((size_t)D.npad + 1) & ~(size_t)1));
@@ -2197,7 +2227,7 @@ int hmx_restart(hmx_ctx* ctx) {
   ctx->head_is_stale = false;
   HIPCHK(hipMemsetAsync(ctx->D.solve_err, 0, sizeof(int), ctx->L.stream));
   if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
-  for (int i = 0; i < 4; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
+  for (int i = 0; i < 4; i++) ctx->sorted_round[i] = -1;      // (sorted_on_side stays: a sort still running on the side stream is waited for before its set is reused)
   for (int i = 0; i < 4; i++) { ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; }
   return 0;
 }

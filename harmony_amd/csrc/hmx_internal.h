@@ -205,6 +205,11 @@ void l_sort_hist(const Launch& L, const Dev& D, bool fused, uint64_t seed, uint6
 void l_sort_tail(const Launch& L, const Dev& D);
 struct SortPtrs { int* blk; int* blkv; int* counts; int* offs; int* binoff; int* bincnt; int* boff; int* lorder; int* lcombo; int2* lpair; };
 struct SortBatch { SortPtrs p[4]; };
+struct ShufSets { int2* posr[4]; int2* lpair[4]; int* lorder[4]; int* lcombo[4]; int* boff[4]; int* partcnt[4]; int* binbase[4]; int* bincnt[4]; int* binacc[4]; };
+int shuffle_parts(uint64_t Nglob, int nb, uint64_t cells_per_block);
+void l_shuffle_blocks(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff, uint64_t cells_per_block);
+void l_shuffle_inv(const Launch& L, const Dev& D, const ShufSets& T, int nr, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+                   uint64_t cells_per_block);
 void l_sort_batch(const Launch& L, const Dev& D, const SortBatch& S, int nr, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
                   uint64_t cells_per_block);
 void l_oldsum(const Launch& L, const Dev& D);

@@ -479,6 +479,158 @@ __global__ __launch_bounds__(WAVE) void k_sort_scatter(Dev D, SortBatch S) {
 }
 
 // --------------------------------------------------------------------------------------
+// The same padded order WITHOUT sorting the cells by block (round 4).  The round's shuffle is a bijection of positions with a closed-form
+// inverse, so the cells of block b are simply the inverse images of the positions [b * cpb, (b + 1) * cpb): the cells arrive grouped by
+// block for free, and only the (next block, combination) bins INSIDE a block are left to count.  Four wide launches serve up to four rounds
+// (blockIdx.y = round of the batch; k_shuf_blocks -- block id per cell, D.blk -- runs only for a round whose old contributions were not
+// carried and must be summed from R); the unit of work is a PART of a block (SHUF_PART consecutive positions, one 1024-thread workgroup):
+//   k_shuf_count   per (round, part): cell = inverse image of the position (-1: another rank's), its next block = block of its image under the
+//                  NEXT round's bijection, its rank inside (part, bin) from a returning LDS atomic -> posr[round][position] = (cell, rank |
+//                  combination | next block); the part's offset inside every bin from a returning atomic on the bin's size
+//   k_shuf_scan    per round, one workgroup: bins padded to 16 -> first slot of every bin, padded block offsets
+//   k_shuf_place   per (round, part): lpair[first slot of the bin + part offset + rank] = (cell, keys); part 0 of a block writes the padding
+// Against the counting sort above (four dependent launches of ONE-WAVE workgroups over an (nb^2 keys) x (N / 512 chunks) count matrix: 150 us
+// per four rounds at 1M cells) the count matrix is (nb * Q bins) x (N / SHUF_PART parts).  The counting sort stays for host-provided
+// orders and sharded runs.
+// --------------------------------------------------------------------------------------
+constexpr int SHUF_PART = 4096;
+__host__ __device__ __forceinline__ uint64_t feistel_invert(const FeistelKeys& fk, uint64_t N, uint64_t pos) {
+  uint64_t x = pos;
+  do {
+    uint32_t L = (uint32_t)(x >> fk.half), Rr = (uint32_t)(x & fk.mask);
+#pragma unroll
+    for (int r = 5; r >= 0; r--) {
+      const uint32_t t = Rr ^ (fmix32(L * 0x9E3779B1u + fk.k[r]) & fk.mask);
+      Rr = L; L = t;
+    }
+    x = ((uint64_t)L << fk.half) | Rr;
+  } while (x >= N);
+  return x;
+}
+struct ShufBatch {
+  FeistelKeys fk[5];
+  int2* posr[4];                // [position] (internal cell | -1, rank inside its (part, bin))
+  int2* lpair[4]; int* lorder[4]; int* lcombo[4]; int* boff[4];
+  int* partcnt[4];              // [block][part][bin] the part's offset inside the bin
+  int* binbase[4]; int* bincnt[4]; int* binacc[4];     // [block][bin] first slot / cells / cells, accumulated by the parts (zero between batches)
+  uint64_t Nglob, goff, cpb; float inv_cpb; int nr, P;
+};
+__global__ __launch_bounds__(256) void k_shuf_blocks(Dev D, BlockIdArgs A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= D.n) return;
+  D.blk[i] = block_of(feistel_apply(A.fk, A.Nglob, A.goff + (uint64_t)D.perm[i]), A, D.nb);
+}
+// positions [s, e) of (block b, part p)
+__device__ __forceinline__ void shuf_range(const ShufBatch& S, int nb, int b, int p, uint64_t& s, uint64_t& e) {
+  const uint64_t p0 = min((uint64_t)b * S.cpb, S.Nglob), p1 = (b == nb - 1) ? S.Nglob : min((uint64_t)(b + 1) * S.cpb, S.Nglob);
+  s = min(p0 + (uint64_t)p * SHUF_PART, p1); e = min(s + SHUF_PART, p1);
+}
+__global__ __launch_bounds__(1024) void k_shuf_count(Dev D, ShufBatch S) {
+  extern __shared__ int sm_[];
+  const int r = blockIdx.y, b = blockIdx.x / S.P, p = blockIdx.x - b * S.P, tid = threadIdx.x, nb = D.nb, Q = D.Q;
+  const int nbin = (D.nxt ? nb : 1) * Q;
+  int* const cnt = sm_; int* const qf = sm_ + nbin;
+  for (int v = tid; v < nbin; v += 1024) cnt[v] = 0;
+  for (int v = tid; v <= Q; v += 1024) qf[v] = D.qstart[v];
+  __syncthreads();
+  uint64_t s, e; shuf_range(S, nb, b, p, s, e);
+  int2* __restrict__ const pr = S.posr[r];
+  const bool nxt = D.nxt != 0;
+  BlockIdArgs A; A.cpb = S.cpb; A.inv_cpb = S.inv_cpb;
+  constexpr int U = SHUF_PART / 1024;
+  int ci[U], nbk[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const uint64_t pos = s + (uint64_t)u * 1024 + tid;
+    ci[u] = -1; nbk[u] = 0;
+    if (pos < e) {
+      const uint64_t g = feistel_invert(S.fk[r], S.Nglob, pos);
+      if (g >= S.goff && g < S.goff + (uint64_t)D.n) {
+        ci[u] = D.invperm[g - S.goff];
+        if (nxt) nbk[u] = block_of(feistel_apply(S.fk[r + 1], S.Nglob, g), A, nb);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const uint64_t pos = s + (uint64_t)u * 1024 + tid;
+    if (pos < e) {
+      int rank = 0;
+      if (ci[u] >= 0) {
+        int lo = 0, hi = Q;                       // qf[q] <= cell < qf[q + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (qf[mid] <= ci[u]) lo = mid; else hi = mid; }
+        rank = atomicAdd(&cnt[nbk[u] * Q + lo], 1) | (lo << 12) | (nbk[u] << 23);     // (a part has 4096 positions: the rank fits 12 bits; combination (11) and next block (6) ride along)
+      }
+      pr[pos] = make_int2(ci[u], rank);
+    }
+  }
+  __syncthreads();
+  // the part's offset inside every bin of its block: whatever a returning atomic on the bin's size hands out (a bin has to be pure, the
+  // order of the parts inside it is free); k_shuf_scan reads the sizes and leaves them zero for the next batch into this order set
+  for (int v = tid; v < nbin; v += 1024) {
+    const int c = cnt[v];
+    S.partcnt[r][((size_t)b * S.P + p) * nbin + v] = c ? atomicAdd(&S.binacc[r][b * nbin + v], c) : 0;
+  }
+}
+__global__ __launch_bounds__(1024) void k_shuf_scan(Dev D, ShufBatch S) {
+  __shared__ int red[16];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nb = D.nb, P = S.P;
+  const int nbin = (D.nxt ? nb : 1) * D.Q, nbt = nb * nbin;
+  const int per = (nbt + 1023) >> 10;
+  int own = 0;
+  for (int k = 0; k < per; k++) {
+    const int t = min(tid * per + k, nbt - 1);
+    const int c = S.binacc[r][t];
+    if (tid * per + k < nbt) { S.binacc[r][t] = 0; S.bincnt[r][t] = c; own += (c + 15) & ~15; }
+  }
+  int incl = own;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+  if (lane == 63) red[w] = incl;
+  __syncthreads();
+  int wbase = 0, total = 0;
+  for (int x = 0; x < 16; x++) { const int t = red[x]; if (x < w) wbase += t; total += t; }
+  int run = wbase + incl - own;
+  for (int k = 0; k < per; k++) {
+    const int t = tid * per + k;
+    if (t < nbt) {
+      S.binbase[r][t] = run;
+      if (t % nbin == 0) S.boff[r][t / nbin] = run;
+      run += (S.bincnt[r][t] + 15) & ~15;
+    }
+  }
+  if (tid == 0) S.boff[r][nb] = total;
+}
+__global__ __launch_bounds__(1024) void k_shuf_place(Dev D, ShufBatch S) {
+  extern __shared__ int sm_[];
+  const int r = blockIdx.y, b = blockIdx.x / S.P, p = blockIdx.x - b * S.P, tid = threadIdx.x, nb = D.nb, Q = D.Q;
+  const int nbin = (D.nxt ? nb : 1) * Q;
+  int* const base = sm_;
+  for (int v = tid; v < nbin; v += 1024) base[v] = S.binbase[r][b * nbin + v] + S.partcnt[r][((size_t)b * S.P + p) * nbin + v];
+  __syncthreads();
+  uint64_t s, e; shuf_range(S, nb, b, p, s, e);
+  const int2* __restrict__ const pr = S.posr[r];
+  const bool nxt = D.nxt != 0;
+  int2* __restrict__ const lp = S.lpair[r];
+  int* __restrict__ const lo_ = S.lorder[r]; int* __restrict__ const lc_ = S.lcombo[r];
+  constexpr int U = SHUF_PART / 1024;
+  int2 cr[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { const uint64_t pos = s + (uint64_t)u * 1024 + tid; cr[u] = pos < e ? pr[pos] : make_int2(-1, 0); }
+#pragma unroll
+  for (int u = 0; u < U; u++) if (cr[u].x >= 0) {
+    const int q = (cr[u].y >> 12) & 0x7FF, nbk = cr[u].y >> 23, dst = base[nbk * Q + q] + (cr[u].y & 0xFFF);
+    if (D.need_lorder) { lo_[dst] = cr[u].x; lc_[dst] = q; }
+    lp[dst] = make_int2(cr[u].x, nxt ? (q | (nbk << 19) | (b << 25)) : q);        // (combination, next block, block): see flush_run in k_tile
+  }
+  if (p == 0)                                    // the padding slots of the block's bins: "no cell"
+    for (int v = tid; v < nbin; v += 1024) {
+      const int c = S.bincnt[r][b * nbin + v], st = S.binbase[r][b * nbin + v], pad = (c + 15) & ~15;
+      for (int k = c; k < pad; k++) { if (D.need_lorder) lo_[st + k] = -1; lp[st + k] = make_int2(-1, -1); }
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // update_R (src/harmony.cpp:269-342) split into:
 //   k_oldsum   one pass: old contribution of EVERY block of this round (:312-313 for all blocks)
 //   k_prepare  tiny: O <- O + new(prev block) - old(this block); penalty table (:322)
@@ -1241,6 +1393,8 @@ constexpr int tile_threads(int nct) { return 256; }
 template <int NCT, int MODE, int WPS = 2, bool USIG = false, bool BF = (HMX_TILE_BF != 0)>
 __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   constexpr bool LEAN = WPS > 2;
+  constexpr bool CHAIN = (MODE == 4 || MODE == 5);     // MODE 5: the chain of a round whose R rows nobody reads (Dev::r_store == 0), see below
+  constexpr bool NOSTORE = (MODE == 5);
   // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits):
   //   [ centroid image: NQ*NS*64 float4 | MODE 0: pen[B][K] + qlev[Q][C] (if they fit) | MODE 2: int64 sums[K][d] + counts[K] ]
   extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
@@ -1252,21 +1406,21 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // publishes O' and zeroes the replica set of the NEXT launch (three sets rotate, so nobody reads what is zeroed).
   const int nBK = D.B * K;
   long long* ldsO = reinterpret_cast<long long*>(lds4 + nY4);
-  float* ldsPen = ((MODE == 0 && D.fused_fold) || MODE == 4) ? reinterpret_cast<float*>(ldsO + nBK) : reinterpret_cast<float*>(lds4 + nY4);
+  float* ldsPen = ((MODE == 0 && D.fused_fold) || CHAIN) ? reinterpret_cast<float*>(ldsO + nBK) : reinterpret_cast<float*>(lds4 + nY4);
   int* ldsQlev = reinterpret_cast<int*>(ldsPen + ((nBK + 3) & ~3));
   long long* ltab = reinterpret_cast<long long*>(lds4 + nY4);
-  constexpr bool UPD = (MODE == 0 || MODE == 4);   // block update modes (gathered cells, penalty, O contributions)
+  constexpr bool UPD = (MODE == 0 || CHAIN);   // block update modes (gathered cells, penalty, O contributions)
   int p0 = 0, ntiles;
   if constexpr (MODE == 0) { p0 = D.boff[j]; ntiles = (D.boff[j + 1] - p0) >> 4; }  // padded: combination-pure tiles
-  else if constexpr (MODE == 4) { p0 = D.boff[0]; ntiles = (D.boff[1] - p0) >> 4; }
+  else if constexpr (CHAIN) { p0 = D.boff[0]; ntiles = (D.boff[1] - p0) >> 4; }
   else if (MODE == 1 && D.head_gather) ntiles = D.boff[D.nb] >> 4;     // the head runs over the NEXT round's padded order (see flush_run)
   else ntiles = D.ntitems;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   // wave index as a SCALAR: tile numbers and all loop control become SALU work (no exec-mask branches in the tile loop)
   // (MODE 4: the last workgroup is the folder, the others are the workers)
-  const int nw = ((gridDim.x - (MODE == 4 ? 1 : 0)) * blockDim.x) >> 6;
+  const int nw = ((gridDim.x - (CHAIN ? 1 : 0)) * blockDim.x) >> 6;
   int wave_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if constexpr (MODE == 4) {
+  if constexpr (CHAIN) {
     // tiles are dealt t = wave + i * nw, so the waves with the low indices get the extra tile of a block: number the first
     // wave of every SIMD (all workgroups) before the second ones, and each SIMD hosts one heavy and one light wave -- the
     // same tile count on every SIMD instead of 4 tiles on half the CUs and 2 on the others
@@ -1296,17 +1450,17 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   // lowest-numbered waves own base + 1 consecutive tiles, the others base.  A wave's tiles of a block are neighbours in the padded
   // order: they mostly share their (combination, next block) key, i.e. one contribution flush and one penalty fetch per wave and
   // block instead of one per tile, and their pair loads share cache lines.
-  constexpr bool CHAIN_CONTIG = (MODE == 4) && !LEAN;
+  constexpr bool CHAIN_CONTIG = (CHAIN) && !LEAN;
   auto chain_range = [&](const int T, int& s0, int& e0) {
     const int base = T / nw, rem = T - base * nw;
     s0 = wave * base + min(wave, rem);
     e0 = s0 + base + (wave < rem ? 1 : 0);
   };
-  const bool strided = (MODE == 4 && !CHAIN_CONTIG) || (MODE == 0 && !D.upd_contig);
+  const bool strided = (CHAIN && !CHAIN_CONTIG) || (MODE == 0 && !D.upd_contig);
   int ts = strided ? wave : wave * per;
   int te = strided ? ntiles : min(ntiles, ts + per);     // (MODE 4 re-derives it for every block)
   if constexpr (CHAIN_CONTIG) chain_range(ntiles, ts, te);
-  if (MODE == 4 && blockIdx.x == gridDim.x - 1) te = ts;   // the folder owns no tiles
+  if (CHAIN && blockIdx.x == gridDim.x - 1) te = ts;   // the folder owns no tiles
   const int tstep = strided ? nw : 1;
   // MODE 0: the first tile's cell ids and the first 16 bytes of their embedding rows are requested BEFORE the
   // LDS staging below, so the two dependent HBM round trips overlap with it
@@ -1433,13 +1587,13 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
       }
     }
-    if constexpr (MODE == 4) for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
+    if constexpr (CHAIN) for (int i = threadIdx.x; i < D.Q * C; i += blockDim.x) ldsQlev[i] = D.qlev[i];
     if constexpr (MODE == 2) for (int i = threadIdx.x; i < K * D.d + K; i += blockDim.x) ltab[i] = 0;
     __syncthreads();
   }
   stamp(2);
-  const float* penT = ((MODE == 0 && (D.pen_lds || D.fused_fold)) || MODE == 4) ? ldsPen : D.pen;
-  const int* qlevT = ((MODE == 0 && (D.pen_lds || D.fused_fold)) || MODE == 4) ? ldsQlev : D.qlev;
+  const float* penT = ((MODE == 0 && (D.pen_lds || D.fused_fold)) || CHAIN) ? ldsPen : D.pen;
+  const int* qlevT = ((MODE == 0 && (D.pen_lds || D.fused_fold)) || CHAIN) ? ldsQlev : D.qlev;
   long long* snew = D.Snew_fx + (size_t)(wave & (D.nrep - 1)) * D.B * K;  // this wave's table replica
   // per-lane cluster constants: exp(-dist/sigma) = exp2(dist * ce), ce = -log2(e)/sigma;  sigma r ln r = cl r log2 r,
   // cl = sigma ln 2;  lpen = log2(penalty of the current combination), clp = cl * lpen (general sigma only).
@@ -1642,7 +1796,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #ifdef HMX_TRACE
         if (!(D.upd_debug & 4))   // timing experiment: no R stores
 #endif
-        if (D.r_store) {    // (a pass whose R rows nobody will read leaves them in the registers: see Dev::r_store)
+        if (!NOSTORE && D.r_store) {    // (a pass whose R rows nobody will read leaves them in the registers: see Dev::r_store)
 #pragma unroll
           for (int i = 0; i < RB; i++) put_row(Rrow[i], acc, r0 + i);
         }
@@ -1654,7 +1808,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
 #ifdef HMX_TRACE
     if (D.upd_debug & 4) return;
 #endif
-    if (!D.r_store) return;
+    if (NOSTORE || !D.r_store) return;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int cell = __shfl(cellA, 4 * g + i, 64);
@@ -1811,7 +1965,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
   auto next_rows = [&](const int2 nxt, const int2 cur) {  // row address of the NEXT tile's lane (any valid row if padding)
     return D.Zc + (size_t)(nxt.x >= 0 ? nxt.x : (cur.x >= 0 ? cur.x : 0)) * zs;
   };
-  if constexpr (MODE == 4) {
+  if constexpr (CHAIN) {
     // ======================= persistent block chain of one round =======================
     // Cross-workgroup traffic (L2s of different XCDs are not coherent, so nothing here relies on plain loads of data another
     // workgroup wrote during this launch):
@@ -2190,6 +2344,12 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
     f32x4 accC[NCT], accS[NCT];
     int2 cellC = make_int2(-1, -1), cellS = make_int2(-1, -1);
     bool have = ts < te, have2 = false;
+    // MODE 5 (no R stores: the accumulators are dead once a tile's contributions are summed): the rows of the wave's SECOND tile of the next
+    // block are requested into a second register buffer in front of the contribution flush -- their latency passes during the flush, the
+    // barrier and the arrival instead of between the two tiles' MFMAs behind it (the workers' phase in the folder's shadow: 5.0 us, the
+    // folder needs 3-4).  With the stores the normalised rows of both tiles occupy the accumulators until behind the arrival: no room
+    // (a second buffer there: 28 spilled VGPRs).
+    RowRegs rowsN2; bool rows2_ok = false;
     // BOTH accumulator sets are filled ahead of the flag: the MFMAs of this wave's first tile of the current block (rows were
     // requested earlier) and, if it owns a second one, of that too -- after the flag only epilogues remain for up to two tiles
     auto first_tile_a = [&]() __attribute__((always_inline)) {
@@ -2197,7 +2357,8 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       const RowRegs rowsA = rowsN;
       cellN = cellNN;
       cellNN = tile_cell(ts + 2 * tstep);
-      ld_rows(next_rows(cellN, cellC), rowsN);
+      if constexpr (NOSTORE) { if (rows2_ok) rowsN = rowsN2; else ld_rows(next_rows(cellN, cellC), rowsN); }
+      else ld_rows(next_rows(cellN, cellC), rowsN);
       dots_regs(rowsA, cellC.x >= 0, accC);
       have2 = HMX_CHAIN_PRE2 && USIG && ts + tstep < te;    // (the general-sigma variant has no registers to spare: 95 spills)
     };
@@ -2347,10 +2508,15 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
           epi_rows(cellS.x, accS, std::true_type{});
         }
         lap(w2);
+        if constexpr (NOSTORE) {
+          rows2_ok = haveN && tsn + tstep < ten;          // (uniform: the wave owns a second tile in the next block)
+          if (rows2_ok) ld_rows(next_rows(cNN1, cN1), rowsN2);
+        }
         if (curq >= 0) flush_run();
         lap(w3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's atomics have been performed (no stores queued behind them)
       } else {
+        rows2_ok = false;
         if (haveN) ld_rows(D.Zc + (size_t)(cN1.x >= 0 ? cN1.x : 0) * zs, rowsN);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -3959,6 +4125,30 @@ void l_sort_batch(const Launch& L, const Dev& D, const SortBatch& S, int nr, uin
   hipLaunchKernelGGL(k_sort_binoff, dim3(nr), dim3(1024), 0, L.stream, D, S);
   hipLaunchKernelGGL(k_sort_scatter, dim3(D.nchunks, nr), dim3(WAVE), lds, L.stream, D, S);
 }
+// the padded orders of rounds round..round + nr - 1 from the inverse of the shuffle (k_shuf_*)
+int shuffle_parts(uint64_t Nglob, int nb, uint64_t cells_per_block) {
+  const uint64_t last = Nglob > (uint64_t)(nb - 1) * cells_per_block ? Nglob - (uint64_t)(nb - 1) * cells_per_block : 0;
+  return (int)((std::max<uint64_t>(std::max(cells_per_block, last), 1) + SHUF_PART - 1) / SHUF_PART);
+}
+void l_shuffle_inv(const Launch& L, const Dev& D, const ShufSets& T, int nr, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff,
+                   uint64_t cells_per_block) {
+  ShufBatch S{};
+  for (int r = 0; r < nr + 1; r++) S.fk[r] = make_keys(seed, round + (uint64_t)r, Nglob);
+  for (int r = 0; r < nr; r++) {
+    S.posr[r] = T.posr[r]; S.lpair[r] = T.lpair[r]; S.lorder[r] = T.lorder[r]; S.lcombo[r] = T.lcombo[r]; S.boff[r] = T.boff[r];
+    S.partcnt[r] = T.partcnt[r]; S.binbase[r] = T.binbase[r]; S.bincnt[r] = T.bincnt[r]; S.binacc[r] = T.binacc[r];
+  }
+  S.Nglob = Nglob; S.goff = goff; S.cpb = cells_per_block; S.inv_cpb = 1.0f / (float)cells_per_block; S.nr = nr;
+  S.P = shuffle_parts(Nglob, D.nb, cells_per_block);
+  const int nbin = (D.nxt ? D.nb : 1) * D.Q;
+  hipLaunchKernelGGL(k_shuf_count, dim3((unsigned)(S.P * D.nb), nr), dim3(1024), ((size_t)nbin + D.Q + 1) * sizeof(int), L.stream, D, S);
+  hipLaunchKernelGGL(k_shuf_scan, dim3(nr), dim3(1024), 0, L.stream, D, S);
+  hipLaunchKernelGGL(k_shuf_place, dim3((unsigned)(S.P * D.nb), nr), dim3(1024), (size_t)nbin * sizeof(int), L.stream, D, S);
+}
+// D.blk of one round (the sort-free shuffle does not need it; the passes that sum a round's old contributions from R do)
+void l_shuffle_blocks(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, uint64_t goff, uint64_t cells_per_block) {
+  hipLaunchKernelGGL(k_shuf_blocks, dim3((unsigned)((D.n + 255) / 256)), dim3(256), 0, L.stream, D, block_id_args(seed, round, Nglob, goff, cells_per_block));
+}
 // oe_arith: the round's shuffled order itself, posord[position] = internal cell id (arma::shuffle's update_order, src/harmony.cpp:272-273,
 // for the documented generator: cell g sits at position feistel(seed, round, g))
 __global__ void k_ref_posord(Dev D, FeistelKeys fk, uint64_t Nglob, int* __restrict__ posord, int* __restrict__ poslev) {
@@ -4157,7 +4347,8 @@ void HMX_LNAME(l_chain)(const Launch& L, const Dev& D, int workgroups) {
   if (D.chain_wps >= 3) lds = ((lds + 15) & ~(size_t)15) + (size_t)(4 * D.chain_wps) * ((D.NT4 + D.tail) * 1024 + 1024);   // per wave: glds row image + pair images
   const dim3 grid((unsigned)workgroups);
 #if HMX_TILE_BF
-#define HMX_CH(N) case N: if (D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 2, true>), grid, dim3(512), lds, D, 0); \
+#define HMX_CH(N) case N: if (D.usig && !D.r_store && !D.chain_old) HMX_LAUNCH_EV((k_tile<N, 5, 2, true>), grid, dim3(512), lds, D, 0); \
+                          else if (D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 2, true>), grid, dim3(512), lds, D, 0); \
                           else HMX_LAUNCH_EV((k_tile<N, 4>), grid, dim3(512), lds, D, 0); break;
 #else
 #define HMX_CH(N) case N: if (D.chain_wps == 4 && D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 4, true>), grid, dim3(1024), lds, D, 0); \
