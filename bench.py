@@ -608,7 +608,14 @@ def main():
         if pm["workload"] == {"cells_per_gpu": n, "pcs": d, "clusters": K, "batches": levels[0]} and len(levels) == 1:
             traffic = pm["hbm_bytes_per_launch"]
             mfma_util = pm.get("mfma_busy_frac")
-            pm_note = "collected %s" % pm.get("collected", "in an earlier round")
+            # rounds whose R rows nobody reads run the chain's variant without the stores (Dev::r_store): the launch-weighted mean of the two
+            cr, nr_ = float(obj._scalar("chain_rounds") or 0), float(obj._scalar("rounds_without_R") or 0)
+            if cr > 0 and "hbm_bytes_per_launch_without_R_stores" in pm:
+                w5 = min(nr_ / cr, 1.0)
+                traffic = (1 - w5) * pm["hbm_bytes_per_launch"] + w5 * pm["hbm_bytes_per_launch_without_R_stores"]
+                mfma_util = (1 - w5) * pm["mfma_busy_frac"] + w5 * pm.get("mfma_busy_frac_without_R_stores", pm["mfma_busy_frac"])
+                pm_note = "launch-weighted over the chain's two variants (%.0f%% of the rounds store no R rows); " % (100 * w5)
+            pm_note += "collected %s" % pm.get("collected", "in an earlier round")
     except Exception:
         pass
     # SURVEY 8(d) whole-run figure: compulsory bytes per cell per harmony iteration = 4d(4 + I_k) + 4K(3 + 2 I_k)
@@ -617,7 +624,7 @@ def main():
     nct = (K + 15) // 16
     on_chain = bool(obj._scalar("chain")) and (world == 1 or bool(obj._scalar("p2p")))
     bf = "true" if obj._scalar("dot_bf") else "false"        # the build of the tile kernels' distance GEMM: split bf16 | fp32 MFMA
-    kname = ("k_tile<%d,4,2,%s,%s> -- the persistent block chain: ONE launch = one round of update_R (%d block steps, every cell once)"
+    kname = ("k_tile<%d,4|5,2,%s,%s> -- the persistent block chain: ONE launch = one round of update_R (%d block steps, every cell once); variant 5 (no R stores) for rounds whose R rows nobody reads"
              % (nct, "true" if obj._scalar("usig") else "false", bf, int(obj._scalar("n_blocks")))) if on_chain else \
             ("k_tile<%d,0,%d,%s,%s> -- one launch = the block update of one block of update_R" % (nct, int(obj._scalar("upd_wps")), "true" if obj._scalar("usig") else "false", bf))
     roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
