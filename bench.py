@@ -371,8 +371,8 @@ def main():
                     "c5: configs[4] shape, K=200, nested covariates 8 > 64 > 128")
     ap.add_argument("--cells-per-gpu", type=int, default=1000000)
     ap.add_argument("--total-cells", type=int, default=0, help="strong scaling: this many cells in TOTAL, sharded over --gpus (overrides --cells-per-gpu)")
-    ap.add_argument("--also", default=None, help="extra legs at N=1, comma separated: ref (reference arithmetic on the main workload), 10M, c5, pbmc "
-                    "(configs[1] at its stated size, with its own CPU oracle timing); default 'ref,10M,c5,pbmc' for the default workload on one GPU, 'none' otherwise")
+    ap.add_argument("--also", default=None, help="extra legs at N=1, comma separated: ref (reference arithmetic on the main workload), 10M, share (1.25M cells / 20 batches: one GPU's part of configs[3] on 8), c5, pbmc "
+                    "(configs[1] at its stated size, with its own CPU oracle timing); default 'ref,10M,share,c5,pbmc' for the default workload on one GPU, 'none' otherwise")
     ap.add_argument("--pcs", type=int, default=50)
     ap.add_argument("--clusters", type=int, default=None)
     ap.add_argument("--batches", type=int, default=10)
@@ -697,7 +697,7 @@ def main():
     if hp:
         out.update({"parity_mode": hp["parity_mode"], "Z_rel_vs_accurate": hp["Z_rel_vs_accurate"], "Z_rel_vs_faithful": hp["Z_rel_vs_faithful"], "parity": hp})
     default_main = world == 1 and a.workload == "c3" and n == 1000000 and levels == (10,) and K == 100 and d == 50
-    also = a.also if a.also is not None else ("ref,10M,c5,pbmc" if default_main else "none")
+    also = a.also if a.also is not None else ("ref,10M,share,c5,pbmc" if default_main else "none")
     if world == 1 and also != "none":
         # extra legs of this invocation (never part of `value`): each one is a full run to convergence from HBM-resident inputs
         del obj
@@ -706,9 +706,12 @@ def main():
             try:
                 if leg == "ref":       # every accumulator group in the reference's fp32 operation order on the main workload
                     legs["reference_arith"] = bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, a.seed, 2, 1, sync, ref_arith=1)
-                    legs["reference_arith"]["parity"] = "vs the faithful oracle: cpu_baseline.gpu_reference_arith_vs_this_run (live, sample) and profiles/r3_parity_table_*.json (full size)"
+                    legs["reference_arith"]["parity"] = "vs the faithful oracle: cpu_baseline.gpu_reference_arith_vs_this_run (live, sample) and profiles/r4_parity_table_*.json (full size: gpu_ref_arith_vs_oracle_faithful)"
                 elif leg == "10M":     # north_star's target size on ONE GPU: 10M x 50, K = 100, 20 batches (configs[3]'s total size)
                     legs["10M_one_gpu"] = bench_leg(Harmony, prepare_setup_args, 10000000, 50, 100, (20,), False, a.seed, 2, 1, sync)
+                elif leg == "share":   # one GPU's share of configs[3] on an 8-GPU node: 1.25M cells of the 10M, 20 batches
+                    legs["configs3_share_1p25M"] = bench_leg(Harmony, prepare_setup_args, 1250000, 50, 100, (20,), False, a.seed, 3, 1, sync)
+                    legs["configs3_share_1p25M"]["note"] = "what each rank of `--total-cells 10000000 --batches 20 --gpus 8` computes per step, without the exchanges (no 8-GPU node here)"
                 elif leg == "c5":      # configs[4] shape at 1M cells
                     legs["c5_shape_1M"] = bench_leg(Harmony, prepare_setup_args, 1000000, 50, 200, (8, 64, 128), True, a.seed, 2, 1, sync)
                 elif leg == "pbmc":    # configs[1] at its stated size, GPU vs CPU oracle
