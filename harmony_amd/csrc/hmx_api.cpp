@@ -1997,7 +1997,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     ctx->oset_mask = ctx->sort_sched == 3 ? 3 : 1;
     { const char* si = getenv("HMX_SHUFFLE_INV"); const int v = si ? atoi(si) : 1;      // 0: counting sort always; 2: sort-free form on sharded runs too
       ctx->shuf_inv = ctx->sort_sched == 3 && v != 0 && (ctx->world == 1 || v == 2) && D.nb < 64 && Q < 2048 && ctx->N_global < ((int64_t)1 << 31) &&
-                      ((size_t)D.nb * Q + (size_t)Q + 1) * sizeof(int) <= 64 * 1024; }     // (lpair packs the combination in 19 bits and the blocks in 6; posr the combination in 11)
+                      ((size_t)D.nb * Q + (size_t)Q + 1) * sizeof(int) + 5 * 4096 <= 64 * 1024; }     // (lpair packs the combination in 19 bits and the blocks in 6; posr the combination in 11)
     if (ctx->shuf_inv) {
       const int P = shuffle_parts((uint64_t)ctx->N_global, D.nb, ctx->cells_per_block);
       for (int i = 0; i < 4; i++) { CHK(dalloc(ctx, &ctx->posr[i], (size_t)ctx->N_global)); CHK(dalloc(ctx, &ctx->shuf_partcnt[i], (size_t)nV * Q * P));
