@@ -1951,11 +1951,14 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   qchunk[Q] = (int)schunks.size();
   D.nchunks = (int)schunks.size();
   { // Old contributions carried from round to round (update_R): tiles keyed by (block, combination, NEXT block) cost up to 16
-    // padding slots per key -- worth it while the expected padding (8 per key) stays below 4 % of the cells.  HMX_SOLD_CARRY=0|1.
+    // padding slots per key -- worth it while the expected padding (8 per key) stays below 4 % (12 % with the chain) of the cells.  HMX_SOLD_CARRY=0|1.
     const char* e = getenv("HMX_SOLD_CARRY"); const char* co = getenv("HMX_CHAIN_OLD");
     const bool fits = D.nb <= 63 && Q < (1 << 19) && D.upd_impl == 0 && !(co && atoi(co) == 1) &&
                       (int64_t)N + (int64_t)D.nb * D.nb * Q * 16 <= 2147483000ll;
-    const bool pays = (int64_t)D.nb * D.nb * Q * 8 * 25 <= (int64_t)N;
+    // (round 4: with the R stores of carried rounds gone as well -- Dev::r_store -- the carry saves ~200 us per round at 1M cells where the
+    //  persistent chain runs (K <= 112): worth up to ~12 % of padding there; measured at 1.25M cells / 20 batches, 5.1 %: 15.5 -> 12.7 ms per run.
+    //  On the launch-per-step path (configs[4] shape, 41 %: 63 -> 70 ms) the old bound stays.)
+    const bool pays = (int64_t)D.nb * D.nb * Q * 8 * (K <= 112 ? 8 : 25) <= (int64_t)N;
     ctx->carry_ok = fits && (e ? atoi(e) == 1 : pays) && !ctx->oe_arith;      // (oe_arith: the tables follow the reference, nothing is carried)
     D.nxt = 0; D.Sold_next = nullptr; D.Sold_head = nullptr; D.head_gather = 0; ctx->carried_rounds = 0;
     D.qmask = ctx->carry_ok ? 0x7FFFF : 0x7FFFFFFF; }
@@ -1996,7 +1999,8 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     { const char* sc = getenv("HMX_SORT_SCHED"); const int v = sc ? atoi(sc) : 3; ctx->sort_sched = (v >= 1 && v <= 3) ? v : 3; if (!ctx->sort_overlap) ctx->sort_sched = 1; }
     ctx->oset_mask = ctx->sort_sched == 3 ? 3 : 1;
     { const char* si = getenv("HMX_SHUFFLE_INV"); const int v = si ? atoi(si) : 1;      // 0: counting sort always; 2: sort-free form on sharded runs too
-      ctx->shuf_inv = ctx->sort_sched == 3 && v != 0 && (ctx->world == 1 || v == 2) && D.nb < 64 && Q < 2048 && ctx->N_global < ((int64_t)1 << 31) &&
+      ctx->shuf_inv = ctx->sort_sched == 3 && v != 0 && (ctx->world == 1 || v == 2) && ctx->carry_ok &&      /* (without the carry every round needs D.blk: the counting sort has it for free) */
+                      D.nb < 64 && Q < 2048 && ctx->N_global < ((int64_t)1 << 31) &&
                       ((size_t)D.nb * Q + (size_t)Q + 1) * sizeof(int) + 5 * 4096 <= 64 * 1024; }     // (lpair packs the combination in 19 bits and the blocks in 6; posr the combination in 11)
     if (ctx->shuf_inv) {
       const int P = shuffle_parts((uint64_t)ctx->N_global, D.nb, ctx->cells_per_block);
