@@ -311,7 +311,8 @@ def main_file_bootstrap(a):
         else:
             obj._scalar("sync")
 
-    for _ in range(a.warmup + (1 if world > 1 else 0)):
+    preroll = int(os.environ.get("HMX_BENCH_PREROLL", "16" if n <= 2000000 else "2"))      # (untimed: see main())
+    for _ in range(preroll + a.warmup + (1 if world > 1 else 0)):
         run_to_convergence(obj)
     obj.set_profile(1)
     sync()
@@ -337,7 +338,7 @@ def main_file_bootstrap(a):
     run_bytes = float(n) * float(np.sum(4.0 * d * (4 + kr) + 4.0 * K * (3 + 2 * kr)))
     on_chain = bool(obj._scalar("chain")) and (world == 1 or bool(obj._scalar("p2p")))
     out = {"metric": "cells_per_sec_to_convergence", "value": N / (ms_per_step * 1e-3), "unit": "cells/s", "n_gpus": world, "steps": a.steps,
-           "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+           "warmup": a.warmup, "preroll_steps_untimed": preroll, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "synthetic %d cells x %d PCs, K=%d, levels %s%s%s" % (N, d, K, "x".join(map(str, levels)), " nested" if nested else "",
                                                                                           "" if world == 1 else ", %d cells/GPU cell-sharded" % n),
@@ -554,6 +555,12 @@ def main():
         if not bool(t.item()):                        # pragma: no cover
             obj.p2p_enable(False)
             comm_kind += " -- SWITCHED OFF after a failed trial run: one launch + one all-reduce per block"
+    # Pre-roll (untimed, in front of the W warmup steps, same count on every rank): a fresh box's first process measured the same code 7 % slower
+    # per chain launch than any later process on that box (profiles/r4_bench_default_first_process.json: 16.05 vs 14.75 us per block step with
+    # W = 1) -- clocks and caches of an idle GPU need a few hundred ms of load.  ~0.25 s of the same workload; HMX_BENCH_PREROLL=0 switches it off.
+    preroll = int(os.environ.get("HMX_BENCH_PREROLL", "16" if n <= 2000000 else "2"))
+    for _ in range(preroll):
+        run_to_convergence(obj)
     for _ in range(a.warmup):
         run_to_convergence(obj)
     # start / stop HIP events attached to every launch of the dominant kernel, on the library's stream (profile level 1; the per-phase event
@@ -680,7 +687,7 @@ def main():
                        "costs (ring allocation, code-object load) are in setup_total, which also holds Phi -> level codes and the combination sort on the host"}
     out = {
         "metric": "cells_per_sec_to_convergence", "value": N / (ms_per_step * 1e-3), "unit": "cells/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "preroll_steps_untimed": preroll, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic %d cells x %d PCs, K=%d, levels %s%s%s (BASELINE %s per GPU)"
                                % (N, d, K, "x".join(map(str, levels)), " nested" if nested else "",

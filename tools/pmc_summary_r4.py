@@ -13,7 +13,7 @@ fe, wr, sq = parse("pmc_fetch.txt"), parse("pmc_write.txt"), parse("pmc_sq.txt")
 stats = {r["Name"].split("(")[0].replace("void ", "").strip(): float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(R, "kernel_stats.csv")))}
 summ = {"source": "rocprofv3 --pmc <counters> --kernel-trace -- python tools/prof_update.py 1000000 (separate passes per counter group, tools/final_profiles_r4.sh); durations from rocprofv3 --kernel-trace --stats of bench.py (profiles/r4_kernel_stats.csv)",
         "notes": ["FETCH_SIZE / WRITE_SIZE are KB per dispatch (mean)",
-                  "gfx950: FETCH_SIZE reports 1/2 of the bytes of coalesced reads (MI355X_MICROARCH.md, HBM section): x2, calibrated on k_copy in the same pass (reads 208.0 MB, FETCH_SIZE 101.6 MB)",
+                  "gfx950: FETCH_SIZE reports 1/2 of the bytes of coalesced reads (MI355X_MICROARCH.md, HBM section): x2, calibrated in round 3 on k_copy (reads 208.0 MB, FETCH_SIZE 101.6 MB: profiles/r3_pmc_summary.json)",
                   "SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_16x16x4_f32, ~16 per v_mfma_f32_16x16x32_bf16); mfma_busy_frac = MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)",
                   "k_tile<7,4,2,true,true> / k_tile<7,5,2,true,true> are the persistent block chain (split-bf16 build) with / without the R stores (Dev::r_store): one dispatch = one clustering round = 20 block steps"], "kernels": {}}
 for k in sorted(set(fe) | set(wr) | set(sq)):
