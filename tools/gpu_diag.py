@@ -68,7 +68,7 @@ def timing(N, K=100, B=10, iters=3):
     res = []
     for rep in range(2):
         g.restart()
-        g.set_profile(True)
+        g.set_profile(2)
         t = time.time(); g.init_cluster_cpp(); t_init = time.time() - t
         tc = tm = 0.0
         nit = 0

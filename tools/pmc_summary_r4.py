@@ -41,7 +41,7 @@ for src, dst in [("kernel_stats.csv", "r4_kernel_stats.csv"), ("bench_rocprof.js
                  ("bench_10M.json", "r4_bench_10M_one_gpu.json"), ("bench_c5_1M.json", "r4_bench_c5_1M.json"), ("bench_c5_5M.json", "r4_bench_c5_5M.json"),
                  ("bench_2ranks_p2p.json", "r4_bench_2ranks_one_gpu_p2p_chain.json"), ("bench_2ranks_allreduce.json", "r4_bench_2ranks_one_gpu_allreduce_per_block.json"),
                  ("ref_kernel_stats.csv", "r4_ref_arith_kernel_stats.csv"), ("ref_profile.json", "r4_ref_arith_profile.json"), ("round_timeline.txt", "r4_round_timeline.txt"),
-                 ("bench_strong_1gpu_10M.json", "r4_bench_total_cells_10M_one_gpu.json"), ("bench_2ranks_file_bootstrap.json", "r4_bench_2ranks_one_gpu_file_bootstrap.json")]:
+                 ("bench_strong_1gpu_10M.json", "r4_bench_total_cells_10M_one_gpu.json")]:
     if os.path.exists(os.path.join(R, src)): shutil.copy(os.path.join(R, src), os.path.join(P, dst))
 for k, v in summ["kernels"].items():
     print(k, {x: (round(y, 3) if isinstance(y, float) else y) for x, y in v.items() if x in ("avg_duration_us", "hbm_GBps", "mfma_busy_frac", "hbm_total_bytes")})

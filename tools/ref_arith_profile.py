@@ -39,7 +39,7 @@ def run():
 
 
 run()
-g.set_profile(True)
+g.set_profile(2)
 t0 = time.perf_counter()
 its = [run() for _ in range(a.steps)]
 g.getZcorr()

@@ -11,7 +11,7 @@ g = Harmony(seed=1); g.set_stream(torch.cuda.current_stream().cuda_stream); g.se
 for dbg in (0,):
     g._set("upd_debug", dbg)
     g.moe_correct_ridge_cpp(); torch.cuda.synchronize()
-    g.set_profile(True)
+    g.set_profile(2)
     for _ in range(5): g.moe_correct_ridge_cpp()
     print("dbg", dbg, "ridge_statistics ms per call", g._scalar("gputimer:ridge_statistics") / 5)
     g.set_profile(False)
