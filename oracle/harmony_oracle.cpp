@@ -29,7 +29,11 @@
 //   arma::kmeans(...,keep_existing,1)  ONE Lloyd iteration: assign to the nearest
 //                           mean (Euclidean), new mean = average of members, an
 //                           empty cluster keeps its previous mean  [our definition]
-//   arma::inv               fp32 LU with partial pivoting (faithful mode)
+//   arma::inv               fp32 LU with partial pivoting (faithful mode): UNBLOCKED, row by row.  Armadillo calls
+//                           LAPACK sgetrf + sgetri, whose blocked update order depends on the BLAS the reference
+//                           package was linked with: the same factorisation, not the same rounding sequence --
+//                           this branch (several covariates, src/harmony.cpp:573) cannot be pinned bit for bit
+//                           without that BLAS.  The GPU's reference-arithmetic mode matches THIS restatement.
 //
 // Two arithmetic modes (hard part 3):
 //   faithful  fp32 state and fp32 accumulators in the reference's operation order
