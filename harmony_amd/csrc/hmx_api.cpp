@@ -2558,6 +2558,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "carried_rounds") return scalar((double)ctx->carried_rounds);
   if (f == "rounds_without_R") return scalar((double)ctx->rounds_without_R);
   if (f == "chain_rounds") return scalar((double)ctx->chain_rounds);
+  if (f == "shuffle_inv") return scalar(ctx->shuf_inv ? 1.0 : 0.0);
   if (f == "p2p:exchange_us") return scalar(ctx->p2p_exchange_us);
   if (f == "p2p:allreduce_calls") return scalar((double)ctx->p2p_ar_calls);
   if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);

@@ -200,6 +200,41 @@ def test_carried_old_contributions_equal_a_fresh_pass(monkeypatch, shape, chain)
     np.testing.assert_allclose(Oa[:, :L0], Odirect, rtol=2e-6, atol=1e-3)
 
 
+@pytest.mark.parametrize("shape", [dict(N=30000, K=100, levels=(10,)), dict(N=20000, K=60, levels=(3, 4)), dict(N=250000, K=100, levels=(3,)), dict(N=70001, K=40, levels=(2,))])
+def test_sort_free_shuffle_equals_the_counting_sort(monkeypatch, shape):
+    """The padded block order of a round (update_R's shuffle, src/harmony.cpp:272-300) is built without a sort on one GPU: the cells of
+    a block are the inverse images of its positions under the shuffle's bijection (k_shuf_count / scan / place).  Against the counting
+    sort of the same (seed, round) permutation: the same cells in the same (block, combination, next block) bins, so every
+    order-independent result -- O, R, Z_corr -- is bit-identical, with the same iteration count.  Sizes that are not multiples of the part
+    size, one and several combinations, a domain with heavy cycle walking (70001 cells in 2^18)."""
+    Z, meta, _ = synth(shape["N"], d=30, levels=shape["levels"], seed=33)
+    vars_use = list(meta)
+    skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=shape["K"])
+    monkeypatch.setenv("HMX_SOLD_CARRY", "1")
+    out = []
+    for inv in ("1", "0"):
+        monkeypatch.setenv("HMX_SHUFFLE_INV", inv)
+        g = Harmony(seed=9)
+        g.setup(**skw)
+        assert int(g._scalar("shuffle_inv")) == int(inv)
+        g.init_cluster_cpp()
+        it = 0
+        for it in range(1, 4):
+            assert g.cluster_cpp() == 0
+            g.moe_correct_ridge_cpp()
+            if g.check_convergence(1):
+                break
+        assert g.cluster_cpp() == 0
+        assert g._scalar("carried_rounds") > 0
+        out.append((it, g.O.copy(), g.R.copy(), g.getZcorr().copy(), list(g.objective_kmeans)))
+    (ia, Oa, Ra, Za, ja), (ib, Ob, Rb, Zb, jb) = out
+    assert ia == ib and len(ja) == len(jb)
+    np.testing.assert_array_equal(Oa, Ob)
+    np.testing.assert_array_equal(Ra, Rb)
+    np.testing.assert_array_equal(Za, Zb)
+    np.testing.assert_allclose(ja, jb, rtol=1e-9)
+
+
 @pytest.mark.parametrize("K", [12, 60, 64, 104, 116, 128, 148, 192, 200, 256])
 def test_every_cluster_tile_shape(K):
     """The tile kernels deal clusters to MFMA columns in quads (a lane's columns are consecutive clusters: 16 / 12 / 8 / 4-byte R
