@@ -312,17 +312,12 @@ struct hmx_ctx {
   SortSet sets[4] = {}; int oset_mask = 1;      // order sets: round & oset_mask (two; four with the batched shuffle, sort_sched = 3)
   hipStream_t side = nullptr; hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   int64_t sorted_round[4] = {-1, -1, -1, -1}; uint64_t sorted_seed[4] = {}; bool sorted_on_side[4] = {}; bool sort_overlap = true;
-  // Round-4 schedule of the shuffle (sort_sched = 2, default): its HISTOGRAM half depends on (seed, round) only and runs rounds ahead on the side
-  // stream, into one of four slots (round & 3: block ids, composite keys, per-chunk counts); its dependent TAIL (bin scan, bin offsets,
-  // scatter) is enqueued on the MAIN stream right behind the block chain of the round before -- in queue order, no cross-stream event between
-  // a chain launch and the next one (round 3: the whole sort of round r + 1 sat on the side stream behind chain r: 30 us of sort tail, a
-  // 27 us event hand-over and the next histogram in front of every chain launch, profiles/r3_round_timeline.txt).
-  struct HistSet { int* blk; int* blkv; int* counts; };
-  HistSet hset[4] = {}; int64_t hist_round[4] = {-1, -1, -1, -1}; uint64_t hist_seed[4] = {0, 0, 0, 0}; bool hist_on_side[4] = {false, false, false, false}, hist_nxt[4] = {false, false, false, false};
-  hipEvent_t ev_hist[4] = {nullptr, nullptr, nullptr, nullptr}; int sort_sched = 2;
-  // sort_sched = 3: the shuffles of FOUR consecutive rounds in one set of four launches on the main stream (l_sort_batch), into four full order
+  int sort_sched = 3;
+  // sort_sched = 3 (default): the shuffles of FOUR consecutive rounds in one set of launches on the main stream (l_sort_batch / l_shuffle_inv), into four full order
   // sets -- rounds keep their numbers across cluster_cpp calls, so a batch serves whichever calls its rounds fall into; between two block
-  // chains of a batch there is no sort kernel and no event at all.  The batches are aligned groups (round >> 2).
+  // chains of a batch there is no sort kernel and no event at all.  The batches are aligned groups (round >> 2).  sort_sched = 1: round 3's
+  // schedule (the whole sort of round r + 1 on the side stream behind chain r; also what host-provided orders use).  (A schedule in between --
+  // histogram halves rounds ahead on the side stream, the dependent tail on the main stream behind the chain -- was built and superseded: DESIGN 4.5.)
   // the sort-free form of the batched shuffle (k_shuf_*): position -> (cell, rank) per order set, the blocks of the round behind a batch,
   // the (block, bin, part) count matrix
   bool shuf_inv = false; int2* posr[4] = {}; int* shuf_partcnt[4] = {}; int* shuf_binacc[4] = {}; int64_t injected_round = -1;   // (injected_round: the round whose order the host provided -- its D.blk came with it)
@@ -361,7 +356,6 @@ void free_all(hmx_ctx* ctx) {
     if (ctx->ev_free[i]) { (void)hipEventDestroy(ctx->ev_free[i]); ctx->ev_free[i] = nullptr; }
   }
   for (int i = 0; i < 4; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
-  for (int i = 0; i < 4; i++) { if (ctx->ev_hist[i]) { (void)hipEventDestroy(ctx->ev_hist[i]); ctx->ev_hist[i] = nullptr; } ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; }
   {   // reference-arithmetic buffers (grown on demand, not in `allocs`)
     void* ps[] = {ctx->sq_start, ctx->sq_end, ctx->sq_total, ctx->sq_mismatch, ctx->headlist, ctx->roundlist, ctx->Of, ctx->Ef, ctx->Mtab, ctx->objT,
                   ctx->inset, ctx->obj_start, ctx->rg_start, ctx->headlev, ctx->roundlev, ctx->pairlist, ctx->pair_idx, ctx->rg_tot, ctx->rp_tot, ctx->rp_start, ctx->plan_pair.d_segs, ctx->plan_pair.d_chains, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
@@ -745,41 +739,6 @@ int kmeans_centers(hmx_ctx* ctx) {
 void apply_set(Dev& D, const hmx_ctx::SortSet& s) {
   D.blk = s.blk; D.lorder = s.lorder; D.lpair = s.lpair; D.lcombo = s.lcombo; D.boff = s.boff; D.binoff = s.binoff; D.counts = s.counts; D.offs = s.offs; D.blkv = s.blkv; D.bincnt = s.bincnt;
 }
-// ---- sort_sched = 2 -----------------------------------------------------------------------------------------------------------
-void apply_hist(Dev& D, const hmx_ctx::HistSet& hs) { D.blk = hs.blk; D.blkv = hs.blkv; D.counts = hs.counts; }
-// the histogram half of round `round` into slot round & 3 (no-op if it is there already)
-int enqueue_hist(hmx_ctx* ctx, uint64_t round, bool on_side) {
-  const int hs = (int)(round & 3);
-  if (ctx->hist_round[hs] == (int64_t)round && ctx->hist_seed[hs] == ctx->seed) return 0;
-  Dev Dt = ctx->D; apply_hist(Dt, ctx->hset[hs]);
-  Dt.nxt = ctx->carry_ok ? 1 : 0;
-  Launch L2 = ctx->L;
-  if (on_side && ctx->side) {
-    // behind everything the main stream has queued so far: the slot's last readers (tail / old-sum pass of round - 4) are among it
-    HIPCHK(hipEventRecord(ctx->ev_free[hs & 1], ctx->L.stream));
-    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_free[hs & 1], 0));
-    L2.stream = ctx->side;
-  } else if (ctx->hist_on_side[hs]) {        // (an older prefetch into this slot may still be running on the side stream)
-    HIPCHK(hipStreamWaitEvent(ctx->L.stream, ctx->ev_hist[hs], 0));
-  }
-  l_sort_hist(L2, Dt, true, ctx->seed, round, (uint64_t)ctx->N_global, (uint64_t)ctx->goff, ctx->cells_per_block); KCHK();
-  ctx->hist_on_side[hs] = on_side && ctx->side;
-  if (ctx->hist_on_side[hs]) HIPCHK(hipEventRecord(ctx->ev_hist[hs], ctx->side));
-  ctx->hist_round[hs] = (int64_t)round; ctx->hist_seed[hs] = ctx->seed; ctx->hist_nxt[hs] = Dt.nxt != 0;
-  return 0;
-}
-// the dependent half of round `round` on the MAIN stream, into order set round & 1 (no-op if it is there already)
-int enqueue_tail(hmx_ctx* ctx, uint64_t round) {
-  const int os = (int)(round & 1), hs = (int)(round & 3);
-  if (ctx->sorted_round[os] == (int64_t)round && ctx->sorted_seed[os] == ctx->seed) return 0;
-  CHK(enqueue_hist(ctx, round, false));                       // (in line if nobody prefetched it)
-  if (ctx->hist_on_side[hs]) { HIPCHK(hipStreamWaitEvent(ctx->L.stream, ctx->ev_hist[hs], 0)); ctx->hist_on_side[hs] = false; }
-  Dev Dt = ctx->D; apply_set(Dt, ctx->sets[os]); apply_hist(Dt, ctx->hset[hs]);
-  Dt.nxt = ctx->hist_nxt[hs] ? 1 : 0;
-  l_sort_tail(ctx->L, Dt); KCHK();
-  ctx->sorted_round[os] = (int64_t)round; ctx->sorted_seed[os] = ctx->seed; ctx->sorted_nxt[os] = Dt.nxt != 0; ctx->sorted_on_side[os] = false;
-  return 0;
-}
 // ---- sort_sched = 3 -----------------------------------------------------------------------------------------------------------
 // rounds first..(first | 3) in one batch of launches on the main stream, into sets round & 3.
 // (Sorting a group AHEAD on the side stream was measured twice and lost twice: next to the persistent block chain every block step got
@@ -810,17 +769,6 @@ int sort_group(hmx_ctx* ctx, uint64_t first) {
   }
   return 0;
 }
-// after the block steps of round `round` have been queued: the next round's tail right behind them, the histograms of the rounds after that
-// (sort_sched = 2)
-int sort_after_round(hmx_ctx* ctx, uint64_t round) {
-  if (ctx->sort_sched != 2 || !ctx->injected.empty() || ctx->rng_mode == 1) return 0;
-  CHK(enqueue_hist(ctx, round + 1, false));
-  // the histograms first: their side-stream wait is then for the block steps just queued only, and they run NEXT TO the tail below (queued
-  // behind the tail they would start as it ends -- right in front of the next chain launch, whose workgroups need every CU empty)
-  for (int k = 2; k <= 3; k++) CHK(enqueue_hist(ctx, round + k, true));
-  CHK(enqueue_tail(ctx, round + 1));
-  return 0;
-}
 int prepare_round(hmx_ctx* ctx, uint64_t round) {
   Dev& D = ctx->D;
   const int sset = (int)(round & (uint64_t)ctx->oset_mask);
@@ -830,20 +778,6 @@ int prepare_round(hmx_ctx* ctx, uint64_t round) {
     apply_set(D, ctx->sets[sset]);
     D.nxt = ctx->sorted_nxt[sset] ? 1 : 0;
     return 0;
-  }
-  if (ctx->sort_sched == 2 && !host_order) {
-    CHK(enqueue_tail(ctx, round));
-    apply_set(D, ctx->sets[sset]); apply_hist(D, ctx->hset[round & 3]);
-    D.nxt = ctx->sorted_nxt[sset] ? 1 : 0;
-    // (no histogram prefetch HERE: queued in front of a chain launch, the side stream's histogram grabs CUs a moment before the persistent
-    //  chain wants all of them -- its small waves then hold up the chain's workgroups, measured 19 us per round.  sort_after_round queues the
-    //  histograms BEHIND the chain: they run next to the sort tail of the following round, while the GPU is nearly idle.)
-    return 0;
-  }
-  if (ctx->sort_sched == 2) {       // host-provided order: the in-line path below, on set `sset` and its own histogram arrays; prefetched slots are void
-    for (int i = 0; i < 4; i++) ctx->hist_round[i] = -1;
-    if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
-    for (int i = 0; i < 4; i++) ctx->hist_on_side[i] = false;
   }
   if (ctx->sorted_on_side[sset]) {   // a prefetch into this set is (or was) in flight on the side stream: order the main stream behind it
     HIPCHK(hipStreamWaitEvent(ctx->L.stream, ctx->ev_sorted[sset], 0));
@@ -1299,7 +1233,6 @@ int update_R(hmx_ctx* ctx) {
     if (j == D.nb) break;
     { Launch Le; CHK(launch_with_events(ctx, Le)); l_update(Le, D, j); KCHK(); if (ctx->profile) ctx->prof_update_steps++; }
   }
-  CHK(sort_after_round(ctx, ctx->round_counter - 1));      // (sort_sched = 2) the next round's sort tail right behind this round's block steps
   if (chain_tail) {
     if (!chain_old) ctx->sold_state[ctx->sold_cur] = 0;
     ctx->sets_clean = true;
@@ -1996,7 +1929,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lowest priority: the shuffle only fills gaps
       HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, lo)); }
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); }
-    { const char* sc = getenv("HMX_SORT_SCHED"); const int v = sc ? atoi(sc) : 3; ctx->sort_sched = (v >= 1 && v <= 3) ? v : 3; if (!ctx->sort_overlap) ctx->sort_sched = 1; }
+    { const char* sc = getenv("HMX_SORT_SCHED"); const int v = sc ? atoi(sc) : 3; ctx->sort_sched = v == 1 ? 1 : 3; if (!ctx->sort_overlap) ctx->sort_sched = 1; }
     ctx->oset_mask = ctx->sort_sched == 3 ? 3 : 1;
     { const char* si = getenv("HMX_SHUFFLE_INV"); const int v = si ? atoi(si) : 1;      // 0: counting sort always; 2: sort-free form on sharded runs too
       ctx->shuf_inv = ctx->sort_sched == 3 && v != 0 && (ctx->world == 1 || v == 2) && ctx->carry_ok &&      /* (without the carry every round needs D.blk: the counting sort has it for free) */
@@ -2013,12 +1946,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
       CHK(dalloc(ctx, &u.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &u.binoff, (size_t)nV * Q + 1)); CHK(dalloc(ctx, &u.boff, (size_t)D.nb + 1));
       CHK(dalloc(ctx, &u.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &u.offs, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &u.blkv, (size_t)N)); CHK(dalloc(ctx, &u.bincnt, (size_t)nV * Q));
     }
-    ctx->hset[0] = {ctx->sets[0].blk, ctx->sets[0].blkv, ctx->sets[0].counts}; ctx->hset[1] = {ctx->sets[1].blk, ctx->sets[1].blkv, ctx->sets[1].counts};
-    for (int i = 2; i < 4; i++) {
-      if (ctx->sort_sched == 2) { CHK(dalloc(ctx, &ctx->hset[i].blk, (size_t)N)); CHK(dalloc(ctx, &ctx->hset[i].blkv, (size_t)N)); CHK(dalloc(ctx, &ctx->hset[i].counts, (size_t)nV * D.nchunks)); }
-      else ctx->hset[i] = ctx->hset[i & 1];
-    }
-    for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_hist[i], hipEventDisableTiming)); ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; } }
+  }
   CHK(dalloc(ctx, &D.items, items.size())); CHK(dalloc(ctx, &D.aitems, aitems.size())); CHK(dalloc(ctx, &D.titems, titems.size()));
   CHK(dalloc(ctx, &D.Sq, (size_t)Q * d * K)); CHK(dalloc(ctx, &D.nq, (size_t)Q * K));
   { const char* e = getenv("HMX_MOE_SOLVE"); ctx->solve_on_device = !(e && std::string(e) == "host") && (size_t)(B + 1) * 16 * 8 + (size_t)(4 * B + 8 + C) * 4 <= 158 * 1024; }   // (LDS panel of the device Cholesky)
@@ -2232,7 +2160,6 @@ int hmx_restart(hmx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->D.solve_err, 0, sizeof(int), ctx->L.stream));
   if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
   for (int i = 0; i < 4; i++) ctx->sorted_round[i] = -1;      // (sorted_on_side stays: a sort still running on the side stream is waited for before its set is reused)
-  for (int i = 0; i < 4; i++) { ctx->hist_round[i] = -1; ctx->hist_on_side[i] = false; }
   return 0;
 }
 
