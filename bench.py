@@ -657,6 +657,10 @@ def main():
             for nm, o in (("wg0", 16), ("wg100", 32)):
                 chain[nm + "_wave_busy_us"] = [round(float(dbg[o + w]) / 100.0 / steps_, 2) for w in range(8)]
                 chain[nm + "_wave_tiles"] = [round(float(dbg[o + 8 + w]) / steps_, 2) for w in range(8)]
+        if len(dbg) >= 64:   # the same worker phases for a SIMD's younger wave (wave 4: two tiles, wave 5: one tile of workgroup 0)
+            ph = ["wait_flag", "copy_table", "wait_atomics", "barrier_arrive", "next_mfma", "tiles_but_last", "last_epilogue", "flush"]
+            for nm, o in (("wg0_wave4", 48), ("wg0_wave5", 56)):
+                chain[nm + "_phases_us"] = {p_: round(float(dbg[o + i]) / 100.0 / steps_, 3) for i, p_ in enumerate(ph)}
     # T_e2e: T_conv + H2D of Z (double, the R seam) + D2H of Z_corr (double); PCIe-inclusive, never `value`
     e2e = None
     if not a.no_e2e:

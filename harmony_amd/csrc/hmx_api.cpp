@@ -2114,9 +2114,9 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
       ctx->chain_ok = hf[0] != 0; ctx->fused_ok = hf[1] != 0;
     }
     CHK(dalloc(ctx, &D.tail_ticket, (size_t)1)); HIPCHK(hipMemsetAsync(D.tail_ticket, 0, sizeof(int), ctx->L.stream));
-    CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)48));
+    CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)64));
     CHK(dalloc(ctx, &D.Sold_rep, (size_t)D.nrep * D.nb * B * K));
-    HIPCHK(hipMemsetAsync(D.chain_dbg, 0, sizeof(unsigned long long) * 48, ctx->L.stream));
+    HIPCHK(hipMemsetAsync(D.chain_dbg, 0, sizeof(unsigned long long) * 64, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.pen_g, 0, sizeof(unsigned long long) * (size_t)B * K, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 24), ctx->L.stream));
     // in-chain old sums (opt-in): measured 25.8 us per block step against 20.4 us + the 100 us k_oldsum pass per round -- a wash at
@@ -2491,10 +2491,10 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);
   if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them
     if (!ctx->ran_setup) return -1;
-    if (!out) return 48;      // [0..12] folder / workgroup 0 wave 0 phases, [16..31] workgroup 0 and [32..47] workgroup 100: per wave busy ticks, tiles
-    std::vector<unsigned long long> h(48);
-    if (d2h(ctx, h.data(), ctx->D.chain_dbg, 48)) return -1;
-    (void)hipMemsetAsync(ctx->D.chain_dbg, 0, sizeof(unsigned long long) * 48, ctx->L.stream);
+    if (!out) return 64;      // [0..12] folder / workgroup 0 wave 0 phases, [16..31] workgroup 0 and [32..47] workgroup 100: per wave busy ticks, tiles; [48..55] / [56..63]: wave 4 / 5 of workgroup 0, the phases of [4..11]
+    std::vector<unsigned long long> h(64);
+    if (d2h(ctx, h.data(), ctx->D.chain_dbg, 64)) return -1;
+    (void)hipMemsetAsync(ctx->D.chain_dbg, 0, sizeof(unsigned long long) * 64, ctx->L.stream);
     return vec(h);
   }
   if (f.rfind("gputimer:", 0) == 0) {   // GPU time of a phase (profile mode), ms; "gputimer:Rcells_update" == "prof:update_ms"

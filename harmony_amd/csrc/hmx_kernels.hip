@@ -2592,6 +2592,10 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       const int o = (blockIdx.x == 0 ? 16 : 32) + (tid >> 6);
       atomicAdd(&D.chain_dbg[o], wv_busy); atomicAdd(&D.chain_dbg[o + 8], wv_tiles);
     }
+    if (blockIdx.x == 0 && (tid == 256 || tid == 320) && D.chain_dbg) {      // the same phase clocks for a SIMD's YOUNGER wave: wave 4 (two tiles), wave 5 (one)
+      unsigned long long* const o = D.chain_dbg + (tid == 256 ? 48 : 56);
+      atomicAdd(&o[0], wq); atomicAdd(&o[1], wg); atomicAdd(&o[2], ww); atomicAdd(&o[3], wd); atomicAdd(&o[4], wm); atomicAdd(&o[5], w1); atomicAdd(&o[6], w2); atomicAdd(&o[7], w3);
+    }
     return;
     }
   }

@@ -10,5 +10,7 @@ import json
 j = json.loads(open("$O/b_${v}_$i.json").read().strip().splitlines()[-1])
 c = j["config"].get("chain_us_per_block_step") or {}
 print("$VAR=$v ms_per_step", round(j["ms_per_step"], 3), "step_us", round(j["roofline"]["avg_block_step_us"], 2), "frac", round(j["roofline"]["frac"], 4), "wg0 busy", c.get("wg0_wave_busy_us"), "barrier", c.get("worker_barrier_arrive"), "mfma", c.get("worker_next_mfma"))
+print("   wave0", {k[7:]: c[k] for k in c if k.startswith("worker_")})
+print("   wave4", c.get("wg0_wave4_phases_us")); print("   wave5", c.get("wg0_wave5_phases_us"))
 PY
 done; done
