@@ -42,6 +42,7 @@ SIGNATURES = {
     "hmx_r_shuffle": (None, [C.c_uint32, C.c_int64, _lp]),
     "hmx_mt19937_by_array": (None, [C.POINTER(C.c_uint32), C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),
     "hmx_feistel_pos": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "hmx_feistel_cell": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "hmx_u01": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "hmx_cluster_of_column": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "hmx_push_update_order": (C.c_int, [C.c_void_p, _lp]),

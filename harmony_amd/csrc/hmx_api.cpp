@@ -1450,6 +1450,22 @@ const char* hmx_last_warning(hmx_ctx* ctx) {   // one-shot: a warning is reporte
   return ctx->warn_ret.c_str();
 }
 
+uint64_t hmx_feistel_cell(uint64_t seed, uint64_t round, uint64_t N, uint64_t pos) {
+  int bits = 2;
+  while (((uint64_t)1 << bits) < N) bits += 2;
+  const int half = bits / 2;
+  const uint32_t mask = (uint32_t)(((uint64_t)1 << half) - 1);
+  uint32_t keys[6];
+  for (int r = 0; r < 6; r++)
+    keys[r] = (uint32_t)(h_splitmix64(seed ^ (round * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(r + 1) << 56)) >> 32);
+  uint64_t x = pos;
+  do {
+    uint32_t L = (uint32_t)(x >> half), R = (uint32_t)(x & mask);
+    for (int r = 5; r >= 0; r--) { uint32_t t = R ^ (h_fmix32(L * 0x9E3779B1u + keys[r]) & mask); R = L; L = t; }
+    x = ((uint64_t)L << half) | R;
+  } while (x >= N);
+  return x;
+}
 uint64_t hmx_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g) {
   int bits = 2;
   while (((uint64_t)1 << bits) < N) bits += 2;

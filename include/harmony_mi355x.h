@@ -165,6 +165,10 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t value);
  * equality with a live R run needs R.  The draws are made on the host (N per round): a compatibility mode, not the
  * fast path. */
 uint64_t hmx_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g);
+/* the inverse of the same bijection: the global cell that sits at position `pos` of round `round` (the rounds run backwards, the cycle walk
+ * likewise).  The cells of block b are hmx_feistel_cell(seed, r, N, p) for p in [b * cells_per_block, (b + 1) * cells_per_block): the library
+ * builds a round's block order from it without sorting (round 4). */
+uint64_t hmx_feistel_cell(uint64_t seed, uint64_t round, uint64_t N, uint64_t pos);
 int hmx_set_uniform_source(hmx_ctx* ctx, double (*unif_rand)(void* user), void* user);
 /* probes of the R-compatible stream (host only, no device needed; used by the CPU tests) */
 void hmx_r_runif(uint32_t seed, int32_t n, double* out);            /* set.seed(seed); runif(n)                      */

@@ -60,6 +60,23 @@ def test_r_compatible_stream_known_answers():
         assert np.array_equal(a, orc.r_shuffle(seed, N))
 
 
+def test_feistel_inverse():
+    """hmx_feistel_cell is the inverse of hmx_feistel_pos (the sort-free shuffle enumerates a block's cells with it): for domains with
+    little and with heavy cycle walking, and it lists every block's cells exactly once."""
+    lib = _lib.load()
+    for seed, rnd, N in [(1, 0, 300), (7, 3, 2370), (123456789, 17, 1000003), (5, 2, 6), (9, 1, 64), (9, 1, 65), (3, 4, 70001)]:
+        gs = np.unique(np.concatenate([np.arange(min(N, 40)), np.random.default_rng(1).integers(0, N, 60)]))
+        for g in gs:
+            p = lib.hmx_feistel_pos(seed, rnd, N, int(g))
+            assert 0 <= p < N and lib.hmx_feistel_cell(seed, rnd, N, p) == int(g)
+    N, nb = 1000, 20
+    cpb = N // nb
+    cells = [lib.hmx_feistel_cell(11, 2, N, p) for p in range(N)]
+    assert sorted(cells) == list(range(N))
+    for b in range(nb):
+        assert all(min(lib.hmx_feistel_pos(11, 2, N, c) // cpb, nb - 1) == b for c in cells[b * cpb:(b + 1) * cpb])
+
+
 def test_feistel_is_a_permutation():
     lib = _lib.load()
     for N in (6, 40, 300, 1000, 4097):
