@@ -267,6 +267,10 @@ struct hmx_ctx {
   unsigned* sq_mismatch = nullptr; int seq_passes = 3; int64_t seq_runs = 0;
   // long chains (>= seq_adaptive_cells cells) are iterated until the starts stop moving (chain-relative residual <= 2^-22) or seq_max_passes
   unsigned* sq_conv = nullptr; int seq_max_passes = 24; int64_t seq_adaptive_cells = 200000, seq_extra_passes = 0; double seq_resid_max = 0.0; uint64_t seq_mismatch_sum = 0;
+  // seq_strict: EVERY group of restarted sums (short chains too) is iterated until no segment start moves any more -- the fixed point, at which
+  // the concatenated segment loops are the reference's one-after-the-other loop bit for bit (tests/test_gpu_seq.py) -- instead of stopping at the
+  // default pass count / the 2^-22 residual.  seq_group_passes / seq_group_runs: passes and runs per group (0 O/E, 1 objective, 2 ridge, 3 level pairs)
+  bool seq_strict = false; uint64_t seq_last_mismatch = 0, seq_unsettled = 0; int64_t seq_group_passes[4] = {0, 0, 0, 0}, seq_group_runs[4] = {0, 0, 0, 0};
   int* headlist = nullptr;                 // [(1 + C) n] cells in original order | cells by (level of covariate c, original order)
   std::vector<int> lev_off, lev_cnt;       // [B] a level's range inside its covariate's part of headlist
   int* headlev = nullptr; int* roundlev = nullptr;     // [min(C, 4)][n] level codes of the positions of headlist's first part / of roundlist
@@ -294,6 +298,10 @@ struct hmx_ctx {
   long long* sold_buf[2] = {nullptr, nullptr}; int sold_cur = 0, sold_state[2] = {1, 1}; int64_t sold_round[2] = {-1, -1}; uint64_t sold_seed[2] = {0, 0};
   bool sets_clean = false;     // the three Snew replica sets are all zero
   bool carry_ok = false, last_round_hint = false, round_may_be_last = true; bool sorted_nxt[4] = {};
+  // R rows that nobody reads are not stored (Dev::r_store = 0: the head inside cluster_cpp, rounds that cannot be a call's last).  R_valid says
+  // whether D.R holds the rows of the LAST head / round: cleared when a pass starts, set when a storing pass has been queued completely.  A call
+  // that fails half way leaves it false, and the getters / the correction refuse to consume stale rows.  r_store_always: HMX_R_STORE=1, read at setup.
+  bool R_valid = false, r_store_always = false;
   int64_t rounds_without_R = 0;
   int64_t carried_rounds = 0;
   bool chain_ok = false; int chain_wgs = 0; uint64_t chain_rounds = 0;   // persistent block chain (one launch per round)
@@ -402,8 +410,12 @@ int allreduce(hmx_ctx* ctx, void* buf, int64_t count, int dtype) {
     if (st) return fail(ctx, HMX_ERR_COMM, "all-reduce callback failed");
     return 0;
   }
-  if (!ctx->comm && !(ctx->p2p_on && ctx->p2p_world == ctx->world)) return fail(ctx, HMX_ERR_COMM, "sharded handle without hmx_comm_init or an all-reduce hook");
+  // (a handle that has inboxes but neither a communicator nor a hook -- hmx_p2p_connect by hand -- gets here with what the inboxes do not take:
+  //  the collectives of hmx_setup, buffers above P2P_CAP entries, everything under HMX_P2P_AR=0.  That is an error, not an RCCL call on a null communicator.)
+  if (!ctx->comm) return fail(ctx, HMX_ERR_COMM, ctx->p2p_on ? "this collective does not fit the peer inboxes (before setup / more than 65536 entries / HMX_P2P_AR=0): the handle also needs hmx_comm_init or an all-reduce hook"
+                                                            : "sharded handle without hmx_comm_init or an all-reduce hook");
   RcclApi* api = rccl_api(nullptr);
+  if (!api || !api->AllReduce) return fail(ctx, HMX_ERR_COMM, "librccl is not loadable");
   ncclResult_t r = api->AllReduce(buf, buf, (size_t)count, dtype == 1 ? ncclFloat64 : ncclInt64,
                                   dtype == 2 ? ncclMin : ncclSum, ctx->comm, ctx->L.stream);
   if (r != ncclSuccess) return fail(ctx, HMX_ERR_COMM, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(r) : "error"));
@@ -550,9 +562,9 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
     // the head of cluster_cpp is followed, inside the same call, by a round that rewrites every R row and takes its old contributions from
     // the sums filed here: the head's own rows are never read (Dev::r_store) -- 4K bytes per cell less.  (init_cluster_cpp's head is followed
     // by the caller, who may read R: it stores.)
-    { const char* rs = getenv("HMX_R_STORE");
-      if (normalise && ctx->max_iter_kmeans >= 1 && !ctx->poll && !(rs && atoi(rs) == 1)) D.r_store = 0; }
+    if (normalise && ctx->max_iter_kmeans >= 1 && !ctx->poll && !ctx->r_store_always) D.r_store = 0;
   }
+  ctx->R_valid = false;
   HIPCHK(hipMemsetAsync(D.O_fx, 0, sizeof(long long) * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.Snew_fx, 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
   HIPCHK(hipMemsetAsync(D.objpart, 0, sizeof(double) * 2 * (size_t)D.objslots * D.nwmax, ctx->L.stream));
@@ -566,6 +578,7 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   CHK(allreduce(ctx, D.O_fx, (int64_t)D.B * D.K, 0));
   CHK(allreduce(ctx, D.obj, 2, 1));
   if (ctx->oe_arith) CHK(oe_head(ctx));        // E = sum(R, 1) Pr_b^T, O = R Phi^T as the reference sums them (:149-150)
+  ctx->R_valid = D.r_store != 0;
   return 0;
 }
 
@@ -865,14 +878,19 @@ int seq_settled(hmx_ctx* ctx, bool* settled) {
   unsigned w[2] = {0, 0};
   CHK(d2h(ctx, w, ctx->sq_conv, 2));
   float r; std::memcpy(&r, &w[1], 4);
-  *settled = w[0] == 0 || r <= 2.4e-7f;
+  *settled = w[0] == 0 || (!ctx->seq_strict && r <= 2.4e-7f);
+  ctx->seq_last_mismatch = w[0];
   ctx->seq_mismatch_sum += w[0]; if ((double)r > ctx->seq_resid_max) ctx->seq_resid_max = (double)r;
   return 0;
 }
 // one restarted-sum iteration scheme for all users: `pass(p, zero_start)` runs the segments, `scan(p, zero_start, conv)` the scan.  The first
 // `seq_passes` passes always run (warm: one less); long chains continue until the starts settled.
-template <class PASS, class SCAN> int seq_iterate(hmx_ctx* ctx, bool warm, bool adaptive, PASS pass, SCAN scan) {
+template <class PASS, class SCAN> int seq_iterate(hmx_ctx* ctx, int group, bool warm, bool adaptive, PASS pass, SCAN scan) {
   int p = warm ? 1 : 0;
+  const int p_first = p;
+  ctx->seq_group_runs[group]++;
+  if (ctx->seq_strict) adaptive = true;
+  struct Count { hmx_ctx* c; int g; const int& p; int p0; ~Count() { c->seq_group_passes[g] += p - p0; } } count{ctx, group, p, p_first};
   for (; p < ctx->seq_passes; p++) {
     const bool last = p == ctx->seq_passes - 1;
     if (last) HIPCHK(hipMemsetAsync(ctx->sq_conv, 0, 2 * sizeof(unsigned), ctx->L.stream));
@@ -891,6 +909,7 @@ template <class PASS, class SCAN> int seq_iterate(hmx_ctx* ctx, bool warm, bool 
     CHK(seq_settled(ctx, &ok));
     ctx->seq_extra_passes++;
   }
+  if (!ok) ctx->seq_unsettled++;       // (seq_max_passes reached with starts still moving: reported, "seq:unsettled")
   return 0;
 }
 // O / E sums of the chain sets [chain0, chain0 + nchains) of plan P over `list`: per chain set (1 + B) * K sequential fp32 sums
@@ -904,7 +923,7 @@ int seq_run_oe(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, const i
   int longest = 0;
   for (int c = chain0; c < chain0 + nchains; c++) longest = std::max(longest, P.seg0[c + 1] - P.seg0[c]);
   const bool adaptive = (int64_t)longest * P.seg_cells >= ctx->seq_adaptive_cells;
-  CHK(seq_iterate(ctx, warm, adaptive,
+  CHK(seq_iterate(ctx, 0, warm, adaptive,
                   [&](bool zero) -> int { l_seq_oe_pass(ctx->L, ctx->D, list, poslev, (int)ctx->N, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
                   [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, chain0, nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->seq_runs++;
@@ -996,7 +1015,7 @@ int seq_objective(hmx_ctx* ctx, const Dev& D) {
   CHK(seq_workspace(ctx, (size_t)3 * nsegs, 3));
   if ((size_t)3 * nsegs > ctx->obj_start_cap) { CHK(seq_grow(ctx, ctx->obj_start, ctx->obj_start_cap, (size_t)3 * nsegs)); ctx->obj_warm = false; }
   l_obj_terms(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->oe_arith ? ctx->Ef : nullptr, ctx->Mtab, ctx->objT, nt); KCHK();
-  CHK(seq_iterate(ctx, ctx->obj_warm, nt >= ctx->seq_adaptive_cells,
+  CHK(seq_iterate(ctx, 1, ctx->obj_warm, nt >= ctx->seq_adaptive_cells,
                   [&](bool zero) -> int { l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, 3, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
                   [&](bool zero, unsigned* conv) -> int { l_seq_scan1(ctx->L, 3, nsegs, ctx->obj_start, ctx->sq_end, ctx->obj_start, ctx->sq_total, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->obj_warm = true;
@@ -1023,7 +1042,7 @@ int seq_ridge_stats(hmx_ctx* ctx) {
   float* const tot = multi ? ctx->rg_tot : ctx->sq_total;          // (after the workspace call: it may have re-allocated sq_total)
   if ((size_t)P.nsegs * W > ctx->rg_start_cap) { CHK(seq_grow(ctx, ctx->rg_start, ctx->rg_start_cap, (size_t)P.nsegs * W)); ctx->rg_warm = false; }
   l_seq_inset(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->sv_cov_bounds, ctx->cutoff, ctx->inset); KCHK();
-  CHK(seq_iterate(ctx, ctx->rg_warm, ctx->N >= ctx->seq_adaptive_cells,
+  CHK(seq_iterate(ctx, 2, ctx->rg_warm, ctx->N >= ctx->seq_adaptive_cells,
                   [&](bool zero) -> int { l_seq_ridge_pass(ctx->L, D, ctx->headlist, P.d_segs, 0, P.nsegs, ctx->inset, ctx->rg_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
                   [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->rg_start, ctx->sq_end, ctx->rg_start, tot, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->rg_warm = true;
@@ -1035,7 +1054,7 @@ int seq_ridge_stats(hmx_ctx* ctx) {
     CHK(seq_workspace(ctx, (size_t)PP.nsegs * ctx->K, 1));
     int longest = 0;
     for (int c = 0; c < PP.nchains; c++) longest = std::max(longest, PP.seg0[c + 1] - PP.seg0[c]);
-    CHK(seq_iterate(ctx, ctx->rp_warm, (int64_t)longest * PP.seg_cells >= ctx->seq_adaptive_cells,
+    CHK(seq_iterate(ctx, 3, ctx->rp_warm, (int64_t)longest * PP.seg_cells >= ctx->seq_adaptive_cells,
                     [&](bool zero) -> int { l_seq_sum_pass(ctx->L, D, ctx->pairlist, PP.d_segs, 0, PP.nsegs, ctx->rp_start, ctx->sq_end, zero ? 1 : 0); KCHK(); return 0; },
                     [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, PP.d_chains, 0, PP.nchains, ctx->K, ctx->rp_start, ctx->sq_end, ctx->rp_start, ctx->rp_tot, conv, zero ? 1 : 0); KCHK(); return 0; }));
     ctx->rp_warm = true;
@@ -1053,6 +1072,7 @@ int update_R_ref(hmx_ctx* ctx) {
   const double t0 = now_ms();
   const int n = (int)ctx->N, B = ctx->B, K = ctx->K, nb = ctx->nb;
   const hmx_ctx::SeqPlan& P = ctx->plan_round;
+  ctx->R_valid = false; D.r_store = 1;
   { PhaseScope ph(ctx, "randomize");
     if (!ctx->injected.empty() || ctx->rng_mode == 1) {       // the host owns the shuffle: its order goes to the device as it is
       if (ctx->injected.empty()) { ensure_rrng(ctx); std::vector<int64_t> o; ctx->rrng.arma_shuffle(ctx->N_global, o); ctx->injected.push_back(std::move(o)); }
@@ -1091,6 +1111,7 @@ int update_R_ref(hmx_ctx* ctx) {
   ctx->sets_clean = false;
   for (int i = 0; i < 2; i++) if (ctx->sold_state[i] == 2) ctx->sold_state[i] = 1;
   if (ctx->profile) ctx->prof_update_cells += ctx->N;
+  ctx->R_valid = true;
   ctx->timers["update_R"] += now_ms() - t0;
   return 0;
 }
@@ -1106,6 +1127,7 @@ int update_R(hmx_ctx* ctx) {
   const bool merged = (size_t)D.B * 128 <= 64 * 1024 && !(fold_env && std::string(fold_env) == "split") &&
                       (ctx->fused_ok || (size_t)D.B * D.K <= 8192 || (fold_env && std::string(fold_env) == "merged"));   // LDS budget of k_foldpen
   const double t0 = now_ms();
+  ctx->R_valid = false;
   { PhaseScope ph(ctx, "randomize");      // the round's shuffle (:272-291, timers "randomize")
     CHK(prepare_round(ctx, ctx->round_counter)); }
   ctx->round_counter++;
@@ -1150,9 +1172,8 @@ int update_R(hmx_ctx* ctx) {
       // (write_next) and this round cannot be the call's last (round_may_be_last, set by hmx_cluster) -- moe_correct_ridge_cpp, the getters
       // and a stand-alone compute_objective only ever see the last round's R.  (A host with an abort poll may leave the call early: it
       // always gets its rows.  HMX_R_STORE=1: always store.)
-      { const char* rs = getenv("HMX_R_STORE");
-        D.r_store = (write_next && !ctx->round_may_be_last && !ctx->poll && !(rs && atoi(rs) == 1)) ? 0 : 1;
-        if (!D.r_store) ctx->rounds_without_R++; }
+      D.r_store = (write_next && !ctx->round_may_be_last && !ctx->poll && !ctx->r_store_always) ? 0 : 1;
+      if (!D.r_store) ctx->rounds_without_R++;
     } }
   // (objpart needs no memset here: k_obj_reduce zeroes every slot it reads, setup / head_pass zero it initially)
   bool round_done = false;   // set by the fused path: all block steps done, skip the step loop below
@@ -1259,6 +1280,7 @@ int update_R(hmx_ctx* ctx) {
   }
   if (!chain_old) ctx->sold_cur ^= 1;      // next round subtracts what this round's tile kernels collected (or a fresh k_oldsum pass)
   D.Sold_next = nullptr;
+  ctx->R_valid = D.r_store != 0;
   if (ctx->profile) { ctx->prof_update_cells += ctx->N; }   // the event pairs are resolved when a "prof:*" field is read
   ctx->timers["update_R"] += now_ms() - t0;
   return 0;
@@ -1701,6 +1723,7 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   }
   else if (f == "stale_dist") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "stale_dist must be set before setup"); ctx->stale_dist = v != 0; }
   else if (f == "seq_passes") { if (v < 2 || v > 64) return fail(ctx, HMX_ERR_ARG, "seq_passes: 2..64"); ctx->seq_passes = (int)v; if (ctx->seq_max_passes < (int)v) ctx->seq_max_passes = (int)v; }
+  else if (f == "seq_strict") { ctx->seq_strict = v != 0; if (v && ctx->seq_max_passes < 64) ctx->seq_max_passes = 64; }
   else if (f == "seq_max_passes") { if (v < 2 || v > 256) return fail(ctx, HMX_ERR_ARG, "seq_max_passes: 2..256"); ctx->seq_max_passes = (int)v; }
   else if (f == "device") ctx->device = (int)v;
   else if (f == "profile") { ctx->profile = (int)(v < 0 ? 0 : v > 2 ? 2 : v); ctx->prof_update_ms = 0; ctx->prof_update_launches = 0; ctx->prof_update_cells = 0; ctx->prof_update_steps = 0; ctx->ev_used = 0;
@@ -1863,6 +1886,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     D.moe_mfma = (K % 4 == 0 && d <= 64 && K <= 256 && !(e && std::string(e) == "v1")) ? 1 : 0;   // K > 128: split statistics kernel
     D.wNT4 = K / 16; D.wtail = (K - 16 * D.wNT4) / 4; D.wNS = 4 * D.wNT4 + D.wtail; D.wNQ = ((d + 15) / 16 + 3) / 4; }
   D.r_store = 1;
+  { const char* rs = getenv("HMX_R_STORE"); ctx->r_store_always = rs && atoi(rs) == 1; }
   D.nwmax = 4 * ctx->L.grid; D.objslots = std::min(D.nb, 64);
   D.pen_lds = ((size_t)D.NQ * 0 + (size_t)B * K * 4 + (size_t)Q * C * 4 <= 24576) ? 1 : 0;
   D.rvec = (K % 4 == 0) ? 1 : 0;
@@ -2215,6 +2239,7 @@ int hmx_init_cluster(hmx_ctx* ctx, const double* Y0) {  // src/harmony.cpp:131-1
 int hmx_compute_objective(hmx_ctx* ctx) {  // src/harmony.cpp:158-170 on the current R, Z_corr, Y, O, E
   if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->R_valid) return fail(ctx, HMX_ERR_STATE, "R is not available: the clustering call that would have stored it did not complete");
   HIPCHK(hipMemsetAsync(ctx->D.objpart, 0, sizeof(double) * 2 * (size_t)ctx->D.objslots * ctx->D.nwmax, ctx->L.stream));
   Dev Ds = ctx->D;
   const bool stale = ctx->stale_dist && ctx->head_is_stale;
@@ -2270,6 +2295,7 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   if (!ctx || !ctx->ran_init) return ctx ? fail(ctx, HMX_ERR_STATE, "init_cluster first") : HMX_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   if (ctx->poll && ctx->poll(ctx->poll_user)) return HMX_ABORTED;  // :355-356
+  if (!ctx->R_valid) return fail(ctx, HMX_ERR_STATE, "R is not available: the clustering call that would have stored it did not complete");
   const double t0 = now_ms();
   const Dev& D = ctx->D;
   const int K = ctx->K, B = ctx->B, d = ctx->d, Q = ctx->Q;
@@ -2544,6 +2570,12 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
     return scalar(f == "seq:mismatch" ? (double)ctx->seq_mismatch_sum : ctx->seq_resid_max);
   }
   if (f == "seq:extra_passes") return scalar((double)ctx->seq_extra_passes);
+  if (f == "seq:unsettled") return scalar((double)ctx->seq_unsettled);
+  if (f == "seq:group_passes" || f == "seq:group_runs") {
+    if (!out) return 4;
+    for (int g = 0; g < 4; g++) out[g] = (double)(f == "seq:group_passes" ? ctx->seq_group_passes[g] : ctx->seq_group_runs[g]);
+    return 4;
+  }
   if (f == "seq:runs") return scalar((double)ctx->seq_runs);
   if (f == "O" || f == "E" || f == "Lambda") {
     const int K = ctx->K, B = ctx->B;
@@ -2560,8 +2592,12 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
     const std::vector<float> E = ctx->oe_arith ? Ef_h : table_E(ctx, ofx);
     if (f == "E") return vec(E);
     std::vector<double> L((size_t)K * (B + 1), 0.0);  // getLambda :657-669
-    for (int k = 0; k < K; k++) for (int b = 0; b < B; b++)
-      L[(size_t)(b + 1) * K + k] = ctx->lambda_estimation ? (double)(E[(size_t)b * K + k] * ctx->alpha) : (double)ctx->lambda[b + 1];
+    // (estimated: find_lambda_cpp's [0, alpha * E[k,:]], src/utils.cpp:159-163; fixed: the caller's whole vector, its entry 0 included)
+    for (int k = 0; k < K; k++) {
+      if (!ctx->lambda_estimation) L[k] = (double)ctx->lambda[0];
+      for (int b = 0; b < B; b++)
+        L[(size_t)(b + 1) * K + k] = ctx->lambda_estimation ? (double)(E[(size_t)b * K + k] * ctx->alpha) : (double)ctx->lambda[b + 1];
+    }
     return vec(L);
   }
   if (f == "Z_corr" || f == "Z_orig" || f == "R") return hmx_get_matrix(ctx, field, out, HMX_F64, HMX_HOST, cap);
@@ -2579,6 +2615,7 @@ int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype
   if ((dtype != HMX_F64 && dtype != HMX_F32) || (location != HMX_HOST && location != HMX_DEVICE)) { ctx->err = "bad dtype / location"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) return -1;
   if (out && f == "Z_corr" && sync_solve_results(ctx)) return -1;      // a singular system of the last correction surfaces here (hmx_last_error says so)
+  if (f == "R" && ctx->ran_init && !ctx->R_valid) { ctx->err = "R is not available: the clustering call that would have stored it did not complete"; return -1; }
   const int w = (f == "R") ? ctx->K : ctx->d;
   const int64_t cnt = ctx->N * w;
   if (!out || cap < cnt) return cnt;

@@ -4337,7 +4337,9 @@ void HMX_LNAME(l_update)(const Launch& L, const Dev& D, int j) {
     // a block holds ~n/nb cells; D.upd_cpw cells per wave (tunable: HMX_UPD_CPW)
     const long long waves = ((long long)D.n / (D.nb > 0 ? D.nb : 1) + D.upd_cpw - 1) / D.upd_cpw + 1;
     const dim3 grid(stream_grid(L, waves));
+    if (L.ev0) (void)hipEventRecord(L.ev0, L.stream);       // (profile mode: the first-generation kernel is launched plainly, the pair is recorded around it)
     HMX_DISPATCH_KD(k_update, , grid, lds_bytes_y(D), D, j);
+    if (L.ev1) (void)hipEventRecord(L.ev1, L.stream);
     return;
   }
 #endif

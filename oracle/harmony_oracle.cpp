@@ -35,6 +35,25 @@
 //                           this branch (several covariates, src/harmony.cpp:573) cannot be pinned bit for bit
 //                           without that BLAS.  The GPU's reference-arithmetic mode matches THIS restatement.
 //
+// LIBERTIES of the faithful mode -- places where "the reference's operation order" is not determined by /root/reference itself but by the
+// (unpinned) Armadillo / BLAS underneath it, what this restatement does there, and the switch that flips it (set_int("liberty", mask);
+// tools/oracle_liberties.py measures how far each one moves a faithful run: "faithful" is an INTERVAL of that width, not a point, and
+// the GPU's reference-arithmetic mode is tuned to the default point of it):
+//   bit 0 (1)  L1 normalisations (src/harmony.cpp:145,150,323,326).  normalise(X, 1, 0) takes norm(col, 1); Armadillo's op_norm sums a
+//              column of fewer than 32 elements with TWO accumulators (even / odd elements, added at the end) and hands longer ones to BLAS
+//              sasum, whose order is the BLAS build's (SIMD partial sums).  Default here: one sequential accumulator.  Bit 0: the
+//              two-accumulator form; bit 1 (2): eight strided partial sums combined pairwise (a SIMD sasum's shape).
+//   bit 2 (4)  Z_corr -= W.t() * Phi_Rk for SEVERAL covariates (:615, dense x sparse): Armadillo's dense-times-sparse walks the sparse
+//              operand's non-zeros and adds A.col(row) * value per non-zero, i.e. fl(W[row_1] r) + fl(W[row_2] r) + ...; default here:
+//              (sum_c W[row_c]) * r -- one product.  Bit 2: one rounded product per non-zero, added in row order.  (One covariate: the same.)
+//   bit 3 (8)  Lloyd iterations of kmeans_centers (src/utils.cpp:56-61): arma::kmeans' accumulation is internal to Armadillo (running
+//              means, its own threading); default here: exact fp64 sums, an empty cluster keeps its mean.  Bit 3: fp32 sums.  (The
+//              parity tests share the centres between the backends, so this liberty is outside every GPU comparison.)
+//   bit 4 (16) L2 normalisations (:42,136,220,633): norm(col, 2) of >= 32 elements is BLAS snrm2 (OpenBLAS accumulates it in double on
+//              x86-64; Armadillo's own loop for short columns uses two fp32 accumulators).  Default: one fp32 accumulator; bit 4: fp64 sum.
+//   not switchable, stated: abs() in check_convergence (:185,194) -- with <cmath> in scope and a float argument, overload resolution
+//              takes std::abs(float) (exact match; ::abs(int) would need a conversion), so the quotient is a float expression, as here.
+//
 // Two arithmetic modes (hard part 3):
 //   faithful  fp32 state and fp32 accumulators in the reference's operation order
 //             (sequential fp32 my_accu, fp32 O/E += / -= drift, fp32 inverse)
@@ -168,11 +187,12 @@ void gemm_tn(int M, int N, int Kd, const float* A, const float* B, float* C) {
     }
 }
 
-template <class T> void normalise_cols_l2(T* X, int rows, int64_t cols) {
+template <class T> void normalise_cols_l2(T* X, int rows, int64_t cols, bool dacc = false) {
   for (int64_t c = 0; c < cols; c++) {
-    T* x = X + c * rows; T s = 0;
-    for (int r = 0; r < rows; r++) s += x[r] * x[r];
-    T nrm = std::sqrt(s); if (nrm == 0) nrm = 1;
+    T* x = X + c * rows; T nrm;
+    if (dacc) { double sd = 0; for (int r = 0; r < rows; r++) sd += (double)x[r] * (double)x[r]; nrm = (T)std::sqrt(sd); }   // (liberty bit 4: snrm2 in double)
+    else { T s = 0; for (int r = 0; r < rows; r++) s += x[r] * x[r]; nrm = std::sqrt(s); }
+    if (nrm == 0) nrm = 1;
     for (int r = 0; r < rows; r++) x[r] /= nrm;
   }
 }
@@ -256,6 +276,13 @@ template <unsigned MASK> struct Oracle : OracleBase {
   std::deque<std::vector<int64_t>> injected;
   int W_rows = 0;
   int64_t subset_clusters = 0, skipped_clusters = 0;
+  int liberty = 0;      // header, "LIBERTIES of the faithful mode"
+  // the L1 norm of a column of R as normalise(X, 1, 0) forms it (all entries are >= 0: |r| = r)
+  float l1_sum(const float* r, int n) const {
+    if (liberty & 1) { float a1 = 0.f, a2 = 0.f; int i = 0; for (; i + 1 < n; i += 2) { a1 += std::fabs(r[i]); a2 += std::fabs(r[i + 1]); } if (i < n) a1 += std::fabs(r[i]); return a1 + a2; }
+    if (liberty & 2) { float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; i++) a[i & 7] += std::fabs(r[i]); return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7])); }
+    float s = 0.f; for (int i = 0; i < n; i++) s += std::fabs(r[i]); return s;
+  }
 
   // ---- setup: src/harmony.cpp:29-128 ----------------------------------------
   int setup(const double* Z, int64_t N_, int d_, const int32_t* phi_i, const int32_t* phi_p, int B_,
@@ -266,7 +293,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
     if (N < 6) { err = "Refusing to run with less than 6 cells"; return 2; }  // :83-85
     Z_orig.resize((size_t)d * N);
     for (size_t i = 0; i < Z_orig.size(); i++) Z_orig[i] = (float)Z[i];          // conv_to :41
-    Z_corr = Z_orig; normalise_cols_l2(Z_corr.data(), d, N);                      // :42
+    Z_corr = Z_orig; normalise_cols_l2(Z_corr.data(), d, N, (liberty & 16) != 0);   // :42
     B_vec.assign(B_vec_, B_vec_ + C);
     covariate_bounds.resize(C); std::partial_sum(B_vec.begin(), B_vec.end(), covariate_bounds.begin());
     if (covariate_bounds.back() != B) { err = "sum(B_vec) != nrow(Phi)"; return 3; }
@@ -344,7 +371,9 @@ template <unsigned MASK> struct Oracle : OracleBase {
           float sc = ynorm[k] - 2.f * dot;  // ||x-y||^2 - ||x||^2
           if (sc < bs) { bs = sc; bk = k; }
         }
-        cnt[bk]++; for (int j = 0; j < d; j++) sums[(size_t)bk * d + j] += x[j];
+        cnt[bk]++;
+        if (liberty & 8) for (int j = 0; j < d; j++) sums[(size_t)bk * d + j] = (double)((float)sums[(size_t)bk * d + j] + x[j]);     // fp32 running sums
+        else for (int j = 0; j < d; j++) sums[(size_t)bk * d + j] += x[j];
       }
       for (int k = 0; k < K; k++) if (cnt[k] > 0)
         for (int j = 0; j < d; j++) Y[(size_t)k * d + j] = (float)(sums[(size_t)k * d + j] / (double)cnt[k]);
@@ -356,8 +385,10 @@ template <unsigned MASK> struct Oracle : OracleBase {
     gemm_tn(K, (int)N, d, Y.data(), Z_corr.data(), dist.data());
     for (size_t i = 0; i < dist.size(); i++) dist[i] = 2.f * (1.f - dist[i]);
     for (int64_t n = 0; n < N; n++) {
-      float* r = &R[n * K]; const float* dm = &dist[n * K]; float s = 0.f;
-      for (int k = 0; k < K; k++) { r[k] = std::exp(-dm[k] / sigma[k]); s += r[k]; }
+      float* r = &R[n * K]; const float* dm = &dist[n * K];
+      for (int k = 0; k < K; k++) r[k] = std::exp(-dm[k] / sigma[k]);
+      float s = l1_sum(r, K);
+      if (s == 0.f) s = 1.f;
       for (int k = 0; k < K; k++) r[k] /= s;
     }
     std::vector<ACC> rs(K, 0);
@@ -371,7 +402,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
     seed = seed_; rs_seeded = false;
     if (Y0) { Y.resize((size_t)d * K); for (size_t i = 0; i < Y.size(); i++) Y[i] = (float)Y0[i]; }
     else kmeans_centers(seed_);
-    normalise_cols_l2(Y.data(), d, K);
+    normalise_cols_l2(Y.data(), d, K, (liberty & 16) != 0);
     dist_R_EO();
     compute_objective();
     objective_harmony.push_back(objective_kmeans.back());
@@ -417,7 +448,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
 
   int cluster() override {  // :208-262
     if (objective_harmony.size() != 1) {
-      normalise_cols_l2(Z_corr.data(), d, N);
+      normalise_cols_l2(Z_corr.data(), d, N, (liberty & 16) != 0);
       dist_R_EO();
     }
     int iter;
@@ -487,15 +518,15 @@ template <unsigned MASK> struct Oracle : OracleBase {
         }
         for (int64_t p = idx_min; p <= idx_max; p++) {
           int64_t i = update_order[p]; float* r = &Rr[p * K]; const float* dm = &Dr[p * K];
-          float s = 0.f;
-          for (int k = 0; k < K; k++) { r[k] = std::exp(-dm[k] / sigma[k]); s += std::fabs(r[k]); }
+          for (int k = 0; k < K; k++) r[k] = std::exp(-dm[k] / sigma[k]);
+          float s = l1_sum(r, K);
           if (s == 0.f) s = 1.f;
           for (int k = 0; k < K; k++) r[k] /= s;
-          s = 0.f;
           for (int k = 0; k < K; k++) {
             float m = 0.f; for (int c = 0; c < C; c++) m += pen[(size_t)codes[(size_t)c * N + i] * K + k];
-            r[k] *= m; s += std::fabs(r[k]);
+            r[k] *= m;
           }
+          s = l1_sum(r, K);
           if (s == 0.f) s = 1.f;
           for (int k = 0; k < K; k++) r[k] /= s;
         }
@@ -600,6 +631,12 @@ template <unsigned MASK> struct Oracle : OracleBase {
       for (int64_t i = 0; i < N; i++) {
         if (!in_set[i]) continue;
         const float r = R[i * K + k]; float* z = &Z_corr[i * d];
+        if (liberty & 4) {      // one rounded product per non-zero of Phi_Rk's column, added in row order (Armadillo's dense x sparse), then ONE subtraction
+          for (int j = 0; j < d; j++) { float o = 0.f;
+            for (int c = 0; c < C; c++) { int ro = row_of[codes[(size_t)c * N + i]]; if (ro >= 0) o += (float)Wk[(size_t)j * m + ro] * r; }
+            z[j] -= o; }
+          continue;
+        }
         for (int j = 0; j < d; j++) { float w = 0.f;
           for (int c = 0; c < C; c++) { int ro = row_of[codes[(size_t)c * N + i]]; if (ro >= 0) w += (float)Wk[(size_t)j * m + ro]; }
           z[j] -= w * r; }
@@ -607,7 +644,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
       W.assign((size_t)m * d, 0.f); W_rows = m;
       for (size_t i = 0; i < W.size(); i++) W[i] = (float)Wk[i];
     }
-    normalise_cols_l2(Y.data(), d, K);  // :633
+    normalise_cols_l2(Y.data(), d, K, (liberty & 16) != 0);  // :633
     return 0;
   }
 
@@ -616,6 +653,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
     if (w == "max_iter_kmeans") max_iter_kmeans = (int)v;
     else if (w == "seed") { seed = (uint64_t)v; rs_seeded = false; }
     else if (w == "rng") { rng_mode = (int)v; rs_seeded = false; }
+    else if (w == "liberty") liberty = (int)v;
   }
 
   template <class T> static int64_t copy_out(const std::vector<T>& v, double* out) {
@@ -647,7 +685,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
     if (w == "subset_clusters") { if (out) out[0] = (double)subset_clusters; return 1; }
     if (w == "skipped_clusters") { if (out) out[0] = (double)skipped_clusters; return 1; }
     if (w == "Lambda") {  // getLambda :657-669  (K x (B+1), column-major)
-      if (out) for (int k = 0; k < K; k++) { out[k] = 0;
+      if (out) for (int k = 0; k < K; k++) { out[k] = lambda_estimation ? 0.0 : (double)lambda[0];
         for (int b = 0; b < B; b++) out[(size_t)(b + 1) * K + k] = lambda_estimation ? (double)((float)E[(size_t)b * K + k] * alpha) : (double)lambda[b + 1]; }
       return (int64_t)K * (B + 1);
     }

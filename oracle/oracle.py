@@ -87,14 +87,19 @@ def _dp(a):
 
 
 class OracleHarmony(object):
-    def __init__(self, accurate=True, seed=0, mask=None, rng=0):
+    def __init__(self, accurate=True, seed=0, mask=None, rng=0, liberty=0):
         """mask: per-group arithmetic (bit 0 O/E tables, 1 objective sums, 2 ridge statistics, 3 ridge solve; bit set =
-        fp64, clear = the reference's fp32).  accurate=True is mask 15, accurate=False (faithful) is mask 0."""
+        fp64, clear = the reference's fp32).  accurate=True is mask 15, accurate=False (faithful) is mask 0.
+        liberty: the places where Armadillo / BLAS -- not /root/reference -- fix the operation order, flipped one by one (bit 0 / 1 L1 sums
+        with two / eight accumulators, 2 one rounded product per non-zero in the several-covariate apply, 3 fp32 Lloyd sums, 4 L2 norms in
+        double; harmony_oracle.cpp header)."""
         self._lib = load()
         self.mask = (15 if accurate else 0) if mask is None else int(mask)
         self._h = C.c_void_p(self._lib.orc_create_mask(self.mask))
         if rng:   # 1: R-compatible stream (MT19937 seeded like set.seed(seed), RcppArmadillo draw order)
             self._lib.orc_set_int(self._h, b"rng", int(rng))
+        if liberty:
+            self._lib.orc_set_int(self._h, b"liberty", int(liberty))
         self.seed = int(seed)
         self._dims = None
 

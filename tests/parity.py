@@ -50,6 +50,8 @@ def compare_state(g, c, what=("R", "O", "E", "Y")):
         out["E_rel"] = relfro(g.E, c.E)
     if "Y" in what:
         out["Y_rel"] = relfro(g.Y, c.Y)
+    if "L" in what:     # getLambda (src/harmony.cpp:657-669): K x (B + 1), column 0 = the intercept's 0
+        out["Lambda_rel"] = relfro(g.getLambda(), c.getLambda())
     if "Z" in what:
         out["Z_rel"] = relfro(g.getZcorr(), c.getZcorr())
     if "obj" in what:
@@ -87,12 +89,13 @@ def run_both(Z, meta, vars_use, max_iter=10, seed=1, gpu_init=True, **kw):
 
 
 def assert_parity(g, c, ig=None, ic=None, tol_z=TOL_Z):
-    s = compare_state(g, c, ("R", "O", "E", "Y", "Z", "obj"))
+    s = compare_state(g, c, ("R", "O", "E", "Y", "Z", "obj", "L"))
     msg = repr(s)
     assert s["Z_rel"] <= tol_z, msg
     assert s["R_maxabs"] <= TOL_R, msg
     assert s["argmax_diff_clear"] == 0, msg
     assert s["O_rel"] <= TOL_TAB and s["E_rel"] <= TOL_TAB and s["Y_rel"] <= TOL_TAB, msg
+    assert s["Lambda_rel"] <= TOL_TAB, msg
     assert s["obj_len"][0] == s["obj_len"][1], msg
     assert s["obj_rel"] <= TOL_OBJ, msg
     assert np.array_equal(g.kmeans_rounds, c.kmeans_rounds), (g.kmeans_rounds, c.kmeans_rounds)

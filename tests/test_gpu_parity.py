@@ -116,6 +116,32 @@ def test_fixed_lambda_tau_vector_sigma(cell_lines):
     assert_parity(g, c, ig, ic)
 
 
+def test_getLambda_against_oracle(cell_lines):
+    """getLambda (src/harmony.cpp:657-669): K x (B + 1); estimated lambda = find_lambda_cpp(alpha, E[k, :]) = [0, alpha * E[k, :]]
+    (src/utils.cpp:159-163) on the CURRENT E -- compared after the head and after every correction --, fixed lambda = the caller's vector in
+    every row (R/ui.R:235-248: c(0, rep(lambda_c, B_c)...))."""
+    K = 15
+    g, c = make_pair(cell_lines["pcs"], _meta(cell_lines), ["dataset", "cell_type"], nclust=K)
+    Y0 = g.kmeans_centers()
+    g.init_cluster_cpp(Y0)
+    c.init_cluster_cpp(Y0)
+    for it in range(3):
+        Lg, Lc = g.getLambda(), c.getLambda()
+        assert Lg.shape == (K, g.B + 1) == Lc.shape
+        assert np.all(Lg[:, 0] == 0) and np.all(Lc[:, 0] == 0)
+        np.testing.assert_allclose(Lg, Lc, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(Lg[:, 1:], np.float32(g.alpha) * g.E.astype(np.float32), rtol=1e-6)      # the definition, on the GPU's own E
+        for o in (g, c):
+            assert o.cluster_cpp() == 0
+            o.moe_correct_ridge_cpp()
+    lam = [0.5, 2.0]
+    g, c, ig, ic = run_both(cell_lines["pcs"], _meta(cell_lines), ["dataset", "cell_type"], max_iter=1, nclust=K, lambda_=lam)
+    Lg, Lc = g.getLambda(), c.getLambda()
+    Bv = g.B_vec
+    want = np.concatenate([[0.0], np.repeat(lam, Bv)])
+    assert np.array_equal(Lg, np.tile(want, (K, 1))) and np.array_equal(Lc, Lg)
+
+
 @pytest.mark.parametrize("N,d,K,levels,nested", [
     (5000, 50, 100, (10,), False),      # BASELINE shape, two clusters per lane
     (3000, 17, 7, (3,), False),         # ragged small shapes
@@ -345,6 +371,41 @@ def test_virtual_shards_equal_single_shard(G, fused, carry, monkeypatch):
     np.testing.assert_allclose(res[0][2], one.objective_kmeans, rtol=1e-6)
     assert relfro(Zs, one.getZcorr()) < 1e-6
     assert np.array_equal(np.concatenate([r[4] for r in res]), one.R.argmax(axis=0))
+
+
+@pytest.mark.parametrize("mode", ["chain", "steps", "sharded"])
+def test_elided_R_stores_change_nothing(mode, monkeypatch):
+    """R rows that nobody reads are not stored (the head inside cluster_cpp and every round that cannot be a call's last keep them in
+    registers; the next round takes its old contributions from the sums the tile kernels filed).  Default against HMX_R_STORE=1 (every
+    pass stores): R, O, the objective series and Z_corr must be BIT-identical -- on the persistent chain, on the launch-per-step kernels
+    and on two virtual shards -- and the default must really have elided rounds ("rounds_without_R")."""
+    monkeypatch.setenv("HMX_SOLD_CARRY", "1")          # (the carry -- and with it the elision -- starts at ~800k cells by default)
+    Z, meta, _ = synth(30000, d=50, levels=(10,), seed=23)
+    K, seed = 100, 9
+    out = []
+    for store in ("0", "1"):
+        monkeypatch.setenv("HMX_R_STORE", store)
+        if mode == "sharded":
+            res = _run_sharded(Z, meta, 2, K, seed, 3)
+            out.append((np.concatenate([r[0] for r in res], axis=1), res[0][1], res[0][2], np.concatenate([r[4] for r in res]), None))
+            continue
+        monkeypatch.setenv("HMX_CHAIN", "1" if mode == "chain" else "0")
+        skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
+        g = Harmony(seed=seed)
+        g.setup(**skw)
+        g.init_cluster_cpp()
+        for it in range(3):
+            assert g.cluster_cpp() == 0
+            g.moe_correct_ridge_cpp()
+        assert g.cluster_cpp() == 0
+        assert int(g._scalar("chain")) == (1 if mode == "chain" else 0)
+        assert (g._scalar("rounds_without_R") > 0) == (store == "0")
+        out.append((g.getZcorr(), g.O, g.objective_kmeans, g.R, int(g._scalar("rounds_without_R"))))
+    a, b = out
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])
+    np.testing.assert_array_equal(a[0], b[0])
 
 
 def test_builtin_rccl_communicator_single_rank():

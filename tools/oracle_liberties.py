@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""CPU only: how wide is "faithful"?  The oracle's faithful mode fixes an operation order in a few places where the reference leaves it
+to Armadillo / BLAS (oracle/harmony_oracle.cpp header, LIBERTIES).  Each liberty is flipped on its own and the run -- synthetic N x 50,
+K = 100 (one covariate, 10 batches) and K = 60 with two crossed covariates, reference defaults, to convergence, shared centres and block
+partitions -- is compared with the default faithful run: rel. Frobenius distance of Z_corr, max |dR|, hard-assignment flips (raw / at a
+top-2 margin >= 1e-5), objective series, iterations.  Output: profiles/r5_oracle_liberties.json (quoted in DESIGN 2.1)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from harmony_amd.ui import prepare_setup_args  # noqa: E402  (host-side argument preparation only: no device)
+from helpers import synth  # noqa: E402
+from oracle.oracle import OracleHarmony  # noqa: E402
+
+BITS = {1: "L1 sums: two accumulators", 2: "L1 sums: eight strided accumulators", 4: "apply: one rounded product per non-zero",
+        16: "L2 norms accumulated in double", 31 - 8: "all of them"}
+
+
+def run(skw, Y0, liberty, seed=3):
+    o = OracleHarmony(mask=0, seed=seed, liberty=liberty)
+    o.setup(**skw)
+    o.init_cluster_cpp(Y0)
+    it = 0
+    for it in range(1, 11):
+        assert o.cluster_cpp() == 0
+        o.moe_correct_ridge_cpp()
+        if o.check_convergence(1):
+            break
+    return dict(Z=o.getZcorr(), R=o.R, it=it, obj=np.array(o.objective_kmeans))
+
+
+def flips(Ra, Rb, margin):
+    aa, ab = Ra.argmax(axis=0), Rb.argmax(axis=0)
+    bad = np.where(aa != ab)[0]
+    if not bad.size:
+        return 0, 0
+    srt = np.sort(Rb[:, bad], axis=0)
+    return int(bad.size), int(((srt[-1] - srt[-2]) >= margin).sum())
+
+
+out = {}
+cases = [("%dk_one_covariate_K100" % (n // 1000), n, (10,), 100) for n in (20000, 100000)] + [("20k_two_covariates_K60", 20000, (3, 4), 60)]
+if len(sys.argv) > 1:
+    cases = [c for c in cases if c[0] in sys.argv[1:]]
+for name, N, levels, K in cases:
+    Z, meta, _ = synth(N, d=50, levels=levels, seed=7)
+    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
+    rng = np.random.default_rng(1)
+    Y0 = np.asfortranarray(Z[rng.choice(N, K, replace=False)].T)
+    base = run(skw, Y0, 0)
+    rows = {}
+    for bit, what in BITS.items():
+        r = run(skw, Y0, bit)
+        n = min(len(r["obj"]), len(base["obj"]))
+        f, fc = flips(r["R"], base["R"], 1e-5)
+        rows[what] = {"liberty": bit, "Z_rel": float(np.linalg.norm(r["Z"] - base["Z"]) / np.linalg.norm(base["Z"])),
+                      "R_maxabs": float(np.abs(r["R"] - base["R"]).max()), "argmax_diff": f, "argmax_diff_margin_ge_1e-5": fc,
+                      "objective_rel_max": float(np.max(np.abs(r["obj"][:n] - base["obj"][:n]) / np.abs(base["obj"][:n]))),
+                      "iterations": [r["it"], base["it"]]}
+        print(name, what, rows[what], flush=True)
+    out[name] = rows
+with open(os.path.join(ROOT, "profiles", "r5_oracle_liberties.json"), "w") as fh:
+    json.dump(out, fh, indent=1)

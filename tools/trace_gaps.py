@@ -39,3 +39,18 @@ if len(ch) > 12:
     for s_, e_, n_ in rows[a + 1:b + 1]:
         print("  %-58s start %8.1f  end %8.1f  (%.1f us)" % (n_, (s_ - base) / 1e3, (e_ - base) / 1e3, (e_ - s_) / 1e3))
 
+
+# reference-arithmetic runs: one clustering round = k_ref_posord ... k_ref_posord (the round's shuffle opens it)
+po = [i for i, r in enumerate(rows) if "k_ref_posord" in r[2]]
+if len(po) > 8:
+    a, b = po[6], po[7]
+    base = rows[a][0]
+    print("\nreference arithmetic: round #6 (k_ref_posord -> next k_ref_posord), %d launches, %.1f us" % (b - a, (rows[b][0] - base) / 1e3))
+    agg = defaultdict(lambda: [0, 0.0, 0.0]); prev_end = rows[a][0]
+    for s_, e_, n_ in rows[a:b]:
+        g_ = agg[n_]; g_[0] += 1; g_[1] += (e_ - s_) / 1e3; g_[2] += max(0, s_ - prev_end) / 1e3; prev_end = max(prev_end, e_)
+    for n_, (c_, bu_, ga_) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+        print("  %-58s x%-4d busy %9.1f us  idle-before %9.1f us" % (n_, c_, bu_, ga_))
+    print("  first 70 launches of the round:")
+    for s_, e_, n_ in rows[a:min(b, a + 70)]:
+        print("    %-56s start %8.1f  (%.1f us)" % (n_, (s_ - base) / 1e3, (e_ - s_) / 1e3))
