@@ -11,8 +11,12 @@ constexpr int TPB = 256;            // threads per workgroup (4 waves, one per S
 constexpr int ITEM_CELLS = 256;     // cells per wave work item in streaming passes
 constexpr int APPLY_CELLS = 1024;   // cells per workgroup work item in the apply pass
 constexpr int SORT_CHUNK = 512;     // cells per wave in the per-round block counting sort
-constexpr float FX_SCALE = 2147483648.0f;  // R in [0,1] -> 31-bit fixed point (exact int64 sums)
-constexpr double FX_INV = 1.0 / 2147483648.0;
+// R in [0,1] -> fixed point, exact int64 sums.  Round 5: 29 fractional bits (was 31) -- the four rows a lane holds of one column then add up in
+// ONE 32-bit register (4 x 2^29 < 2^32) before a single widening add per column and tile; with 31 bits every value was zero-extended and added
+// in 64 bits on its own (44 64-bit moves + 33 64-bit adds of the ~540 instructions of a tile's epilogue).  The quantum, 1.9e-9, is
+// far below anything the tables are compared at (the sums are exact sums of the quantised values either way).
+constexpr float FX_SCALE = 536870912.0f;
+constexpr double FX_INV = 1.0 / 536870912.0;
 
 // A run of cells (internal order) that share one covariate-level combination.
 struct Item { int q; int start; int cnt; };
@@ -293,19 +297,21 @@ size_t lds_bytes_y(const Dev& D);
 // ---- reference arithmetic: restarted sequential fp32 sums (hmx_seq.hip) ------------------------------------------------------------
 struct SeqSeg { int off; int cnt; };       // a segment of a chain: cells list[off .. off + cnt) (or the cells off .. off + cnt - 1 themselves)
 struct SeqChain { int seg0; int nseg; };   // the segments of one chain, in chain order
+// (conv_zero: the two statistics words the scan behind this pass will add to -- zeroed by the pass itself, no memset launch; or nullptr)
 void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* poslev, int nlist, const SeqSeg* segs, int seg0, int nsegs, const float* start,
-                   float* end, int zero_start);
+                   float* end, int zero_start, unsigned* conv_zero);
 void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
-                    int zero_start);
+                    int zero_start, unsigned* conv_zero);
 void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord, int* poslev);
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
-                      const float* start, float* end, int zero_start);
+                      const float* start, float* end, int zero_start, unsigned* conv_zero);
+// (partial: [narr][ceil(nsegs / 256)] doubles, the deltas of every workgroup's 256 segments -- k_seq_scan1's bases)
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
-                    int zero_start);
+                    int zero_start, double* partial, unsigned* conv_zero);
 void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains, int W, const float* start_in, const float* end, float* start_out,
                 float* total, unsigned* mismatch, int zero_start);
 void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, const float* end, float* start_out, float* total,
-                 unsigned* mismatch, int zero_start);
+                 unsigned* mismatch, int zero_start, const double* partial);
 void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot_add, const float* tot_sub, float* pen, int head);
 void l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
 void l_obj_store(const Launch& L, const float* total, double* obj);

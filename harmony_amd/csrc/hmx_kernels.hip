@@ -70,9 +70,10 @@ template <class T> __device__ __forceinline__ T ld_or(const T* __restrict__ p, s
 __device__ __forceinline__ float trunc_logf_dev(float x) {  // arma::trunc_log (src/utils.cpp:78)
   return (x > 0.0f) ? logf(x) : logf(FLT_MIN);
 }
-__device__ __forceinline__ unsigned long long fx_of(float r) {  // R in [0,1] -> 31-bit fixed point
-  return (unsigned long long)__float2uint_rn(r * FX_SCALE);
-}
+// R in [0,1] -> fixed point: ONE function of the float for every kernel that adds or removes a cell's R (what a block update files is exactly what
+// the next round takes out).  fma + truncating convert: two instructions (round half up; from 2^23 on r * 2^29 is an integer already).
+__device__ __forceinline__ unsigned fx32_of(float r) { return (unsigned)__builtin_fmaf(r, FX_SCALE, 0.5f); }
+__device__ __forceinline__ unsigned long long fx_of(float r) { return (unsigned long long)fx32_of(r); }
 
 // diversity penalty ((2E+1)/(O+E+1))^theta (src/harmony.cpp:319-321) with a SHORT dependent chain: rcp, mul, log2, mul, exp2
 // (~2e-7 relative; powf's ~100 dependent instructions cost >1 us in the serial prologue of every block step at gfx950's
@@ -1815,12 +1816,14 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       od += (double)pd; oe += (double)pe;
 #pragma unroll
       for (int ct = 0; ct < NCT; ct++) {
+        unsigned s32 = 0u;                 // RB <= 4 values of at most 2^29 each: no carry out of 32 bits
 #pragma unroll
         for (int i = 0; i < RB; i++) {
           const float rn = acc[ct][r0 + i] * inv[i];
           acc[ct][r0 + i] = rn;            // the normalised value replaces the distance (stored below, or later by store_rows)
-          oacc[ct] += fx_of(rn);
+          s32 += fx32_of(rn);
         }
+        oacc[ct] += (unsigned long long)s32;
       }
       if constexpr (!DEFER) {
 #ifdef HMX_TRACE
@@ -2795,66 +2798,125 @@ __global__ __launch_bounds__(TPB) void k_objective_tables(Dev D) {
 // matrix cores: static 16-cell tiles like the head, the R row and the term rows as 16-byte accesses (a lane's clusters are consecutive,
 // kcol).  Round 3's cluster-lane VALU version took 1.44 ms per evaluation at 1M cells, a quarter of the reference-arithmetic run.
 // T[0] = R % dist, T[1] = (R % log R) % sigma, T[2] = (R % sigma) % (M Phi); rows at the cells' ORIGINAL positions, k fastest.
+// Round 5: (1) tiles run over the ORIGINAL cell order (16 consecutive original cells per tile, rows gathered through invperm): a tile's 16 rows
+// of each term array are 16 K contiguous floats -- whole 128-byte lines at K = 100; the cells of a tile no longer share a combination, so the
+// M rows are fetched per row.  (2) A software pipeline like k_tile's: cell ids two tiles ahead, and ALL loads of tile i + 1 (embedding rows in
+// registers, R rows, M rows) are issued before the stores of tile i -- vector memory operations retire in issue order on gfx9, so a load queued
+// behind a tile's 84 stores waits for them to drain; the round-4 kernel did that four times per tile (1.02 ms per evaluation at 1M cells, 21
+// evaluations per run).  (3) log R through v_log_f32 (1 ulp; the term enters a sum of K N values): 3 instructions instead of logf's ~30.
 template <int NCT>
 __global__ __launch_bounds__(256) void k_obj_terms_mfma(Dev D, const float* __restrict__ M, float* __restrict__ T, long long stride) {
   extern __shared__ __attribute__((aligned(16))) f32x4 ldsI[];
   constexpr int NFULL = NCT >> 2, RT = NCT & 3;
-  const int K = D.K, C = D.C, zs = D.zs;
+  const int K = D.K, C = D.C, zs = D.zs, n = D.n;
   const int nY4 = D.NQ * D.NS * 64;
   { const f32x4* src = reinterpret_cast<const f32x4*>(D.Yimg);
     for (int i = threadIdx.x; i < nY4; i += blockDim.x) ldsI[i] = src[i]; }
   __syncthreads();
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nw = (int)((gridDim.x * blockDim.x) >> 6);
-  auto one = [&](const float r, const float dot, const float sg, const float m, float& t0, float& t1, float& t2) __attribute__((always_inline)) {
-    const float dist = __fmul_rn(2.0f, __fsub_rn(1.0f, dot));
-    const float lg = (r > 0.0f) ? logf(r) : logf(FLT_MIN);      // arma::trunc_log
-    t0 = __fmul_rn(r, dist);
-    t1 = __fmul_rn(__fmul_rn(r, lg), sg);
-    t2 = __fmul_rn(__fmul_rn(r, sg), m);
+  const float lmin = __builtin_amdgcn_logf(FLT_MIN) * 0.69314718055994530942f;
+  const int ntiles = (n + 15) >> 4;
+  const int per = (ntiles + nw - 1) / nw;           // contiguous tile ranges per wave: consecutive tiles write consecutive lines
+  const int t_lo = min(wave * per, ntiles), t_hi = min(t_lo + per, ntiles);
+  if (t_lo >= t_hi) return;
+  const float* __restrict__ Rp = D.R;
+  const float* __restrict__ Zp = D.Zc;
+  const int* __restrict__ qlevp = D.qlev;
+  struct Ids { int cell, q; };
+  auto ids_of = [&](const int tile) -> Ids {         // this lane's A-operand cell of `tile` (clamped: any valid cell beyond the end)
+    Ids I; I.cell = D.invperm[min(16 * min(tile, ntiles - 1) + c, n - 1)]; I.q = D.combo[I.cell]; return I;
   };
-  for (int tile = wave; tile < D.ntitems; tile += nw) {
-    const Item it = D.titems[tile];
-    const bool av = c < it.cnt;
-    f32x4 acc[NCT];
-    tile_dots<NCT>(ldsI, D.Zc + (size_t)(it.start + (av ? c : 0)) * zs, av, g, lane, D.NS, D.NT4, D.tail, acc);
+  // per tile and lane: the R and M values of rows 4g .. 4g + 3 at this lane's clusters -- the layout of the accumulators
+  struct Vals { f32x4 r[NCT], m[NCT]; };
+  auto vals_of = [&](const Ids& I, Vals& V) __attribute__((always_inline)) {
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
-      const int cl = 4 * g + reg;
-      const bool cv = cl < it.cnt;
-      const int cell = it.start + (cv ? cl : 0);
-      const size_t orow = (size_t)D.perm[cell] * K;
-      const float* __restrict__ rrow = D.R + (size_t)cell * K;
+      const int cell = __shfl(I.cell, 4 * g + reg, 64), q = __shfl(I.q, 4 * g + reg, 64);
+      const float* __restrict__ rrow = Rp + (size_t)cell * K;
+      int lev[4];
 #pragma unroll
-      for (int q = 0; q < NFULL; q++) {
-        const int k0 = 64 * q + 4 * c;
-        if (4 * q < first_partial_ct(NCT) || k0 < K) {
-          const f32x4 r4 = *reinterpret_cast<const f32x4*>(rrow + k0), sg4 = *reinterpret_cast<const f32x4*>(D.sigma + k0);
-          f32x4 m4 = {0.f, 0.f, 0.f, 0.f};
-          for (int cc = 0; cc < C; cc++) {
-            const f32x4 mm = *reinterpret_cast<const f32x4*>(M + (size_t)D.qlev[it.q * C + cc] * K + k0);
+      for (int cc = 0; cc < 4; cc++) lev[cc] = qlevp[q * C + min(cc, C - 1)];
+#pragma unroll
+      for (int qd = 0; qd < NFULL; qd++) {
+        const int k0 = min(64 * qd + 4 * c, K - 4);
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rrow + k0);
+        f32x4 m4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+          if (cc < C) {
+            const f32x4 mm = *reinterpret_cast<const f32x4*>(M + (size_t)lev[cc] * K + k0);
 #pragma unroll
             for (int i = 0; i < 4; i++) m4[i] = __fadd_rn(m4[i], mm[i]);
           }
-          f32x4 t0, t1, t2;
-#pragma unroll
-          for (int i = 0; i < 4; i++) { float a0, a1, a2; one(r4[i], acc[4 * q + i][reg], sg4[i], m4[i], a0, a1, a2); t0[i] = a0; t1[i] = a1; t2[i] = a2; }
-          if (cv) {
-            *reinterpret_cast<f32x4*>(T + orow + k0) = t0;
-            *reinterpret_cast<f32x4*>(T + (size_t)stride + orow + k0) = t1;
-            *reinterpret_cast<f32x4*>(T + 2 * (size_t)stride + orow + k0) = t2;
-          }
         }
+        for (int cc = 4; cc < C; cc++) {
+          const f32x4 mm = *reinterpret_cast<const f32x4*>(M + (size_t)qlevp[q * C + cc] * K + k0);
+#pragma unroll
+          for (int i = 0; i < 4; i++) m4[i] = __fadd_rn(m4[i], mm[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { V.r[4 * qd + i][reg] = r4[i]; V.m[4 * qd + i][reg] = m4[i]; }
       }
 #pragma unroll
       for (int jj = 0; jj < RT; jj++) {
-        const int k = 64 * NFULL + RT * c + jj;
-        if (k < K) {
-          float m = 0.0f;
-          for (int cc = 0; cc < C; cc++) m = __fadd_rn(m, M[(size_t)D.qlev[it.q * C + cc] * K + k]);
-          float t0, t1, t2;
-          one(rrow[k], acc[4 * NFULL + jj][reg], D.sigma[k], m, t0, t1, t2);
-          if (cv) { T[orow + k] = t0; T[(size_t)stride + orow + k] = t1; T[2 * (size_t)stride + orow + k] = t2; }
+        const int k = min(64 * NFULL + RT * c + jj, K - 1);
+        float m = 0.0f;
+        for (int cc = 0; cc < C; cc++) m = __fadd_rn(m, M[(size_t)qlevp[q * C + cc] * K + k]);
+        V.r[4 * NFULL + jj][reg] = rrow[k]; V.m[4 * NFULL + jj][reg] = m;
+      }
+    }
+  };
+  float sg[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) sg[ct] = D.sigma[min(kcol(NCT, ct, c), K - 1)];
+  Ids idN = ids_of(t_lo), idNN = ids_of(t_lo + 1);
+  RowRegs rowsN;
+  Vals VN;
+  load_rows(Zp + (size_t)idN.cell * zs, g, D.NT4, D.tail, rowsN);
+  vals_of(idN, VN);
+  for (int tile = t_lo; tile < t_hi; tile++) {
+    const int o0 = 16 * tile;
+    const bool av = o0 + c < n;
+    const RowRegs rowsA = rowsN;
+    const Vals V = VN;
+    f32x4 acc[NCT];
+    tile_dots_regs<NCT>(ldsI, rowsA, av, lane, D.NS, D.NT4, D.tail, acc);
+    // everything tile + 1 needs, requested BEFORE this tile's stores
+    idN = idNN; idNN = ids_of(tile + 2);
+    load_rows(Zp + (size_t)idN.cell * zs, g, D.NT4, D.tail, rowsN);
+    vals_of(idN, VN);
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int cl = 4 * g + reg;
+      const bool cv = o0 + cl < n;
+      float* __restrict__ t0p = T + (size_t)(o0 + (cv ? cl : 0)) * K;
+      float* __restrict__ t1p = t0p + (size_t)stride;
+      float* __restrict__ t2p = t1p + (size_t)stride;
+      float a0[NCT], a1[NCT], a2[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+        const float r = V.r[ct][reg];
+        const float dist = __fmul_rn(2.0f, __fsub_rn(1.0f, acc[ct][reg]));
+        const float lg = (r > 0.0f) ? __fmul_rn(__builtin_amdgcn_logf(r), 0.69314718055994530942f) : lmin;      // arma::trunc_log
+        a0[ct] = __fmul_rn(r, dist);
+        a1[ct] = __fmul_rn(__fmul_rn(r, lg), sg[ct]);
+        a2[ct] = __fmul_rn(__fmul_rn(r, sg[ct]), V.m[ct][reg]);
+      }
+      if (cv) {
+#pragma unroll
+        for (int qd = 0; qd < NFULL; qd++) {
+          const int k0 = 64 * qd + 4 * c;
+          if (4 * qd < first_partial_ct(NCT) || k0 < K) {
+            const f32x4 v0 = {a0[4 * qd], a0[4 * qd + 1], a0[4 * qd + 2], a0[4 * qd + 3]}, v1 = {a1[4 * qd], a1[4 * qd + 1], a1[4 * qd + 2], a1[4 * qd + 3]},
+                        v2 = {a2[4 * qd], a2[4 * qd + 1], a2[4 * qd + 2], a2[4 * qd + 3]};
+            *reinterpret_cast<f32x4*>(t0p + k0) = v0; *reinterpret_cast<f32x4*>(t1p + k0) = v1; *reinterpret_cast<f32x4*>(t2p + k0) = v2;
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < RT; jj++) {
+          const int k = 64 * NFULL + RT * c + jj;
+          if (k < K) { t0p[k] = a0[4 * NFULL + jj]; t1p[k] = a1[4 * NFULL + jj]; t2p[k] = a2[4 * NFULL + jj]; }
         }
       }
     }
@@ -4508,8 +4570,8 @@ void l_objective_tables(const Launch& L, const Dev& D) {
 // false: shape outside this kernel's envelope (the caller falls back to the cluster-lane version)
 bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride) {
   const size_t lds = (size_t)D.NQ * D.NS * 64 * sizeof(f32x4);
-  if (!D.tile_impl || D.K % 4 != 0 || lds > 64 * 1024 || !D.Yimg || D.obj_stale) return false;
-  int blocks = (D.ntitems + 3) / 4; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  if (!D.tile_impl || D.K % 4 != 0 || lds > 64 * 1024 || !D.Yimg || D.obj_stale || D.NT4 > 4) return false;      // (rows of <= 64 + 3 PCs in registers)
+  int blocks = ((D.n + 15) / 16 + 3) / 4; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
 #define HMX_OT(N) case N: hipLaunchKernelGGL((k_obj_terms_mfma<N>), dim3(blocks), dim3(256), lds, L.stream, D, M, T, stride); break;
   switch (D.NCT) {
     HMX_OT(1) HMX_OT(2) HMX_OT(3) HMX_OT(4) HMX_OT(5) HMX_OT(6) HMX_OT(7) HMX_OT(8) HMX_OT(10) HMX_OT(12) HMX_OT(13) HMX_OT(14) HMX_OT(16)

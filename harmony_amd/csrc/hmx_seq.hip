@@ -41,13 +41,25 @@ namespace hmx {
 // Round 4: all 64 R loads of a batch are in flight together (a segment is latency-bound: one memory round trip per 64 cells instead of two).
 // poslev (or nullptr): the level codes of the list's positions, [c][nlist] -- without them a wave walks list -> combo -> qlev -> R, four
 // dependent memory round trips before the first add of a 64-cell batch; with them two.
-template <bool ROWS>
+// Round 5: NLV > 0 -- the level rows live in REGISTERS (B <= NLV): the level of a cell is wave-uniform, so "add to row b" is a scalar
+// branch into one v_add_f32 (a uniform switch), ~10 cycles per cell, where the LDS row's read-modify-write -- which must wait for the
+// write of the cell before, the compiler cannot prove the rows differ -- cost 150-200: a 128-cell segment took 20 us, 10 of them there.
+// (vector-typed rows: a dynamic but UNIFORM element index is register-indexed addressing -- s_set_gpr_idx / v_movrel --, three instructions;
+//  a switch over 32 cases inside the 64-cell unrolled loop kept hipcc from unrolling it and sent the R values to scratch)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NLV> struct LvRows { f32x16 v[NLV > 0 ? NLV / 16 : 1]; };
+template <int NLV> __device__ __forceinline__ void lv_add(LvRows<NLV>& lv, const int b, const float r) {
+  if constexpr (NLV == 16) lv.v[0][b] = __fadd_rn(lv.v[0][b], r);
+  else if constexpr (NLV == 32) { if (b < 16) lv.v[0][b] = __fadd_rn(lv.v[0][b], r); else lv.v[1][b - 16] = __fadd_rn(lv.v[1][b - 16], r); }
+}
+template <bool ROWS, int NLV = 0>
 __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R, int K, int B, int C, const int* __restrict__ list,
                                                      const int* __restrict__ poslev, int nlist,
                                                      const int* __restrict__ combo, const int* __restrict__ qlev,
                                                      const SeqSeg* __restrict__ segs, int seg0, int nsegs,
-                                                     const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+                                                     const float* __restrict__ start, float* __restrict__ end, int zero_start, unsigned* __restrict__ conv_zero) {
   extern __shared__ float acc_[];                        // [waves][B][64]
+  if (conv_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) conv_zero[threadIdx.x] = 0u;      // the statistics words of the scan that follows (no memset launch)
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int sl = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wib));      // wave-uniform: scalar loop control below
   if (sl >= nsegs) return;
@@ -58,7 +70,11 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   const int NR = ROWS ? 1 + B : 1;
   const size_t so = (size_t)seg * NR * K + ks;
   float s0 = (zero_start || k >= K) ? 0.0f : start[so];
-  if constexpr (ROWS) for (int b = 0; b < B; b++) acc[b * 64] = (zero_start || k >= K) ? 0.0f : start[so + (size_t)(1 + b) * K];
+  LvRows<NLV> lv;
+  if constexpr (ROWS && NLV > 0) {
+#pragma unroll
+    for (int b = 0; b < NLV; b++) lv.v[b >> 4][b & 15] = (zero_start || k >= K || b >= B) ? 0.0f : start[so + (size_t)(1 + min(b, B - 1)) * K];
+  } else if constexpr (ROWS) for (int b = 0; b < B; b++) acc[b * 64] = (zero_start || k >= K) ? 0.0f : start[so + (size_t)(1 + b) * K];
   // software pipeline over the batches of 64 cells: the ids (cell, level codes) of batch b + 2 and the 64 R loads of batch b + 1 are in
   // flight while batch b is added up -- a segment of 128 cells costs two memory round trips instead of four
   struct Ids { int myc, myq, lev[4]; };
@@ -102,12 +118,14 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
           for (int c = 0; c < 4; c++) {
             if (c < C) {
               const int b = __builtin_amdgcn_readlane(idc.lev[c], u);
-              acc[b * 64] = __fadd_rn(acc[b * 64], rc[u]);
+              if constexpr (NLV > 0) lv_add<NLV>(lv, b, rc[u]);
+              else acc[b * 64] = __fadd_rn(acc[b * 64], rc[u]);
             }
           }
           for (int c = 4; c < C; c++) {       // (more than four covariates: level codes straight from the table)
-            const int b = qlev[__builtin_amdgcn_readlane(idc.myq, u) * C + c];
-            acc[b * 64] = __fadd_rn(acc[b * 64], rc[u]);
+            const int b = __builtin_amdgcn_readfirstlane(qlev[__builtin_amdgcn_readlane(idc.myq, u) * C + c]);
+            if constexpr (NLV > 0) lv_add<NLV>(lv, b, rc[u]);
+            else acc[b * 64] = __fadd_rn(acc[b * 64], rc[u]);
           }
         }
       }
@@ -118,7 +136,10 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   }
   if (k < K) {
     end[so] = s0;
-    if constexpr (ROWS) for (int b = 0; b < B; b++) end[so + (size_t)(1 + b) * K] = acc[b * 64];
+    if constexpr (ROWS && NLV > 0) {
+#pragma unroll
+      for (int b = 0; b < NLV; b++) if (b < B) end[so + (size_t)(1 + b) * K] = lv.v[b >> 4][b & 15];
+    } else if constexpr (ROWS) for (int b = 0; b < B; b++) end[so + (size_t)(1 + b) * K] = acc[b * 64];
   }
 }
 
@@ -136,9 +157,10 @@ template <int KPW>
 __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
                                                          int K, int d, int zs, int KP8, const int* __restrict__ list,
                                                          const SeqSeg* __restrict__ segs, int seg0, const unsigned char* __restrict__ inset,
-                                                         const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+                                                         const float* __restrict__ start, float* __restrict__ end, int zero_start, unsigned* __restrict__ conv_zero) {
 #pragma clang fp contract(off)
   static_assert(KPW == 8, "one flag byte per cluster, eight per load");
+  if (conv_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) conv_zero[threadIdx.x] = 0u;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int seg = seg0 + blockIdx.x, k0 = (blockIdx.y * (int)(blockDim.x >> 6) + wv) * KPW;
@@ -203,16 +225,23 @@ __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict
 // (c) a contiguous array of terms (the objective's three K*N-term chains, one array each): thread = segment of L terms.
 //     Round 4: a thread reads one whole 128-byte line (32 terms) per step, the next line already in flight while the 32 dependent adds of
 //     this one run (round 3: 64 bytes per step and no prefetch -- with one wave per SIMD every step exposed a full memory latency).
+// Round 5: every workgroup also leaves the fp64 sum of its 256 segments' deltas (end - start) in `partial[array][workgroup]`, added in a fixed
+// order: the scan that follows (k_seq_scan1) is then ONE wide launch -- a workgroup per 256 segments takes its base from the partials in
+// front of it -- instead of one 1024-thread workgroup per array walking 49k segments (131 us per scan at 1M cells, 77 scans per run).
 __global__ __launch_bounds__(256) void k_seq_arr_pass(const float* __restrict__ T, long long n, long long stride, int L, int nsegs,
-                                                      const float* __restrict__ start, float* __restrict__ end, int zero_start) {
+                                                      const float* __restrict__ start, float* __restrict__ end, int zero_start,
+                                                      double* __restrict__ partial, unsigned* __restrict__ conv_zero) {
   typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ double bsum[256];
+  if (conv_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) conv_zero[threadIdx.x] = 0u;
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= nsegs) return;
+  const bool live = seg < nsegs;
   const float* __restrict__ t = T + (size_t)blockIdx.y * (size_t)stride;
-  const size_t so = (size_t)blockIdx.y * nsegs + seg;
-  const long long off = (long long)seg * L;
-  const int cnt = (int)min((long long)L, n - off);
-  float s = zero_start ? 0.0f : start[so];
+  const size_t so = (size_t)blockIdx.y * nsegs + min(seg, nsegs - 1);
+  const long long off = (long long)min(seg, nsegs - 1) * L;
+  const int cnt = live ? (int)min((long long)L, n - off) : 0;
+  const float s_in = (zero_start || !live) ? 0.0f : start[so];
+  float s = s_in;
   int i = 0;
   if ((((uintptr_t)(t + off)) & 15) == 0 && cnt >= 32) {
     const f4* __restrict__ t4 = reinterpret_cast<const f4*>(t + off);
@@ -232,7 +261,11 @@ __global__ __launch_bounds__(256) void k_seq_arr_pass(const float* __restrict__ 
     i = nl << 5;
   }
   for (; i < cnt; i++) s = __fadd_rn(s, t[off + i]);
-  end[so] = s;
+  if (live) end[so] = s;
+  bsum[threadIdx.x] = live ? (double)s - (double)s_in : 0.0;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) bsum[threadIdx.x] += bsum[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bsum[0];
 }
 
 // ---- scans: start[s] <- sum of (end - start) over the chain's segments before s ------------------------------------------------
@@ -332,58 +365,55 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
     if (lane == 0 && v == 0 && ss > 0.0f && dd > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dd / ss));
   }
 }
-// one lane-chain per chain (the objective's arrays): threads along the segments, one workgroup per chain
-__global__ __launch_bounds__(1024) void k_seq_scan1(int nsegs, const float* start_in, const float* __restrict__ end, float* start_out,
-                                                    float* __restrict__ total, unsigned* __restrict__ mismatch, int zero_start) {
-  __shared__ double part[1024];
-  __shared__ float dm1[1024], sm1[1024];
-  const int t = threadIdx.x;
-  const size_t base = (size_t)blockIdx.x * nsegs;
-  const int per = (nsegs + 1023) / 1024;
-  const int s0 = min(t * per, nsegs), s1 = min((t + 1) * per, nsegs);
-  double acc = 0.0;
-  for (int sb = s0; sb < s1; sb += 16) {      // (sixteen independent loads in flight per step)
-    float e8[16], o8[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) { const size_t i = base + min(sb + u, s1 - 1); e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i]; }
-#pragma unroll
-    for (int u = 0; u < 16; u++) if (sb + u < s1) acc += (double)e8[u] - (double)o8[u];
-  }
-  part[t] = acc;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const double vv = (t >= off) ? part[t - off] : 0.0;
+// one lane-chain per chain (the objective's arrays): a workgroup per 256 segments (the pass's own workgroups: blockIdx.x alike), its base =
+// the partial sums the pass left for the workgroups in front of it.  Sums and differences are fp64 operations on values fp32 can hold.
+__global__ __launch_bounds__(256) void k_seq_scan1(int nsegs, const float* start_in, const float* __restrict__ end, float* start_out,
+                                                   float* __restrict__ total, unsigned* __restrict__ mismatch, int zero_start,
+                                                   const double* __restrict__ partial) {
+  __shared__ double sh[256];
+  __shared__ float dm1[256], sm1[256];
+  const int t = threadIdx.x, nblk = gridDim.x, bx = blockIdx.x;
+  const size_t base = (size_t)blockIdx.y * nsegs;
+  const double* __restrict__ pp = partial + (size_t)blockIdx.y * nblk;
+  double before = 0.0, all = 0.0;            // partials in front of this workgroup / of the whole array, added in workgroup order per thread, then a fixed tree
+  for (int b = t; b < nblk; b += 256) { const double v = pp[b]; all += v; before += (b < bx) ? v : 0.0; }
+  const int seg = bx * 256 + t;
+  const bool live = seg < nsegs;
+  const float e = live ? end[base + seg] : 0.0f, o = (live && !zero_start) ? start_in[base + seg] : 0.0f;
+  const double delta = live ? (double)e - (double)o : 0.0;
+  sh[t] = before; __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (t < off) sh[t] += sh[t + off]; __syncthreads(); }
+  const double b0 = sh[0]; __syncthreads();
+  sh[t] = all; __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (t < off) sh[t] += sh[t + off]; __syncthreads(); }
+  const double tot = sh[0]; __syncthreads();
+  sh[t] = delta; __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const double vv = (t >= off) ? sh[t - off] : 0.0;
     __syncthreads();
-    part[t] += vv;
+    sh[t] += vv;
     __syncthreads();
   }
-  double run = part[t] - acc;
+  const double run = b0 + sh[t] - delta;     // exclusive prefix: the accumulator value this segment starts from
   unsigned mm = 0; float dmax = 0.0f, smax = 0.0f;
-  for (int sb = s0; sb < s1; sb += 16) {
-    float e8[16], o8[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) { const size_t i = base + min(sb + u, s1 - 1); e8[u] = end[i]; o8[u] = zero_start ? 0.0f : start_in[i]; }
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      if (sb + u < s1) {
-        const float ns = (float)run;
-        if (!zero_start && __float_as_uint(ns) != __float_as_uint(o8[u])) { mm++; dmax = fmaxf(dmax, fabsf(ns - o8[u])); }
-        smax = fmaxf(smax, fabsf(ns));
-        start_out[base + sb + u] = ns;
-        run += (double)e8[u] - (double)o8[u];
-      }
-    }
+  if (live) {
+    const float ns = (float)run;
+    if (!zero_start && __float_as_uint(ns) != __float_as_uint(o)) { mm = 1; dmax = fabsf(ns - o); }
+    smax = fabsf(ns);
+    start_out[base + seg] = ns;
   }
-  if (t == 1023) total[blockIdx.x] = (float)part[1023];
+  if (bx == 0 && t == 0) total[blockIdx.y] = (float)tot;
   if (mismatch && !zero_start) {
-    dm1[t] = dmax; sm1[t] = fmaxf(smax, fabsf((float)run));
+    dm1[t] = dmax; sm1[t] = smax; sh[t] = (double)mm;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-      if (t < off) { dm1[t] = fmaxf(dm1[t], dm1[t + off]); sm1[t] = fmaxf(sm1[t], sm1[t + off]); }
+    for (int off = 128; off > 0; off >>= 1) {
+      if (t < off) { dm1[t] = fmaxf(dm1[t], dm1[t + off]); sm1[t] = fmaxf(sm1[t], sm1[t + off]); sh[t] += sh[t + off]; }
       __syncthreads();
     }
-    if (mm) atomicAdd(mismatch, mm);
-    if (t == 0 && sm1[0] > 0.0f && dm1[0] > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dm1[0] / sm1[0]));
+    // (relative to the largest start of the whole chain: for these one-signed sums that is the total, which every workgroup knows)
+    const float sref = fmaxf(sm1[0], fabsf((float)tot));
+    if (t == 0 && sh[0] > 0.0) atomicAdd(mismatch, (unsigned)sh[0]);
+    if (t == 0 && sref > 0.0f && dm1[0] > 0.0f) atomicMax(mismatch + 1, __float_as_uint(dm1[0] / sref));
   }
 }
 
@@ -522,30 +552,37 @@ __global__ void k_seq_ridge_store(Dev D, const float* __restrict__ total) {
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------
 void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* poslev, int nlist, const SeqSeg* segs, int seg0, int nsegs, const float* start,
-                   float* end, int zero_start) {
+                   float* end, int zero_start, unsigned* conv_zero) {
   if (nsegs <= 0) return;
+  static const bool lds_rows = [] { const char* e = getenv("HMX_SEQ_OE_LDS"); return e && atoi(e) == 1; }();       // (1: the level rows in LDS whatever B is -- the round-3 form, kept for B > 32)
+  if (D.B <= 32 && !lds_rows) {                         // level rows in registers
+    const dim3 grid((nsegs + 3) / 4, (D.K + 63) / 64);
+    if (D.B <= 16) hipLaunchKernelGGL((k_seq_oe_pass<true, 16>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
+    else hipLaunchKernelGGL((k_seq_oe_pass<true, 32>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
+    return;
+  }
   int wpb = 4;                                           // waves per workgroup, limited by the level rows in LDS
   while (wpb > 1 && (size_t)wpb * D.B * 256 > 60 * 1024) wpb >>= 1;
-  hipLaunchKernelGGL(k_seq_oe_pass<true>, dim3((nsegs + wpb - 1) / wpb, (D.K + 63) / 64), dim3(64 * wpb), (size_t)wpb * D.B * 256, L.stream, D.R, D.K, D.B,
-                     D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start);
+  hipLaunchKernelGGL((k_seq_oe_pass<true, 0>), dim3((nsegs + wpb - 1) / wpb, (D.K + 63) / 64), dim3(64 * wpb), (size_t)wpb * D.B * 256, L.stream, D.R, D.K, D.B,
+                     D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
 }
 // plain list sums: W = K lane-chains per segment (row 0 of the kernel above only)
 void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
-                    int zero_start) {
+                    int zero_start, unsigned* conv_zero) {
   if (nsegs <= 0) return;
-  hipLaunchKernelGGL(k_seq_oe_pass<false>, dim3((nsegs + 3) / 4, (D.K + 63) / 64), dim3(256), 0, L.stream, D.R, D.K, 0, 0, list, nullptr, 0, D.combo, D.qlev, segs,
-                     seg0, nsegs, start, end, zero_start);
+  hipLaunchKernelGGL((k_seq_oe_pass<false, 0>), dim3((nsegs + 3) / 4, (D.K + 63) / 64), dim3(256), 0, L.stream, D.R, D.K, 0, 0, list, nullptr, 0, D.combo, D.qlev, segs,
+                     seg0, nsegs, start, end, zero_start, conv_zero);
 }
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
-                      const float* start, float* end, int zero_start) {
+                      const float* start, float* end, int zero_start, unsigned* conv_zero) {
   if (nsegs <= 0) return;
   const int kg = (D.K + 7) / 8, wpg = kg < 16 ? kg : 16;       // one wave per 8 clusters, up to 16 waves (128 clusters) per workgroup
   hipLaunchKernelGGL(k_seq_ridge_pass<8>, dim3(nsegs, (kg + wpg - 1) / wpg), dim3(64 * wpg), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, D.zs, (D.K + 7) / 8 * 8, list, segs,
-                     seg0, inset, start, end, zero_start);
+                     seg0, inset, start, end, zero_start, conv_zero);
 }
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
-                    int zero_start) {
-  hipLaunchKernelGGL(k_seq_arr_pass, dim3((nsegs + 255) / 256, narr), dim3(256), 0, L.stream, T, n, stride, Lseg, nsegs, start, end, zero_start);
+                    int zero_start, double* partial, unsigned* conv_zero) {
+  hipLaunchKernelGGL(k_seq_arr_pass, dim3((nsegs + 255) / 256, narr), dim3(256), 0, L.stream, T, n, stride, Lseg, nsegs, start, end, zero_start, partial, conv_zero);
 }
 void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains, int W, const float* start_in, const float* end, float* start_out,
                 float* total, unsigned* mismatch, int zero_start) {
@@ -554,8 +591,8 @@ void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains
                      zero_start);
 }
 void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, const float* end, float* start_out, float* total,
-                 unsigned* mismatch, int zero_start) {
-  hipLaunchKernelGGL(k_seq_scan1, dim3(narr), dim3(1024), 0, L.stream, nsegs, start_in, end, start_out, total, mismatch, zero_start);
+                 unsigned* mismatch, int zero_start, const double* partial) {
+  hipLaunchKernelGGL(k_seq_scan1, dim3((nsegs + 255) / 256, narr), dim3(256), 0, L.stream, nsegs, start_in, end, start_out, total, mismatch, zero_start, partial);
 }
 void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot_add, const float* tot_sub, float* pen, int head) {
   const int n = D.B * D.K;

@@ -48,7 +48,7 @@ def test_arithmetic_gap_table(N):
     ridge statistics, O / E tables, objective sums, closed-form inverse) against the oracle in accurate (fp64 accumulators) AND
     faithful (the reference's fp32 arithmetic) mode: N x 50, K = 100, 10 batches, reference defaults, to convergence -- N = 1M is
     BASELINE configs[2] exactly, N = 2M pins a faithful comparison beyond it in the regular suite.  Shared random choices: the GPU's k-means centres, the documented Feistel block partitions (same
-    seed).  The numbers go to gpurun_out/r4_parity_table_<N>.json (copied to profiles/ and quoted in DESIGN.md section 2)."""
+    seed).  The numbers go to gpurun_out/r5_parity_table_<N>.json (copied to profiles/ and quoted in DESIGN.md section 2)."""
     K, B, seed = 100, 10, 3
     Z, meta, _ = synth(N, d=50, levels=(B,), seed=7)
     skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
@@ -69,8 +69,8 @@ def test_arithmetic_gap_table(N):
         if ref_arith:
             res[name]["seq_residual"] = float(o._scalar("seq:residual"))
 
-    def cpu(name, mask):
-        o = OracleHarmony(mask=mask, seed=seed)
+    def cpu(name, mask, liberty=0):
+        o = OracleHarmony(mask=mask, seed=seed, liberty=liberty)
         o.setup(**skw)
         t0 = time.time()
         o.init_cluster_cpp(Y0)
@@ -80,14 +80,19 @@ def test_arithmetic_gap_table(N):
 
     orc.use_openblas(4)
     th = [threading.Thread(target=cpu, args=("oracle_accurate", 15)), threading.Thread(target=cpu, args=("oracle_faithful", 0))]
+    if N == 1000000:       # BASELINE configs[2]: the width of "faithful" itself, measured next to the GPU -- the same oracle with ONE of its liberties flipped
+        th.append(threading.Thread(target=cpu, args=("oracle_faithful_liberty1", 0, 1)))      # (L1 sums with Armadillo's two accumulators, oracle header)
     [t.start() for t in th]
     gpu("gpu", 0)
     gpu("gpu_ref_arith", 1)
     [t.join() for t in th]
-    assert set(res) == {"gpu", "gpu_ref_arith", "oracle_accurate", "oracle_faithful"}
+    assert {"gpu", "gpu_ref_arith", "oracle_accurate", "oracle_faithful"} <= set(res)
     rows = {}
-    for a, b in [("gpu", "oracle_accurate"), ("gpu", "oracle_faithful"), ("gpu_ref_arith", "oracle_faithful"),
-                 ("gpu_ref_arith", "oracle_accurate"), ("oracle_faithful", "oracle_accurate")]:
+    pairs = [("gpu", "oracle_accurate"), ("gpu", "oracle_faithful"), ("gpu_ref_arith", "oracle_faithful"),
+             ("gpu_ref_arith", "oracle_accurate"), ("oracle_faithful", "oracle_accurate")]
+    if "oracle_faithful_liberty1" in res:
+        pairs.append(("oracle_faithful_liberty1", "oracle_faithful"))
+    for a, b in pairs:
         ra, rb = res[a], res[b]
         n = min(len(ra["obj"]), len(rb["obj"]))
         f, f5 = _flips(ra["R"], rb["R"], 1e-5)
@@ -100,25 +105,32 @@ def test_arithmetic_gap_table(N):
     out = {"workload": {"cells": N, "pcs": 50, "clusters": K, "batches": B}, "seconds": timing, "pairs": rows,
            "seq_residual": res["gpu_ref_arith"]["seq_residual"]}
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "r4_parity_table_%d.json" % N), "w") as fh:
+    with open(os.path.join(OUT, "r5_parity_table_%d.json" % N), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
     ga, gf, rf = rows["gpu_vs_oracle_accurate"], rows["gpu_vs_oracle_faithful"], rows["gpu_ref_arith_vs_oracle_faithful"]
-    # the parity target proper: same algorithm, exact accumulators -> tight bar, SURVEY's 1e-5 assignment margin
-    # hard assignments: none may differ where the oracle's top-2 margin is 1e-5 or more up to BASELINE's 1M cells; beyond it
-    # (2M: max |dR| between two independent implementations is 2-3e-5, and a handful of the 2M cells sit within that of a tie) the bar is
-    # "none at a margin of 1e-4, at most N / 10^5 at a margin of 1e-5", the counts are in the table
+    # (1) The parity target proper -- same algorithm, exact accumulators: the STRICT bar at every size of the suite (round 4 had loosened it at
+    # exactly BASELINE's 1M cells): Z_corr 2e-5, max |dR| within tests/parity.py's TOL_R, NO hard assignment differs where the oracle's top-2
+    # margin is 1e-5 or more, objective series 1e-4, same iteration count.
+    assert ga["Z_rel"] <= 2e-5 and ga["R_maxabs"] <= 5e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1], ga
+    assert ga["objective_rel_max"] <= 1e-4, ga
+    # (2) The reference's own arithmetic: with its operation order reproduced the GPU follows the reference's fp32 results, not the exact ones:
+    # Z_corr 1e-5 (north_star: 1e-4), objective 1e-4, same iterations.  Hard assignments and max |dR|: a faithful fp32 run is a CHAOTIC
+    # trajectory at the 1e-4 level of R -- the oracle moves its own R by 1.5e-4 .. 2.8e-4 (Z_corr by 1.7 .. 2.4e-6, hundreds of raw flips at 1M)
+    # when ONE of its sums is taken in another order that Armadillo / BLAS are free to choose (profiles/r5_oracle_liberties.json; at 1M the row
+    # oracle_faithful_liberty1_vs_oracle_faithful of this very table), and iterating the GPU's restarted sums to their bit-exact fixed point leaves
+    # its distance to the oracle where it is (tools/strict_probe.py, profiles/r5_strict_probe_1M_*.json: 1.9e-6 / 3.3e-4 / 1 with seq_strict, the
+    # largest |dR| always the same cell of one small cluster).  So below 1M cells: no flip at margin 1e-5; from 1M on: none at margin 1e-4, at most
+    # N / 10^5 at 1e-5 (what the liberties themselves produce), max |dR| inside the width of "faithful" (1e-3).
     def flips_ok(row):
-        # (a hard assignment may differ where the two leading memberships are closer than the rows themselves agree -- max|dR| is 3e-5 (exact mode) /
-        #  3e-4 (reference arithmetic) at 1M; from 1M cells on a handful of cells sit that close)
         if N < 1000000:
             return row["argmax_diff_margin_ge_1e-5"] == 0
         return row["argmax_diff_margin_ge_1e-4"] == 0 and row["argmax_diff_margin_ge_1e-5"] <= N // 100000
-    assert ga["Z_rel"] <= 2e-5 and flips_ok(ga) and ga["iterations"][0] == ga["iterations"][1], ga
-    assert ga["objective_rel_max"] <= 1e-4, ga
-    # the reference's own arithmetic: with its operation order reproduced the GPU follows the reference's fp32 results, not the exact ones
-    assert rf["Z_rel"] <= 1e-5 and flips_ok(rf) and rf["iterations"][0] == rf["iterations"][1], rf
+    assert rf["Z_rel"] <= 1e-5 and rf["R_maxabs"] <= 1e-3 and flips_ok(rf) and rf["iterations"][0] == rf["iterations"][1], rf
     assert rf["objective_rel_max"] <= 1e-4, rf
+    if "oracle_faithful_liberty1_vs_oracle_faithful" in rows:      # the GPU is as close to the oracle as the oracle is to itself
+        lf = rows["oracle_faithful_liberty1_vs_oracle_faithful"]
+        assert rf["Z_rel"] <= 3 * lf["Z_rel"] and rf["R_maxabs"] <= 3 * lf["R_maxabs"], (rf, lf)
     # (gf -- default GPU vs the reference's fp32 drift -- is REPORTED, not asserted: it is the reference's N-dependent bias)
     assert gf["iterations"][0] == gf["iterations"][1], gf
 
@@ -400,8 +412,8 @@ def _run_pair_to_convergence(Z, meta, K, seed, gpu_kw, masks, max_iter=10, blas_
         timing[name] = time.time() - t0
         res[name] = dict(Z=o.getZcorr(), R=o.R, it=it, obj=np.array(o.objective_kmeans), rounds=np.array(o.kmeans_rounds), subset=subset)
 
-    def cpu(name, mask):
-        o = OracleHarmony(mask=mask, seed=seed)
+    def cpu(name, mask, liberty=0):
+        o = OracleHarmony(mask=mask, seed=seed, liberty=liberty)
         o.setup(**skw)
         drive(name, o)
 
@@ -432,7 +444,7 @@ def test_config5_shape_1M_to_convergence():
     (7 harmony iterations): GPU (default arithmetic) against the oracle with exact accumulators, and GPU REFERENCE ARITHMETIC (round 4:
     ridge statistics of several covariates as sequential fp32 chains incl. the level-pair sums of Phi_Rk * Phi_moe_t, arma::inv as the
     oracle's unblocked fp32 LU, src/harmony.cpp:561-574) against the faithful oracle; the batch-subset ridge path counted per iteration
-    (:440-547).  Table -> gpurun_out/r4_parity_c5_1M.json (profiles/)."""
+    (:440-547).  Table -> gpurun_out/r5_parity_c5_1M.json (profiles/)."""
     Z, meta, _ = synth(1_000_000, d=50, levels=(8, 64, 128), seed=11, nested=True)
     res, timing = _run_pair_to_convergence(Z, meta, 200, 5, {"gpu": {}, "gpu_ref_arith": {"ref_arith": 1}}, {"oracle_accurate": 15, "oracle_faithful": 0})
     rows = {"gpu_vs_oracle_accurate": _pair_row(res["gpu"], res["oracle_accurate"]), "gpu_vs_oracle_faithful": _pair_row(res["gpu"], res["oracle_faithful"]),
@@ -440,7 +452,7 @@ def test_config5_shape_1M_to_convergence():
             "oracle_faithful_vs_oracle_accurate": _pair_row(res["oracle_faithful"], res["oracle_accurate"])}
     out = {"workload": {"cells": 1000000, "pcs": 50, "clusters": 200, "levels": [8, 64, 128], "nested": True}, "seconds": timing, "pairs": rows}
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "r4_parity_c5_1M.json"), "w") as fh:
+    with open(os.path.join(OUT, "r5_parity_c5_1M.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
     ga = rows["gpu_vs_oracle_accurate"]
@@ -453,6 +465,9 @@ def test_config5_shape_1M_to_convergence():
     assert rf["Z_rel"] <= 1e-4 and rf["iterations"][0] == rf["iterations"][1] and rf["kmeans_rounds_equal"], rf
     assert rf["objective_rel_max"] <= 1e-4, rf
     assert rf["subset_clusters_per_iteration"][0] == rf["subset_clusters_per_iteration"][1], rf
+    # (hard assignments / max |dR| of this pair: inside the width of "faithful" itself -- test_arithmetic_gap_table's comment; here the fp32 LU of
+    #  condition 5e3 .. 1.6e4 widens it further: bounded, not zero)
+    assert rf["R_maxabs"] <= 2e-3 and rf["argmax_diff_margin_ge_1e-5"] <= 100, rf
     gf = rows["gpu_vs_oracle_faithful"]      # reported: the default mode against the reference's fp32 drift at this shape
     assert gf["iterations"][0] == gf["iterations"][1], gf
 
@@ -461,7 +476,7 @@ def test_config5_shape_1M_to_convergence():
 @pytest.mark.skipif(os.environ.get("HMX_SLOW", "0") != "1", reason="builder run (HMX_SLOW=1): ~15 minutes of CPU for the oracle at 10M cells; table in profiles/")
 def test_config4_10M_against_the_oracle():
     """BASELINE configs[3] at FULL size on one GPU -- 10M x 50, K = 100, 20 batches, to convergence: GPU default vs the oracle with exact
-    accumulators, and GPU reference arithmetic vs the faithful oracle.  Table -> gpurun_out/r4_parity_c4_10M.json (profiles/)."""
+    accumulators, and GPU reference arithmetic vs the faithful oracle.  Table -> gpurun_out/r5_parity_c4_10M.json (profiles/)."""
     with open("/proc/meminfo") as fh:
         avail_gb = [int(l.split()[1]) for l in fh if l.startswith("MemAvailable")][0] / 1048576.0
     if avail_gb < 120:
@@ -473,11 +488,38 @@ def test_config4_10M_against_the_oracle():
             "gpu_vs_oracle_faithful": _pair_row(res["gpu"], res["oracle_faithful"]), "oracle_faithful_vs_oracle_accurate": _pair_row(res["oracle_faithful"], res["oracle_accurate"])}
     out = {"workload": {"cells": 10000000, "pcs": 50, "clusters": 100, "batches": 20}, "seconds": timing, "pairs": rows}
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "r4_parity_c4_10M.json"), "w") as fh:
+    with open(os.path.join(OUT, "r5_parity_c4_10M.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
     ga, rf = rows["gpu_vs_oracle_accurate"], rows["gpu_ref_arith_vs_oracle_faithful"]
     assert ga["Z_rel"] <= 2e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1], ga
+    assert rf["Z_rel"] <= 1e-4 and rf["iterations"][0] == rf["iterations"][1], rf
+
+
+@pytest.mark.timeout(4000, method="thread")
+@pytest.mark.skipif(os.environ.get("HMX_SLOW", "0") != "1", reason="builder run (HMX_SLOW=1): ~20 minutes of CPU for the oracle at 5M cells x 200 clusters; table in profiles/")
+def test_config5_5M_against_the_oracle():
+    """BASELINE configs[4] at its FULL stated size on one GPU -- 5M x 50, K = 200, three nested covariates 8 > 64 > 128 = 200 levels, to
+    convergence: GPU default vs the oracle with exact accumulators (subset-cluster counts per iteration included), and GPU reference arithmetic
+    vs the faithful oracle.  Table -> gpurun_out/r5_parity_c5_5M.json (profiles/)."""
+    with open("/proc/meminfo") as fh:
+        avail_gb = [int(l.split()[1]) for l in fh if l.startswith("MemAvailable")][0] / 1048576.0
+    if avail_gb < 150:
+        pytest.skip("two 5M-cell x 200-cluster oracles need ~100 GB of host memory (%.0f GB available)" % avail_gb)
+    Z, meta, _ = synth(5_000_000, d=50, levels=(8, 64, 128), seed=11, nested=True)
+    res, timing = _run_pair_to_convergence(Z, meta, 200, 5, {"gpu": {}, "gpu_ref_arith": {"ref_arith": 1}}, {"oracle_accurate": 15, "oracle_faithful": 0},
+                                           blas_threads=8)
+    rows = {"gpu_vs_oracle_accurate": _pair_row(res["gpu"], res["oracle_accurate"]), "gpu_ref_arith_vs_oracle_faithful": _pair_row(res["gpu_ref_arith"], res["oracle_faithful"]),
+            "gpu_vs_oracle_faithful": _pair_row(res["gpu"], res["oracle_faithful"]), "oracle_faithful_vs_oracle_accurate": _pair_row(res["oracle_faithful"], res["oracle_accurate"])}
+    out = {"workload": {"cells": 5000000, "pcs": 50, "clusters": 200, "levels": [8, 64, 128], "nested": True}, "seconds": timing, "pairs": rows}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "r5_parity_c5_5M.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+    ga, rf = rows["gpu_vs_oracle_accurate"], rows["gpu_ref_arith_vs_oracle_faithful"]
+    assert ga["Z_rel"] <= 2e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1] and ga["kmeans_rounds_equal"], ga
+    assert ga["objective_rel_max"] <= 1e-4, ga
+    assert ga["subset_clusters_per_iteration"][0] == ga["subset_clusters_per_iteration"][1], ga
     assert rf["Z_rel"] <= 1e-4 and rf["iterations"][0] == rf["iterations"][1], rf
 
 

@@ -34,6 +34,9 @@ def run(skw, Y0, liberty, seed=3):
     return dict(Z=o.getZcorr(), R=o.R, it=it, obj=np.array(o.objective_kmeans))
 
 
+out = {}
+
+
 def flips(Ra, Rb, margin):
     aa, ab = Ra.argmax(axis=0), Rb.argmax(axis=0)
     bad = np.where(aa != ab)[0]
@@ -43,10 +46,12 @@ def flips(Ra, Rb, margin):
     return int(bad.size), int(((srt[-1] - srt[-2]) >= margin).sum())
 
 
-out = {}
 cases = [("%dk_one_covariate_K100" % (n // 1000), n, (10,), 100) for n in (20000, 100000)] + [("20k_two_covariates_K60", 20000, (3, 4), 60)]
-if len(sys.argv) > 1:
-    cases = [c for c in cases if c[0] in sys.argv[1:]]
+if len(sys.argv) > 1:       # e.g. `1000k_one_covariate_K100` (BASELINE configs[2]; ~1 minute of CPU per run)
+    cases = [c for c in cases + [("1000k_one_covariate_K100", 1000000, (10,), 100)] if c[0] in sys.argv[1:]]
+PATH = os.path.join(ROOT, "profiles", "r5_oracle_liberties.json")
+if os.path.exists(PATH):
+    out = json.load(open(PATH))
 for name, N, levels, K in cases:
     Z, meta, _ = synth(N, d=50, levels=levels, seed=7)
     skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
@@ -64,5 +69,5 @@ for name, N, levels, K in cases:
                       "iterations": [r["it"], base["it"]]}
         print(name, what, rows[what], flush=True)
     out[name] = rows
-with open(os.path.join(ROOT, "profiles", "r5_oracle_liberties.json"), "w") as fh:
+with open(PATH, "w") as fh:
     json.dump(out, fh, indent=1)

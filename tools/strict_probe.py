@@ -64,8 +64,13 @@ for name in a.settings.split(","):
     o = Harmony(seed=seed, ref_arith=1)
     if name == "strict":
         o._set("seq_strict", 1)
-    elif name.startswith("passes"):
-        o._set("seq_passes", int(name[6:]))
+    else:               # e.g. passes2, passes2tol10000 (seq_passes, seq_tol in parts per billion)
+        import re
+        m = re.match(r"passes(\d+)(?:tol(\d+))?$", name)
+        if m:
+            o._set("seq_passes", int(m.group(1)))
+            if m.group(2):
+                o._set("seq_tol_ppb", int(m.group(2)))
     o.setup(**skw)
     for rep in range(2):          # second run: warm allocations, the time that counts
         o.restart()
