@@ -213,7 +213,7 @@ struct hmx_ctx {
   // peer-to-peer block chain (hmx_p2p_*): inboxes shared through HIP IPC; on only after the connection self-test passed everywhere
   unsigned long long* p2p_self = nullptr; unsigned long long* p2p_peer[8] = {}; int p2p_rank = 0, p2p_world = 0; bool p2p_on = false;
   unsigned p2p_tests = 0; int* p2p_result = nullptr; double p2p_exchange_us = 0.0; std::string p2p_note = "not connected";
-  unsigned p2p_ar_seq = 0, p2p_xseq = 0; int64_t p2p_ar_calls = 0;     // generic inbox all-reduces issued (same on every rank) / chain exchanges issued
+  unsigned p2p_ar_seq = 0, p2p_xseq = 0; int64_t p2p_ar_calls = 0, p2p_ar_big_windows = 0;     // generic inbox all-reduces issued (same on every rank) / chain exchanges issued
   int (*poll)(void*) = nullptr; void* poll_user = nullptr;
   // ---- problem --------------------------------------------------------------------
   int64_t N = 0;  // local cells
@@ -264,7 +264,8 @@ struct hmx_ctx {
   float* rg_tot = nullptr; float* rp_tot = nullptr; float* rp_start = nullptr; bool rp_warm = false;
   float* sq_start = nullptr; float* sq_end = nullptr; size_t sq_cap = 0;
   float* sq_total = nullptr; size_t sq_total_cap = 0;
-  unsigned* sq_mismatch = nullptr; int seq_passes = 2; int64_t seq_runs = 0;      // (round 5: 2 passes, see seq_tol)
+  unsigned* sq_mismatch = nullptr; int seq_passes = 2, seq_warm_passes = 2; int64_t seq_runs = 0;      // (round 5: 2 passes cold AND warm, see seq_tol / seq_iterate)
+  bool seq_stats = false;     // the last scan of NON-adaptive groups also counts the starts that still moved ("seq:mismatch" / "seq:residual" then cover every group)
   // long chains (>= seq_adaptive_cells cells) are iterated until the starts stop moving (chain-relative residual <= 2^-22) or seq_max_passes
   unsigned* sq_conv = nullptr; int seq_max_passes = 24; int64_t seq_adaptive_cells = 200000, seq_extra_passes = 0; double seq_resid_max = 0.0; uint64_t seq_mismatch_sum = 0;
   // seq_strict: EVERY group of restarted sums (short chains too) is iterated until no segment start moves any more -- the fixed point, at which
@@ -403,14 +404,24 @@ int allreduce(hmx_ctx* ctx, void* buf, int64_t count, int dtype) {
   if (ctx->world <= 1 && !ctx->comm_force) return 0;
   // small buffers go through the peers' inboxes when they are connected and tested (k_p2p_allreduce: one launch, one trip over xGMI, no ring):
   // everything but the big ridge statistics of many-level designs.  HMX_P2P_AR=0: always the communicator / hook.
-  if (ctx->p2p_on && ctx->p2p_world == ctx->world && !ctx->comm_force && count <= (int64_t)P2P_CAP && ctx->ran_setup && ctx->D.chain_ctl) {
+  if (ctx->p2p_on && ctx->p2p_world == ctx->world && !ctx->comm_force && ctx->ran_setup && ctx->D.chain_ctl) {
     static const bool off = [] { const char* e = getenv("HMX_P2P_AR"); return e && atoi(e) == 0; }();
-    if (!off) {
+    static const bool big_off = [] { const char* e = getenv("HMX_P2P_AR_BIG"); return e && atoi(e) == 0; }();      // (0: buffers above P2P_CAP entries go to the communicator / hook as in round 4)
+    if (!off && (count <= (int64_t)P2P_CAP || !big_off)) {
       Dev T = ctx->D; T.p2p_world = ctx->p2p_world; T.p2p_rank = ctx->p2p_rank;
       for (int g = 0; g < 8; g++) T.p2p_inbox[g] = ctx->p2p_peer[g];
-      l_p2p_allreduce(ctx->L, T, buf, (int)count, dtype, ctx->p2p_ar_seq++, ctx->D.chain_ctl + 1);
+      if (count <= (int64_t)P2P_CAP) {
+        l_p2p_allreduce(ctx->L, T, buf, (int)count, dtype, ctx->p2p_ar_seq++, ctx->D.chain_ctl + 1);
+        ctx->p2p_ar_calls++;
+      } else {
+        // big buffers (ridge statistics of many-level designs): reduce-scatter + all-gather through the inboxes, a window at a time
+        const int64_t win = (int64_t)(P2P_CAP / 2) * ctx->p2p_world;
+        for (int64_t off0 = 0; off0 < count; off0 += win) {
+          l_p2p_allreduce_big(ctx->L, T, (char*)buf + 8 * off0, (int)std::min(win, count - off0), dtype, ctx->p2p_ar_seq++, ctx->D.chain_ctl + 1);
+          ctx->p2p_ar_calls++; ctx->p2p_ar_big_windows++;
+        }
+      }
       if (hipGetLastError() != hipSuccess) return fail(ctx, HMX_ERR_COMM, "inbox all-reduce launch failed");
-      ctx->p2p_ar_calls++;
       return 0;
     }
   }
@@ -422,7 +433,7 @@ int allreduce(hmx_ctx* ctx, void* buf, int64_t count, int dtype) {
   }
   // (a handle that has inboxes but neither a communicator nor a hook -- hmx_p2p_connect by hand -- gets here with what the inboxes do not take:
   //  the collectives of hmx_setup, buffers above P2P_CAP entries, everything under HMX_P2P_AR=0.  That is an error, not an RCCL call on a null communicator.)
-  if (!ctx->comm) return fail(ctx, HMX_ERR_COMM, ctx->p2p_on ? "this collective does not fit the peer inboxes (before setup / more than 65536 entries / HMX_P2P_AR=0): the handle also needs hmx_comm_init or an all-reduce hook"
+  if (!ctx->comm) return fail(ctx, HMX_ERR_COMM, ctx->p2p_on ? "this collective does not go through the peer inboxes (before setup / HMX_P2P_AR=0): the handle also needs hmx_comm_init or an all-reduce hook"
                                                             : "sharded handle without hmx_comm_init or an all-reduce hook");
   RcclApi* api = rccl_api(nullptr);
   if (!api || !api->AllReduce) return fail(ctx, HMX_ERR_COMM, "librccl is not loadable");
@@ -896,15 +907,18 @@ int seq_settled(hmx_ctx* ctx, bool* settled) {
 // one restarted-sum iteration scheme for all users: `pass(p, zero_start)` runs the segments, `scan(p, zero_start, conv)` the scan.  The first
 // `seq_passes` passes always run (warm: one less); long chains continue until the starts settled.
 template <class PASS, class SCAN> int seq_iterate(hmx_ctx* ctx, int group, bool warm, bool adaptive, PASS pass, SCAN scan) {
-  int p = warm ? 1 : 0;
+  // cold: seq_passes passes from zero starts.  warm: seq_warm_passes passes from the starts the workspace still holds -- NOT one pass less by
+  // default: a warm start of a block's put-back sums is as far from the truth as R moved in the block update, and ONE pass from it carries a
+  // first-order error (100k cells: Z_corr 5.8e-6 from the oracle instead of 2.2e-6, tools/strict_probe.py); two passes from zero are second order.
+  int p = warm ? std::max(0, ctx->seq_passes - ctx->seq_warm_passes) : 0;
   const int p_first = p;
   ctx->seq_group_runs[group]++;
   if (ctx->seq_strict) adaptive = true;
   struct Count { hmx_ctx* c; int g; const int& p; int p0; ~Count() { c->seq_group_passes[g] += p - p0; } } count{ctx, group, p, p_first};
   for (; p < ctx->seq_passes; p++) {
-    const bool last = p == ctx->seq_passes - 1;
-    CHK(pass(p == 0, last ? ctx->sq_conv : nullptr));       // (the pass zeroes the statistics words its scan adds to)
-    CHK(scan(p == 0, last ? ctx->sq_conv : nullptr));
+    const bool last = p == ctx->seq_passes - 1 && (adaptive || ctx->seq_stats);     // (short chains: statistics only on request, "seq_stats")
+    CHK(pass(p == 0 && !warm, last ? ctx->sq_conv : nullptr));       // (the pass zeroes the statistics words its scan adds to)
+    CHK(scan(p == 0 && !warm, last ? ctx->sq_conv : nullptr));
   }
   if (!adaptive) {      // (short chains: three passes are far inside fp32 noise; their last scan's statistics are read when a getter asks)
     return 0;
@@ -1732,6 +1746,8 @@ int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t v) {
   }
   else if (f == "stale_dist") { if (ctx->ran_setup) return fail(ctx, HMX_ERR_STATE, "stale_dist must be set before setup"); ctx->stale_dist = v != 0; }
   else if (f == "seq_passes") { if (v < 2 || v > 64) return fail(ctx, HMX_ERR_ARG, "seq_passes: 2..64"); ctx->seq_passes = (int)v; if (ctx->seq_max_passes < (int)v) ctx->seq_max_passes = (int)v; }
+  else if (f == "seq_warm_passes") { if (v < 1 || v > 64) return fail(ctx, HMX_ERR_ARG, "seq_warm_passes: 1..64"); ctx->seq_warm_passes = (int)v; }
+  else if (f == "seq_stats") ctx->seq_stats = v != 0;
   else if (f == "seq_tol_ppb") { if (v < 0 || v > 100000000) return fail(ctx, HMX_ERR_ARG, "seq_tol_ppb: 0 .. 1e8 (parts per billion)"); ctx->seq_tol = 1e-9 * (double)v; }
   else if (f == "seq_strict") { ctx->seq_strict = v != 0; if (v && ctx->seq_max_passes < 64) ctx->seq_max_passes = 64; }
   else if (f == "seq_max_passes") { if (v < 2 || v > 256) return fail(ctx, HMX_ERR_ARG, "seq_max_passes: 2..256"); ctx->seq_max_passes = (int)v; }
@@ -2413,7 +2429,7 @@ int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level,
     HIPCHK(hipMalloc((void**)&dlev, sizeof(int) * (size_t)n)); HIPCHK(hipMalloc((void**)&dq, sizeof(int) * (size_t)B));
     std::vector<int> ident(B); std::iota(ident.begin(), ident.end(), 0);
     CHK(h2d(ctx, dR, R, (size_t)n * K)); CHK(h2d(ctx, dl, list, (size_t)nlist)); CHK(h2d(ctx, dlev, level, (size_t)n)); CHK(h2d(ctx, dq, ident.data(), (size_t)B));
-    ctx->K = K; ctx->B = B; ctx->seq_passes = passes;
+    ctx->K = K; ctx->B = B; ctx->seq_passes = passes; ctx->seq_stats = true;
     ctx->D.R = dR; ctx->D.K = K; ctx->D.B = B; ctx->D.C = 1; ctx->D.combo = dlev; ctx->D.qlev = dq;      // one covariate: combination == level
     std::vector<std::pair<int, int>> ch;
     for (int c = 0; c < nchains; c++) ch.push_back({chain_off[c], chain_cnt[c]});
@@ -2541,6 +2557,7 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap) {
   if (f == "shuffle_inv") return scalar(ctx->shuf_inv ? 1.0 : 0.0);
   if (f == "p2p:exchange_us") return scalar(ctx->p2p_exchange_us);
   if (f == "p2p:allreduce_calls") return scalar((double)ctx->p2p_ar_calls);
+  if (f == "p2p:allreduce_big_windows") return scalar((double)ctx->p2p_ar_big_windows);
   if (f == "p2p") return scalar(ctx->p2p_on && ctx->p2p_world == ctx->world ? 1.0 : 0.0);
   if (f == "chain_dbg") {   // accumulated 100 MHz ticks of the persistent chain's phases (see hmx_internal.h); reading resets them
     if (!ctx->ran_setup) return -1;

@@ -278,6 +278,8 @@ constexpr size_t P2P_INBOX_GRANULES = P2P_TEST_BASE + 64;
 // generic all-reduce of a small buffer through the inboxes (k_p2p_allreduce): dtype 0 int64 sum | 1 float64 sum (rank order: identical on
 // every rank) | 2 int64 min; `seq` = the call's number (same on every rank: plane 2 + (seq & 1), tag 0x40000000 + seq)
 void l_p2p_allreduce(const Launch& L, const Dev& D, void* buf, int n, int dtype, unsigned seq, int* err);
+// the same for a window of up to (P2P_CAP / 2) * world entries as reduce-scatter + all-gather (big buffers: one call per window, own `seq` each)
+void l_p2p_allreduce_big(const Launch& L, const Dev& D, void* buf, int n, int dtype, unsigned seq, int* err);
 void l_p2p_selftest(const Launch& L, const Dev& D, unsigned tag, int* result);   // the whole block chain of a round: one persistent launch
 void l_objective_tables(const Launch& L, const Dev& D);  // cross-entropy term only -> obj[4]
 void l_moe_stats(const Launch& L, const Dev& D);

@@ -4564,6 +4564,70 @@ __global__ void __launch_bounds__(1024) k_p2p_allreduce(Dev D, unsigned long lon
 void l_p2p_allreduce(const Launch& L, const Dev& D, void* buf, int n, int dtype, unsigned seq, int* err) {
   hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(1024), 0, L.stream, D, (unsigned long long*)buf, n, dtype, seq, err);
 }
+// LARGE buffers (the ridge statistics of many-level designs: Q K (d + 1) doubles, 10 MB at BASELINE configs[4]) through the same inboxes as
+// reduce-scatter + all-gather: the one-shot form above would push every rank's WHOLE buffer over each of its links; here entry e of a
+// window belongs to rank e / S (S = P2P_CAP / 2 entries per rank and window): (1) every rank sends its value of e to the owner only, (2) the owner
+// adds the G values in RANK ORDER (fp64 sums identical on every rank) and sends the result to everybody, (3) the others pick it up -- 2 (G - 1) / G
+// of the buffer per link instead of (G - 1) times it, many workgroups wide.  Inbox layout per (plane, source): entries [0, S) carry the
+// scattered values, [S, 2 S) the gathered results; planes and tags as k_p2p_allreduce (one call = one window = one `seq`).  Three separate
+// sweeps, so no thread waits while a peer still needs one of its sends; every spin is bounded (err = 7).
+__device__ __forceinline__ void p2p_send_to(const Dev& D, int peer, size_t par, int i, unsigned tag, unsigned long long v) {
+  const unsigned long long tb = (unsigned long long)tag << 32;
+  const unsigned long long lo = tb | (v & 0xffffffffull), hi = tb | (v >> 32);
+#pragma unroll
+  for (int gq = 0; gq < 8; gq++) if (gq == peer) {       // (static indices only: a dynamic one would spill the kernarg copy)
+    unsigned long long* dst = D.p2p_inbox[gq] + ((par + D.p2p_rank) * P2P_CAP + i) * 2;
+    __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__device__ __forceinline__ unsigned long long p2p_wait(const Dev& D, size_t par, int src_rank, int i, unsigned tag, int* err) {
+  const unsigned long long* src = D.p2p_inbox_self() + ((par + src_rank) * P2P_CAP + i) * 2;
+  unsigned long long lo = 0, hi = 0;
+  bool got = false;
+  for (int spins = 0; spins < (1 << 20); spins++) {
+    lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) { got = true; break; }
+    if ((spins & 255) == 255 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (!got && err) atomicExch(err, 7);
+  return (hi << 32) | (lo & 0xffffffffull);
+}
+__global__ void __launch_bounds__(1024) k_p2p_allreduce_big(Dev D, unsigned long long* __restrict__ buf, int n, int dtype, unsigned seq, int* err) {
+  const int G = D.p2p_world, me = D.p2p_rank;
+  constexpr int S = P2P_CAP / 2;
+  const unsigned tag = 0x40000000u + (seq & 0x3fffffffu);
+  const size_t par = (size_t)(2 + (seq & 1u)) * 8;
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (int e = t0; e < n; e += nt) {                       // (1) scatter: my value of every entry another rank owns
+    const int owner = e / S;
+    if (owner != me) p2p_send_to(D, owner, par, e - owner * S, tag, buf[e]);
+  }
+  for (int l = t0; l < S; l += nt) {                       // (2) my slice: reduce in rank order, gather out
+    const int e = me * S + l;
+    if (e >= n) break;
+    unsigned long long val[8];
+#pragma unroll
+    for (int gq = 0; gq < 8; gq++) { val[gq] = buf[e]; if (gq < G && gq != me) val[gq] = p2p_wait(D, par, gq, l, tag, err); }
+    unsigned long long out;
+    if (dtype == 1) { double a = 0.0; for (int gq = 0; gq < G; gq++) a += __longlong_as_double((long long)val[gq]); out = (unsigned long long)__double_as_longlong(a); }
+    else if (dtype == 2) { long long a = (long long)val[0]; for (int gq = 1; gq < G; gq++) a = min(a, (long long)val[gq]); out = (unsigned long long)a; }
+    else { long long a = 0; for (int gq = 0; gq < G; gq++) a += (long long)val[gq]; out = (unsigned long long)a; }
+    buf[e] = out;
+#pragma unroll
+    for (int gq = 0; gq < 8; gq++) if (gq < G && gq != me) p2p_send_to(D, gq, par, S + l, tag, out);
+  }
+  for (int e = t0; e < n; e += nt) {                       // (3) the other ranks' slices
+    const int owner = e / S;
+    if (owner != me) buf[e] = p2p_wait(D, par, owner, S + (e - owner * S), tag, err);
+  }
+}
+void l_p2p_allreduce_big(const Launch& L, const Dev& D, void* buf, int n, int dtype, unsigned seq, int* err) {
+  int blocks = (n + 4095) / 4096; if (blocks > 128) blocks = 128; if (blocks < 1) blocks = 1;        // (all resident at once: the sweeps wait on peers, never on each other)
+  hipLaunchKernelGGL(k_p2p_allreduce_big, dim3(blocks), dim3(1024), 0, L.stream, D, (unsigned long long*)buf, n, dtype, seq, err);
+}
 void l_objective_tables(const Launch& L, const Dev& D) {
   hipLaunchKernelGGL(k_objective_tables, dim3(1), dim3(TPB), 0, L.stream, D);
 }

@@ -130,7 +130,8 @@ int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype
 /* writable fields: "max_iter_kmeans" (vignettes/detailedWalkthrough.Rmd:364), "seed",
  * "device" (before setup), "profile" (HIP-event timing of the update kernel, see below),
  * "rng" (0 counter-based generator | 1 R-compatible stream, see "randomness"),
- * "ridge_arith" / "oe_arith" / "obj_arith" / "solve_arith" / "ref_arith" (see "reference arithmetic" below), "seq_passes",
+ * "ridge_arith" / "oe_arith" / "obj_arith" / "solve_arith" / "ref_arith", "seq_passes" / "seq_warm_passes" / "seq_tol_ppb" / "seq_strict" /
+ * "seq_stats" / "seq_max_passes" (see "reference arithmetic" below),
  * "stale_dist" (before setup; see hmx_compute_objective).
  * Tuning / fallback selectors (tests and measurements; the defaults are the measured best):
  *   fields "grid", "upd_wps" (before setup), "upd_tpw", "upd_cpw", "upd_impl", "comm_force";
@@ -234,9 +235,18 @@ int hmx_set_abort_poll(hmx_ctx* ctx, int (*poll)(void*), void* user);
  *   "solve_arith"  the closed-form fp32 arrowhead inverse of the one-covariate ridge system               (src/harmony.cpp:575-586)
  *   "ref_arith"    all four.
  * The sequential sums are computed as RESTARTED sequential sums (segments in parallel, their starting values by fixed-point
- * iteration; at the fixed point the result is bit-identical to the one-after-the-other loop.  "seq_passes" = passes per sum,
- * default 3; hmx_get "seq:mismatch" / "seq:residual" = how many segment starts still moved in the last scans and by how much,
- * relatively).  Probes of that machinery on caller-provided data (device needed): */
+ * iteration; at the fixed point the result is bit-identical to the one-after-the-other loop).  Settings (hmx_set_int):
+ *   "seq_passes" passes of a sum that starts from zero (default 2), "seq_warm_passes" passes of a sum that starts from the starts of its
+ *   last evaluation (default 2); long chains (>= 200k cells, the objective's K N terms) continue until the largest move of a start in the last
+ *   scan is below "seq_tol_ppb" parts per billion of the largest start of its lane group (default 10000 = 1e-5; at most "seq_max_passes");
+ *   "seq_strict" = 1: EVERY sum is iterated until no start moves any more -- the bit-exact fixed point (slow: ~1.2 s per run at 1M cells).
+ *   Measured at BASELINE configs[2] (profiles/r5_strict_probe_1M_*.json): the default, six passes and the strict fixed point all end
+ *   1.9e-6 .. 2.1e-6 from the faithful oracle and as far from EACH OTHER -- the faithful fp32 trajectory itself moves by that much under any
+ *   ulp-level change (profiles/r5_oracle_liberties.json).
+ *   hmx_get "seq:mismatch" / "seq:residual" = how many segment starts still moved in the last scans and by how much, relatively (long chains
+ *   always; the short per-block sums only with "seq_stats" = 1); "seq:group_passes" / "seq:group_runs" = passes / evaluations per group (O/E,
+ *   objective, ridge, level pairs); "seq:unsettled" = sums that hit seq_max_passes.
+ * Probes of that machinery on caller-provided data (device needed): */
 int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level, int32_t B, const int32_t* list, int64_t nlist,
                      const int32_t* chain_off, const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals,
                      int64_t* mismatch, double* residual);

@@ -60,6 +60,7 @@ def test_arithmetic_gap_table(N):
     def gpu(name, ref_arith):
         o = g if ref_arith == 0 else Harmony(seed=seed, ref_arith=1)
         if ref_arith:
+            o._set("seq_stats", 1)
             o.setup(**skw)
         t0 = time.time()
         o.init_cluster_cpp(Y0)
@@ -627,6 +628,24 @@ def test_two_processes_peer_to_peer_chain():
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dist_two_proc.py"), "--p2p", "--carry"],
                        capture_output=True, text=True, timeout=500, stdin=subprocess.DEVNULL)
     assert "DIST2_OK world=2" in p.stdout and "p2p=1" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_two_processes_configs4_shape_through_the_inboxes():
+    """BASELINE configs[4]'s shape on two ranks (K = 200, 8 > 64 > 128 nested levels, 40k cells): no persistent chain above K = 112, so every
+    block step's K x B table is an inbox all-reduce of its own, and the ridge statistics (Q K (d + 1) doubles, far above the 65536 entries
+    of the one-shot form) take the inboxes' reduce-scatter + all-gather windows (round 5) -- what is left on the hook is the setup's handful.
+    Rank 0 checks against the unsharded run."""
+    import subprocess
+    import sys
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dist_two_proc.py"), "--p2p", "--workload", "c5", "--cells", "40000"],
+                       capture_output=True, text=True, timeout=600, stdin=subprocess.DEVNULL)
+    assert "DIST2_OK world=2" in p.stdout and "p2p=1" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+    print(p.stdout[-400:])
+    assert int(p.stdout.split("collectives/rank=")[1].split()[0]) <= 12, p.stdout[-400:]
+    assert int(p.stdout.split("big_windows/rank=")[1].split()[0]) > 0, p.stdout[-400:]
 
 
 def test_bench_bootstraps_without_torch():

@@ -127,6 +127,7 @@ def _iterate(obj, max_iter=10):
 def _pair(Z, meta, vars_use, seed, max_iter=10, **kw):
     skw, _ = prepare_setup_args(Z, meta, vars_use, **kw)
     g = Harmony(seed=seed, ref_arith=1)
+    g._set("seq_stats", 1)
     g.setup(**skw)
     Y0 = g.kmeans_centers()
     c = OracleHarmony(mask=0, seed=seed)          # faithful: all four accumulator groups in the reference's fp32

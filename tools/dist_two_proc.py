@@ -23,6 +23,8 @@ ap.add_argument("--p2p", action="store_true", help="sum the block contributions 
                 "(hmx_p2p_*; the handles travel through torch.distributed) instead of one all-reduce per block")
 ap.add_argument("--carry", action="store_true", help="force the round-to-round carry of the old contributions (HMX_SOLD_CARRY=1)")
 ap.add_argument("--split", type=float, default=0.0, help="two ranks: rank 0 holds this fraction of the cells (unequal shards)")
+ap.add_argument("--workload", default="c3", choices=["c3", "c5"], help="c5: BASELINE configs[4]'s shape (K = 200, nested covariates 8 > 64 > 128): block steps one launch each "
+                "(no chain above K = 112), ridge statistics of Q K (d + 1) > 65536 entries -- the inboxes' reduce-scatter + all-gather path")
 ap.add_argument("--chain-max-tpw", default=None, help="HMX_CHAIN_MAX_TPW: tiles per wave up to which a rank would pick the persistent chain")
 a = ap.parse_args()
 if a.carry:
@@ -42,14 +44,18 @@ from harmony_amd import Harmony, prepare_setup_args  # noqa: E402
 from harmony_amd.dist import TorchAllReduce, shard_bounds  # noqa: E402
 
 N, K, B = a.cells, 100, 10
-Z, meta, _ = synth(N, d=50, levels=(B,), seed=21)          # every rank generates the global problem, keeps its shard
+levels, nested = (B,), False
+if a.workload == "c5":
+    K, levels, nested = 200, (8, 64, 128), True
+Z, meta, _ = synth(N, d=50, levels=levels, seed=21, nested=nested)          # every rank generates the global problem, keeps its shard
+vars_use = list(meta)
 bounds = shard_bounds(N, world)
 if a.split > 0 and world == 2:
     cut = int(N * a.split)
     bounds = [(0, cut), (cut, N)]
 lo, hi = bounds[rank]
-N_b = np.bincount(meta["cov0"], minlength=B).astype(float)
-skw, _ = prepare_setup_args(Z[lo:hi], {"cov0": meta["cov0"][lo:hi]}, "cov0", nclust=K, N_b=N_b, levels={"cov0": np.arange(B)})
+N_b = np.concatenate([np.bincount(meta[v], minlength=L).astype(float) for v, L in zip(vars_use, levels)])
+skw, _ = prepare_setup_args(Z[lo:hi], {v: meta[v][lo:hi] for v in vars_use}, vars_use, nclust=K, N_b=N_b, levels={v: np.arange(L) for v, L in zip(vars_use, levels)})
 
 
 def run(obj):
@@ -96,7 +102,7 @@ else:
 O_sh, obj_sh = g.O, g.objective_kmeans
 if rank == 0:
     one = Harmony(device=dev.index, seed=4)
-    skw1, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
+    skw1, _ = prepare_setup_args(Z, meta, vars_use, nclust=K)
     one.setup(**skw1)
     it1 = run(one)
     Zall = torch.cat(parts).numpy().T
@@ -107,10 +113,10 @@ if rank == 0:
     np.testing.assert_allclose(obj_sh, one.objective_kmeans, rtol=1e-6)
     rel = np.linalg.norm(Zall - one.getZcorr()) / np.linalg.norm(one.getZcorr())
     assert rel < 1e-6, rel
-    if a.p2p and not a.chain_max_tpw:
+    if a.p2p and not a.chain_max_tpw and a.workload == "c3":
         assert g._scalar("p2p") == 1 and g._scalar("chain") == 1, (g.p2p_status, g._scalar("chain"))
-    print("DIST2_OK world=%d backend=%s p2p=%d chain=%d iterations=%d collectives/rank=%d inbox_allreduces/rank=%d Z_rel=%.1e run=%.1f ms (%s)"
-          % (world, a.backend, int(a.p2p), int(g._scalar("chain")), it, hook.calls, int(g._scalar("p2p:allreduce_calls")), rel, 1e3 * t_run, g.p2p_status),
-          flush=True)
+    print("DIST2_OK world=%d backend=%s p2p=%d chain=%d iterations=%d collectives/rank=%d inbox_allreduces/rank=%d big_windows/rank=%d Z_rel=%.1e run=%.1f ms (%s)"
+          % (world, a.backend, int(a.p2p), int(g._scalar("chain")), it, hook.calls, int(g._scalar("p2p:allreduce_calls")), int(g._scalar("p2p:allreduce_big_windows")),
+             rel, 1e3 * t_run, g.p2p_status), flush=True)
 dist.barrier()
 dist.destroy_process_group()
