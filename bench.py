@@ -355,6 +355,81 @@ def main_file_bootstrap(a):
         print(json.dumps(out), flush=True)
 
 
+def pmc_refresh(n, d, K, B):
+    """--pmc: the dominant kernel's HBM bytes and MFMA-busy cycles per launch, collected NOW with rocprofv3 (when it is on PATH) exactly as
+    MI355X_MICROARCH.md's HBM section prescribes -- separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES), each with
+    --kernel-trace only, over tools/prof_update.py (setup + init + two clustering calls of this workload); FETCH_SIZE x 2 on gfx950 (it reports
+    half the bytes of coalesced reads; calibrated on a plain copy kernel in round 3), KB -> bytes.  Writes profiles/pmc_traffic_update_kernel.json
+    -- the file the roofline's `traffic` / `mfma_busy_frac` are read from -- and returns it; None (and the old file stays) when rocprofv3 is missing
+    or a pass fails."""
+    import collections
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    tmp = tempfile.mkdtemp(prefix="hmx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", HMX_BENCH_PREROLL="0")
+    means, durs = {}, {}
+    try:
+        for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES"])):
+            out = os.path.join(tmp, tag)
+            cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "prof_update.py"), str(n), str(K), str(B)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, stdin=subprocess.DEVNULL)
+            found = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not found:
+                return None
+            agg, cnt = collections.defaultdict(float), collections.Counter()
+            for row in csv.DictReader(open(found[0])):
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                agg[(k, row["Counter_Name"])] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
+            for key, v in agg.items():
+                means[key] = v / cnt[key]
+            if tag == "sq":      # durations of the same dispatches (the kernel trace of this pass)
+                tr = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("kernel_trace.csv")]
+                if tr:
+                    dsum, dcnt = collections.defaultdict(float), collections.Counter()
+                    for row in csv.DictReader(open(tr[0])):
+                        k = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                        dsum[k] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"]); dcnt[k] += 1
+                    durs = {k: dsum[k] / dcnt[k] for k in dsum}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    nct = (K + 15) // 16
+
+    def kern(mode):
+        for (k, c) in means:
+            if k.startswith("hmx::k_tile<%d, %d, 2," % (nct, mode)) and c == "FETCH_SIZE":
+                return k
+        return None
+
+    k4, k5 = kern(4), kern(5)
+    if not k4:
+        return None
+
+    def total(k):
+        return 2.0 * 1000.0 * means[(k, "FETCH_SIZE")] + 1000.0 * means[(k, "WRITE_SIZE")]
+
+    def busy(k):
+        ns = durs.get(k)
+        return means.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), 0.0) / (ns * 1e-9 * 2.4e9 * 1024) if ns else None
+
+    pm = {"workload": {"cells_per_gpu": n, "pcs": d, "clusters": K, "batches": B},
+          "kernel": "k_tile<%d,4|5,2,...> (persistent block chain; 5: a round whose R rows nobody reads)" % nct,
+          "hbm_bytes_per_launch": total(k4), "mfma_busy_frac": busy(k4),
+          "collected": "by this bench.py invocation (--pmc): rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES> --kernel-trace, one pass each, over tools/prof_update.py",
+          "source": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB -> bytes, mean per dispatch; SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)"}
+    if k5:
+        pm["hbm_bytes_per_launch_without_R_stores"] = total(k5); pm["mfma_busy_frac_without_R_stores"] = busy(k5)
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic_update_kernel.json"), "w") as fh:
+        json.dump(pm, fh, indent=1)
+    return pm
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -380,6 +455,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100000, help="cells for the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--no-e2e", action="store_true", help="skip the T_e2e measurement (ingest + egress over PCIe)")
+    ap.add_argument("--pmc", action="store_true", help="N = 1: collect the dominant kernel's HBM traffic and MFMA-busy counters with rocprofv3 first (three separate "
+                    "--pmc passes, ~1 minute) and refresh profiles/pmc_traffic_update_kernel.json, which the roofline's `traffic` is read from")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for smoke tests on one GPU)")
     ap.add_argument("--bootstrap", default="torch", choices=["torch", "file"], help="torch: torch.distributed bootstraps the communicator (default); "
                     "file: no torch in the process -- unique id through a file, hmx_comm_init, host reductions through the library")
@@ -393,6 +470,11 @@ def main():
                "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
 
+    pmc_now = None
+    if a.pmc and a.gpus == 1 and a.workload == "c3":      # (before this process touches the GPU: the passes are processes of their own)
+        pmc_now = pmc_refresh(a.total_cells or a.cells_per_gpu, a.pcs, a.clusters or 100, a.batches)
+        if pmc_now is None:
+            print("--pmc: rocprofv3 not found or a counter pass failed; the committed profiles/pmc_traffic_update_kernel.json is replayed", file=sys.stderr)
     import torch
     from harmony_amd import Harmony, prepare_setup_args
 
@@ -650,8 +732,9 @@ def main():
                 "achieved_weighted_by_variant": {"achieved": achieved_moved, "frac": achieved_moved / 8000.0, "share_of_rounds_without_R_stores": share_noR,
                                                  "note": "rounds whose R rows nobody reads store none (4d bytes per cell): the bytes the timed launches had to move"},
                 "distance_gemm": "split bf16: 6 x v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block on three exact bf16 parts per fp32 operand" if bf == "true" else "v_mfma_f32_16x16x4_f32",
-                "traffic_and_mfma_busy_are": ("replayed from profiles/pmc_traffic_update_kernel.json (separate rocprofv3 --pmc passes over this kernel, "
-                                              "%s); not collected in this run" % pm_note) if traffic is not None else None,
+                "traffic_and_mfma_busy_are": (("collected by THIS invocation (--pmc: three separate rocprofv3 --pmc passes over tools/prof_update.py just before the timed run; %s)" % pm_note) if pmc_now
+                                              else ("replayed from profiles/pmc_traffic_update_kernel.json (separate rocprofv3 --pmc passes over this kernel, "
+                                                    "%s); not collected in this run -- `bench.py --pmc` refreshes it" % pm_note)) if traffic is not None else None,
                 "avg_launch_us": 1e3 * upd_ms / max(upd_launches, 1), "launches": int(upd_launches),
                 "avg_block_step_us": 1e3 * upd_ms / max(prof["update_steps"], 1),
                 "alg_bytes_per_launch": alg_bytes / max(upd_launches, 1),

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
 //     (no contraction: the reference multiplies, rounds, then adds).  10 VALU instructions per (cell, 8 clusters) instead of ~30.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int KPW>
-__global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
+__global__ __launch_bounds__(1024, 7) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
                                                          int K, int d, int zs, int KP8, const int* __restrict__ list,
                                                          const SeqSeg* __restrict__ segs, int seg0, const unsigned char* __restrict__ inset,
                                                          const float* __restrict__ start, float* __restrict__ end, int zero_start, unsigned* __restrict__ conv_zero) {
