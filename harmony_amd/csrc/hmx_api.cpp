@@ -559,7 +559,7 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   const bool sharded_ = ctx->world > 1 || ctx->comm_force;
   // (the head of init_cluster_cpp too: the first round then finds its old contributions filed as well -- no pass over R at all)
   const bool gather = ctx->carry_ok && ctx->injected.empty() && ctx->rng_mode == 0 && ctx->D.upd_impl == 0 &&
-                      ctx->D.tile_impl && (size_t)ctx->D.NQ * ctx->D.NS * 1024 <= 160 * 1024 && !getenv("HMX_HEAD_GATHER_OFF");
+                      ctx->D.tile_impl && (size_t)ctx->D.NQ * ctx->D.NS * 1024 <= 160 * 1024;
   if (gather) {
     PhaseScope ph(ctx, "randomize");
     CHK(prepare_round(ctx, ctx->round_counter));     // (update_R finds this round sorted and the next one in flight)
@@ -569,7 +569,7 @@ int head_pass(hmx_ctx* ctx, bool normalise = false) {   // normalise: Z_corr <- 
   ctx->head_is_stale = false;      // (dist_mat is recomputed here)
   const bool tiles = D.tile_impl && (size_t)D.NQ * D.NS * 1024 <= 160 * 1024;
   // the register-pipelined head (two accumulator sets, rows of a tile in registers) normalises the rows it has loaded anyway
-  const bool fused_norm = normalise && tiles && D.NT4 <= 4 && D.NCT <= 7 && D.upd_wps != 4 && !getenv("HMX_HEAD_NORM_SPLIT");
+  const bool fused_norm = normalise && tiles && D.NT4 <= 4 && D.NCT <= 7 && D.upd_wps != 4;
   if (normalise && !fused_norm) { l_normalize(ctx->L, D.Zc, D.n, D.d, D.zs); KCHK(); }
   D.head_norm = fused_norm ? 1 : 0;
   for (int i = 0; i < 2; i++) if (ctx->sold_state[i] == 2) ctx->sold_state[i] = 1;     // R is rewritten: carried old contributions are void
@@ -1159,13 +1159,9 @@ int update_R(hmx_ctx* ctx) {
   const bool chain_path = merged && ctx->fused_ok && ctx->chain_ok && (!sharded || p2p);
   D.p2p_world = p2p ? ctx->p2p_world : 0; D.p2p_rank = ctx->p2p_rank;
   for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g];
-  const bool chain_old = chain_path && !p2p && D.chain_old && D.chain_wps == 2 && D.K % 4 == 0;   // (16-byte row loads)
   { PhaseScope ph(ctx, "EO_update");      // removal of every block's old contribution (:312-313)
     D.r_store = 1;
-    if (chain_old) {   // gathered inside the persistent chain, two blocks ahead of their use: only the replica tables are reset here
-      HIPCHK(hipMemsetAsync(D.Sold_rep, 0, sizeof(long long) * (size_t)D.nrep * D.nb * D.B * D.K, ctx->L.stream));
-      HIPCHK(hipMemsetAsync(D.Snew_set[0], 0, sizeof(long long) * (size_t)D.nrep * D.B * D.K, ctx->L.stream));
-    } else {
+    {
       const size_t nBKs = (size_t)D.B * D.K, nSold = (size_t)D.nb * nBKs, nSets = 3 * (size_t)D.nrep * nBKs;
       const int cur = ctx->sold_cur, oth = cur ^ 1;
       const int64_t rnd = (int64_t)ctx->round_counter - 1;          // this round
@@ -1183,7 +1179,7 @@ int update_R(hmx_ctx* ctx) {
       ctx->sold_state[cur] = 1;
       if (!(chain_path && p2p)) CHK(allreduce(ctx, D.Sold_fx, (int64_t)nSold, 0));      // (p2p chain: the folder exchanges new(j - 1) - old_local(j), the ranks' old sums meet there)
       // this round's tile kernels collect the next round's old contributions if this round's tiles are keyed by the next block
-      const bool write_next = ctx->carry_ok && ctx->sorted_nxt[rnd & ctx->oset_mask] && !ctx->last_round_hint && !chain_old && D.upd_impl == 0;
+      const bool write_next = ctx->carry_ok && ctx->sorted_nxt[rnd & ctx->oset_mask] && !ctx->last_round_hint && D.upd_impl == 0;
       D.Sold_next = nullptr;
       if (write_next) {
         if (ctx->sold_state[oth] != 0) HIPCHK(hipMemsetAsync(ctx->sold_buf[oth], 0, sizeof(long long) * nSold, ctx->L.stream));
@@ -1210,17 +1206,16 @@ int update_R(hmx_ctx* ctx) {
     D.chain_xseq = ctx->p2p_xseq;
     long long* const keep_snew = D.Snew_fx;
     D.Snew_fx = D.Snew_set[0];     // one replica set: the folder resets it by exchange (zeroed by the round's memset)
-    const int keep_old = D.chain_old; D.chain_old = chain_old ? 1 : 0;
     // one GPU: the chain's folder also closes the round (objective snapshot, table clears, control reset): no k_round_tail launch
     // (sharded runs with the in-launch exchange too: the ranks' objective sums travel through the inboxes, entries nBK and nBK + 1)
-    chain_tail = (!sharded || (p2p && (size_t)D.B * D.K + 2 <= (size_t)P2P_CAP && D.nb <= 62)) && !ctx->obj_arith && D.chain_wps == 2 && !getenv("HMX_CHAIN_TAIL_OFF");
+    chain_tail = (!sharded || (p2p && (size_t)D.B * D.K + 2 <= (size_t)P2P_CAP && D.nb <= 62)) && !ctx->obj_arith;
     D.chain_tail = chain_tail ? 1 : 0;
     if (p2p) ctx->p2p_xseq += (unsigned)D.nb + 1u + (chain_tail ? 1u : 0u);      // exchanges of this round: nb + 1 block steps (+ the objective's)
     if (chain_tail) {
       double* slot = nullptr;
       CHK(objective_slot(ctx, &slot));
       const size_t nBKs = (size_t)D.B * D.K;
-      D.tail_host_slot = slot; D.tail_z0 = chain_old ? nullptr : D.Sold_fx; D.tail_n0 = chain_old ? 0 : (unsigned long long)D.nb * nBKs;
+      D.tail_host_slot = slot; D.tail_z0 = D.Sold_fx; D.tail_n0 = (unsigned long long)D.nb * nBKs;
       D.tail_z1 = D.Snew_set[0]; D.tail_n1 = 3ull * (unsigned long long)D.nrep * nBKs;
     }
     {
@@ -1234,7 +1229,7 @@ int update_R(hmx_ctx* ctx) {
       HIPCHK(hipEventRecord(ev, ctx->L.stream));
       owner = (const void*)ctx->L.stream;
     }
-    D.chain_old = keep_old; D.chain_tail = 0;
+    D.chain_tail = 0;
     if (ctx->profile) ctx->prof_update_steps += D.nb;
     D.Snew_fx = keep_snew;
     ctx->chain_check = true;
@@ -1278,7 +1273,7 @@ int update_R(hmx_ctx* ctx) {
     { Launch Le; CHK(launch_with_events(ctx, Le)); l_update(Le, D, j); KCHK(); if (ctx->profile) ctx->prof_update_steps++; }
   }
   if (chain_tail) {
-    if (!chain_old) ctx->sold_state[ctx->sold_cur] = 0;
+    ctx->sold_state[ctx->sold_cur] = 0;
     ctx->sets_clean = true;
     HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
     ctx->obj_pending++;
@@ -1289,8 +1284,8 @@ int update_R(hmx_ctx* ctx) {
     CHK(objective_slot(ctx, &slot));
     {   // the table this round consumed and the replica sets are cleared by the same launch
       const size_t nBKs = (size_t)D.B * D.K;
-      l_round_tail(ctx->L, D, slot, chain_old ? nullptr : D.Sold_fx, chain_old ? 0 : (size_t)D.nb * nBKs, D.Snew_set[0], 3 * (size_t)D.nrep * nBKs); KCHK();
-      if (!chain_old) ctx->sold_state[ctx->sold_cur] = 0;
+      l_round_tail(ctx->L, D, slot, D.Sold_fx, (size_t)D.nb * nBKs, D.Snew_set[0], 3 * (size_t)D.nrep * nBKs); KCHK();
+      ctx->sold_state[ctx->sold_cur] = 0;
       ctx->sets_clean = true;
     }
     HIPCHK(hipEventRecord(ctx->obj_event, ctx->L.stream));
@@ -1301,7 +1296,7 @@ int update_R(hmx_ctx* ctx) {
     CHK(objective_snapshot(ctx));
     CHK(push_objective(ctx));  // asynchronous: resolved by flush_objectives when a value is needed
   }
-  if (!chain_old) ctx->sold_cur ^= 1;      // next round subtracts what this round's tile kernels collected (or a fresh k_oldsum pass)
+  ctx->sold_cur ^= 1;      // next round subtracts what this round's tile kernels collected (or a fresh k_oldsum pass)
   D.Sold_next = nullptr;
   ctx->R_valid = D.r_store != 0;
   if (ctx->profile) { ctx->prof_update_cells += ctx->N; }   // the event pairs are resolved when a "prof:*" field is read
@@ -1896,14 +1891,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   D.n = (int)N; D.d = d; D.K = K; D.B = B; D.C = C; D.Q = Q; D.B0 = ctx->B_vec[0];
   D.KP = (K + 63) / 64 * 64; D.nb = ctx->nb;
   D.zs = (d + 3) / 4 * 4;
-  { // HMX_ZS_PAD=1: rows of whole 128-byte lines where that costs at most 30 % more bytes (d = 50: 208 -> 256 B).  The block chain GATHERS
-    // the rows of a block's cells, and a 208-byte row at 16-byte alignment touches 2.6 lines on average (404 B of HBM reads per cell for
-    // 200 B of payload, rocprof FETCH_SIZE) -- but the chain is not bound by those reads: measured back to back on one box (round 4) the
-    // padded layout shortened the phase behind an arrival by 0.5 us and left the block step where it was (17.7 vs 17.4 us), for 23 % more
-    // memory.  Off by default.
-    const char* e = getenv("HMX_ZS_PAD");
-    const int zp = (D.zs + 31) / 32 * 32;
-    if (e && atoi(e) == 1 && zp != D.zs && zp * 10 <= D.zs * 13) D.zs = zp; }
+  // (rows padded to whole 128-byte lines -- 208 -> 256 B at d = 50 -- were measured in round 4: the block step stayed where it was for 23 % more memory; the switch is gone)
   { const char* e = getenv("HMX_NREP"); int want = e ? atoi(e) : 8; if (want > 8) want = 8; D.nrep = 1; while (D.nrep * 2 <= want && (size_t)D.nrep * 2 * B * K <= (1u << 20)) D.nrep *= 2; }
   { static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 14, 16};     // (13: K = 200, BASELINE configs[4])
     const int need = (K + 15) / 16; D.NCT = 16; for (int v : sup) if (v >= need) { D.NCT = v; break; } }
@@ -1939,7 +1927,7 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   // per SIMD the K > 64 kernels get) re-stages the centroid image once instead of four times: head 213 -> 200 us at 1M
   { const char* e = getenv("HMX_STATIC_MAXBLOCKS"); D.static_maxblocks = e ? atoi(e) : (D.NCT >= 5 ? 512 : D.NCT >= 3 ? 768 : 1024); }
   { const char* e = getenv("HMX_OLDSUM_IMPL"); D.oldsum_stream = (e && std::string(e) == "gather") ? 0 : (e && std::string(e) == "stream1") ? 2 : 1; }   // 1: 16-byte stream, 2: dword stream
-  D.need_lorder = (D.upd_impl == 1 || D.oldsum_stream == 0 || (size_t)D.nb * K * 8 > 64 * 1024 || getenv("HMX_NEED_LORDER")) ? 1 : 0;
+  D.need_lorder = (D.upd_impl == 1 || D.oldsum_stream == 0 || (size_t)D.nb * K * 8 > 64 * 1024) ? 1 : 0;
   { const char* e = getenv("HMX_UPD_TPW"); D.upd_tpw = ctx->tun_tpw > 0 ? ctx->tun_tpw : (e ? atoi(e) : 1); if (D.upd_tpw < 1) D.upd_tpw = 1; }
   { const char* e = getenv("HMX_UPD_CPW"); D.upd_cpw = ctx->tun_cpw > 0 ? ctx->tun_cpw : (e ? atoi(e) : 128); if (D.upd_cpw < 4) D.upd_cpw = 4; }
   std::vector<Item> schunks; std::vector<int> qchunk((size_t)Q + 1, 0);
@@ -1951,8 +1939,8 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   D.nchunks = (int)schunks.size();
   { // Old contributions carried from round to round (update_R): tiles keyed by (block, combination, NEXT block) cost up to 16
     // padding slots per key -- worth it while the expected padding (8 per key) stays below 4 % (12 % with the chain) of the cells.  HMX_SOLD_CARRY=0|1.
-    const char* e = getenv("HMX_SOLD_CARRY"); const char* co = getenv("HMX_CHAIN_OLD");
-    const bool fits = D.nb <= 63 && Q < (1 << 19) && D.upd_impl == 0 && !(co && atoi(co) == 1) &&
+    const char* e = getenv("HMX_SOLD_CARRY");
+    const bool fits = D.nb <= 63 && Q < (1 << 19) && D.upd_impl == 0 &&
                       (int64_t)N + (int64_t)D.nb * D.nb * Q * 16 <= 2147483000ll;
     // (round 4: with the R stores of carried rounds gone as well -- Dev::r_store -- the carry saves ~200 us per round at 1M cells where the
     //  persistent chain runs (K <= 112): worth up to ~12 % of padding there; measured at 1.25M cells / 20 batches, 5.1 %: 15.5 -> 12.7 ms per run.
@@ -1985,17 +1973,17 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
   CHK(dalloc(ctx, &D.blkv, (size_t)N)); CHK(dalloc(ctx, &D.bincnt, (size_t)nV * Q));
   CHK(dalloc(ctx, &D.ce, (size_t)K)); CHK(dalloc(ctx, &D.cl, (size_t)K)); CHK(dalloc(ctx, &D.boff, (size_t)D.nb + 1));
   CHK(dalloc(ctx, &D.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &D.offs, (size_t)nV * D.nchunks));
-  { // second buffer set + side stream for the overlapped shuffle of the next round (HMX_SORT_OVERLAP=0: always sort in line)
+  { // second buffer set + side stream for the overlapped shuffle of the next round 
     ctx->sets[0] = {D.blk, D.lorder, D.lpair, D.lcombo, D.boff, D.binoff, D.counts, D.offs, D.blkv, D.bincnt};
     hmx_ctx::SortSet& t = ctx->sets[1];
     CHK(dalloc(ctx, &t.blk, (size_t)N)); CHK(dalloc(ctx, &t.lorder, (size_t)3 * D.npad + 2)); t.lpair = reinterpret_cast<int2*>(t.lorder + (((size_t)D.npad + 1) & ~(size_t)1));
     CHK(dalloc(ctx, &t.lcombo, (size_t)D.npad)); CHK(dalloc(ctx, &t.binoff, (size_t)nV * Q + 1)); CHK(dalloc(ctx, &t.boff, (size_t)D.nb + 1));
     CHK(dalloc(ctx, &t.counts, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &t.offs, (size_t)nV * D.nchunks)); CHK(dalloc(ctx, &t.blkv, (size_t)N)); CHK(dalloc(ctx, &t.bincnt, (size_t)nV * Q));
-    const char* e = getenv("HMX_SORT_OVERLAP"); ctx->sort_overlap = !(e && atoi(e) == 0);
+    ctx->sort_overlap = true;
     { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lowest priority: the shuffle only fills gaps
       HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, lo)); }
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); }
-    { const char* sc = getenv("HMX_SORT_SCHED"); const int v = sc ? atoi(sc) : 3; ctx->sort_sched = v == 1 ? 1 : 3; if (!ctx->sort_overlap) ctx->sort_sched = 1; }
+    ctx->sort_sched = 3;      // (the per-round schedule, sort_sched = 1, lost round 4 to the batched shuffle; its switches are gone)
     ctx->oset_mask = ctx->sort_sched == 3 ? 3 : 1;
     { const char* si = getenv("HMX_SHUFFLE_INV"); const int v = si ? atoi(si) : 1;      // 0: counting sort always; 2: sort-free form on sharded runs too
       ctx->shuf_inv = ctx->sort_sched == 3 && v != 0 && (ctx->world == 1 || v == 2) && ctx->carry_ok &&      /* (without the carry every round needs D.blk: the counting sort has it for free) */
@@ -2181,24 +2169,17 @@ int hmx_setup_ex(hmx_ctx* ctx, const void* Z, int32_t z_dtype, int32_t z_locatio
     }
     CHK(dalloc(ctx, &D.tail_ticket, (size_t)1)); HIPCHK(hipMemsetAsync(D.tail_ticket, 0, sizeof(int), ctx->L.stream));
     CHK(dalloc(ctx, &D.pen_g, (size_t)B * K)); CHK(dalloc(ctx, &D.chain_ctl, (size_t)8 * D.nb + 24)); CHK(dalloc(ctx, &D.chain_dbg, (size_t)64));
-    CHK(dalloc(ctx, &D.Sold_rep, (size_t)D.nrep * D.nb * B * K));
     HIPCHK(hipMemsetAsync(D.chain_dbg, 0, sizeof(unsigned long long) * 64, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.pen_g, 0, sizeof(unsigned long long) * (size_t)B * K, ctx->L.stream));
     HIPCHK(hipMemsetAsync(D.chain_ctl, 0, sizeof(int) * ((size_t)8 * D.nb + 24), ctx->L.stream));
-    // in-chain old sums (opt-in): measured 25.8 us per block step against 20.4 us + the 100 us k_oldsum pass per round -- a wash at
-    // 1M cells (the extra device-scope atomics and the folder's extra loads land on the chain's critical path)
-    { const char* o = getenv("HMX_CHAIN_OLD"); D.chain_old = (o && atoi(o) == 1) ? 1 : 0; }
-    { const char* w = getenv("HMX_CHAIN_WPS"); D.chain_wps = (w && (atoi(w) == 4 || atoi(w) == 3) && D.usig) ? atoi(w) : 2;
-      // the 4-waves-per-SIMD variant keeps one LDS-DMA row image per wave: 16 KB per 16-byte group of a row
-      if (D.chain_wps >= 3 && (size_t)D.NQ * D.NS * 1024 + (size_t)B * K * 12 + (size_t)Q * C * 4 + 64 + (size_t)16 * (D.NT4 + D.tail + 1) * 1024 > 158 * 1024) D.chain_wps = 2; }
+    D.chain_wps = 2;      // (the 3- / 4-waves-per-SIMD chain variants and the in-chain gathering of the old contributions lost rounds 2 and 3: removed in round 5)
     // the folder reads AND resets every replica of the contribution table inside a block step (atomic exchanges on its critical
     // path): 4 replicas measured 0.4 us per step faster than 8 there (2: the workers' atomics start to queue, +2 us)
     if (ctx->chain_ok && !getenv("HMX_NREP") && D.nrep > 4) {
       D.nrep = 4;
       for (int i = 0; i < 3; i++) D.Snew_set[i] = ctx->sold_buf[0] + (size_t)2 * D.nb * B * K + (size_t)i * D.nrep * B * K;   // keep the three sets contiguous
     }
-    { const char* uc = getenv("HMX_UPD_CONTIG");     // launch-per-step path: contiguous tile ranges once a wave has several tiles per block
-      D.upd_contig = uc ? atoi(uc) : ((!ctx->chain_ok && tiles_per_wave >= 4.0) ? 1 : 0); }
+    D.upd_contig = (!ctx->chain_ok && tiles_per_wave >= 4.0) ? 1 : 0;     // launch-per-step path: contiguous tile ranges once a wave has several tiles per block
     ctx->chain_rounds = 0;
     D.p2p_world = 0; D.p2p_rank = ctx->p2p_rank;
     for (int g = 0; g < 8; g++) D.p2p_inbox[g] = ctx->p2p_peer[g]; }

@@ -81,8 +81,6 @@ struct Dev {
   int* chain_ctl;              // [0] block flag (tag), [1] error, [2 + j] arrivals of block j
   unsigned chain_tag;
   unsigned chain_xseq;         // sharded chain: number of this round's first inbox exchange (plane = exchange number & 1, carried across rounds)
-  int chain_old;               // 1: the chain gathers the blocks' old contributions itself (no k_oldsum pass); DUAL variant only
-  long long* Sold_rep;         // [nrep][nb][B][K] replicas of the old contributions (chain_old)
   int* tail_ticket;            // k_round_tail: workgroups done (the last one finishes the round's objective)
   // round tail inside the persistent chain (one GPU): the folder closes the round itself -- objective snapshot into the pinned host
   // slot, consumed tables cleared, control words reset -- instead of a k_round_tail launch behind every chain launch
@@ -105,7 +103,7 @@ struct Dev {
   int r_store;
   int obj_stale;               // compute_objective on the stale snapshot (stale_dist): Yt / Zc are not the ones the MFMA images were built from
   int rvec;                    // K % 4 == 0: R rows are 16-byte aligned, the tile kernels store them with vector stores
-  int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets) | 4 (lean, uniform sigma only)
+  int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets)
   // peer-to-peer block chain (sharded runs, one process per GPU on a node): p2p_inbox[g] = rank g's inbox as mapped into THIS
   // process (fine-grained device memory shared through HIP IPC), [2 parities][8 sources][P2P_CAP entries][2 granules]
   int p2p_world, p2p_rank;

@@ -1325,6 +1325,41 @@ __device__ __forceinline__ void tile_dots_bf_regs(const u32x4* __restrict__ ldsB
     }
   }
 }
+// TWO tiles against ONE read of the centroid image (round 5, the chain's hoisted MFMA phase): a wave that owns two tiles of a block used to
+// walk the 42 KB image twice -- the LDS operand reads of a SIMD's three tiles were 1.6 of the 5.4 us the workers need behind an arrival
+// (DESIGN 7.1); with both tiles' rows in registers every (cluster tile, step) operand triple is read once and feeds twelve MFMAs, two
+// independent accumulator chains.
+template <int NCT>
+__device__ __forceinline__ void tile_dots_bf_regs2(const u32x4* __restrict__ ldsB, const RowRegs& ra, bool valida, const RowRegs& rb, bool validb,
+                                                   int rowmask, int lane, int NS2, f32x4 (&acca)[NCT], f32x4 (&accb)[NCT]) {
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto mf = [](const u32x4 A, const u32x4 B, const f32x4 C) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0);
+  };
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) { acca[ct] = zero4; accb[ct] = zero4; }
+  const int ma = valida ? rowmask : 0, mb = validb ? rowmask : 0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    if (s < NS2) {
+      const Bf3 a = bf3_split8((ma >> (2 * s)) & 1 ? ra.v[2 * s] : zero4, (ma >> (2 * s + 1)) & 1 ? ra.v[2 * s + 1] : zero4);
+      const Bf3 b = bf3_split8((mb >> (2 * s)) & 1 ? rb.v[2 * s] : zero4, (mb >> (2 * s + 1)) & 1 ? rb.v[2 * s + 1] : zero4);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) {
+        const u32x4* y = ldsB + ((size_t)(ct * NS2 + s) * 3) * 64 + lane;
+        const u32x4 y0 = y[0], y1 = y[64], y2 = y[128];
+        f32x4 va = acca[ct], vb = accb[ct];          // (the same order of the six terms as bf_step: smallest first -- bit-identical to the one-tile form)
+        va = mf(a.p[0], y2, va); vb = mf(b.p[0], y2, vb);
+        va = mf(a.p[2], y0, va); vb = mf(b.p[2], y0, vb);
+        va = mf(a.p[1], y1, va); vb = mf(b.p[1], y1, vb);
+        va = mf(a.p[0], y1, va); vb = mf(b.p[0], y1, vb);
+        va = mf(a.p[1], y0, va); vb = mf(b.p[1], y0, vb);
+        va = mf(a.p[0], y0, va); vb = mf(b.p[0], y0, vb);
+        acca[ct] = va; accb[ct] = vb;
+      }
+    }
+  }
+}
 // rows streamed from memory one step ahead (any NS2 <= 4)
 template <int NCT>
 __device__ __forceinline__ void tile_dots_bf(const u32x4* __restrict__ ldsB, const float* __restrict__ zrow, bool valid, int rowmask, int g,
@@ -2034,20 +2069,7 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       for (int jj = 0; jj <= nbk; jj++) {
         long long sv[FE];
 #pragma unroll
-        for (int e = 0; e < FE; e++) sv[e] = (jj < nbk && !D.chain_old) ? D.Sold_fx[(size_t)jj * nBK + min(tid + e * bd, nBK - 1)] : 0;   // before the wait
-        if (jj == 0 && D.chain_old) {     // the old sums of blocks 0 and 1 come from the workers' prologue: wait for it
-          if (tid == 0) {
-            int spins = 0;
-            const int* arr = &ctl[8 + 8 * nbk];
-            auto arrived = [&]() { int t = 0; for (int x = 0; x < 8; x++) t += __hip_atomic_load(&arr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return t; };
-            while (arrived() < nworkWG) {
-              __builtin_amdgcn_s_sleep(1);
-              if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 4); break; }
-              if (dead(spins)) break;
-            }
-          }
-          __syncthreads();
-        }
+        for (int e = 0; e < FE; e++) sv[e] = (jj < nbk) ? D.Sold_fx[(size_t)jj * nBK + min(tid + e * bd, nBK - 1)] : 0;   // before the wait
         if (jj > 0) {
           if (tid == 0) {
             int spins = 0;
@@ -2133,16 +2155,13 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         }
         auto fold_entry = [&](int i, long long soldv) {
           long long o = ldsO[i];
-          // every memory operation of the entry in flight before the first is consumed: the new contributions (exchange = read +
-          // reset) and, with in-chain old sums, block jj's old contributions (filled two blocks ago by the workers)
-          unsigned long long a[8]; long long b8[8];
+          // every memory operation of the entry in flight before the first is consumed: the new contributions (exchange = read + reset)
+          unsigned long long a[8];
 #pragma unroll
           for (int r = 0; r < 8; r++) a[r] = (jj > 0 && r < D.nrep) ? atomicExch((unsigned long long*)&D.Snew_fx[(size_t)r * nBK + i], 0ull) : 0ull;
 #pragma unroll
-          for (int r = 0; r < 8; r++) b8[r] = (D.chain_old && jj < nbk && r < D.nrep) ? (long long)__hip_atomic_load((unsigned long long*)&D.Sold_rep[((size_t)r * nbk + jj) * nBK + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ll;
-#pragma unroll
-          for (int r = 0; r < 8; r++) o += (long long)a[r] - b8[r];
-          if (jj < nbk && !D.chain_old) o -= soldv;
+          for (int r = 0; r < 8; r++) o += (long long)a[r];
+          if (jj < nbk) o -= soldv;
           if (i < nRS && o != ldsO[i]) atomicAdd((unsigned long long*)&ldsRS[i % K], (unsigned long long)(o - ldsO[i]));
           ldsO[i] = o;
           if (jj == nbk) D.O_fx[i] = o;      // the round's final O (read by the kernels that follow this launch)
@@ -2264,116 +2283,8 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       return;
     }
     // ---------------- the workers
-    if constexpr (LEAN) {
-      static_assert(!BF, "the lean chain reads its rows from an LDS image in fp32-step order");
-      // 4 waves per SIMD (1024-thread workgroups, <= 128 VGPRs): one accumulator set, rows streamed inside the MFMA loop.  With
-      // ~4000 resident waves a block's ~3100 tiles are ONE tile per wave: after the flag only a single epilogue remains.
-      f32x4 accC[NCT];
-      int2 cellC = make_int2(-1, -1);
-      bool have = ts < te;
-      auto mfma_tile = [&](const int2 cq) __attribute__((always_inline)) {
-        cellC = cq;
-        // all of the row's operand loads in flight at once (tile_dots streams them one group ahead: three exposed latencies)
-        if (D.NT4 <= 4) {
-          RowRegs rr;
-          ld_rows(D.Zc + (size_t)(cq.x >= 0 ? cq.x : 0) * zs, rr);
-          dots_regs(rr, cq.x >= 0, accC);
-        } else dots_stream(D.Zc + (size_t)(cq.x >= 0 ? cq.x : 0) * zs, cq.x >= 0, accC);
-      };
-      if (have) mfma_tile(cellN);
-      // rows of the NEXT block's first tile travel global -> LDS by LDS-DMA while this block's epilogue runs (no registers, no
-      // exposed latency in the MFMA phase); the (cell, combination) pairs are fetched two blocks ahead.
-      const int NG = D.NT4 + D.tail;                                    // 16-byte groups per row (<= 7)
-      // per wave: [NG][64] float4 row image + [2 parities][2][64] ints (cell, combination) of the first tile of a block
-      f32x4* const rowimg = lds4 + nY4 + ((nBK * 8 + ((nBK + 3) & ~3) * 4 + D.Q * C * 4 + 15) >> 4) + (size_t)(tid >> 6) * (NG * 64 + 64);
-      int* const pimg = reinterpret_cast<int*>(rowimg + NG * 64);
-      auto geom = [&](int jb, int& p0b, int& teb) { p0b = 0; teb = 0; if (jb < nbk) { p0b = D.boff[jb]; teb = (D.boff[jb + 1] - p0b) >> 4; } };
-      auto pair_fetch = [&](int jb, int p0b, int teb) {     // LDS-DMA of block jb's first-tile pairs into parity jb & 1 (no registers held)
-        if (ts < teb) {
-          const int* src = reinterpret_cast<const int*>(D.lpair + p0b + 16 * ts + c);
-          glds4(src, pimg + (jb & 1) * 128);
-          glds4(src + 1, pimg + (jb & 1) * 128 + 64);
-        }
-      };
-      int p0n, ten, p0nn, tenn;
-      geom(1, p0n, ten); geom(2, p0nn, tenn);
-      pair_fetch(1, p0n, ten);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned long long wq = 0, wg = 0, ww = 0, wd = 0, wm = 0, w1 = 0, w2 = 0, w3 = 0, wcyc = 0, w_prev = wall_clock64();
-      auto lap = [&](unsigned long long& acc) { const unsigned long long t = wall_clock64(); acc += t - w_prev; w_prev = t; };
-      for (int jj = 0; jj < nbk; jj++) {
-        const unsigned tag = tag0 + (unsigned)jj;
-        if (tid == 0) {
-          int spins = 0;
-          while ((int)((unsigned)__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tag) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) { atomicExch(&ctl[1], 2); break; }
-            if (dead(spins)) break;
-          }
-        }
-        __syncthreads();
-        lap(wq);
-        for (int i = tid; i < nBK; i += bd) {
-          unsigned long long gv = __hip_atomic_load(&peng[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          int spins = 0;
-          while ((unsigned)(gv >> 32) != tag && ++spins < SPIN_LIMIT && !dead(spins)) { __builtin_amdgcn_s_sleep(1); gv = __hip_atomic_load(&peng[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-          if ((unsigned)(gv >> 32) != tag) atomicExch(&ctl[1], 3);
-          ldsPen[i] = __uint_as_float((unsigned)(gv & 0xffffffffu));
-        }
-        __syncthreads();
-        lap(wg);
-        curq = -1;
-        od = 0.0; oe = 0.0;
-        const bool haveN = ts < ten;
-        if (haveN) {       // next block's first tile: its rows -> this wave's LDS image
-          const int cx = pimg[((jj + 1) & 1) * 128 + lane];
-          const float* zr = D.Zc + (size_t)(cx >= 0 ? cx : 0) * zs;
-          for (int t = 0; t < D.NT4; t++) glds16(zr + 16 * t + 4 * g, rowimg + t * 64);
-          for (int u = 0; u < D.tail; u++) glds16(zr + 16 * D.NT4 + 4 * u, rowimg + (D.NT4 + u) * 64);
-        }
-        pair_fetch(jj + 2, p0nn, tenn);                                                     // two blocks ahead
-        if (have) {
-          for (int tile = ts; tile + tstep < te; tile += tstep) {     // all but the last tile of this wave in the block
-            epilogue(cellC.x, tile_q(cellC), accC);
-            mfma_tile(tile_cell(tile + tstep));
-          }
-          lap(w1);
-          epi_begin(tile_q(cellC));
-          epi_rows(cellC.x, accC, std::true_type{});
-          lap(w2);
-          od = wsumd(od); oe = wsumd(oe);
-          if (lane == 0) {
-            double* slot = D.objpart + ((size_t)(jj % D.objslots) * D.nwmax + wave) * 2;
-            if (D.nb <= D.objslots) { slot[0] = od; slot[1] = oe; } else { slot[0] += od; slot[1] += oe; }
-          }
-          if (curq >= 0) flush_run();
-          store_rows(cellC.x, accC);
-          lap(w3);
-          __builtin_amdgcn_s_waitcnt(0x0F70 | ((NCT * 4 - 4) & 15) | ((((NCT * 4 - 4) >> 4) & 3) << 14));
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        lap(ww);
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) atomicAdd(&ctl[8 + 8 * jj + ((int)blockIdx.x & 7)], 1);
-        p0 = p0n; te = ten;
-        lap(wd);
-        have = haveN;
-        const unsigned long long cyc0 = __builtin_readcyclecounter();
-        if (have) {                         // the next block's first tile, operands from the LDS image: off the critical path
-          cellC = make_int2(pimg[((jj + 1) & 1) * 128 + lane], pimg[((jj + 1) & 1) * 128 + 64 + lane]);
-          tile_dots_lds<NCT>(lds4, rowimg, cellC.x >= 0, g, lane, D.NS, D.NT4, D.tail, accC);
-        }
-        wcyc += __builtin_readcyclecounter() - cyc0;
-        p0n = p0nn; ten = tenn; geom(jj + 3, p0nn, tenn);
-        lap(wm);
-      }
-      if (blockIdx.x == 0 && tid == 0 && D.chain_dbg) {
-        atomicAdd(&D.chain_dbg[4], wq); atomicAdd(&D.chain_dbg[5], wg); atomicAdd(&D.chain_dbg[6], ww); atomicAdd(&D.chain_dbg[7], wd); atomicAdd(&D.chain_dbg[8], wm);
-        atomicAdd(&D.chain_dbg[9], w1); atomicAdd(&D.chain_dbg[10], w2); atomicAdd(&D.chain_dbg[11], w3); atomicAdd(&D.chain_dbg[12], wcyc);
-      }
-      return;
-    } else {
+    {
+    static_assert(!LEAN, "the chain runs two waves per SIMD (the 3- and 4-wave variants lost rounds 2 and 3 and were removed in round 5)");
     f32x4 accC[NCT], accS[NCT];
     int2 cellC = make_int2(-1, -1), cellS = make_int2(-1, -1);
     bool have = ts < te, have2 = false;
@@ -2405,49 +2316,22 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
         dots_regs(rowsB, cellS.x >= 0, accS);
       }
     };
-    if (have) { first_tile_a(); first_tile_b(); }
-    // Old contributions inside the chain (D.chain_old): the sums "remove block b's cells from O" (:312-313) of block b are
-    // gathered by the waves that will update it, TWO blocks ahead, in the slack between their arrival and the next flag --
-    // one pass over R per round disappears (k_oldsum).  Same fixed-point sums, same replica scheme as the new contributions.
-    auto old_block = [&](int blk) __attribute__((always_inline)) {
-      const int pb = D.boff[blk], nt = (D.boff[blk + 1] - pb) >> 4;
-      long long* tab = D.Sold_rep + ((size_t)(wave & (D.nrep - 1)) * nbk + blk) * nBK;
-      // lane -> four consecutive clusters (K % 4 == 0), lane half -> eight of the tile's sixteen rows: every load instruction
-      // reads two whole R rows (16 bytes per lane); the per-cluster sums need one cross-half add and no 16-lane reduction
-      const int kq = 4 * (lane & 31), half = lane >> 5;
-      const bool kv = kq < K;
-      for (int tile = wave; tile < nt; tile += nw) {
-        const int2 cq = D.lpair[pb + 16 * tile + c];
-        f32x4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int cell = __shfl(cq.x, 8 * half + i, 64);
-          v[i] = *reinterpret_cast<const f32x4*>(D.R + (size_t)(cell >= 0 ? cell : D.n) * K + (kv ? kq : 0));   // padding: the dummy row
-        }
-        unsigned long long oa[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-          for (int e = 0; e < 4; e++) oa[e] += fx_of(v[i][e]);
-        const int q0 = __builtin_amdgcn_readfirstlane(cq.y) & D.qmask;
-#pragma unroll
-        for (int e = 0; e < 4; e++) oa[e] += shfl_xor_u64(oa[e], 32);
-        if (half == 0 && kv) {
-          for (int cc = 0; cc < C; cc++) {
-            const int b = qlevT[q0 * C + cc];
-#pragma unroll
-            for (int e = 0; e < 4; e++) if (oa[e]) atomicAdd((unsigned long long*)&tab[(size_t)b * K + kq + e], oa[e]);
-          }
+    // both hoisted tiles against one read of the centroid image, when the second tile's rows are in registers already (MODE 5: rowsN2)
+    auto first_tiles = [&]() __attribute__((always_inline)) {
+      if constexpr (NOSTORE && BF) {
+        if (rows2_ok && HMX_CHAIN_PRE2 && USIG && ts + tstep < te) {
+          cellC = cellN; cellS = cellNN;
+          const RowRegs rowsA = rowsN, rowsB = rowsN2;
+          cellN = tile_cell(ts + 2 * tstep); cellNN = tile_cell(ts + 3 * tstep);
+          tile_dots_bf_regs2<NCT>(ldsB, rowsA, cellC.x >= 0, rowsB, cellS.x >= 0, rowmask, lane, D.NS2, accC, accS);
+          ld_rows(next_rows(cellN, cellS), rowsN);
+          have2 = true;
+          return;
         }
       }
+      first_tile_a(); first_tile_b();
     };
-    if (D.chain_old) {
-      old_block(0);
-      if (nbk > 1) old_block(1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (tid == 0) atomicAdd(&ctl[8 + 8 * nbk + ((int)blockIdx.x & 7)], 1);
-    }
+    if (have) first_tiles();
     // Geometry of the block AFTER the current one and the (cell, combination) pairs of this wave's first two tiles in it.  Requested
     // in the slack behind an arrival, a whole block ahead of their use: at the top of the epilogue phase the two dependent round trips
     // (scalar load of the block offsets, then the pairs) were 1.6 us of every block step's critical path.
@@ -2565,12 +2449,14 @@ __global__ __launch_bounds__(256 * WPS) void k_tile(Dev D, int j) {
       lap(wd);
       have = haveN;
       // off the critical path, in the folder's shadow: rows of the finished tiles out, MFMAs of the next block's tiles in
-      if (st1) store_rows(sc1, accC);
-      if (have) first_tile_a();
-      if (st2) store_rows(sc2, accS);
-      if (have) first_tile_b(); else have2 = false;
+      if constexpr (NOSTORE) { if (have) first_tiles(); else have2 = false; }
+      else {
+        if (st1) store_rows(sc1, accC);
+        if (have) first_tile_a();
+        if (st2) store_rows(sc2, accS);
+        if (have) first_tile_b(); else have2 = false;
+      }
       fetch_next(jj + 2);
-      if (D.chain_old && jj + 2 < nbk) old_block(jj + 2);
       lap(wm);
     }
     od = wsumd(od); oe = wsumd(oe);
@@ -4439,19 +4325,17 @@ void HMX_LNAME(l_update)(const Launch& L, const Dev& D, int j) {
 void HMX_LNAME(l_chain)(const Launch& L, const Dev& D, int workgroups) {
   const size_t rest = (size_t)D.B * D.K * 8 + ((size_t)((D.B * D.K + 3) & ~3) + (size_t)D.Q * D.C) * 4;
 #if !HMX_TILE_BF
-  if (D.chain_wps == 2 && bf_image_bytes(D) + rest + 64 <= 150 * 1024 && bf_fits(D, rest, 1)) { l_chain_bf(L, D, workgroups); return; }
+  if (bf_image_bytes(D) + rest + 64 <= 150 * 1024 && bf_fits(D, rest, 1)) { l_chain_bf(L, D, workgroups); return; }
 #endif
-  size_t lds = tile_image_bytes(D) + rest;
-  if (D.chain_wps >= 3) lds = ((lds + 15) & ~(size_t)15) + (size_t)(4 * D.chain_wps) * ((D.NT4 + D.tail) * 1024 + 1024);   // per wave: glds row image + pair images
+  const size_t lds = tile_image_bytes(D) + rest;
   const dim3 grid((unsigned)workgroups);
+  // (two waves per SIMD, two accumulator sets; MODE 5 = the variant without R stores, split-bf16 build only)
 #if HMX_TILE_BF
-#define HMX_CH(N) case N: if (D.usig && !D.r_store && !D.chain_old) HMX_LAUNCH_EV((k_tile<N, 5, 2, true>), grid, dim3(512), lds, D, 0); \
+#define HMX_CH(N) case N: if (D.usig && !D.r_store) HMX_LAUNCH_EV((k_tile<N, 5, 2, true>), grid, dim3(512), lds, D, 0); \
                           else if (D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 2, true>), grid, dim3(512), lds, D, 0); \
                           else HMX_LAUNCH_EV((k_tile<N, 4>), grid, dim3(512), lds, D, 0); break;
 #else
-#define HMX_CH(N) case N: if (D.chain_wps == 4 && D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 4, true>), grid, dim3(1024), lds, D, 0); \
-                          else if (D.chain_wps == 3 && D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 3, true>), grid, dim3(768), lds, D, 0); \
-                          else if (D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 2, true>), grid, dim3(512), lds, D, 0); \
+#define HMX_CH(N) case N: if (D.usig) HMX_LAUNCH_EV((k_tile<N, 4, 2, true>), grid, dim3(512), lds, D, 0); \
                           else HMX_LAUNCH_EV((k_tile<N, 4>), grid, dim3(512), lds, D, 0); break;
 #endif
   switch (D.NCT) {

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
 //     (no contraction: the reference multiplies, rounds, then adds).  10 VALU instructions per (cell, 8 clusters) instead of ~30.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int KPW>
-__global__ __launch_bounds__(1024, 7) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
+__global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
                                                          int K, int d, int zs, int KP8, const int* __restrict__ list,
                                                          const SeqSeg* __restrict__ segs, int seg0, const unsigned char* __restrict__ inset,
                                                          const float* __restrict__ start, float* __restrict__ end, int zero_start, unsigned* __restrict__ conv_zero) {
@@ -554,8 +554,7 @@ __global__ void k_seq_ridge_store(Dev D, const float* __restrict__ total) {
 void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* poslev, int nlist, const SeqSeg* segs, int seg0, int nsegs, const float* start,
                    float* end, int zero_start, unsigned* conv_zero) {
   if (nsegs <= 0) return;
-  static const bool lds_rows = [] { const char* e = getenv("HMX_SEQ_OE_LDS"); return e && atoi(e) == 1; }();       // (1: the level rows in LDS whatever B is -- the round-3 form, kept for B > 32)
-  if (D.B <= 32 && !lds_rows) {                         // level rows in registers
+  if (D.B <= 32) {                         // level rows in registers (more levels: in LDS, the round-3 form)
     const dim3 grid((nsegs + 3) / 4, (D.K + 63) / 64);
     if (D.B <= 16) hipLaunchKernelGGL((k_seq_oe_pass<true, 16>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
     else hipLaunchKernelGGL((k_seq_oe_pass<true, 32>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);

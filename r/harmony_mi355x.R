@@ -26,7 +26,9 @@ new_harmony_mi355x <- function(seed = NULL, r_rng = FALSE, reference_arithmetic 
     obj$setup <- function(Z, Phi, sigma, theta, lambda, alpha, max_iter_kmeans, epsilon_kmeans, epsilon_harmony,
                           K, block_size, B_vec, batch_proportion_cutoff, verbose) {
         Phi <- methods::as(Phi, "dgCMatrix")
-        invisible(.Call("C_hmx_setup", ptr, Z, Phi@i, Phi@p, as.numeric(Phi@x), nrow(Phi), as.numeric(sigma),
+        ## a float::float32 matrix goes down as it is (its @Data integer matrix holds the fp32 bits): no double copy, half the PCIe bytes
+        single <- methods::is(Z, "float32")
+        invisible(.Call(if (single) "C_hmx_setup_f32" else "C_hmx_setup", ptr, if (single) Z@Data else Z, Phi@i, Phi@p, as.numeric(Phi@x), nrow(Phi), as.numeric(sigma),
                         as.numeric(theta), as.numeric(lambda), alpha, as.integer(max_iter_kmeans), epsilon_kmeans,
                         epsilon_harmony, as.integer(K), block_size, as.integer(B_vec), batch_proportion_cutoff,
                         verbose))
@@ -36,7 +38,9 @@ new_harmony_mi355x <- function(seed = NULL, r_rng = FALSE, reference_arithmetic 
     obj$moe_correct_ridge_cpp <- function() invisible(.Call("C_hmx_moe_correct_ridge", ptr))
     obj$check_convergence     <- function(type) .Call("C_hmx_check_convergence", ptr, as.integer(type))
     obj$compute_objective     <- function() invisible(.Call("C_hmx_compute_objective", ptr))
-    obj$getZcorr     <- function() mat("Z_corr", get("d"), get("N"))
+    ## single = TRUE: a float::float32 matrix (needs the `float` package), fetched as fp32 -- half the bytes, no fp64 copy on the host
+    mat32 <- function(field, nr, nc) float::float32(.Call("C_hmx_get_matrix_f32", ptr, field, as.integer(nr), as.integer(nc)))
+    obj$getZcorr     <- function(single = FALSE) if (single) mat32("Z_corr", get("d"), get("N")) else mat("Z_corr", get("d"), get("N"))
     obj$getZorig     <- function() mat("Z_orig", get("d"), get("N"))
     obj$getR         <- function() mat("R", get("K"), get("N"))
     obj$getCentroids <- function() mat("Y", get("d"), get("K"))

@@ -3,7 +3,7 @@
 exec </dev/null
 R=$GRAFT_REPO_ROOT; cd $R || exit 1
 O=gpurun_out/${1:-r5e}; mkdir -p $O
-timeout 1500 python -m pytest tests -q -m gpu --durations=12 -x 2>&1 | tail -40 > $O/tests.log; tail -25 $O/tests.log
+timeout 1800 python -m pytest tests -q -m gpu --durations=12 2>&1 | tail -40 > $O/tests.log; tail -25 $O/tests.log
 timeout 100 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.err
 python - $O/bench_default.json <<'P'
