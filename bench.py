@@ -12,7 +12,7 @@ Other driver-reproducible modes:
     --cells-per-gpu 10000000 --batches 20          north_star target: 10M x 50 x K=100 on ONE GPU (configs[3]'s size)
     --workload c5 [--cells-per-gpu N]              configs[4] shape: K=200, 3 nested covariates 8 > 64 > 128 (200 levels)
     --total-cells 10000000 --batches 20 --gpus N   STRONG scaling: configs[3] = 10M cells in total, sharded over the N GPUs
-    --also ref,10M,c5,pbmc (default at N=1; "none")  extra legs of the same invocation, reported under "also": the reference-arithmetic
+    --also ref,10M,share,c5,pbmc (default at N=1; "none"; "shares": the per-rank shares of the 8-GPU configs at G = 2 / 4 / 8)  extra legs of the same invocation, reported under "also": the reference-arithmetic
                                                    mode on the main workload, 10M cells on this one GPU, the configs[4] shape at 1M,
                                                    configs[1] (pbmc, 30k cells) with its own CPU-oracle timing and parity check
 
@@ -821,6 +821,11 @@ def main():
                 elif leg == "share":   # one GPU's share of configs[3] on an 8-GPU node: 1.25M cells of the 10M, 20 batches
                     legs["configs3_share_1p25M"] = bench_leg(Harmony, prepare_setup_args, 1250000, 50, 100, (20,), False, a.seed, 3, 1, sync)
                     legs["configs3_share_1p25M"]["note"] = "what each rank of `--total-cells 10000000 --batches 20 --gpus 8` computes per step, without the exchanges (no 8-GPU node here)"
+                elif leg == "shares":  # (not in the default set) what ONE rank of the 8-GPU configs computes at G = 2 / 4 / 8, without the exchanges: the inputs of DESIGN 5.2's scaling prediction
+                    for cells in (5000000, 2500000):
+                        legs["configs3_share_%dk" % (cells // 1000)] = bench_leg(Harmony, prepare_setup_args, cells, 50, 100, (20,), False, a.seed, 2, 1, sync)
+                    for cells in (2500000, 1250000, 625000):
+                        legs["configs4_share_%dk" % (cells // 1000)] = bench_leg(Harmony, prepare_setup_args, cells, 50, 200, (8, 64, 128), True, a.seed, 2, 1, sync)
                 elif leg == "c5":      # configs[4] shape at 1M cells
                     legs["c5_shape_1M"] = bench_leg(Harmony, prepare_setup_args, 1000000, 50, 200, (8, 64, 128), True, a.seed, 2, 1, sync)
                 elif leg == "pbmc":    # configs[1] at its stated size, GPU vs CPU oracle

@@ -23,6 +23,8 @@ double Rf_asReal(SEXP);
 int Rf_asInteger(SEXP);
 int Rf_asLogical(SEXP);
 SEXP Rf_allocVector(unsigned int, R_xlen_t);
+SEXP Rf_allocMatrix(unsigned int, int, int);
+int TYPEOF(SEXP);
 SEXP Rf_ScalarLogical(int);
 SEXP Rf_ScalarInteger(int);
 SEXP Rf_ScalarReal(double);

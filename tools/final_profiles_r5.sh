@@ -33,9 +33,12 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/refstats 
 cp $O/refstats/r_kernel_stats.csv $O/ref_kernel_stats.csv 2>/dev/null; rm -rf $O/refstats
 timeout 600 python $R/bench.py --cpu-sample 0 --workload c5 --cells-per-gpu 5000000 --steps 2 --warmup 1 --no-e2e --also none > $O/bench_c5_5M.json 2> $O/bench_c5_5M.err
 timeout 400 python $R/bench.py --cpu-sample 0 --total-cells 10000000 --batches 20 --steps 3 --also none > $O/bench_strong_1gpu_10M.json 2> $O/bench_strong_1gpu_10M.err
+timeout 600 python $R/bench.py --cpu-sample 0 --no-e2e --steps 2 --also shares > $O/bench_shares.json 2> $O/bench_shares.err
 # two ranks sharing this box's one GPU (gloo for the remaining collectives): the in-launch exchange of the block chain vs one all-reduce per block
 timeout 600 python $R/bench.py --gpus 2 --backend gloo --cells-per-gpu 500000 --steps 3 --warmup 1 --no-e2e > $O/bench_2ranks_p2p.json 2> $O/bench_2ranks_p2p.err
 HMX_BENCH_P2P=0 timeout 600 python $R/bench.py --gpus 2 --backend gloo --cells-per-gpu 500000 --steps 3 --warmup 1 --no-e2e > $O/bench_2ranks_allreduce.json 2> $O/bench_2ranks_allreduce.err
+# configs[4] shape on two ranks sharing the GPU: every block step's K x B table an inbox all-reduce of its own, ridge statistics / old sums as reduce-scatter + all-gather windows
+timeout 600 python $R/bench.py --gpus 2 --backend gloo --workload c5 --cells-per-gpu 500000 --steps 2 --warmup 1 --no-e2e > $O/bench_2ranks_c5.json 2> $O/bench_2ranks_c5.err
 # (the torch-free bootstrap -- bench.py --bootstrap file -- uses the built-in RCCL communicator, which wants one GPU per rank: covered at world 1 by
 #  tests/test_gpu_parity2.py::test_bench_bootstraps_without_torch, at world 2 only on a node)
 cd $R

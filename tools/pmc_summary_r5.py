@@ -41,7 +41,9 @@ for src, dst in [("kernel_stats.csv", "r5_kernel_stats.csv"), ("bench_rocprof.js
                  ("bench_10M.json", "r5_bench_10M_one_gpu.json"), ("bench_c5_1M.json", "r5_bench_c5_1M.json"), ("bench_c5_5M.json", "r5_bench_c5_5M.json"),
                  ("bench_2ranks_p2p.json", "r5_bench_2ranks_one_gpu_p2p_chain.json"), ("bench_2ranks_allreduce.json", "r5_bench_2ranks_one_gpu_allreduce_per_block.json"),
                  ("ref_kernel_stats.csv", "r5_ref_arith_kernel_stats.csv"), ("ref_profile.json", "r5_ref_arith_profile.json"), ("round_timeline.txt", "r5_round_timeline.txt"),
-                 ("bench_strong_1gpu_10M.json", "r5_bench_total_cells_10M_one_gpu.json")]:
+                 ("bench_strong_1gpu_10M.json", "r5_bench_total_cells_10M_one_gpu.json"), ("bench_shares.json", "r5_bench_shares.json"),
+                 ("bench_pmc_selfcollected.json", "r5_bench_pmc_selfcollected.json"), ("bench_2ranks_c5.json", "r5_bench_2ranks_one_gpu_configs4_shape.json"),
+                 ("../r5_parity_c5_5M.json", "r5_parity_c5_5M.json"), ("../r5_parity_c4_10M.json", "r5_parity_c4_10M.json")]:
     if os.path.exists(os.path.join(R, src)): shutil.copy(os.path.join(R, src), os.path.join(P, dst))
 for k, v in summ["kernels"].items():
     print(k, {x: (round(y, 3) if isinstance(y, float) else y) for x, y in v.items() if x in ("avg_duration_us", "hbm_GBps", "mfma_busy_frac", "hbm_total_bytes")})
