@@ -824,7 +824,7 @@ def main():
                 elif leg == "shares":  # (not in the default set) what ONE rank of the 8-GPU configs computes at G = 2 / 4 / 8, without the exchanges: the inputs of DESIGN 5.2's scaling prediction
                     for cells in (5000000, 2500000):
                         legs["configs3_share_%dk" % (cells // 1000)] = bench_leg(Harmony, prepare_setup_args, cells, 50, 100, (20,), False, a.seed, 2, 1, sync)
-                    for cells in (2500000, 1250000, 625000):
+                    for cells in (2500000, 1250000, 625000, 500000):
                         legs["configs4_share_%dk" % (cells // 1000)] = bench_leg(Harmony, prepare_setup_args, cells, 50, 200, (8, 64, 128), True, a.seed, 2, 1, sync)
                 elif leg == "c5":      # configs[4] shape at 1M cells
                     legs["c5_shape_1M"] = bench_leg(Harmony, prepare_setup_args, 1000000, 50, 200, (8, 64, 128), True, a.seed, 2, 1, sync)

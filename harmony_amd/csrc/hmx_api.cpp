@@ -281,6 +281,7 @@ struct hmx_ctx {
   double seq_tol = 1e-5;
   bool seq_strict = false; uint64_t seq_last_mismatch = 0, seq_unsettled = 0; int64_t seq_group_passes[4] = {0, 0, 0, 0}, seq_group_runs[4] = {0, 0, 0, 0};
   int* headlist = nullptr;                 // [(1 + C) n] cells in original order | cells by (level of covariate c, original order)
+  int* headq = nullptr;                    // the same entries' combinations (ridge_arith: static, saves a dependent load per batch of the ridge pass)
   std::vector<int> lev_off, lev_cnt;       // [B] a level's range inside its covariate's part of headlist
   int* headlev = nullptr; int* roundlev = nullptr;     // [min(C, 4)][n] level codes of the positions of headlist's first part / of roundlist
   int* roundlist = nullptr;                // [(1 + C) n] this round's cells in shuffled order | by (block, level of covariate c), shuffled order
@@ -376,10 +377,10 @@ void free_all(hmx_ctx* ctx) {
   for (int i = 0; i < 4; i++) { ctx->sorted_round[i] = -1; ctx->sorted_on_side[i] = false; }
   {   // reference-arithmetic buffers (grown on demand, not in `allocs`)
     void* ps[] = {ctx->sq_start, ctx->sq_end, ctx->sq_total, ctx->sq_mismatch, ctx->headlist, ctx->roundlist, ctx->Of, ctx->Ef, ctx->Mtab, ctx->objT,
-                  ctx->inset, ctx->obj_start, ctx->obj_partial, ctx->rg_start, ctx->headlev, ctx->roundlev, ctx->pairlist, ctx->pair_idx, ctx->rg_tot, ctx->rp_tot, ctx->rp_start, ctx->plan_pair.d_segs, ctx->plan_pair.d_chains, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
+                  ctx->inset, ctx->headq, ctx->obj_start, ctx->obj_partial, ctx->rg_start, ctx->headlev, ctx->roundlev, ctx->pairlist, ctx->pair_idx, ctx->rg_tot, ctx->rp_tot, ctx->rp_start, ctx->plan_pair.d_segs, ctx->plan_pair.d_chains, ctx->plan_head.d_segs, ctx->plan_head.d_chains, ctx->plan_ridge.d_segs, ctx->plan_ridge.d_chains,
                   ctx->plan_round.d_segs, ctx->plan_round.d_chains};
     for (void* q : ps) if (q) (void)hipFree(q);
-    ctx->sq_start = ctx->sq_end = ctx->sq_total = nullptr; ctx->sq_mismatch = nullptr; ctx->sq_conv = nullptr; ctx->headlist = ctx->roundlist = nullptr;
+    ctx->sq_start = ctx->sq_end = ctx->sq_total = nullptr; ctx->sq_mismatch = nullptr; ctx->sq_conv = nullptr; ctx->headlist = ctx->roundlist = nullptr; ctx->headq = nullptr;
     ctx->Of = ctx->Ef = ctx->Mtab = ctx->objT = nullptr; ctx->inset = nullptr; ctx->sq_cap = ctx->sq_total_cap = ctx->objT_cap = 0;
     ctx->obj_start = ctx->rg_start = nullptr; ctx->obj_start_cap = ctx->rg_start_cap = 0; ctx->obj_warm = ctx->rg_warm = false;
     ctx->obj_partial = nullptr; ctx->obj_partial_cap = 0;
@@ -970,6 +971,11 @@ int seq_setup_static(hmx_ctx* ctx) {
     for (int i = 0; i < n; i++) { const int cell = ctx->invperm_h[i]; const int l = ctx->qlev[(size_t)ctx->combo_h[cell] * C + c] - b0; hl[(size_t)(1 + c) * n + cur[l]++] = cell; }
   }
   { size_t cap = 0; CHK(seq_grow(ctx, ctx->headlist, cap, hl.size())); CHK(h2d(ctx, ctx->headlist, hl.data(), hl.size())); }
+  if (ctx->ridge_arith) {      // the list's combinations (static): the ridge pass fetches (cell, combination) with two independent loads
+    std::vector<int> hq(hl.size());
+    for (size_t i = 0; i < hl.size(); i++) hq[i] = ctx->combo_h[hl[i]];
+    size_t cap = 0; CHK(seq_grow(ctx, ctx->headq, cap, hq.size())); CHK(h2d(ctx, ctx->headq, hq.data(), hq.size()));
+  }
   { size_t c1 = 0, c2 = 0, c3 = 0; CHK(seq_grow(ctx, ctx->Of, c1, (size_t)B * K)); CHK(seq_grow(ctx, ctx->Ef, c2, (size_t)B * K)); CHK(seq_grow(ctx, ctx->Mtab, c3, (size_t)B * K));
     HIPCHK(hipMemsetAsync(ctx->Of, 0, sizeof(float) * (size_t)B * K, ctx->L.stream)); HIPCHK(hipMemsetAsync(ctx->Ef, 0, sizeof(float) * (size_t)B * K, ctx->L.stream)); }
   if (ctx->oe_arith) {
@@ -1066,7 +1072,7 @@ int seq_ridge_stats(hmx_ctx* ctx) {
   if ((size_t)P.nsegs * W > ctx->rg_start_cap) { CHK(seq_grow(ctx, ctx->rg_start, ctx->rg_start_cap, (size_t)P.nsegs * W)); ctx->rg_warm = false; }
   l_seq_inset(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->sv_cov_bounds, ctx->cutoff, ctx->inset); KCHK();
   CHK(seq_iterate(ctx, 2, ctx->rg_warm, ctx->N >= ctx->seq_adaptive_cells,
-                  [&](bool zero, unsigned* cz) -> int { l_seq_ridge_pass(ctx->L, D, ctx->headlist, P.d_segs, 0, P.nsegs, ctx->inset, ctx->rg_start, ctx->sq_end, zero ? 1 : 0, cz); KCHK(); return 0; },
+                  [&](bool zero, unsigned* cz) -> int { l_seq_ridge_pass(ctx->L, D, ctx->headlist, ctx->headq, P.d_segs, 0, P.nsegs, ctx->inset, ctx->rg_start, ctx->sq_end, zero ? 1 : 0, cz); KCHK(); return 0; },
                   [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, 0, P.nchains, W, ctx->rg_start, ctx->sq_end, ctx->rg_start, tot, conv, zero ? 1 : 0); KCHK(); return 0; }));
   ctx->rg_warm = true;
   ctx->seq_runs++;

@@ -303,7 +303,8 @@ void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* po
 void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
                     int zero_start, unsigned* conv_zero);
 void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, uint64_t Nglob, int* posord, int* poslev);
-void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
+// (listq: the combination of every entry of `list`, or nullptr -- the kernel then looks it up through D.combo, one more dependent load per batch)
+void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const int* listq, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start, unsigned* conv_zero);
 // (partial: [narr][ceil(nsegs / 256)] doubles, the deltas of every workgroup's 256 segments -- k_seq_scan1's bases)
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,

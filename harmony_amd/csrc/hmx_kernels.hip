@@ -2691,7 +2691,7 @@ __global__ __launch_bounds__(TPB) void k_objective_tables(Dev D) {
 // behind a tile's 84 stores waits for them to drain; the round-4 kernel did that four times per tile (1.02 ms per evaluation at 1M cells, 21
 // evaluations per run).  (3) log R through v_log_f32 (1 ulp; the term enters a sum of K N values): 3 instructions instead of logf's ~30.
 template <int NCT>
-__global__ __launch_bounds__(256) void k_obj_terms_mfma(Dev D, const float* __restrict__ M, float* __restrict__ T, long long stride) {
+__global__ __launch_bounds__(256, (NCT <= 8 ? 2 : 1)) void k_obj_terms_mfma(Dev D, const float* __restrict__ M, float* __restrict__ T, long long stride) {      // (two waves per SIMD: with 268 registers there was one, and nothing hid the tile's memory latencies)
   extern __shared__ __attribute__((aligned(16))) f32x4 ldsI[];
   constexpr int NFULL = NCT >> 2, RT = NCT & 3;
   const int K = D.K, C = D.C, zs = D.zs, n = D.n;
@@ -2796,7 +2796,9 @@ __global__ __launch_bounds__(256) void k_obj_terms_mfma(Dev D, const float* __re
           if (4 * qd < first_partial_ct(NCT) || k0 < K) {
             const f32x4 v0 = {a0[4 * qd], a0[4 * qd + 1], a0[4 * qd + 2], a0[4 * qd + 3]}, v1 = {a1[4 * qd], a1[4 * qd + 1], a1[4 * qd + 2], a1[4 * qd + 3]},
                         v2 = {a2[4 * qd], a2[4 * qd + 1], a2[4 * qd + 2], a2[4 * qd + 3]};
-            *reinterpret_cast<f32x4*>(t0p + k0) = v0; *reinterpret_cast<f32x4*>(t1p + k0) = v1; *reinterpret_cast<f32x4*>(t2p + k0) = v2;
+            // (streaming stores: the arrays are read back by the passes only after the whole evaluation has been written -- 1.2 GB, nothing to keep in L2)
+            __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(t0p + k0)); __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(t1p + k0));
+            __builtin_nontemporal_store(v2, reinterpret_cast<f32x4*>(t2p + k0));
           }
         }
 #pragma unroll
