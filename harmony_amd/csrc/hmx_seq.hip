@@ -152,11 +152,9 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
 //     pass at 1M cells).  The cell's 8 R values are wave-uniform: they travel through the SCALAR cache (s_load_dwordx8) and feed
 //     v_pk_mul_f32 / v_pk_add_f32 straight from SGPR pairs -- two clusters per VALU instruction, each component rounded on its own
 //     (no contraction: the reference multiplies, rounds, then adds).  10 VALU instructions per (cell, 8 clusters) instead of ~30.
-//     Round 5: a software pipeline over the batches of 64 cells.  The round-4 loop exposed ~7 memory latencies per batch (list -> combination ->
-//     in-set flags -> R, then four groups of 16 embedding rows, each requested only when the group before it had been added up): 1.2 ms per pass at
-//     1M cells, 0.5 TB/s, with ~3 waves per SIMD to hide them.  Now: (cell, combination) ids two batches ahead (`listq` = the list's combinations,
-//     static, built at setup: no dependent load), flags and R values one batch ahead (kept RAW: the mask is applied when they are used, so
-//     nothing waits for them early), and all 64 embedding rows of the current batch in flight together, issued first.
+//     (Round 5 tried a software pipeline over the batches -- ids two ahead through a static combination list `listq`, raw R / flags one ahead, all 64
+//      rows of a batch in flight together: 128 VGPRs, 1.20 -> 1.46 ms per pass.  The form below stays; `listq` is accepted and unused.  Two workgroups
+//      per CU at 72 VGPRs: 21 -> 35 ms per run.  Both measured on the final code, tools/gpu_runs/r5_probe2.sh.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int KPW>
 __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,
@@ -178,54 +176,41 @@ __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict
   // lane j < d: z_j; lane 63: 1 (the mass chain); the others 0 -- as z * zmask + one63 (exact: x * 1 + 0), NOT as a select around the load:
   // hipcc sinks the load into the select's branch and waits for it on the spot (one exposed memory latency per cell)
   const float zmask = lane < d ? 1.0f : 0.0f, one63 = lane == 63 ? 1.0f : 0.0f;
-  struct Ids { int myc, q; };
-  auto fetch_ids = [&](const int base) __attribute__((always_inline)) {       // (clamped into the segment: harmless beyond its end)
-    const int ci = sg.off + min(base + lane, sg.cnt - 1);
-    Ids I; I.myc = list ? list[ci] : ci; I.q = listq ? listq[ci] : combo[I.myc];
-    return I;
-  };
-  // lane l of load i holds cluster k0 + (l & 7) of cell 8 i + (l >> 3): the batch's R values with EIGHT vector loads, its in-set flags with one
-  struct Raw { float rl[8]; unsigned long long fl; };
-  auto fetch_raw = [&](const Ids& I, Raw& W) __attribute__((always_inline)) {
-    W.fl = *reinterpret_cast<const unsigned long long*>(inset + (size_t)I.q * KP8 + k0);     // 8 flag bytes of this lane's cell
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int cellv = __shfl(I.myc, 8 * i + (lane >> 3), 64);
-      W.rl[i] = R[(size_t)cellv * K + k0 + (lane & 7)];       // (clusters >= K of the last group read into the next row -- R has a dummy row behind the last cell -- and are never stored)
-    }
-  };
-  Ids idC = fetch_ids(0), idN = fetch_ids(64);
-  Raw rawC, rawN;
-  fetch_raw(idC, rawC);
   for (int base = 0; base < sg.cnt; base += 64) {
     const int nc = min(64, sg.cnt - base);
-    // (1) the 64 embedding rows of THIS batch: issued first, consumed below
-    float z[64];
-#pragma unroll
-    for (int u = 0; u < 64; u++) {
-      const int cell = __builtin_amdgcn_readlane(idC.myc, u);       // (lanes past the end hold the segment's last cell: a valid row)
-      z[u] = Zo[(size_t)cell * zs + js];
-    }
-    // (2) prefetches: ids of batch + 2, flags and R of batch + 1 (raw)
-    const Ids idNN = fetch_ids(base + 128);
-    fetch_raw(idN, rawN);
-    // (3) this batch: masks applied to the R values now (a masked term is +0: the inner loop has no branches)
+    const int ci = sg.off + min(base + lane, sg.cnt - 1);
+    const int myc = list ? list[ci] : ci;
+    const unsigned long long fl = *reinterpret_cast<const unsigned long long*>(inset + (size_t)combo[myc] * KP8 + k0);     // 8 flag bytes
     unsigned mym = 0;
 #pragma unroll
-    for (int kk = 0; kk < KPW; kk++) mym |= ((rawC.fl >> (8 * kk)) & 0xffull) ? (1u << kk) : 0u;
+    for (int kk = 0; kk < KPW; kk++) mym |= ((fl >> (8 * kk)) & 0xffull) ? (1u << kk) : 0u;
+    // R of the whole batch with EIGHT vector loads -- lane l of load i holds cluster k0 + (l & 7) of cell 8 i + (l >> 3) -- all in flight
+    // together (vector loads retire in order: counted waits, unlike scalar loads); a cell's 8 values then reach the SGPRs by v_readlane and
+    // feed the packed multiplies from there.  The in-set flags (and the end of a partial batch) are applied to the loaded value, lane by
+    // lane: a masked term is +0 and the inner loop has no branches.  (Clusters >= K of the last group read into the next row -- R has a
+    // dummy row behind the last cell -- and are never stored.)  Z rows 16 cells at a time.
     float rq[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const int src = 8 * i + (lane >> 3);
+      const int cellv = __shfl(myc, src, 64);
       const unsigned mv = (unsigned)__shfl((int)mym, src, 64);
-      rq[i] = rawC.rl[i] * ((src < nc && ((mv >> (lane & 7)) & 1u)) ? 1.0f : 0.0f);
+      const float rl = R[(size_t)cellv * K + k0 + (lane & 7)];
+      rq[i] = rl * ((src < nc && ((mv >> (lane & 7)) & 1u)) ? 1.0f : 0.0f);       // (a product, not a select around the load: see zmask)
     }
 #pragma unroll
-    for (int u = 0; u < 64; u++) {
-      if (u < nc) {
-        const float zu = __builtin_fmaf(z[u], zmask, one63);
-        const f32x2 zz = {zu, zu};
-        const float rsrc = rq[u >> 3];
+    for (int i = 0; i < 4; i++) {
+      if (16 * i >= nc) break;
+      float z[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int cell = __builtin_amdgcn_readlane(myc, 16 * i + u);       // (lanes past the end hold the segment's last cell: a valid row)
+        z[u] = __builtin_fmaf(Zo[(size_t)cell * zs + js], zmask, one63);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const f32x2 zz = {z[u], z[u]};
+        const float rsrc = rq[2 * i + (u >> 3)];
 #pragma unroll
         for (int h = 0; h < KPW / 2; h++) {
           const f32x2 r2 = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsrc), 8 * (u & 7) + 2 * h)),
@@ -234,7 +219,6 @@ __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict
         }
       }
     }
-    idC = idN; idN = idNN; rawC = rawN;
   }
 #pragma unroll
   for (int kk = 0; kk < KPW; kk++)

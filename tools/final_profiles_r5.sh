@@ -12,6 +12,9 @@ if [[ $PART == *c* ]]; then     # full-size oracle tables of the two 8-GPU confi
 SLOWPID=$!
 sleep 90      # (their GPU runs happen in the first minute: keep them out of the timed benches)
 fi
+if [[ $PART == *s* ]]; then     # the whole GPU suite + smoke, as the driver runs them
+( cd $R && timeout 1800 python -m pytest tests -q -m gpu --durations=8 2>&1 | tail -20 > $O/suite.log; timeout 100 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> $O/suite.log ); tail -4 $O/suite.log | cut -c1-200
+fi
 if [[ $PART == *a* ]]; then
 timeout 900 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python $R/bench.py --pmc --also none --cpu-sample 0 --no-e2e > $O/bench_pmc_selfcollected.json 2> $O/bench_pmc_selfcollected.err; cp $R/profiles/pmc_traffic_update_kernel.json $O/pmc_traffic_from_bench_pmc.json 2>/dev/null
