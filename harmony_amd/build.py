@@ -12,7 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in ("hmx_kernels.hip", "hmx_tile_bf.hip", "hmx_seq.hip", "hmx_api.cpp")]
 # (hmx_tile_bf.hip is hmx_kernels.hip's tile kernel built a second time with the split-bf16 distance GEMM: it includes that file)
-EXTRA_DEP = {"hmx_tile_bf.hip": [os.path.join(HERE, "csrc", "hmx_kernels.hip")]}
+_INC = [os.path.join(HERE, "csrc", f) for f in ("hmx_k_stream.inc", "hmx_k_tile.inc", "hmx_k_correct.inc", "hmx_k_launch.inc")]      # the kernels, by section (included by hmx_kernels.hip)
+EXTRA_DEP = {"hmx_kernels.hip": _INC, "hmx_tile_bf.hip": [os.path.join(HERE, "csrc", "hmx_kernels.hip")] + _INC}
 HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "csrc", "hmx_rrng.h"), os.path.join(HERE, "..", "include", "harmony_mi355x.h")]
 OUT = os.path.join(HERE, "lib", "libharmony_mi355x.so")
 
@@ -34,7 +35,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(p) > t for p in SRC + HDR)
+    return any(os.path.getmtime(p) > t for p in SRC + HDR + _INC)
 
 
 def build(force=False, verbose=True, trace=False):

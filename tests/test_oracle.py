@@ -133,3 +133,31 @@ def test_injected_order_equals_generated(cell_lines_small):
     b.cluster_cpp()
     b.moe_correct_ridge_cpp()
     np.testing.assert_array_equal(a.getZcorr(), b.getZcorr())
+
+
+def test_getLambda_definition(cell_lines_small, cell_lines):
+    """getLambda (src/harmony.cpp:657-669): K x (B + 1); estimated lambda = [0, alpha * E[k, :]] (find_lambda_cpp, src/utils.cpp:159-163),
+    fixed lambda = the caller's vector in every row"""
+    o = run_backend(OracleHarmony(accurate=False, seed=1), cell_lines_small["pcs"], _meta(cell_lines_small), "dataset", nclust=10, max_iter=2)
+    L = o.getLambda()
+    assert L.shape == (o.K, o.B + 1) and np.all(L[:, 0] == 0)
+    np.testing.assert_allclose(L[:, 1:], np.float32(0.2) * o.E.astype(np.float32), rtol=1e-6)
+    o = run_backend(OracleHarmony(accurate=False, seed=1), cell_lines["pcs"], _meta(cell_lines), ["dataset", "cell_type"], nclust=8, max_iter=1,
+                    lambda_=[0.5, 2.0])
+    assert np.array_equal(o.getLambda(), np.tile(np.concatenate([[0.0], np.repeat([0.5, 2.0], [3, 2])]), (8, 1)))
+
+
+def test_liberties_of_the_faithful_mode_are_ulp_level(cell_lines):
+    """The places where Armadillo / BLAS -- not /root/reference -- fix the operation order (oracle header, LIBERTIES): each one flipped on its
+    own changes the faithful run (it IS a different rounding sequence) but only at the level of fp32 noise amplified by the iteration --
+    nowhere near the reference's accumulation bias the mode exists to reproduce."""
+    m = _meta(cell_lines)
+    kw = dict(theta=[1, 1], nclust=30, max_iter=4, options=harmony_options(max_iter_cluster=6))
+    base = run_backend(OracleHarmony(accurate=False, seed=2), cell_lines["pcs"], m, ["cell_type", "dataset"], **kw).getZcorr()
+    moved = 0
+    for bit in (1, 2, 4, 8, 16):
+        z = run_backend(OracleHarmony(accurate=False, seed=2, liberty=bit), cell_lines["pcs"], m, ["cell_type", "dataset"], **kw).getZcorr()
+        rel = float(np.linalg.norm(z - base) / np.linalg.norm(base))
+        assert rel < 1e-4, (bit, rel)
+        moved += rel > 0
+    assert moved >= 3      # (the switches are really wired: the L1 / L2 sum orders and the per-non-zero apply change bits)
