@@ -16,13 +16,14 @@ from harmony_amd import Harmony, prepare_setup_args  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cells", type=int, default=1000000)
 ap.add_argument("--steps", type=int, default=2)
-ap.add_argument("--passes", type=int, default=3)
+ap.add_argument("--passes", type=int, default=0, help="seq_passes (0: the library's default, 2 since round 5)")
 ap.add_argument("--mode", default="ref_arith")
 a = ap.parse_args()
 Z, meta, _ = synth(a.cells, d=50, levels=(10,), seed=7)
 skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
 g = Harmony(seed=1, **({a.mode: 1} if a.mode != "default" else {}))
-g._set("seq_passes", a.passes)
+if a.passes:
+    g._set("seq_passes", a.passes)
 g.setup(**skw)
 
 
