@@ -265,6 +265,7 @@ struct hmx_ctx {
   float* sq_start = nullptr; float* sq_end = nullptr; size_t sq_cap = 0;
   float* sq_total = nullptr; size_t sq_total_cap = 0;
   unsigned* sq_mismatch = nullptr; int seq_passes = 2, seq_warm_passes = 2; int64_t seq_runs = 0;      // (round 5: 2 passes cold AND warm, see seq_tol / seq_iterate)
+  bool seq_scan_final = false;      // set by seq_iterate around the scan behind the last pass of a non-adaptive sum (the O / E scans then only reduce)
   bool seq_stats = false;     // the last scan of NON-adaptive groups also counts the starts that still moved ("seq:mismatch" / "seq:residual" then cover every group)
   // long chains (>= seq_adaptive_cells cells) are iterated until the starts stop moving (chain-relative residual <= 2^-22) or seq_max_passes
   unsigned* sq_conv = nullptr; int seq_max_passes = 24; int64_t seq_adaptive_cells = 200000, seq_extra_passes = 0; double seq_resid_max = 0.0; uint64_t seq_mismatch_sum = 0;
@@ -919,7 +920,9 @@ template <class PASS, class SCAN> int seq_iterate(hmx_ctx* ctx, int group, bool 
   for (; p < ctx->seq_passes; p++) {
     const bool last = p == ctx->seq_passes - 1 && (adaptive || ctx->seq_stats);     // (short chains: statistics only on request, "seq_stats")
     CHK(pass(p == 0 && !warm, last ? ctx->sq_conv : nullptr));       // (the pass zeroes the statistics words its scan adds to)
+    ctx->seq_scan_final = (p == ctx->seq_passes - 1) && !adaptive && !last;      // nobody reads the starts this scan would write: totals only
     CHK(scan(p == 0 && !warm, last ? ctx->sq_conv : nullptr));
+    ctx->seq_scan_final = false;
   }
   if (!adaptive) {      // (short chains: three passes are far inside fp32 noise; their last scan's statistics are read when a getter asks)
     return 0;
@@ -948,7 +951,7 @@ int seq_run_oe(hmx_ctx* ctx, const hmx_ctx::SeqPlan& P, const int* list, const i
   const bool adaptive = (int64_t)longest * P.seg_cells >= ctx->seq_adaptive_cells;
   CHK(seq_iterate(ctx, 0, warm, adaptive,
                   [&](bool zero, unsigned* cz) -> int { l_seq_oe_pass(ctx->L, ctx->D, list, poslev, (int)ctx->N, P.d_segs, lo, n, ctx->sq_start, ctx->sq_end, zero ? 1 : 0, cz); KCHK(); return 0; },
-                  [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, chain0, nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, conv, zero ? 1 : 0); KCHK(); return 0; }));
+                  [&](bool zero, unsigned* conv) -> int { l_seq_scan(ctx->L, P.d_chains, chain0, nchains, W, ctx->sq_start, ctx->sq_end, ctx->sq_start, ctx->sq_total, conv, zero ? 1 : 0, ctx->seq_scan_final ? 1 : 0); KCHK(); return 0; }));
   ctx->seq_runs++;
   return 0;
 }
@@ -1043,9 +1046,13 @@ int seq_objective(hmx_ctx* ctx, const Dev& D) {
   CHK(seq_workspace(ctx, (size_t)3 * nsegs, 3));
   if ((size_t)3 * nsegs > ctx->obj_start_cap) { CHK(seq_grow(ctx, ctx->obj_start, ctx->obj_start_cap, (size_t)3 * nsegs)); ctx->obj_warm = false; }
   CHK(seq_grow(ctx, ctx->obj_partial, ctx->obj_partial_cap, (size_t)3 * ((nsegs + 255) / 256)));
-  l_obj_terms(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->oe_arith ? ctx->Ef : nullptr, ctx->Mtab, ctx->objT, nt); KCHK();
+  const int mat = l_obj_terms(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->oe_arith ? ctx->Ef : nullptr, ctx->Mtab, ctx->objT, nt); KCHK();
+  // mat == 1: only R % dist is materialised; the entropy / cross-entropy chains are summed straight from R (k_seq_objr_pass)
   CHK(seq_iterate(ctx, 1, ctx->obj_warm, nt >= ctx->seq_adaptive_cells,
-                  [&](bool zero, unsigned* cz) -> int { l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, 3, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial, cz); KCHK(); return 0; },
+                  [&](bool zero, unsigned* cz) -> int {
+                    l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, mat, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial, cz); KCHK();
+                    if (mat == 1) { l_seq_objr_pass(ctx->L, D, ctx->Mtab, nt, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial); KCHK(); }
+                    return 0; },
                   [&](bool zero, unsigned* conv) -> int { l_seq_scan1(ctx->L, 3, nsegs, ctx->obj_start, ctx->sq_end, ctx->obj_start, ctx->sq_total, conv, zero ? 1 : 0, ctx->obj_partial); KCHK(); return 0; }));
   ctx->obj_warm = true;
   l_obj_store(ctx->L, ctx->sq_total, D.obj); KCHK();

@@ -310,13 +310,17 @@ void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const int*
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
                     int zero_start, double* partial, unsigned* conv_zero);
 void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains, int W, const float* start_in, const float* end, float* start_out,
-                float* total, unsigned* mismatch, int zero_start);
+                float* total, unsigned* mismatch, int zero_start, int reduce_only = 0);
 void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, const float* end, float* start_out, float* total,
                  unsigned* mismatch, int zero_start, const double* partial);
 void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot_add, const float* tot_sub, float* pen, int head);
-void l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
+// returns the number of term arrays materialised in T: 1 (T[0] = R % dist only: the MFMA kernel; the passes recompute the other two from R,
+// l_seq_objr_pass) or 3 (the cluster-lane fallback kernel / HMX_OBJ_TERMS=3)
+int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
+// arrays 1 and 2 of the objective (entropy, cross-entropy) as sequential sums straight from R: same segments, starts / ends / partials as l_seq_arr_pass's arrays 1, 2
+void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial);
 void l_obj_store(const Launch& L, const float* total, double* obj);
-bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride);
+bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride, int all3);
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M);
 void l_seq_inset(const Launch& L, const Dev& D, const float* Of, const int* cov_bounds, float cutoff, unsigned char* inset);
 void l_seq_ridge_store(const Launch& L, const Dev& D, const float* total);

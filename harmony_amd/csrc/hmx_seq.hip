@@ -271,12 +271,86 @@ __global__ __launch_bounds__(256) void k_seq_arr_pass(const float* __restrict__ 
   if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bsum[0];
 }
 
+// (c') Round 5: the objective's entropy and cross-entropy chains WITHOUT their term arrays.  T[1] = (R % log R) % sigma and T[2] = (R % sigma) % (M Phi)
+//     (src/harmony.cpp:161-162) are functions of R alone: thread = the same segment of L consecutive terms (original cell order, k fastest) as in
+//     k_seq_arr_pass, walking the cells' R rows through invperm and forming both terms on the fly with exactly the roundings k_obj_terms_mfma used
+//     (v_log_f32 * ln 2; product, round, product, round; M rows added in covariate order) -- two dependent chains per thread instead of one, 400 MB read per
+//     pass instead of 800 MB, and 800 MB less written per evaluation.  Needs K % 4 == 0 and L % 4 == 0 (16-byte loads stay inside a row).
+__global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __restrict__ M, long long n, int L, int nsegs,
+                                                       const float* __restrict__ start, float* __restrict__ end, int zero_start, double* __restrict__ partial) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ double bsum[2][256];
+  const int K = D.K, C = D.C;
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = seg < nsegs;
+  const long long off = (long long)min(seg, nsegs - 1) * L;
+  int cnt = live ? (int)min((long long)L, n - off) : 0;
+  const size_t so1 = (size_t)nsegs + min(seg, nsegs - 1), so2 = (size_t)2 * nsegs + min(seg, nsegs - 1);
+  const float s1_in = (zero_start || !live) ? 0.0f : start[so1], s2_in = (zero_start || !live) ? 0.0f : start[so2];
+  float s1 = s1_in, s2 = s2_in;
+  const float lmin = __builtin_amdgcn_logf(FLT_MIN) * 0.69314718055994530942f;
+  int cell = (int)(off / K), k = (int)(off - (long long)cell * K);
+  const float* __restrict__ Rp = D.R;
+  while (cnt > 0) {
+    const int icell = D.invperm[min(cell, D.n - 1)];
+    const int q = D.combo[icell];
+    const float* __restrict__ rrow = Rp + (size_t)icell * K;
+    int lev[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) lev[cc] = D.qlev[q * C + min(cc, C - 1)];
+    const int kend = min(K, k + cnt);
+    for (int k0 = k; k0 < kend; k0 += 32) {            // up to 32 terms of this row per step: all loads of the step in flight together
+      const int nq = min(8, (kend - k0 + 3) >> 2);
+      f4 r4[8], g4[8], m4[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int kk = min(k0 + 4 * u, K - 4);
+        r4[u] = *reinterpret_cast<const f4*>(rrow + kk);
+        g4[u] = *reinterpret_cast<const f4*>(D.sigma + kk);
+        f4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+          if (cc < C) { const f4 mm = *reinterpret_cast<const f4*>(M + (size_t)lev[cc] * K + kk);
+#pragma unroll
+            for (int i = 0; i < 4; i++) m[i] = __fadd_rn(m[i], mm[i]); }
+        }
+        for (int cc = 4; cc < C; cc++) { const f4 mm = *reinterpret_cast<const f4*>(M + (size_t)D.qlev[q * C + cc] * K + kk);
+#pragma unroll
+          for (int i = 0; i < 4; i++) m[i] = __fadd_rn(m[i], mm[i]); }
+        m4[u] = m;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (u < nq) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            if (k0 + 4 * u + i < kend) {
+              const float r = r4[u][i], sg = g4[u][i];
+              const float lg = (r > 0.0f) ? __fmul_rn(__builtin_amdgcn_logf(r), 0.69314718055994530942f) : lmin;      // arma::trunc_log
+              s1 = __fadd_rn(s1, __fmul_rn(__fmul_rn(r, lg), sg));
+              s2 = __fadd_rn(s2, __fmul_rn(__fmul_rn(r, sg), m4[u][i]));
+            }
+          }
+        }
+      }
+    }
+    cnt -= kend - k; cell++; k = 0;
+  }
+  if (live) { end[so1] = s1; end[so2] = s2; }
+  bsum[0][threadIdx.x] = live ? (double)s1 - (double)s1_in : 0.0;
+  bsum[1][threadIdx.x] = live ? (double)s2 - (double)s2_in : 0.0;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { bsum[0][threadIdx.x] += bsum[0][threadIdx.x + o]; bsum[1][threadIdx.x] += bsum[1][threadIdx.x + o]; } __syncthreads(); }
+  if (threadIdx.x == 0) { partial[(size_t)gridDim.x + blockIdx.x] = bsum[0][0]; partial[(size_t)2 * gridDim.x + blockIdx.x] = bsum[1][0]; }
+}
+
 // ---- scans: start[s] <- sum of (end - start) over the chain's segments before s ------------------------------------------------
 // lanes = lane-chains (w), 16 waves split the chain's segments; the differences and their partial sums are fp64 operations on values
 // that fp32 can hold: exact.  mismatch counts the (segment, lane-chain) pairs whose new start differs from the one the pass used.
 __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ chains, int chain0, int W, const float* start_in,
                                                    const float* __restrict__ end, float* start_out, float* __restrict__ total,
-                                                   unsigned* __restrict__ mismatch, int zero_start) {
+                                                   unsigned* __restrict__ mismatch, int zero_start, int reduce_only) {
+  // reduce_only (round 5): the scan behind the LAST pass of a sum nobody iterates further -- only the chain totals are wanted: one sweep, no starts written
   __shared__ double tot[16][64];
   __shared__ float dmx[16][64], smx[16][64];
   const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
@@ -304,6 +378,7 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
     tot[v][lane] = acc;
     __syncthreads();
     for (int u = 0; u < v; u++) run += tot[u][lane];
+    if (reduce_only) { if (v == 15 && w < W) total[(size_t)chain * W + w] = (float)(run + acc); return; }
 #pragma unroll
     for (int u = 0; u < PC; u++) {
       if (s0 + u < s1) {
@@ -333,6 +408,7 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const SeqChain* __restrict__ 
   tot[v][lane] = acc;
   __syncthreads();
   for (int u = 0; u < v; u++) run += tot[u][lane];
+  if (reduce_only) { if (v == 15 && w < W) total[(size_t)chain * W + w] = (float)(run + acc); return; }
   for (int sb = s0; sb < s1; sb += 16) {
     float e8[16], o8[16];
 #pragma unroll
@@ -587,10 +663,10 @@ void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stri
   hipLaunchKernelGGL(k_seq_arr_pass, dim3((nsegs + 255) / 256, narr), dim3(256), 0, L.stream, T, n, stride, Lseg, nsegs, start, end, zero_start, partial, conv_zero);
 }
 void l_seq_scan(const Launch& L, const SeqChain* chains, int chain0, int nchains, int W, const float* start_in, const float* end, float* start_out,
-                float* total, unsigned* mismatch, int zero_start) {
+                float* total, unsigned* mismatch, int zero_start, int reduce_only) {
   if (nchains <= 0) return;
   hipLaunchKernelGGL(k_seq_scan, dim3(nchains, (W + 63) / 64), dim3(1024), 0, L.stream, chains, chain0, W, start_in, end, start_out, total, mismatch,
-                     zero_start);
+                     zero_start, (reduce_only && !mismatch) ? 1 : 0);
 }
 void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, const float* end, float* start_out, float* total,
                  unsigned* mismatch, int zero_start, const double* partial) {
@@ -600,12 +676,18 @@ void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float*
   const int n = D.B * D.K;
   hipLaunchKernelGGL(k_oe_fold, dim3((n + 255) / 256), dim3(256), 0, L.stream, Of, Ef, tot_add, tot_sub, D.Pr_b, D.theta, pen, D.B, D.K, head);
 }
-void l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride) {
+int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride) {
   const int n = D.B * D.K;
   hipLaunchKernelGGL(k_obj_mtable, dim3((n + 255) / 256), dim3(256), 0, L.stream, D, Of, Ef, M);
-  if (l_obj_terms_mfma(L, D, M, T, stride)) return;          // distances on the matrix cores, 16-byte rows (hmx_kernels.hip)
+  static const bool all3_env = [] { const char* e = getenv("HMX_OBJ_TERMS"); return e && atoi(e) == 3; }();       // (3: materialise all three term arrays as in round 4)
+  const int all3 = all3_env ? 1 : 0;
+  if (l_obj_terms_mfma(L, D, M, T, stride, all3)) return all3 ? 3 : 1;          // distances on the matrix cores, 16-byte rows (hmx_k_correct.inc)
   int blocks = (D.n + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_obj_terms, dim3(blocks), dim3(256), (size_t)D.d * D.KP * sizeof(float), L.stream, D, M, T, stride);
+  return 3;
+}
+void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial) {
+  hipLaunchKernelGGL(k_seq_objr_pass, dim3((nsegs + 255) / 256), dim3(256), 0, L.stream, D, M, nterms, Lseg, nsegs, start, end, zero_start, partial);
 }
 void l_obj_store(const Launch& L, const float* total, double* obj) { hipLaunchKernelGGL(k_obj_store, dim3(1), dim3(64), 0, L.stream, total, obj); }
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M) {
