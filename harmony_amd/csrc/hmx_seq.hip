@@ -299,11 +299,12 @@ __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __res
 #pragma unroll
     for (int cc = 0; cc < 4; cc++) lev[cc] = D.qlev[q * C + min(cc, C - 1)];
     const int kend = min(K, k + cnt);
-    for (int k0 = k; k0 < kend; k0 += 32) {            // up to 32 terms of this row per step: all loads of the step in flight together
-      const int nq = min(8, (kend - k0 + 3) >> 2);
-      f4 r4[8], g4[8], m4[8];
+    constexpr int NU = 4;                                  // 16 terms of this row per step, all loads of the step in flight together (few registers: the
+    for (int k0 = k; k0 < kend; k0 += 4 * NU) {            // latency of a step is hidden by the other waves of the SIMD, segments are short -- L = 512 -- and many)
+      const int nq = min(NU, (kend - k0 + 3) >> 2);
+      f4 r4[NU], g4[NU], m4[NU];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < NU; u++) {
         const int kk = min(k0 + 4 * u, K - 4);
         r4[u] = *reinterpret_cast<const f4*>(rrow + kk);
         g4[u] = *reinterpret_cast<const f4*>(D.sigma + kk);
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __res
         m4[u] = m;
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < NU; u++) {
         if (u < nq) {
 #pragma unroll
           for (int i = 0; i < 4; i++) {
@@ -654,7 +655,10 @@ void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const int* listq, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start, unsigned* conv_zero) {
   if (nsegs <= 0) return;
-  const int kg = (D.K + 7) / 8, wpg = kg < 16 ? kg : 16;       // one wave per 8 clusters, up to 16 waves (128 clusters) per workgroup
+  // one wave per 8 clusters.  Round 5: at most TWELVE waves per workgroup -- at 80 VGPRs a CU holds 24 waves, i.e. two 12-wave workgroups where a
+  // 13-wave one (K = 100) left the rest of the CU empty; the clusters beyond 96 go to a second, small workgroup of the same segment (grid.y)
+  static const int wmax = [] { const char* e = getenv("HMX_SEQ_RIDGE_WPG"); const int v = e ? atoi(e) : 12; return v >= 1 && v <= 16 ? v : 12; }();
+  const int kg = (D.K + 7) / 8, wpg = kg < wmax ? kg : wmax;
   hipLaunchKernelGGL(k_seq_ridge_pass<8>, dim3(nsegs, (kg + wpg - 1) / wpg), dim3(64 * wpg), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, D.zs, (D.K + 7) / 8 * 8, list, listq, segs,
                      seg0, inset, start, end, zero_start, conv_zero);
 }
