@@ -203,7 +203,11 @@ int hmx_comm_allreduce_host(hmx_ctx* ctx, double* inout, int32_t count, int32_t 
  * With the inboxes connected the library also sends every SMALL collective of a run through them (O after a head, the objective's sums, the
  * Lloyd sums, the seeding minima, ridge statistics up to 65 536 values: one launch and one trip over xGMI each instead of a ring; the old
  * contributions of a round's blocks travel with the chain's own exchange) -- hmx_get "p2p:allreduce_calls" counts them, "comm:calls" what is
- * left on the communicator / hook.  HMX_P2P_AR=0 keeps them on the communicator.
+ * left on the communicator / hook.  HMX_P2P_AR=0 keeps them on the communicator.  Round 5: LARGER buffers (the ridge statistics of many-level
+ * designs -- Q K (d + 1) doubles, 1.3M at BASELINE configs[4] --, the per-round old sums of the launch-per-step path) go through the same inboxes
+ * as reduce-scatter + all-gather windows of 32768 x world entries (rank e / 32768 owns entry e of a window, adds the ranks' values in rank order,
+ * sends the result to everybody: 2 (G - 1) / G of the buffer per link instead of G - 1 times it) -- hmx_get "p2p:allreduce_big_windows" counts the
+ * windows; HMX_P2P_AR_BIG=0 sends those buffers to the communicator / hook instead.
  * hmx_comm_init sets all of this up by itself (HMX_P2P=0 disables it).  A host that brings its own all-reduce hook can do it by
  * hand: every rank exports a handle (a hipIpcMemHandle_t, HMX_P2P_HANDLE_BYTES bytes), the host all-gathers them (rank order),
  * every rank connects, then -- after a host barrier -- every rank runs the self-test AT THE SAME TIME, and only if it passed on
