@@ -998,12 +998,6 @@ int seq_setup_static(hmx_ctx* ctx) {
       for (int i = 0; i < n; i++) for (int c = 0; c < Cl; c++) hv[(size_t)c * n + i] = ctx->qlev[(size_t)ctx->combo_h[ctx->invperm_h[i]] * C + c];
       CHK(h2d(ctx, ctx->headlev, hv.data(), hv.size())); }
   }
-  if (ctx->obj_arith && !ctx->oe_arith) {      // the level codes in original cell order for the objective's cooperative pass (oe_arith builds them above)
-    const int Cl = std::min(C, 4); size_t c2 = 0; CHK(seq_grow(ctx, ctx->headlev, c2, (size_t)Cl * n));
-    std::vector<int> hv((size_t)Cl * n);
-    for (int i = 0; i < n; i++) for (int c = 0; c < Cl; c++) hv[(size_t)c * n + i] = ctx->qlev[(size_t)ctx->combo_h[ctx->invperm_h[i]] * C + c];
-    CHK(h2d(ctx, ctx->headlev, hv.data(), hv.size()));
-  }
   if (ctx->ridge_arith) {
     if (ctx->d > 62) return fail(ctx, HMX_ERR_LIMIT, "ridge_arith = 1 supports d <= 62");
     if (!ctx->solve_on_device) return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 needs the device-side ridge solve");
@@ -1053,13 +1047,9 @@ int seq_objective(hmx_ctx* ctx, const Dev& D) {
   if ((size_t)3 * nsegs > ctx->obj_start_cap) { CHK(seq_grow(ctx, ctx->obj_start, ctx->obj_start_cap, (size_t)3 * nsegs)); ctx->obj_warm = false; }
   CHK(seq_grow(ctx, ctx->obj_partial, ctx->obj_partial_cap, (size_t)3 * ((nsegs + 255) / 256)));
   const int mat = l_obj_terms(ctx->L, D, ctx->oe_arith ? ctx->Of : nullptr, ctx->oe_arith ? ctx->Ef : nullptr, ctx->Mtab, ctx->objT, nt); KCHK();
-  // mat == 1: only R % dist is materialised; the entropy / cross-entropy chains are summed straight from R (k_seq_obj_coop: all three chains in one
-  // wave-cooperative pass; k_seq_arr_pass + k_seq_objr_pass where its envelope does not apply)
-  static const bool coop_off = [] { const char* e = getenv("HMX_OBJ_COOP"); return e && atoi(e) == 0; }();      // (temporary A/B switch)
-  const bool coop = !coop_off && ctx->headlev && ctx->C <= 4 && nt < (1ll << 32) && LSEG % 16 == 0 && ctx->K % 4 == 0;
+  // mat == 1: only R % dist is materialised; the entropy / cross-entropy chains are summed straight from R (k_seq_objr_pass)
   CHK(seq_iterate(ctx, 1, ctx->obj_warm, nt >= ctx->seq_adaptive_cells,
                   [&](bool zero, unsigned* cz) -> int {
-                    if (mat == 1 && coop) { l_seq_obj_coop(ctx->L, D, ctx->objT, ctx->Mtab, ctx->headlev, nt, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial, cz); KCHK(); return 0; }
                     l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, mat, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial, cz); KCHK();
                     if (mat == 1) { l_seq_objr_pass(ctx->L, D, ctx->Mtab, nt, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial); KCHK(); }
                     return 0; },

@@ -319,9 +319,6 @@ void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float*
 int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
 // arrays 1 and 2 of the objective (entropy, cross-entropy) as sequential sums straight from R: same segments, starts / ends / partials as l_seq_arr_pass's arrays 1, 2
 void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial);
-// all three chains in one wave-cooperative pass (T0 = the materialised R % dist; origlev = [C][n] level codes in original cell order, C <= 4; nterms < 2^32)
-void l_seq_obj_coop(const Launch& L, const Dev& D, const float* T0, const float* M, const int* origlev, long long nterms, int Lseg, int nsegs, const float* start,
-                    float* end, int zero_start, double* partial, unsigned* conv_zero);
 void l_obj_store(const Launch& L, const float* total, double* obj);
 bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride, int all3);
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M);

@@ -345,98 +345,6 @@ __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __res
   if (threadIdx.x == 0) { partial[(size_t)gridDim.x + blockIdx.x] = bsum[0][0]; partial[(size_t)2 * gridDim.x + blockIdx.x] = bsum[1][0]; }
 }
 
-// (c'') Round 5, second form: the objective's THREE chains in one wave-cooperative pass.  The thread-per-segment passes above stream 16 bytes per lane from 64
-//     different cache lines per load instruction and expose a memory latency per step (0.08 + 0.26 ms per pass at 1M cells for 800 MB).  Here a wave owns 64
-//     consecutive segments and walks them in slices of 16 terms: in the LOAD phase lane = (segment, 16-byte group) -- four lanes read 64 contiguous bytes
-//     of a row, all index loads of a slice in flight together --, the terms (T[0] from the materialised array, T[1] / T[2] formed from R with the terms
-//     kernel's roundings) go to an LDS tile [term][segment] (stride 65: two-way conflicts at most); in the SUM phase lane = segment adds its 16 terms of
-//     the three chains in order.  Same segments, starts, ends and per-256-segment partial sums as the passes above: bit-identical results.
-//     origlev: [C][n] level codes in ORIGINAL cell order (C <= 4), terms < 2^32, K % 4 == 0, L % 16 == 0.
-__global__ __launch_bounds__(256) void k_seq_obj_coop(Dev D, const float* __restrict__ T0, const float* __restrict__ M, const int* __restrict__ origlev,
-                                                      long long n_terms, int L, int nsegs, const float* __restrict__ start, float* __restrict__ end,
-                                                      int zero_start, double* __restrict__ partial, unsigned* __restrict__ conv_zero) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  constexpr int ST = 16, LDW = 65;
-  __shared__ float tile[4][3][ST * LDW];
-  __shared__ double bsum[3][256];
-  if (conv_zero && blockIdx.x == 0 && threadIdx.x < 2) conv_zero[threadIdx.x] = 0u;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int K = D.K, C = D.C, n = D.n;
-  const int seg0 = ((int)blockIdx.x * 4 + wv) * 64, myseg = seg0 + lane;
-  const bool live = myseg < nsegs;
-  const int sseg = min(myseg, nsegs - 1);
-  float sin[3], sc[3];
-#pragma unroll
-  for (int a = 0; a < 3; a++) { sin[a] = (zero_start || !live) ? 0.0f : start[(size_t)a * nsegs + sseg]; sc[a] = sin[a]; }
-  const float lmin = __builtin_amdgcn_logf(FLT_MIN) * 0.69314718055994530942f;
-  const int fi = lane & 3;
-  const unsigned nt = (unsigned)n_terms;
-  float* const t0 = tile[wv][0]; float* const t1 = tile[wv][1]; float* const t2 = tile[wv][2];
-  for (int j = 0; j < L / ST; j++) {
-    // ---- load phase: 4 (segment, 16-byte group) elements per lane; every load of the slice is issued before the first is used
-    unsigned Tt[4]; int cell[4], kk[4], ic[4], lv[4][4]; bool ok[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int si = (lane >> 2) + 16 * r;
-      const unsigned long long T64 = (unsigned long long)(seg0 + si) * (unsigned)L + (unsigned)(ST * j + 4 * fi);
-      ok[r] = T64 < (unsigned long long)nt;
-      Tt[r] = ok[r] ? (unsigned)T64 : 0u;
-      cell[r] = (int)(Tt[r] / (unsigned)K); kk[r] = (int)(Tt[r] - (unsigned)cell[r] * (unsigned)K);
-      ic[r] = D.invperm[cell[r]];
-#pragma unroll
-      for (int cc = 0; cc < 4; cc++) lv[r][cc] = origlev[(size_t)min(cc, C - 1) * n + cell[r]];
-    }
-    f4 r4[4], g4[4], m4[4], d4[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      r4[r] = *reinterpret_cast<const f4*>(D.R + (size_t)ic[r] * K + kk[r]);
-      g4[r] = *reinterpret_cast<const f4*>(D.sigma + kk[r]);
-      d4[r] = *reinterpret_cast<const f4*>(T0 + Tt[r]);
-      f4 m = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int cc = 0; cc < 4; cc++) {
-        if (cc < C) { const f4 mm = *reinterpret_cast<const f4*>(M + (size_t)lv[r][cc] * K + kk[r]);
-#pragma unroll
-          for (int i = 0; i < 4; i++) m[i] = __fadd_rn(m[i], mm[i]); }
-      }
-      m4[r] = m;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int si = (lane >> 2) + 16 * r;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float rr = r4[r][i], sg = g4[r][i];
-        const float lg = (rr > 0.0f) ? __fmul_rn(__builtin_amdgcn_logf(rr), 0.69314718055994530942f) : lmin;      // arma::trunc_log
-        const int o = (4 * fi + i) * LDW + si;
-        t0[o] = ok[r] ? d4[r][i] : 0.0f;
-        t1[o] = ok[r] ? __fmul_rn(__fmul_rn(rr, lg), sg) : 0.0f;
-        t2[o] = ok[r] ? __fmul_rn(__fmul_rn(rr, sg), m4[r][i]) : 0.0f;
-      }
-    }
-    __syncthreads();
-    // ---- sum phase: lane = segment, its 16 terms of the three chains in order (a term beyond the end is +0)
-#pragma unroll
-    for (int tt = 0; tt < ST; tt++) {
-      sc[0] = __fadd_rn(sc[0], t0[tt * LDW + lane]);
-      sc[1] = __fadd_rn(sc[1], t1[tt * LDW + lane]);
-      sc[2] = __fadd_rn(sc[2], t2[tt * LDW + lane]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    if (live) end[(size_t)a * nsegs + myseg] = sc[a];
-    bsum[a][threadIdx.x] = live ? (double)sc[a] - (double)sin[a] : 0.0;
-  }
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { bsum[0][threadIdx.x] += bsum[0][threadIdx.x + o]; bsum[1][threadIdx.x] += bsum[1][threadIdx.x + o]; bsum[2][threadIdx.x] += bsum[2][threadIdx.x + o]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { partial[blockIdx.x] = bsum[0][0]; partial[(size_t)gridDim.x + blockIdx.x] = bsum[1][0]; partial[(size_t)2 * gridDim.x + blockIdx.x] = bsum[2][0]; }
-}
-
 // ---- scans: start[s] <- sum of (end - start) over the chain's segments before s ------------------------------------------------
 // lanes = lane-chains (w), 16 waves split the chain's segments; the differences and their partial sums are fp64 operations on values
 // that fp32 can hold: exact.  mismatch counts the (segment, lane-chain) pairs whose new start differs from the one the pass used.
@@ -779,10 +687,6 @@ int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef,
   int blocks = (D.n + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_obj_terms, dim3(blocks), dim3(256), (size_t)D.d * D.KP * sizeof(float), L.stream, D, M, T, stride);
   return 3;
-}
-void l_seq_obj_coop(const Launch& L, const Dev& D, const float* T0, const float* M, const int* origlev, long long nterms, int Lseg, int nsegs, const float* start,
-                    float* end, int zero_start, double* partial, unsigned* conv_zero) {
-  hipLaunchKernelGGL(k_seq_obj_coop, dim3((nsegs + 255) / 256), dim3(256), 0, L.stream, D, T0, M, origlev, nterms, Lseg, nsegs, start, end, zero_start, partial, conv_zero);
 }
 void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial) {
   hipLaunchKernelGGL(k_seq_objr_pass, dim3((nsegs + 255) / 256), dim3(256), 0, L.stream, D, M, nterms, Lseg, nsegs, start, end, zero_start, partial);
