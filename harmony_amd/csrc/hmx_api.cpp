@@ -998,12 +998,6 @@ int seq_setup_static(hmx_ctx* ctx) {
       for (int i = 0; i < n; i++) for (int c = 0; c < Cl; c++) hv[(size_t)c * n + i] = ctx->qlev[(size_t)ctx->combo_h[ctx->invperm_h[i]] * C + c];
       CHK(h2d(ctx, ctx->headlev, hv.data(), hv.size())); }
   }
-  if (ctx->obj_arith && !ctx->oe_arith) {      // the level codes in original cell order for the objective's R-based pass (oe_arith builds them above)
-    const int Cl = std::min(C, 4); size_t c2 = 0; CHK(seq_grow(ctx, ctx->headlev, c2, (size_t)Cl * n));
-    std::vector<int> hv((size_t)Cl * n);
-    for (int i = 0; i < n; i++) for (int c = 0; c < Cl; c++) hv[(size_t)c * n + i] = ctx->qlev[(size_t)ctx->combo_h[ctx->invperm_h[i]] * C + c];
-    CHK(h2d(ctx, ctx->headlev, hv.data(), hv.size()));
-  }
   if (ctx->ridge_arith) {
     if (ctx->d > 62) return fail(ctx, HMX_ERR_LIMIT, "ridge_arith = 1 supports d <= 62");
     if (!ctx->solve_on_device) return fail(ctx, HMX_ERR_ARG, "ridge_arith = 1 needs the device-side ridge solve");
@@ -1057,7 +1051,7 @@ int seq_objective(hmx_ctx* ctx, const Dev& D) {
   CHK(seq_iterate(ctx, 1, ctx->obj_warm, nt >= ctx->seq_adaptive_cells,
                   [&](bool zero, unsigned* cz) -> int {
                     l_seq_arr_pass(ctx->L, ctx->objT, nt, nt, mat, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial, cz); KCHK();
-                    if (mat == 1) { l_seq_objr_pass(ctx->L, D, ctx->Mtab, ctx->objT + nt, ctx->headlev, nt, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial); KCHK(); }
+                    if (mat == 1) { l_seq_objr_pass(ctx->L, D, ctx->Mtab, nt, LSEG, nsegs, ctx->obj_start, ctx->sq_end, zero ? 1 : 0, ctx->obj_partial); KCHK(); }
                     return 0; },
                   [&](bool zero, unsigned* conv) -> int { l_seq_scan1(ctx->L, 3, nsegs, ctx->obj_start, ctx->sq_end, ctx->obj_start, ctx->sq_total, conv, zero ? 1 : 0, ctx->obj_partial); KCHK(); return 0; }));
   ctx->obj_warm = true;

@@ -318,10 +318,7 @@ void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float*
 // l_seq_objr_pass) or 3 (the cluster-lane fallback kernel: K % 4 != 0, rows of more than 67 PCs, the stale-distance snapshot)
 int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
 // arrays 1 and 2 of the objective (entropy, cross-entropy) as sequential sums straight from R: same segments, starts / ends / partials as l_seq_arr_pass's arrays 1, 2
-// (Rorig: R in original cell order = slot 1 of the term array as k_obj_terms_mfma leaves it, or nullptr: rows gathered through invperm; origlev: [min(C,4)][cells] level
-//  codes in original cell order, or nullptr)
-void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, const float* Rorig, const int* origlev, long long nterms, int Lseg, int nsegs, const float* start, float* end,
-                     int zero_start, double* partial);
+void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial);
 void l_obj_store(const Launch& L, const float* total, double* obj);
 bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride, int all3);
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M);

@@ -276,10 +276,7 @@ __global__ __launch_bounds__(256) void k_seq_arr_pass(const float* __restrict__ 
 //     k_seq_arr_pass, walking the cells' R rows through invperm and forming both terms on the fly with exactly the roundings k_obj_terms_mfma used
 //     (v_log_f32 * ln 2; product, round, product, round; M rows added in covariate order) -- two dependent chains per thread instead of one, 400 MB read per
 //     pass instead of 800 MB, and 800 MB less written per evaluation.  Needs K % 4 == 0 and L % 4 == 0 (16-byte loads stay inside a row).
-//     Rorig (or nullptr): R in ORIGINAL cell order, left by k_obj_terms_mfma in slot 1 of the term array -- without it the rows are gathered through invperm, at
-//     random over the 400 MB of R (partial lines at both ends of every 400-byte row, no DRAM page locality: 0.26 ms per pass where 400 contiguous MB take 0.09);
-//     origlev (or nullptr): [min(C, 4)][cells] level codes in original cell order -- without them combo -> qlev, two more dependent loads per cell.
-__global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __restrict__ M, const float* __restrict__ Rorig, const int* __restrict__ origlev, long long n, int L, int nsegs,
+__global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __restrict__ M, long long n, int L, int nsegs,
                                                        const float* __restrict__ start, float* __restrict__ end, int zero_start, double* __restrict__ partial) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ double bsum[2][256];
@@ -295,13 +292,12 @@ __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __res
   int cell = (int)(off / K), k = (int)(off - (long long)cell * K);
   const float* __restrict__ Rp = D.R;
   while (cnt > 0) {
-    const int ocell = min(cell, D.n - 1);
-    const int icell = (Rorig && origlev && C <= 4) ? 0 : D.invperm[ocell];
-    const int q = (origlev && C <= 4) ? 0 : D.combo[icell];
-    const float* __restrict__ rrow = Rorig ? Rorig + (size_t)ocell * K : Rp + (size_t)icell * K;
+    const int icell = D.invperm[min(cell, D.n - 1)];
+    const int q = D.combo[icell];
+    const float* __restrict__ rrow = Rp + (size_t)icell * K;
     int lev[4];
 #pragma unroll
-    for (int cc = 0; cc < 4; cc++) lev[cc] = (origlev && C <= 4) ? origlev[(size_t)min(cc, C - 1) * D.n + ocell] : D.qlev[q * C + min(cc, C - 1)];
+    for (int cc = 0; cc < 4; cc++) lev[cc] = D.qlev[q * C + min(cc, C - 1)];
     const int kend = min(K, k + cnt);
     constexpr int NU = 4;                                  // 16 terms of this row per step, all loads of the step in flight together (few registers: the
     for (int k0 = k; k0 < kend; k0 += 4 * NU) {            // latency of a step is hidden by the other waves of the SIMD, segments are short -- L = 512 -- and many)
@@ -692,9 +688,8 @@ int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef,
   hipLaunchKernelGGL(k_obj_terms, dim3(blocks), dim3(256), (size_t)D.d * D.KP * sizeof(float), L.stream, D, M, T, stride);
   return 3;
 }
-void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, const float* Rorig, const int* origlev, long long nterms, int Lseg, int nsegs, const float* start, float* end,
-                     int zero_start, double* partial) {
-  hipLaunchKernelGGL(k_seq_objr_pass, dim3((nsegs + 255) / 256), dim3(256), 0, L.stream, D, M, Rorig, origlev, nterms, Lseg, nsegs, start, end, zero_start, partial);
+void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial) {
+  hipLaunchKernelGGL(k_seq_objr_pass, dim3((nsegs + 255) / 256), dim3(256), 0, L.stream, D, M, nterms, Lseg, nsegs, start, end, zero_start, partial);
 }
 void l_obj_store(const Launch& L, const float* total, double* obj) { hipLaunchKernelGGL(k_obj_store, dim3(1), dim3(64), 0, L.stream, total, obj); }
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M) {
