@@ -276,11 +276,22 @@ __global__ __launch_bounds__(256) void k_seq_arr_pass(const float* __restrict__ 
 //     k_seq_arr_pass, walking the cells' R rows through invperm and forming both terms on the fly with exactly the roundings k_obj_terms_mfma used
 //     (v_log_f32 * ln 2; product, round, product, round; M rows added in covariate order) -- two dependent chains per thread instead of one, 400 MB read per
 //     pass instead of 800 MB, and 800 MB less written per evaluation.  Needs K % 4 == 0 and L % 4 == 0 (16-byte loads stay inside a row).
+//     LDSTAB (counters of round 5, profiles/r5_ref_arith_pmc_sq.txt: the waves of this pass wait on memory 78 % of their life -- every lane of a load addresses its
+//     own cache line, the texture-address unit serves them one line per cycle, and two of the three loads of a term are table lookups): the M table (B x K) and
+//     sigma are staged in LDS once per workgroup and read from there (ds_read_b128); only the R row stays a global load.  Tables beyond 32 KB: the global form.
+template <bool LDSTAB>
 __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __restrict__ M, long long n, int L, int nsegs,
                                                        const float* __restrict__ start, float* __restrict__ end, int zero_start, double* __restrict__ partial) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ double bsum[2][256];
+  extern __shared__ __attribute__((aligned(16))) float ltab[];      // [B][K] M, then [K] sigma (LDSTAB)
   const int K = D.K, C = D.C;
+  if constexpr (LDSTAB) {
+    for (int i = threadIdx.x; i < D.B * K; i += blockDim.x) ltab[i] = M[i];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) ltab[D.B * K + i] = D.sigma[i];
+    __syncthreads();
+  }
+  const float* const lsig = ltab + D.B * K;
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = seg < nsegs;
   const long long off = (long long)min(seg, nsegs - 1) * L;
@@ -307,11 +318,13 @@ __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __res
       for (int u = 0; u < NU; u++) {
         const int kk = min(k0 + 4 * u, K - 4);
         r4[u] = *reinterpret_cast<const f4*>(rrow + kk);
-        g4[u] = *reinterpret_cast<const f4*>(D.sigma + kk);
+        if constexpr (LDSTAB) g4[u] = *reinterpret_cast<const f4*>(lsig + kk); else g4[u] = *reinterpret_cast<const f4*>(D.sigma + kk);
         f4 m = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
-          if (cc < C) { const f4 mm = *reinterpret_cast<const f4*>(M + (size_t)lev[cc] * K + kk);
+          if (cc < C) {
+            f4 mm;
+            if constexpr (LDSTAB) mm = *reinterpret_cast<const f4*>(ltab + lev[cc] * K + kk); else mm = *reinterpret_cast<const f4*>(M + (size_t)lev[cc] * K + kk);
 #pragma unroll
             for (int i = 0; i < 4; i++) m[i] = __fadd_rn(m[i], mm[i]); }
         }
@@ -689,7 +702,12 @@ int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef,
   return 3;
 }
 void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial) {
-  hipLaunchKernelGGL(k_seq_objr_pass, dim3((nsegs + 255) / 256), dim3(256), 0, L.stream, D, M, nterms, Lseg, nsegs, start, end, zero_start, partial);
+  const size_t tab = ((size_t)D.B * D.K + D.K) * sizeof(float);
+  static const bool lds_off = [] { const char* e = getenv("HMX_OBJR_LDS"); return e && atoi(e) == 0; }();      // (temporary A/B switch)
+  if (tab <= 32 * 1024 && D.K % 4 == 0 && !lds_off)
+    hipLaunchKernelGGL(k_seq_objr_pass<true>, dim3((nsegs + 255) / 256), dim3(256), tab, L.stream, D, M, nterms, Lseg, nsegs, start, end, zero_start, partial);
+  else
+    hipLaunchKernelGGL(k_seq_objr_pass<false>, dim3((nsegs + 255) / 256), dim3(256), 0, L.stream, D, M, nterms, Lseg, nsegs, start, end, zero_start, partial);
 }
 void l_obj_store(const Launch& L, const float* total, double* obj) { hipLaunchKernelGGL(k_obj_store, dim3(1), dim3(64), 0, L.stream, total, obj); }
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M) {
