@@ -230,3 +230,26 @@ def test_split_bf16_helpers(tmp_path):
                     assert slot == j % 8 and lane // 16 == (j % 32) // 8 and ((i // 8) // 64) % 3 == part
                     ct = (i // 8) // 64 // 3 // ns2
                     assert lib.probe_kcol(nct, ct, lane % 16) == k and ((i // 8) // 64 // 3) % ns2 == j // 32
+
+
+def test_writable_fields_validate_their_values():
+    """hmx_set_int needs no device: the settings of the restarted sums (round 5) and the arithmetic switches accept their documented ranges and refuse
+    the rest with HMX_ERR_ARG and a message -- a typo must not silently select a default."""
+    import ctypes as C
+    from harmony_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p(lib.hmx_create())
+    try:
+        ok = {"seq_passes": 2, "seq_warm_passes": 2, "seq_tol_ppb": 10000, "seq_strict": 1, "seq_stats": 1, "seq_max_passes": 64, "ref_arith": 1, "rng": 1,
+              "max_iter_kmeans": 7, "seed": 42}
+        for f, v in ok.items():
+            assert lib.hmx_set_int(h, f.encode(), v) == 0, (f, lib.hmx_last_error(h))
+        bad = {"seq_passes": 1, "seq_warm_passes": 0, "seq_tol_ppb": -1, "seq_max_passes": 1000, "ref_arith": 2, "rng": 3, "no_such_field": 1}
+        for f, v in bad.items():
+            assert lib.hmx_set_int(h, f.encode(), v) != 0, f
+            assert len(lib.hmx_last_error(h)) > 0
+        # getters of scalar settings that need no device
+        out = (C.c_double * 1)()
+        assert lib.hmx_get(h, b"max_iter_kmeans", out, 1) == 1 and out[0] == 7.0
+    finally:
+        lib.hmx_destroy(h)
