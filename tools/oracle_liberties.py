@@ -48,12 +48,12 @@ def flips(Ra, Rb, margin):
 
 cases = [("%dk_one_covariate_K100" % (n // 1000), n, (10,), 100) for n in (20000, 100000)] + [("20k_two_covariates_K60", 20000, (3, 4), 60)]
 if len(sys.argv) > 1:       # e.g. `1000k_one_covariate_K100` (BASELINE configs[2]; ~1 minute of CPU per run)
-    cases = [c for c in cases + [("1000k_one_covariate_K100", 1000000, (10,), 100)] if c[0] in sys.argv[1:]]
+    cases = [c for c in cases + [("1000k_one_covariate_K100", 1000000, (10,), 100), ("100k_three_nested_covariates_K200", 100000, (8, 64, 128), 200)] if c[0] in sys.argv[1:]]
 PATH = os.path.join(ROOT, "profiles", "r5_oracle_liberties.json")
 if os.path.exists(PATH):
     out = json.load(open(PATH))
 for name, N, levels, K in cases:
-    Z, meta, _ = synth(N, d=50, levels=levels, seed=7)
+    Z, meta, _ = synth(N, d=50, levels=levels, seed=7, nested=(len(levels) == 3))
     skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
     rng = np.random.default_rng(1)
     Y0 = np.asfortranarray(Z[rng.choice(N, K, replace=False)].T)
