@@ -14,11 +14,17 @@
 //   moe_correct_ridge_cpp        src/harmony.cpp:345-638
 //   kmeans_centers et al.        src/utils.cpp:10-108,159-163
 //
-// PARITY UNPINNED: the reference's tests hold no golden numeric vectors
-// (tests/testthat/*.R assert shapes, probability-simplex, finiteness and a chi2
-// ordering only) and the reference cannot be built here (needs R, Rcpp,
-// RcppArmadillo, RcppProgress).  This oracle is therefore pinned only against
-// those invariants on the reference's bundled fixtures (tests/test_oracle.py).
+// HOW FAR PARITY IS PINNED.  The reference's tests hold no golden numeric vectors (tests/testthat/*.R assert shapes, probability-simplex,
+// finiteness and a chi2 ordering only) and the package as R builds it (R, Rcpp, RcppArmadillo, RcppProgress, BLAS/LAPACK) cannot be
+// built here.  Two pins instead:
+//   (1) the reference's OWN engine sources -- src/harmony.cpp, utils.cpp, timer.cpp, compiled where they lie, unmodified -- over
+//       oracle/shim/ (a minimal stand-in for the Armadillo / Rcpp headers) give oracle/_ref/libharmony_ref.so, and this oracle's faithful
+//       mode must equal it BIT FOR BIT after every call on R's random stream (tests/test_oracle_ref.py: the bundled fixtures, one / two /
+//       three covariates, the subset and skip branches, fixed lambda, vector sigma, tau, tiny inputs).  That pins every line of control
+//       flow and every expression order restated below to the reference's source.
+//   (2) the reference's test invariants on its bundled fixtures (tests/test_oracle.py).
+// STILL UNPINNED: the arithmetic INSIDE Armadillo's kernels (sum, norm, the products, inv, kmeans) -- the stand-in restates them exactly
+// as this file does ("Third-party arithmetic" and "LIBERTIES" below), so pin (1) cannot see a misreading of Armadillo shared by both.
 //
 // Third-party arithmetic whose source is NOT under /root/reference (RcppArmadillo,
 // unpinned version; DESCRIPTION:54) is restated by its published semantics:

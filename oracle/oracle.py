@@ -1,8 +1,8 @@
 """ctypes wrapper of the CPU oracle (oracle/harmony_oracle.cpp).
 
 TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg -- never by the harmony_amd package.  PARITY UNPINNED: see the header of
-harmony_oracle.cpp.
+cpu_baseline leg -- never by the harmony_amd package.  How far parity is pinned (to the reference's own
+sources over a stand-in for Armadillo: oracle/ref.py; Armadillo's kernels remain restated): header of harmony_oracle.cpp.
 
 `OracleHarmony` exposes the same method/field names as the reference's module object (and as
 harmony_amd.Harmony), so `harmony_amd.utils.harmonize` can drive either.

@@ -1,0 +1,117 @@
+// =============================================================================
+// TEST INFRASTRUCTURE ONLY -- C entry points around the REFERENCE'S OWN `harmony` class, compiled from the reference's sources where
+// they lie (/root/reference/src/harmony.cpp, utils.cpp, timer.cpp -- not copied, not modified) against oracle/shim/ (a minimal stand-in
+// for the Armadillo / Rcpp / RcppProgress headers the reference needs and this image lacks; see shim/arma_min.hpp for exactly what that
+// stand-in restates).  Built only where /root/reference exists, by `make -C oracle _ref`, into oracle/_ref/libharmony_ref.so.
+//
+// Purpose: tests/test_oracle_ref.py runs this and the restated oracle (oracle/harmony_oracle.cpp, faithful mode) on the same inputs and
+// the same random stream and requires bit-identical state after every call.  That pins the oracle's restatement of the reference's
+// control flow and expression order (every line of harmony.cpp / utils.cpp) to the reference's source; what it cannot pin is the
+// arithmetic inside Armadillo's own kernels, which both sides restate the same way (the oracle's header, "LIBERTIES").
+//
+// The entry points mirror oracle/harmony_oracle.cpp's orc_* (same argument lists) so that one Python wrapper shape drives both.
+// =============================================================================
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "harmony.h"   // the reference's (found through -I/root/reference/src)
+
+namespace {
+struct Handle {
+  harmony h;
+  std::string err;
+  int n_covariates = 0;
+};
+template <class V> int64_t copy_out(const V* p, size_t n, double* out) {
+  if (out) for (size_t i = 0; i < n; i++) out[i] = (double)p[i];
+  return (int64_t)n;
+}
+template <class V> int64_t copy_vec(const std::vector<V>& v, double* out) { return copy_out(v.data(), v.size(), out); }
+template <class F> int guarded(Handle* H, F f) {
+  try { return f(); }
+  catch (const std::exception& e) { H->err = e.what(); return 100; }
+  catch (...) { H->err = "unknown exception"; return 101; }
+}
+}  // namespace
+
+extern "C" {
+void* ref_create() { return new Handle(); }
+void ref_destroy(void* p) { delete (Handle*)p; }
+const char* ref_last_error(void* p) { return ((Handle*)p)->err.c_str(); }
+
+// harmony::setup (src/harmony.cpp:29-111).  Phi arrives as the C-hot design's row indices / column pointers (one entry per covariate and
+// cell, unit values), as RunHarmony builds it (R/ui.R:210-213).
+int ref_setup(void* p, const double* Z, int64_t N, int d, const int32_t* phi_i, const int32_t* phi_p, int B, const double* sigma,
+              const double* theta, const double* lambda, int n_lambda, double alpha, int max_iter_kmeans, double eps_k, double eps_h, int K,
+              double block_size, const int32_t* B_vec, int C, double cutoff) {
+  Handle* H = (Handle*)p;
+  return guarded(H, [&]() {
+    RMAT Zm((arma::uword)d, (arma::uword)N);
+    std::memcpy(Zm.memptr(), Z, sizeof(double) * (size_t)d * (size_t)N);
+    const int64_t nnz = phi_p[N];
+    arma::uvec rowind((arma::uword)nnz), colptr((arma::uword)N + 1);
+    for (int64_t q = 0; q < nnz; q++) rowind[q] = (arma::uword)phi_i[q];
+    for (int64_t i = 0; i <= N; i++) colptr[i] = (arma::uword)phi_p[i];
+    RSPMAT Phi(rowind, colptr, RVEC((arma::uword)nnz, arma::fill::ones), (arma::uword)B, (arma::uword)N);
+    RVEC sg((arma::uword)K), th((arma::uword)B), lm((arma::uword)n_lambda);
+    for (int k = 0; k < K; k++) sg[k] = sigma[k];
+    for (int b = 0; b < B; b++) th[b] = theta[b];
+    for (int i = 0; i < n_lambda; i++) lm[i] = lambda[i];
+    std::vector<int> bv(B_vec, B_vec + C);
+    H->n_covariates = C;
+    H->h.setup(Zm, Phi, sg, th, lm, (float)alpha, max_iter_kmeans, (float)eps_k, (float)eps_h, K, (float)block_size, bv, (float)cutoff, false);
+    return 0;
+  });
+}
+// set.seed(seed), then harmony::init_cluster_cpp (src/harmony.cpp:131-156): the k-means++ race and the Lloyd iterations draw from R's stream
+int ref_init_cluster(void* p, uint64_t seed) {
+  Handle* H = (Handle*)p;
+  return guarded(H, [&]() { arma::shim::rng().set_seed((uint32_t)seed); H->h.init_cluster_cpp(); return 0; });
+}
+int ref_cluster(void* p) { Handle* H = (Handle*)p; return guarded(H, [&]() { return H->h.cluster_cpp(); }); }
+int ref_moe_correct_ridge(void* p) { Handle* H = (Handle*)p; return guarded(H, [&]() { H->h.moe_correct_ridge_cpp(); return 0; }); }
+int ref_check_convergence(void* p, int type) { Handle* H = (Handle*)p; return guarded(H, [&]() { return H->h.check_convergence(type) ? 1 : 0; }); }
+int ref_compute_objective(void* p) { Handle* H = (Handle*)p; return guarded(H, [&]() { H->h.compute_objective(); return 0; }); }
+// the next update_R's arma::shuffle returns this order instead of drawing one
+void ref_push_update_order(void* p, const int64_t* order) {
+  Handle* H = (Handle*)p;
+  std::vector<arma::uword> o((size_t)H->h.N);
+  for (size_t i = 0; i < o.size(); i++) o[i] = (arma::uword)order[i];
+  arma::shim::injected_orders().push_back(std::move(o));
+}
+void ref_set_int(void* p, const char* what, int64_t v) {
+  Handle* H = (Handle*)p;
+  if (std::string(what) == "max_iter_kmeans") H->h.max_iter_kmeans = (unsigned)v;
+}
+int64_t ref_get(void* p, const char* what, double* out) {
+  Handle* H = (Handle*)p; harmony& h = H->h; const std::string w(what);
+  try {
+    if (w == "Z_corr") return copy_out(h.Z_corr.memptr(), h.Z_corr.n_elem, out);
+    if (w == "Z_orig") return copy_out(h.Z_orig.memptr(), h.Z_orig.n_elem, out);
+    if (w == "R") return copy_out(h.R.memptr(), h.R.n_elem, out);
+    if (w == "dist") return copy_out(h.dist_mat.memptr(), h.dist_mat.n_elem, out);
+    if (w == "Y") return copy_out(h.Y.memptr(), h.Y.n_elem, out);
+    if (w == "O") return copy_out(h.O.memptr(), h.O.n_elem, out);
+    if (w == "E") return copy_out(h.E.memptr(), h.E.n_elem, out);
+    if (w == "W") return copy_out(h.W.memptr(), h.W.n_elem, out);
+    if (w == "W_rows") { if (out) out[0] = (double)h.W.n_rows; return 1; }
+    if (w == "Pr_b") return copy_out(h.Pr_b.memptr(), h.Pr_b.n_elem, out);
+    if (w == "theta") return copy_out(h.theta.memptr(), h.theta.n_elem, out);
+    if (w == "sigma") return copy_out(h.sigma.memptr(), h.sigma.n_elem, out);
+    if (w == "lambda") return copy_out(h.lambda.memptr(), h.lambda.n_elem, out);
+    if (w == "block_size") { if (out) out[0] = (double)h.block_size; return 1; }
+    if (w == "objective_kmeans") return copy_vec(h.objective_kmeans, out);
+    if (w == "objective_kmeans_dist") return copy_vec(h.objective_kmeans_dist, out);
+    if (w == "objective_kmeans_entropy") return copy_vec(h.objective_kmeans_entropy, out);
+    if (w == "objective_kmeans_cross") return copy_vec(h.objective_kmeans_cross, out);
+    if (w == "objective_harmony") return copy_vec(h.objective_harmony, out);
+    if (w == "kmeans_rounds") return copy_vec(h.kmeans_rounds, out);
+    if (w == "update_order") return copy_out(h.update_order.memptr(), h.update_order.n_elem, out);
+    if (w == "Lambda") { RMAT L = h.getLambda(); return copy_out(L.memptr(), L.n_elem, out); }   // getLambda (src/harmony.cpp:657-669)
+    if (w == "warnings") { if (out) out[0] = (double)Rcpp::shim_warnings().size(); return 1; }
+  } catch (const std::exception& e) { H->err = e.what(); return -2; }
+  return -1;
+}
+}

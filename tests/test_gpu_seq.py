@@ -184,6 +184,37 @@ def test_reference_arithmetic_100k():
     assert relfro(d.getZcorr(), c.getZcorr()) > 5 * s["Z_rel"]
 
 
+@pytest.mark.parametrize("case", ["cell_lines", "synth20k"])
+def test_reference_arithmetic_against_the_reference_sources(case, cell_lines):
+    """The product's reference-arithmetic mode against THE REFERENCE'S OWN harmony.cpp / utils.cpp (oracle/_ref: compiled where they lie,
+    unmodified, over oracle/shim/ -- tests/test_oracle_ref.py), on R's stream after the same set.seed and with NO shared random choice:
+    each side runs its own k-means++ race, Lloyd iterations and one arma::shuffle per round.  The restated oracle (faithful, same stream)
+    must equal the reference's sources bit for bit here too (the library travelled to this machine, it was not rebuilt)."""
+    from oracle import ref as oref
+    if not oref.available():
+        pytest.skip("oracle/_ref/libharmony_ref.so did not travel with the tree")
+    if case == "cell_lines":
+        Z, meta, vu, K = cell_lines["pcs"], {"dataset": cell_lines["dataset_levels"][cell_lines["dataset"]]}, "dataset", 20
+    else:
+        (Z, meta, _), vu, K = synth(20000, d=50, levels=(5,), seed=3), "cov0", 50
+    skw, _ = prepare_setup_args(Z, meta, vu, nclust=K)
+    orc.load().orc_set_sgemm(None)               # the oracle's own sequential dot products, as the shim's dense product
+    g = Harmony(seed=42, rng="R", ref_arith=1)
+    g.setup(**skw)
+    r = oref.RefHarmony(seed=42)
+    r.setup(**skw)
+    c = OracleHarmony(mask=0, seed=42, rng=1)
+    c.setup(**skw)
+    g.init_cluster_cpp(); r.init_cluster_cpp(); c.init_cluster_cpp()
+    ig, ir, ic = _iterate(g, 4), _iterate(r, 4), _iterate(c, 4)
+    assert ic == ir and np.array_equal(c.getZcorr(), r.getZcorr()) and np.array_equal(c.R, r.R) and np.array_equal(c.objective_kmeans, r.objective_kmeans)
+    s = _report(g, r)
+    print("ref_arith vs the reference's sources (%s):" % case, s)
+    assert ig == ir and s["obj_len"][0] == s["obj_len"][1] and np.array_equal(g.kmeans_rounds, r.kmeans_rounds), (ig, ir, s)
+    assert s["Z_rel"] <= 1e-5 and s["clear_flips"] == 0 and s["obj_rel"] <= 1e-4 and s["R_maxabs"] <= 1e-3, s
+    assert s["O_rel"] <= 1e-4 and s["E_rel"] <= 1e-4 and s["Y_rel"] <= 1e-4, s
+
+
 def test_reference_arithmetic_groups_can_be_switched_one_by_one(cell_lines_small):
     """each switch alone against the oracle with the matching arithmetic mask (oracle bit set = fp64: mask = 15 minus the group)"""
     meta = {"dataset": cell_lines_small["dataset_levels"][cell_lines_small["dataset"]]}

@@ -1,0 +1,175 @@
+"""CPU tests: the restated oracle (oracle/harmony_oracle.cpp, faithful mode) against THE REFERENCE'S OWN ENGINE SOURCES
+(/root/reference/src/harmony.cpp, utils.cpp, timer.cpp, compiled where they lie and unmodified into oracle/_ref/libharmony_ref.so over
+oracle/shim/ -- a minimal stand-in for the Armadillo / Rcpp headers, which this image lacks; oracle/shim/arma_min.hpp).
+
+Both sides get the same inputs and R's random stream after the same set.seed (k-means++ race, re-sampling of a duplicate winner, Lloyd
+iterations, one arma::shuffle per round) and must hold BIT-IDENTICAL state after init_cluster_cpp and after every cluster_cpp /
+moe_correct_ridge_cpp call: centroids, R, dist_mat, O, E, Z_corr, W, the four objective series, kmeans_rounds, getLambda, the convergence
+decisions.  What this pins: every line of control flow and every expression order the oracle restates from the reference.  What it does
+not: the arithmetic inside Armadillo's kernels (sums, norms, products, inverse), restated the same way on both sides (the oracle's header,
+"LIBERTIES"; with several covariates the shim's generic dense x sparse loop is that header's bit 2, hence liberty=4 there).
+
+The library is built where /root/reference exists and travels with the tree otherwise; with neither, the module is skipped."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture
+from harmony_amd import harmony_options, prepare_setup_args
+from helpers import synth
+from oracle import ref as oref
+from oracle.oracle import OracleHarmony
+
+pytestmark = pytest.mark.skipif(not oref.available(), reason="oracle/_ref/libharmony_ref.so absent and /root/reference not on disk")
+
+
+
+@pytest.fixture(autouse=True)
+def _own_dot_products():
+    """The oracle's dense product must be its own sequential sum (what the shim's is), not an injected BLAS sgemm (some GPU-side tests set one)."""
+    from oracle import oracle as orc
+    orc.load().orc_set_sgemm(None)
+
+
+FIELDS = ("Y", "R", "dist_mat", "O", "E", "W", "Pr_b", "objective_kmeans", "objective_kmeans_dist", "objective_kmeans_entropy",
+          "objective_kmeans_cross", "objective_harmony", "kmeans_rounds")
+
+
+def _state(o):
+    s = {f: np.asarray(getattr(o, f)) for f in FIELDS}
+    s["Z_corr"], s["Lambda"] = o.getZcorr(), o.getLambda()
+    return s
+
+
+def _same(o, r, where):
+    so, sr = _state(o), _state(r)
+    for f in so:
+        assert so[f].shape == sr[f].shape, (where, f, so[f].shape, sr[f].shape)
+        if not np.array_equal(so[f], sr[f]):
+            d = np.abs(so[f] - sr[f])
+            raise AssertionError("%s: %s differs in %d entries, max %.3e" % (where, f, int((d > 0).sum()), float(d.max())))
+
+
+def _pair(Z, meta, vars_use, K, seed=1, liberty=0, **kw):
+    skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=K, **kw)
+    o = OracleHarmony(mask=0, seed=seed, rng=1, liberty=liberty)
+    r = oref.RefHarmony(seed=seed)
+    o.setup(**skw)
+    r.setup(**skw)
+    return o, r
+
+
+def _walk(o, r, iters):
+    o.init_cluster_cpp()
+    r.init_cluster_cpp()
+    _same(o, r, "init_cluster_cpp")
+    for it in range(iters):
+        assert o.cluster_cpp() == 0 and r.cluster_cpp() == 0
+        _same(o, r, "cluster_cpp %d" % it)
+        o.moe_correct_ridge_cpp()
+        r.moe_correct_ridge_cpp()
+        _same(o, r, "moe_correct_ridge_cpp %d" % it)
+        co, cr = o.check_convergence(1), r.check_convergence(1)
+        assert co == cr
+        if co:
+            return it + 1
+    return iters
+
+
+def _cell_lines(name):
+    fx = load_fixture(name)
+    return fx["pcs"], {"dataset": fx["dataset_levels"][fx["dataset"]], "cell_type": fx["cell_type_levels"][fx["cell_type"]]}
+
+
+NEVER = dict(epsilon_harmony=-1e9)   # no early stop: walk every iteration asked for
+
+
+def test_bundled_fixture_one_covariate():
+    """The reference's small fixture as its integration test runs it (tests/testthat/test_integration.R:5-7: theta 1, 50 clusters,
+    10 rounds per clustering): the arrowhead inverse, lambda estimation, the duplicate-winner retry of the seeding."""
+    Z, meta = _cell_lines("cell_lines_small")
+    o, r = _pair(Z, meta, "dataset", 50, theta=1, options=harmony_options(max_iter_cluster=10, **NEVER))
+    assert _walk(o, r, 4) == 4
+
+
+def test_bundled_fixture_two_covariates():
+    """test_two_variable.R:5-11: two crossed covariates -> arma::inv and the several-covariate dense x sparse apply."""
+    Z, meta = _cell_lines("cell_lines")
+    o, r = _pair(Z, meta, ["cell_type", "dataset"], 50, liberty=4, theta=[1, 1], options=harmony_options(max_iter_cluster=10, **NEVER))
+    assert _walk(o, r, 3) == 3
+
+
+def test_early_stop_decisions_agree():
+    Z, meta = _cell_lines("cell_lines")
+    o, r = _pair(Z, meta, "dataset", 30)        # default epsilon_harmony: both stop at the same iteration
+    n = _walk(o, r, 10)
+    assert 1 <= n < 10 and np.array_equal(o.kmeans_rounds, r.kmeans_rounds)
+
+
+@pytest.mark.parametrize("cutoff,want", [(1e-5, (0, 0)), (5e-3, (24, 0)), (5e-2, (40, 17))])
+def test_nested_covariates_take_the_subset_path(cutoff, want):
+    """Three nested covariates.  With the default cut-off every level stays in every cluster at this size; with a larger one clusters drop
+    levels -> the reference's subset branch (src/harmony.cpp:441-546: new row indices / column pointers, the re-mapped index lists,
+    lambda and R subsets, the scatter back into Z_corr), and at 0.05 some clusters have no active covariate left and are skipped (:449-452)."""
+    Z, meta, _ = synth(6000, d=20, levels=(3, 6, 12), seed=5, nested=True)
+    o, r = _pair(Z, meta, list(meta), 40, liberty=4, options=harmony_options(batch_prop_cutoff=cutoff, **NEVER))
+    assert _walk(o, r, 3) == 3
+    assert (o.subset_clusters, o.skipped_clusters) == want                    # (of the last correction)
+
+
+def test_fixed_lambda_vector_sigma_tau_and_an_odd_block_size():
+    Z, meta, _ = synth(3000, d=12, levels=(4,), seed=2)
+    o, r = _pair(Z, meta, "cov0", 17, lambda_=[0.7], sigma=np.linspace(0.05, 0.2, 17), theta=0.5,
+                 options=harmony_options(tau=50, block_size=0.13, **NEVER))
+    assert _walk(o, r, 3) == 3
+    assert np.array_equal(o.getLambda(), np.tile([0.0, 0.7, 0.7, 0.7, 0.7], (17, 1)).astype(np.float32))
+
+
+def test_fewer_than_forty_cells_change_the_block_size():
+    Z, meta, _ = synth(35, d=5, levels=(2,), seed=3)
+    o, r = _pair(Z, meta, "cov0", 4, options=harmony_options(**NEVER))
+    assert abs(r.block_size - 0.2) < 1e-7                                      # src/harmony.cpp:86-88
+    assert _walk(o, r, 2) == 2
+
+
+def test_fewer_than_six_cells_are_refused_by_both():
+    Z, meta, _ = synth(5, d=3, levels=(2,), seed=4)
+    meta = {"cov0": np.array([0, 1, 0, 1, 0])}
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=2)
+    with pytest.raises(RuntimeError, match="less than 6 cells"):              # src/harmony.cpp:83-85
+        oref.RefHarmony().setup(**skw)
+    with pytest.raises(RuntimeError, match="less than 6 cells"):
+        OracleHarmony(mask=0).setup(**skw)
+
+
+def test_an_injected_order_is_what_update_R_walks():
+    """The shim's shuffle hook (the parity tests' injected orders): the order pushed is the order the reference's update_R uses, and both
+    sides agree on the result."""
+    Z, meta, _ = synth(2000, d=10, levels=(3,), seed=6)
+    o, r = _pair(Z, meta, "cov0", 12, options=harmony_options(max_iter_cluster=2, **NEVER))
+    o.init_cluster_cpp()
+    r.init_cluster_cpp()
+    g = np.random.default_rng(0)
+    orders = [g.permutation(2000) for _ in range(2)]
+    for od in orders:
+        o.push_update_order(od)
+        r.push_update_order(od)
+    assert o.cluster_cpp() == 0 and r.cluster_cpp() == 0
+    assert np.array_equal(r.update_order, orders[-1])
+    _same(o, r, "cluster_cpp with injected orders")
+
+
+def test_with_several_covariates_the_apply_is_the_liberty_that_separates_them():
+    """Honesty check on the liberty switch: with ONE rounded product per cell (the oracle's default) instead of one per non-zero, the
+    two-covariate run leaves the reference's trajectory at the first correction -- by rounding noise, not more."""
+    Z, meta = _cell_lines("cell_lines")
+    o, r = _pair(Z, meta, ["cell_type", "dataset"], 20, liberty=0, theta=[1, 1])
+    o.init_cluster_cpp()
+    r.init_cluster_cpp()
+    _same(o, r, "init_cluster_cpp")
+    assert o.cluster_cpp() == 0 and r.cluster_cpp() == 0
+    _same(o, r, "cluster_cpp 0")
+    o.moe_correct_ridge_cpp()
+    r.moe_correct_ridge_cpp()
+    a, b = o.getZcorr(), r.getZcorr()
+    assert not np.array_equal(a, b)
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
