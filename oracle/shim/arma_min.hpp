@@ -301,14 +301,16 @@ ARMA_SHIM_EACH_BIN(+, +=) ARMA_SHIM_EACH_BIN(-, -=) ARMA_SHIM_EACH_BIN(%, %=) AR
 
 // X.cols(indices) / X.rows(indices) / X.elem(indices): gather on read, scatter on assignment
 template <class T> struct ColsProxy : public Base<T, ColsProxy<T>> {
-  Mat<T>* m; Mat<uword> idx;
+  Mat<T>* m = nullptr; Mat<uword> idx;
+  ColsProxy() = default; ColsProxy(const ColsProxy&) = default;
   Mat<T> to_mat() const { Mat<T> o(m->n_rows, idx.n_elem, fill::none); for (uword j = 0; j < idx.n_elem; j++) { shim::need(idx.mem[j] < m->n_cols, "cols(): index out of bounds"); std::memcpy(o.colptr(j), m->colptr(idx.mem[j]), sizeof(T) * m->n_rows); } return o; }
   template <class D> void operator=(const Base<T, D>& x) const { const Mat<T>& a = unwrap(x); shim::need(a.n_rows == m->n_rows && a.n_cols == idx.n_elem, "cols(): assignment of a different size");
     for (uword j = 0; j < idx.n_elem; j++) { shim::need(idx.mem[j] < m->n_cols, "cols(): index out of bounds"); std::memcpy(m->colptr(idx.mem[j]), a.colptr(j), sizeof(T) * m->n_rows); } }
   void operator=(const ColsProxy& o) const { Mat<T> t = o.to_mat(); *this = t; }
 };
 template <class T> struct RowsProxy : public Base<T, RowsProxy<T>> {
-  Mat<T>* m; Mat<uword> idx;
+  Mat<T>* m = nullptr; Mat<uword> idx;
+  RowsProxy() = default; RowsProxy(const RowsProxy&) = default;
   Mat<T> to_mat() const { Mat<T> o(idx.n_elem, m->n_cols, fill::none); for (uword c = 0; c < m->n_cols; c++) for (uword j = 0; j < idx.n_elem; j++) { shim::need(idx.mem[j] < m->n_rows, "rows(): index out of bounds"); o.at(j, c) = m->at(idx.mem[j], c); } return o; }
   template <class D> void operator=(const Base<T, D>& x) const { const Mat<T>& a = unwrap(x); shim::need(a.n_rows == idx.n_elem && a.n_cols == m->n_cols, "rows(): assignment of a different size");
     for (uword c = 0; c < m->n_cols; c++) for (uword j = 0; j < idx.n_elem; j++) { shim::need(idx.mem[j] < m->n_rows, "rows(): index out of bounds"); m->at(idx.mem[j], c) = a.at(j, c); } }
