@@ -13,8 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_ref", "libharmony_ref.so")
-_REF_SRC = "/root/reference/src"
+_SO = os.environ.get("HARMONY_REF_SO", os.path.join(_HERE, "_ref", "libharmony_ref.so"))
+_REF_SRC = os.environ.get("HARMONY_REFERENCE_SRC", "/root/reference/src")
 _lib = None
 
 
@@ -26,7 +26,7 @@ def available():
 def build(force=False):
     """(Re)build where the reference's sources exist; elsewhere use the file that travelled with the tree."""
     if os.path.exists(os.path.join(_REF_SRC, "harmony.cpp")):
-        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "_ref"])
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "_ref", "REF=" + _REF_SRC])
     if not os.path.exists(_SO):
         raise RuntimeError("oracle/_ref/libharmony_ref.so is absent and /root/reference is not here to build it from")
     return _SO

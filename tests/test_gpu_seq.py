@@ -215,6 +215,35 @@ def test_reference_arithmetic_against_the_reference_sources(case, cell_lines):
     assert s["O_rel"] <= 1e-4 and s["E_rel"] <= 1e-4 and s["Y_rel"] <= 1e-4, s
 
 
+@pytest.mark.parametrize("case", ["ref_sources_cell_lines_small", "ref_sources_cell_lines_small_test_integration", "ref_sources_cell_lines_two_covariates"])
+def test_reference_arithmetic_against_the_golden_vectors_of_the_reference_sources(case):
+    """tests/golden/ref_sources_*.npz: what the reference's own sources (over oracle/shim/) leave after three harmony iterations on the
+    reference's bundled fixtures, R's stream after set.seed(1) (tools/make_ref_goldens.py) -- committed, so this comparison needs neither
+    /root/reference nor the built library.  The product (ref_arith, rng = R) draws its own race, Lloyd iterations and shuffles."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_ref_goldens as mrg
+    from conftest import load_fixture
+    gold = load_fixture(case)
+    skw, seed, max_iter = mrg.setup_kwargs(case)
+    g = Harmony(seed=seed, rng="R", ref_arith=1)
+    g.setup(**skw)
+    g.init_cluster_cpp()
+    it = mrg.walk(g, max_iter)
+    Zg, Zr, Rg, Rr = g.getZcorr(), gold["Z_corr"].astype(np.float64), g.R, gold["R"].astype(np.float64)
+    bad = np.where(Rg.argmax(axis=0) != Rr.argmax(axis=0))[0]
+    srt = np.sort(Rr[:, bad], axis=0) if bad.size else np.zeros((2, 0))
+    og, orf = g.objective_kmeans, gold["objective_kmeans"].astype(np.float64)
+    s = dict(Z_rel=relfro(Zg, Zr), R_maxabs=float(np.abs(Rg - Rr).max()), flips=int(bad.size), clear_flips=int(((srt[-1] - srt[-2]) >= 1e-5).sum()) if bad.size else 0,
+             Y_rel=relfro(g.Y, gold["Y"].astype(np.float64)), O_rel=relfro(g.O, gold["O"].astype(np.float64)), obj_len=(len(og), len(orf)),
+             obj_rel=float(np.max(np.abs(og[:len(orf)] - orf[:len(og)]) / np.abs(orf[:len(og)]))), iterations=(it, int(gold["iterations"])))
+    print("ref_arith vs golden vectors of the reference's sources (%s):" % case, s)
+    assert it == int(gold["iterations"]) and s["obj_len"][0] == s["obj_len"][1] and np.array_equal(g.kmeans_rounds, gold["kmeans_rounds"]), s
+    tol = 1e-4 if "two_covariates" in case else 1e-5
+    assert s["Z_rel"] <= tol and s["clear_flips"] == 0 and s["obj_rel"] <= 1e-4 and s["Y_rel"] <= 1e-4 and s["O_rel"] <= 1e-4, s
+
+
 def test_reference_arithmetic_groups_can_be_switched_one_by_one(cell_lines_small):
     """each switch alone against the oracle with the matching arithmetic mask (oracle bit set = fp64: mask = 15 minus the group)"""
     meta = {"dataset": cell_lines_small["dataset_levels"][cell_lines_small["dataset"]]}

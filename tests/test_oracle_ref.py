@@ -19,7 +19,7 @@ from helpers import synth
 from oracle import ref as oref
 from oracle.oracle import OracleHarmony
 
-pytestmark = pytest.mark.skipif(not oref.available(), reason="oracle/_ref/libharmony_ref.so absent and /root/reference not on disk")
+needs_ref = pytest.mark.skipif(not oref.available(), reason="oracle/_ref/libharmony_ref.so absent and /root/reference not on disk")
 
 
 
@@ -83,6 +83,7 @@ def _cell_lines(name):
 NEVER = dict(epsilon_harmony=-1e9)   # no early stop: walk every iteration asked for
 
 
+@needs_ref
 def test_bundled_fixture_one_covariate():
     """The reference's small fixture as its integration test runs it (tests/testthat/test_integration.R:5-7: theta 1, 50 clusters,
     10 rounds per clustering): the arrowhead inverse, lambda estimation, the duplicate-winner retry of the seeding."""
@@ -91,6 +92,7 @@ def test_bundled_fixture_one_covariate():
     assert _walk(o, r, 4) == 4
 
 
+@needs_ref
 def test_bundled_fixture_two_covariates():
     """test_two_variable.R:5-11: two crossed covariates -> arma::inv and the several-covariate dense x sparse apply."""
     Z, meta = _cell_lines("cell_lines")
@@ -98,6 +100,7 @@ def test_bundled_fixture_two_covariates():
     assert _walk(o, r, 3) == 3
 
 
+@needs_ref
 def test_early_stop_decisions_agree():
     Z, meta = _cell_lines("cell_lines")
     o, r = _pair(Z, meta, "dataset", 30)        # default epsilon_harmony: both stop at the same iteration
@@ -105,6 +108,7 @@ def test_early_stop_decisions_agree():
     assert 1 <= n < 10 and np.array_equal(o.kmeans_rounds, r.kmeans_rounds)
 
 
+@needs_ref
 @pytest.mark.parametrize("cutoff,want", [(1e-5, (0, 0)), (5e-3, (24, 0)), (5e-2, (40, 17))])
 def test_nested_covariates_take_the_subset_path(cutoff, want):
     """Three nested covariates.  With the default cut-off every level stays in every cluster at this size; with a larger one clusters drop
@@ -116,6 +120,7 @@ def test_nested_covariates_take_the_subset_path(cutoff, want):
     assert (o.subset_clusters, o.skipped_clusters) == want                    # (of the last correction)
 
 
+@needs_ref
 def test_fixed_lambda_vector_sigma_tau_and_an_odd_block_size():
     Z, meta, _ = synth(3000, d=12, levels=(4,), seed=2)
     o, r = _pair(Z, meta, "cov0", 17, lambda_=[0.7], sigma=np.linspace(0.05, 0.2, 17), theta=0.5,
@@ -124,6 +129,7 @@ def test_fixed_lambda_vector_sigma_tau_and_an_odd_block_size():
     assert np.array_equal(o.getLambda(), np.tile([0.0, 0.7, 0.7, 0.7, 0.7], (17, 1)).astype(np.float32))
 
 
+@needs_ref
 def test_fewer_than_forty_cells_change_the_block_size():
     Z, meta, _ = synth(35, d=5, levels=(2,), seed=3)
     o, r = _pair(Z, meta, "cov0", 4, options=harmony_options(**NEVER))
@@ -131,6 +137,7 @@ def test_fewer_than_forty_cells_change_the_block_size():
     assert _walk(o, r, 2) == 2
 
 
+@needs_ref
 def test_fewer_than_six_cells_are_refused_by_both():
     Z, meta, _ = synth(5, d=3, levels=(2,), seed=4)
     meta = {"cov0": np.array([0, 1, 0, 1, 0])}
@@ -141,6 +148,7 @@ def test_fewer_than_six_cells_are_refused_by_both():
         OracleHarmony(mask=0).setup(**skw)
 
 
+@needs_ref
 def test_an_injected_order_is_what_update_R_walks():
     """The shim's shuffle hook (the parity tests' injected orders): the order pushed is the order the reference's update_R uses, and both
     sides agree on the result."""
@@ -158,6 +166,7 @@ def test_an_injected_order_is_what_update_R_walks():
     _same(o, r, "cluster_cpp with injected orders")
 
 
+@needs_ref
 def test_with_several_covariates_the_apply_is_the_liberty_that_separates_them():
     """Honesty check on the liberty switch: with ONE rounded product per cell (the oracle's default) instead of one per non-zero, the
     two-covariate run leaves the reference's trajectory at the first correction -- by rounding noise, not more."""
@@ -173,3 +182,47 @@ def test_with_several_covariates_the_apply_is_the_liberty_that_separates_them():
     a, b = o.getZcorr(), r.getZcorr()
     assert not np.array_equal(a, b)
     assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------------ committed golden vectors
+# tests/golden/ref_sources_*.npz: outputs of the reference's sources (over the shim) on the reference's bundled fixtures, written by
+# tools/make_ref_goldens.py in the build container.  They survive where neither /root/reference nor the built library exists.
+import os  # noqa: E402
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import make_ref_goldens as mrg  # noqa: E402
+
+GOLD_FIELDS = ("R", "Y", "O", "E", "objective_kmeans", "objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross",
+               "objective_harmony", "kmeans_rounds")
+
+
+def _against_golden(obj, it, gold, where):
+    assert it == int(gold["iterations"]), (where, it, int(gold["iterations"]))
+    got = {f: np.asarray(getattr(obj, f)) for f in GOLD_FIELDS}
+    got["Z_corr"], got["Lambda"] = obj.getZcorr(), obj.getLambda()
+    for f, v in got.items():
+        want = gold[f].astype(np.float64)
+        assert v.shape == want.shape, (where, f, v.shape, want.shape)
+        assert np.array_equal(v, want), "%s: %s differs from the golden vector in %d entries, max %.3e" % (where, f, int((v != want).sum()), float(np.abs(v - want).max()))
+
+
+@pytest.mark.parametrize("case", sorted(mrg.CASES))
+def test_golden_vectors_of_the_reference_sources_are_reproduced_by_the_oracle(case):
+    gold = load_fixture(case)
+    skw, seed, max_iter = mrg.setup_kwargs(case)
+    o = OracleHarmony(mask=0, seed=seed, rng=1, liberty=4 if len(mrg.CASES[case][1]) > 1 else 0)
+    o.setup(**skw)
+    o.init_cluster_cpp()
+    _against_golden(o, mrg.walk(o, max_iter), gold, case)
+
+
+@needs_ref
+@pytest.mark.parametrize("case", sorted(mrg.CASES))
+def test_golden_vectors_are_what_the_reference_sources_give_today(case):
+    gold = load_fixture(case)
+    skw, seed, max_iter = mrg.setup_kwargs(case)
+    r = oref.RefHarmony(seed=seed)
+    r.setup(**skw)
+    r.init_cluster_cpp()
+    _against_golden(r, mrg.walk(r, max_iter), gold, case)
