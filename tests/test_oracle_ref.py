@@ -121,6 +121,16 @@ def test_nested_covariates_take_the_subset_path(cutoff, want):
 
 
 @needs_ref
+def test_configs4_shape_200_clusters_200_levels_in_three_nested_covariates():
+    """BASELINE configs[4]'s shape (K = 200, levels 8 / 64 / 128 nested) at 10k cells: two thirds of the clusters run the subset branch with a
+    few dozen of the 201 design rows each.  (Ad hoc at 30k cells and three iterations: equal as well, 153 - 156 subset clusters.)"""
+    Z, meta, _ = synth(10000, d=50, levels=(8, 64, 128), seed=7, nested=True)
+    o, r = _pair(Z, meta, list(meta), 200, seed=3, liberty=4, options=harmony_options(**NEVER))
+    assert _walk(o, r, 2) == 2
+    assert o.subset_clusters > 100
+
+
+@needs_ref
 def test_fixed_lambda_vector_sigma_tau_and_an_odd_block_size():
     Z, meta, _ = synth(3000, d=12, levels=(4,), seed=2)
     o, r = _pair(Z, meta, "cov0", 17, lambda_=[0.7], sigma=np.linspace(0.05, 0.2, 17), theta=0.5,
