@@ -1,9 +1,13 @@
 /* harmony_mi355x_glue.c -- .Call glue between R and libharmony_mi355x.so.
  *
- * NOT COMPILED IN THIS REPOSITORY'S CI: the build container has no R (no Rinternals.h).  This file is the
+ * NEVER BUILT AGAINST R HERE: the build container has no R (no Rinternals.h, no libR).  This file is the
  * binding a maintainer of the reference would add in place of the Rcpp module
  * (/root/reference/src/harmony.cpp:672-709, registered at src/RcppExports.cpp:57-70); it only marshals
  * SEXPs to the plain-pointer C ABI of include/harmony_mi355x.h.  See INTEGRATION.md.
+ * What the test-suite does with it: type-checks it against declarations of the R API (tests/stubs/R.h), and EXECUTES it linked with an
+ * emulation of the R API calls it makes (tests/stubs/r_emul.c, driven by tests/r_emul.py the way r/harmony_mi355x.R drives it): error
+ * paths on the CPU (tests/test_abi_cpu.py), the whole setup -> init -> cluster / correct -> getters sequence, the fp32 seam, R's stream
+ * through unif_rand, a user interrupt, the warning and the finalizer on the GPU (tests/test_gpu_parity2.py), bit-identical to the ctypes path.
  *
  *   R CMD SHLIB harmony_mi355x_glue.c -I../include -L../harmony_amd/lib -lharmony_mi355x
  */

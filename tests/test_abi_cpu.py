@@ -145,6 +145,36 @@ def test_r_glue_type_checks_against_the_c_abi():
     assert p.returncode == 0, p.stderr[-3000:]
 
 
+def test_r_glue_runs_against_an_emulated_r_api_and_fails_the_r_way():
+    """The same glue, EXECUTED: linked with tests/stubs/r_emul.c (an emulation of the R C API calls it makes) and driven like
+    r/harmony_mi355x.R drives it -- .Call names resolved through the table R_init_harmony registers, R-typed arguments.  Without a GPU
+    every path ends in an R error: the library's no-fallback message arrives through Rf_error, wrong argument counts and unknown
+    routines are refused like .Call refuses them, a finalized object is detected.  (The whole sequence: tests/test_gpu_parity2.py.)"""
+    import numpy as np
+    import r_emul
+    from harmony_amd import prepare_setup_args
+    g = r_emul.GlueHarmony(seed=5)
+    assert g.get("N")[0] == 0 and g.get("objective_kmeans").size == 0
+    rng = np.random.default_rng(0)
+    skw, _ = prepare_setup_args(rng.normal(size=(200, 6)), {"b": np.arange(200) % 3}, "b", nclust=4)
+    with pytest.raises(r_emul.RError, match="setup: no HIP device available: libharmony_mi355x has no CPU fallback"):
+        g.setup(**skw)
+    with pytest.raises(r_emul.RError, match="setup: no HIP device"):
+        g.setup(single=True, **skw)
+    with pytest.raises(r_emul.RError, match="expected the integer bit matrix of a float32 object"):
+        r_emul.dot_call("C_hmx_setup_f32", g.ptr, r_emul.numeric(skw["Z"]), *[r_emul.numeric([0.0])] * 16)
+    with pytest.raises(r_emul.RError, match="unknown field 'nope'"):
+        g.get("nope")
+    with pytest.raises(r_emul.RError, match="expecting 2 for 'C_hmx_get'"):
+        r_emul.dot_call("C_hmx_get", g.ptr)
+    with pytest.raises(r_emul.RError, match="not in the registration table"):
+        r_emul.dot_call("C_hmx_nope", g.ptr)
+    g.release()                                       # the finalizer destroys the handle and clears the pointer ...
+    with pytest.raises(r_emul.RError, match="harmony object has been destroyed"):
+        g.get("N")
+    g.release()                                       # ... and running it again is harmless
+
+
 def test_plain_c_host_links_and_fails_loudly_without_gpu(tmp_path):
     """examples/host_example.c drives the library from C exactly like R/ui.R drives the Rcpp module.  It must compile and
     link against the C ABI alone (no Python, no torch); on this GPU-less box hmx_setup must fail with the no-fallback error."""

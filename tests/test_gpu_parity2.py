@@ -339,6 +339,71 @@ def test_r_compatible_stream_end_to_end(case, cell_lines):
     assert relfro(g2.Y, g.Y) > 1e-3
 
 
+# ---------------------------------------------------------------- the .Call glue, executed (against an emulated R API)
+def test_r_glue_executes_the_whole_sequence():
+    """r/harmony_mi355x_glue.c linked with tests/stubs/r_emul.c (R is not installed: an emulation of the R C API calls the glue makes) and
+    driven exactly like r/harmony_mi355x.R drives it (tests/r_emul.py: .Call names through the registered table, R-typed arguments,
+    results rebuilt from numeric vectors + dims): setup -> init -> cluster / correct until convergence -> getters must equal the ctypes
+    path bit for bit; the fp32 seam both ways; R's own stream through unif_rand between GetRNGstate / PutRNGstate; a user interrupt;
+    the N < 40 warning through Rf_warning; the finalizer."""
+    import r_emul
+    Z, meta, _ = synth(20000, d=30, levels=(4,), seed=11)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=40)
+    a = Harmony(seed=7)
+    a.setup(**skw)
+    a.init_cluster_cpp()
+    ia = _iterate(a, 5)
+    g = r_emul.GlueHarmony(seed=7)
+    g.setup(**skw)
+    assert (g.get("N")[0], g.get("d")[0], g.get("K")[0], g.get("B")[0]) == (20000, 30, 40, 4)
+    g.init_cluster_cpp()
+    ig = _iterate(g, 5)
+    assert ig == ia and np.array_equal(g.kmeans_rounds, a.kmeans_rounds)
+    for name in ("R", "O", "E", "Y", "objective_kmeans"):
+        np.testing.assert_array_equal(getattr(g, name), getattr(a, name), err_msg=name)
+    np.testing.assert_array_equal(g.getZcorr(), a.getZcorr())
+    np.testing.assert_array_equal(g.getLambda(), a.getLambda())
+    # fp32 seam: a float32 object's bit matrix in, fp32 bits out
+    np.testing.assert_array_equal(g.getZcorr(single=True), a.getZcorr().astype(np.float32))
+    g32 = r_emul.GlueHarmony(seed=7)
+    g32.setup(single=True, **skw)
+    g32.init_cluster_cpp()
+    assert _iterate(g32, 5) == ia
+    np.testing.assert_array_equal(g32.getZcorr(), a.getZcorr())          # (the library rounds the doubles to fp32 first thing, as the reference does)
+    # vignette: max_iter_kmeans is writable
+    g32.set_max_iter_kmeans(2)
+    assert g32.get("max_iter_kmeans")[0] == 2
+    # R's own stream: set.seed(42) in the "interpreter", the library draws through unif_rand -- same run as the built-in R-compatible generator
+    b = Harmony(seed=42, rng="R")
+    b.setup(**skw)
+    b.init_cluster_cpp()
+    ib = _iterate(b, 3)
+    r_emul.load().emul_set_seed(42)
+    h = r_emul.GlueHarmony(r_rng=True)
+    h.setup(**skw)
+    h.init_cluster_cpp()
+    assert r_emul.load().emul_rng_brackets() == 1                        # (counted per .Call: emul_clear resets it)
+    assert _iterate(h, 3) == ib
+    np.testing.assert_array_equal(h.getZcorr(), b.getZcorr())
+    np.testing.assert_array_equal(h.R, b.R)
+    # Progress::check_abort(): a pending user interrupt ends cluster_cpp with -1 (R/utils.R:26-32 turns that into a message)
+    r_emul.load().emul_set_interrupt(1)
+    assert h.cluster_cpp() == -1
+    # Rcpp::warning -> Rf_warning
+    rng = np.random.default_rng(1)
+    skw30, _ = prepare_setup_args(rng.normal(size=(30, 8)), {"b": np.arange(30) % 2}, "b", nclust=3)
+    w = r_emul.GlueHarmony(seed=1)
+    w.setup(**skw30)
+    assert "Too few cells" in w.warnings()
+    with pytest.raises(r_emul.RError, match="less than 6 cells"):
+        skw5, _ = prepare_setup_args(rng.normal(size=(5, 3)), {"b": np.array([0, 1, 0, 1, 0])}, "b", nclust=2)
+        r_emul.GlueHarmony(seed=1).setup(**skw5)
+    for o in (g, g32, h, w):
+        o.release()
+    with pytest.raises(r_emul.RError, match="has been destroyed"):
+        g.get("N")
+
+
 # ---------------------------------------------------------------- SURVEY 8f-3: single precision / device pointers
 def test_f32_and_device_pointer_ingest_egress():
     import ctypes as C
