@@ -237,6 +237,9 @@ def headline_parity(n, d, K, levels):
                                          "clear_flips_vs_faithful": pr["gpu_ref_arith_vs_oracle_faithful"]["argmax_diff_margin_ge_1e-5"],
                                          "timed_as": "also.reference_arith"},
                 "the_reference_itself_faithful_vs_accurate": pr["oracle_faithful_vs_oracle_accurate"]["Z_rel"],
+                "oracle_pinned_to": "the reference's own src/harmony.cpp / utils.cpp / timer.cpp compiled in place over oracle/shim (a stand-in for the Armadillo / "
+                                    "Rcpp headers): the faithful oracle equals them bit for bit (tests/test_oracle_ref.py, tests/golden/ref_sources_*.npz); "
+                                    "Armadillo's own kernels stay restated; GPU reference arithmetic vs that library: profiles/r5_gpu_vs_reference_sources.txt",
                 "replayed_from": "profiles/%s_parity_table_%d.json (not measured in this run; cpu_baseline.gpu_reference_arith_vs_this_run is a live check on a sample)" % (tag, n)}
     return None
 
