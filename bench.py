@@ -239,7 +239,9 @@ def headline_parity(n, d, K, levels):
                 "the_reference_itself_faithful_vs_accurate": pr["oracle_faithful_vs_oracle_accurate"]["Z_rel"],
                 "oracle_pinned_to": "the reference's own src/harmony.cpp / utils.cpp / timer.cpp compiled in place over oracle/shim (a stand-in for the Armadillo / "
                                     "Rcpp headers): the faithful oracle equals them bit for bit (tests/test_oracle_ref.py, tests/golden/ref_sources_*.npz); "
-                                    "Armadillo's own kernels stay restated; GPU reference arithmetic vs that library: profiles/r5_gpu_vs_reference_sources.txt",
+                                    "Armadillo's own kernels stay restated; GPU reference arithmetic vs that library: profiles/r5_gpu_vs_reference_sources.txt.  "
+                                    "The accurate oracle (this mode's target) is 2.5e-7 from the same sources built with the reference's own -DHARMONY_SCALAR_DOUBLE, "
+                                    "this mode 1.2e-7 (20k cells; profiles/r5_reference_double_precision.json); the reference as it ships is 5e-5 ... 2e-4 from that build",
                 "replayed_from": "profiles/%s_parity_table_%d.json (not measured in this run; cpu_baseline.gpu_reference_arith_vs_this_run is a live check on a sample)" % (tag, n)}
     return None
 

@@ -14,8 +14,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("HARMONY_REF_SO", os.path.join(_HERE, "_ref", "libharmony_ref.so"))
+_SO64 = os.path.join(os.path.dirname(_SO), "libharmony_ref_f64.so")    # the same sources with -DHARMONY_SCALAR_DOUBLE (src/types.h:5-9)
 _REF_SRC = os.environ.get("HARMONY_REFERENCE_SRC", "/root/reference/src")
 _lib = None
+_lib64 = None
 
 
 def available():
@@ -27,15 +29,28 @@ def build(force=False):
     """(Re)build where the reference's sources exist; elsewhere use the file that travelled with the tree."""
     if os.path.exists(os.path.join(_REF_SRC, "harmony.cpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "_ref", "REF=" + _REF_SRC])
-    if not os.path.exists(_SO):
-        raise RuntimeError("oracle/_ref/libharmony_ref.so is absent and /root/reference is not here to build it from")
+    if not os.path.exists(_SO) or not os.path.exists(_SO64):
+        raise RuntimeError("oracle/_ref/libharmony_ref*.so absent and /root/reference is not here to build them from")
     return _SO
 
 
-def load():
-    global _lib
+def load(double=False):
+    """double=True: the double-precision build of the reference's sources"""
+    global _lib, _lib64
+    if double:
+        if _lib64 is None:
+            build()
+            _lib64 = _prototypes(C.CDLL(_SO64))
+            assert _lib64.ref_scalar_bytes() == 8
+        return _lib64
     if _lib is None:
-        lib = C.CDLL(build())
+        _lib = _prototypes(C.CDLL(build()))
+        assert _lib.ref_scalar_bytes() == 4
+    return _lib
+
+
+def _prototypes(lib):
+    if True:
         dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         lib.ref_create.restype = C.c_void_p
         lib.ref_destroy.argtypes = [C.c_void_p]
@@ -51,8 +66,9 @@ def load():
         lib.ref_get.argtypes = [C.c_void_p, C.c_char_p, dp]
         lib.ref_push_update_order.argtypes = [C.c_void_p, lp]
         lib.ref_set_int.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
-        _lib = lib
-    return _lib
+        lib.ref_init_cluster_from.argtypes = [C.c_void_p, dp, C.c_uint64]
+        lib.ref_clear_update_orders.restype = None
+    return lib
 
 
 def _dp(a):
@@ -60,8 +76,9 @@ def _dp(a):
 
 
 class RefHarmony(object):
-    def __init__(self, seed=0):
-        self._lib = load()
+    def __init__(self, seed=0, double=False):
+        """double=True: the reference's sources built with their own precision switch (SCALAR = double)"""
+        self._lib = load(double)
         self._h = C.c_void_p(self._lib.ref_create())
         self.seed = int(seed)
         self._dims = None
@@ -109,8 +126,16 @@ class RefHarmony(object):
             raise RuntimeError("%s raised: %s" % (name, self._err()))
         return st
 
-    def init_cluster_cpp(self):
-        assert self._call("ref_init_cluster", self.seed) == 0
+    def init_cluster_cpp(self, Y0=None):
+        """Y0 given: init from these centroids (ref_driver.cpp: ref_init_cluster_from -- every number still from the reference's own lines)"""
+        if Y0 is None:
+            assert self._call("ref_init_cluster", self.seed) == 0
+        else:
+            Y0 = np.asfortranarray(Y0, dtype=np.float64)
+            assert self._call("ref_init_cluster_from", _dp(Y0), self.seed) == 0
+
+    def clear_update_orders(self):
+        self._lib.ref_clear_update_orders()
 
     def push_update_order(self, order):
         order = np.ascontiguousarray(order, dtype=np.int64)

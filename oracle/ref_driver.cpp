@@ -70,6 +70,37 @@ int ref_init_cluster(void* p, uint64_t seed) {
   Handle* H = (Handle*)p;
   return guarded(H, [&]() { arma::shim::rng().set_seed((uint32_t)seed); H->h.init_cluster_cpp(); return 0; });
 }
+// init_cluster_cpp from GIVEN centroids (the parity tests share the initial centroids between backends; the reference has no such entry:
+// setY is declared, src/harmony.h:41, and defined nowhere).  Every number still comes out of the reference's own lines: its
+// init_cluster_cpp runs first (its own seeds and Lloyd iterations: discarded), then Y = normalise(Y0) (:136), then R, dist_mat, E, O through
+// cluster_cpp's cold-start branch (:214-228) entered with no round to run, then compute_objective (:153) and the first objective_harmony
+// entry (:154).  The one deviation from a genuine init: the cold-start branch normalises the already normalised Z_corr once more (an ulp
+// in single precision -- which is why the bit-for-bit tests never use this entry --, nothing in the double-precision build it exists for).
+int ref_init_cluster_from(void* p, const double* Y0, uint64_t seed) {
+  Handle* H = (Handle*)p;
+  return guarded(H, [&]() {
+    harmony& h = H->h;
+    arma::shim::rng().set_seed((uint32_t)seed);
+    h.init_cluster_cpp();
+    MATTYPE Ym(h.d, h.K);
+    for (arma::uword i = 0; i < Ym.n_elem; i++) Ym[i] = (SCALAR)Y0[i];
+    h.Y = arma::normalise(Ym, 2, 0);
+    const unsigned keep = h.max_iter_kmeans;
+    h.max_iter_kmeans = 0;
+    h.objective_harmony.assign(2, 0.f);
+    h.objective_kmeans.assign(1, 0.f);
+    const int st = h.cluster_cpp();
+    h.max_iter_kmeans = keep;
+    h.objective_kmeans.clear(); h.objective_kmeans_dist.clear(); h.objective_kmeans_entropy.clear(); h.objective_kmeans_cross.clear();
+    h.objective_harmony.clear(); h.kmeans_rounds.clear();
+    h.compute_objective();
+    h.objective_harmony.push_back(h.objective_kmeans.back());
+    arma::shim::rng().set_seed((uint32_t)seed);          // shuffles drawn from R's stream start at its beginning, as for a backend that drew no seeds
+    return st;
+  });
+}
+int ref_scalar_bytes() { return (int)sizeof(SCALAR); }      // 4: the reference as it ships; 8: built with -DHARMONY_SCALAR_DOUBLE (src/types.h:5-9)
+void ref_clear_update_orders() { arma::shim::injected_orders().clear(); }
 int ref_cluster(void* p) { Handle* H = (Handle*)p; return guarded(H, [&]() { return H->h.cluster_cpp(); }); }
 int ref_moe_correct_ridge(void* p) { Handle* H = (Handle*)p; return guarded(H, [&]() { H->h.moe_correct_ridge_cpp(); return 0; }); }
 int ref_check_convergence(void* p, int type) { Handle* H = (Handle*)p; return guarded(H, [&]() { return H->h.check_convergence(type) ? 1 : 0; }); }

@@ -339,6 +339,53 @@ def test_r_compatible_stream_end_to_end(case, cell_lines):
     assert relfro(g2.Y, g.Y) > 1e-3
 
 
+# ---------------------------------------------------------------- the default mode against the reference's own sources in double precision
+def test_default_mode_against_the_reference_in_double_precision():
+    """oracle/_ref/libharmony_ref_f64.so: the reference's own harmony.cpp / utils.cpp built with the reference's own precision switch
+    (-DHARMONY_SCALAR_DOUBLE, src/types.h:5-9) over oracle/shim/ -- what the reference's algorithm computes without its fp32 rounding
+    (tests/test_oracle_ref.py).  The product's DEFAULT mode (fp32 state, exact accumulators), same centroids, same shuffles (injected into the
+    reference's arma::shuffle), to convergence: a few 1e-7 from it, no assignment flipped, same iteration count -- while the reference's own
+    single-precision build is two orders of magnitude further from its double-precision one."""
+    from oracle import ref as oref
+    if not oref.available():
+        pytest.skip("oracle/_ref/libharmony_ref_f64.so did not travel with the tree")
+    from oracle.oracle import feistel_order
+    N, K, seed = 20000, 100, 3
+    Z, meta, _ = synth(N, d=50, levels=(10,), seed=7)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
+    g = Harmony(seed=seed)
+    g.setup(**skw)
+    Y0 = g.kmeans_centers()
+    g.init_cluster_cpp(Y0)
+    ig = _iterate(g)
+
+    def walk_ref(double):
+        r = oref.RefHarmony(seed=seed, double=double)
+        r.setup(**skw)
+        r.init_cluster_cpp(Y0)
+        done, it = 0, 0
+        for it in range(1, 11):
+            r.clear_update_orders()
+            for k in range(4):
+                r.push_update_order(feistel_order(seed, done + k, N))
+            assert r.cluster_cpp() == 0
+            done = int(np.sum(r.kmeans_rounds))
+            r.moe_correct_ridge_cpp()
+            if r.check_convergence(1):
+                break
+        return r, it
+    r64, i64 = walk_ref(True)
+    r32, i32 = walk_ref(False)
+    Zg, Z64, Z32 = g.getZcorr(), r64.getZcorr(), r32.getZcorr()
+    fl = _flips(g.R, r64.R, 1e-5)[1]
+    s = dict(gpu_default_vs_reference_double=relfro(Zg, Z64), reference_single_vs_reference_double=relfro(Z32, Z64), gpu_default_vs_reference_single=relfro(Zg, Z32),
+             R_maxabs=float(np.abs(g.R - r64.R).max()), clear_flips=fl, iterations=(ig, i64, i32))
+    print("default mode vs the reference's sources in double precision:", s)
+    assert ig == i64 and np.array_equal(g.kmeans_rounds, r64.kmeans_rounds), s
+    assert s["gpu_default_vs_reference_double"] <= 2e-6 and fl == 0 and s["R_maxabs"] <= 5e-5, s
+    assert s["reference_single_vs_reference_double"] >= 10 * s["gpu_default_vs_reference_double"], s
+
+
 # ---------------------------------------------------------------- SURVEY 8f-2: the .Call glue, executed (against an emulated R API)
 def test_r_glue_executes_the_whole_sequence():
     """r/harmony_mi355x_glue.c linked with tests/stubs/r_emul.c (R is not installed: an emulation of the R C API calls the glue makes) and
