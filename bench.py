@@ -105,13 +105,43 @@ def cpu_baseline(cells, d, K, levels, nested, seed):
             break
     v1, it, dt, blas = out["one"]
     va, _, dta, _ = out["all"]
-    return {"value": v1, "unit": "cells/s", "cores": 1, "kind": "port",
+    return {"value": v1, "unit": "cells/s", "cores": 1, "kind": "port", "reference_sources": _reference_sources_cpu(d, K, levels, nested, seed),
             "sample": "oracle (faithful fp32%s), %d cells x %d PCs, K=%d, levels %s, to convergence (%d iterations, %.1f s); the "
                       "algorithm is O(N) per iteration, so cells/s at the full size is the same figure up to the iteration count"
                       % (", OpenBLAS sgemm" if blas else "", cells, d, K, "x".join(map(str, levels)), it, dt),
             "all_cores": {"value": va, "cores": ncpu, "seconds": dta},
             "host_cores_available": ncpu, "full_size": _full_size_cpu(),
             "gpu_reference_arith_vs_this_run": ref_check}
+
+
+def _reference_sources_cpu(d, K, levels, nested, seed, cells=40000):
+    """oracle/_ref/libharmony_ref.so -- the reference's OWN src/harmony.cpp / utils.cpp / timer.cpp, compiled in the build container where
+    they lie over oracle/shim's stand-in for the Armadillo / Rcpp headers; the file travels with the tree -- timed on a smaller sample of the
+    same workload, one thread.  Reported beside `value`, not instead of it: the shim's Armadillo kernels are eager and BLAS-free, so the
+    port with OpenBLAS's sgemm is the faster (= fairer) CPU figure."""
+    try:
+        from harmony_amd import prepare_setup_args
+        from oracle import ref as oref
+        if not os.path.exists(oref._SO):
+            return None
+        Z, meta, _ = synth(cells, d=d, levels=levels, seed=seed, nested=nested)
+        skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
+        r = oref.RefHarmony(seed=1)
+        r.setup(**skw)
+        t0 = time.time()
+        r.init_cluster_cpp()
+        it = 0
+        for it in range(1, 11):
+            r.cluster_cpp()
+            r.moe_correct_ridge_cpp()
+            if r.check_convergence(1):
+                break
+        dt = time.time() - t0
+        return {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "reference",
+                "sample": "the reference's own engine sources (oracle/_ref, over oracle/shim's Armadillo stand-in: eager, no BLAS), %d cells x %d PCs, K=%d, "
+                          "levels %s, to convergence (%d iterations, %.1f s)" % (cells, d, K, "x".join(map(str, levels)), it, dt)}
+    except Exception as e:                # pragma: no cover
+        return {"error": repr(e)}
 
 
 def _full_size_cpu():
