@@ -40,6 +40,7 @@
 //                           package was linked with: the same factorisation, not the same rounding sequence --
 //                           this branch (several covariates, src/harmony.cpp:573) cannot be pinned bit for bit
 //                           without that BLAS.  The GPU's reference-arithmetic mode matches THIS restatement.
+//                           (Liberty bits 5 / 6 below run it through the one real LAPACK on this machine instead.)
 //
 // LIBERTIES of the faithful mode -- places where "the reference's operation order" is not determined by /root/reference itself but by the
 // (unpinned) Armadillo / BLAS underneath it, what this restatement does there, and the switch that flips it (set_int("liberty", mask);
@@ -57,6 +58,12 @@
 //              parity tests share the centres between the backends, so this liberty is outside every GPU comparison.)
 //   bit 4 (16) L2 normalisations (:42,136,220,633): norm(col, 2) of >= 32 elements is BLAS snrm2 (OpenBLAS accumulates it in double on
 //              x86-64; Armadillo's own loop for short columns uses two fp32 accumulators).  Default: one fp32 accumulator; bit 4: fp64 sum.
+//   bit 5 (32) arma::inv of the several-covariate ridge system (:573) through a REAL LAPACK -- OpenBLAS 0.3.28's sgetrf + sgetri (the
+//              release the reference's docs were built on; it sits inside scipy here and is injected from Python, oracle.use_lapack()) --
+//              in Armadillo's auxlib::inv call sequence; bit 6 (64): spotrf + spotri + mirror (auxlib::inv_sympd, which Armadillo's inv()
+//              tries first for a matrix that looks symmetric positive definite, as this one is).  Default: the unblocked LU below.
+//              lapack_inv.hpp; the reference's own sources take the same two routes through the stand-in header (ref_set_inv_mode), and
+//              tests/test_oracle_ref.py requires the two to agree bit for bit there as well.
 //   not switchable, stated: abs() in check_convergence (:185,194) -- with <cmath> in scope and a float argument, overload resolution
 //              takes std::abs(float) (exact match; ::abs(int) would need a conversion), so the quotient is a float expression, as here.
 //
@@ -80,6 +87,8 @@
 #include <string>
 #include <type_traits>
 #include <vector>
+
+#include "lapack_inv.hpp"
 
 namespace {
 
@@ -623,6 +632,9 @@ template <unsigned MASK> struct Oracle : OracleBase {
           Wk[(size_t)j * m + r2] = s; }
       } else if (std::is_same<ASV, float>::value) {
         std::vector<float> A(cov.begin(), cov.end()), I((size_t)m * m, 0); for (int a = 0; a < m; a++) I[(size_t)a * m + a] = 1;
+        if ((liberty & (32 | 64)) && lapack_inv::ready()) {   // arma::inv through a real LAPACK (lapack_inv.hpp): bit 5 sgetrf + sgetri, bit 6 spotrf + spotri
+          I = A; ok = lapack_inv::inv(I.data(), m, (liberty & 64) ? 2 : 1);
+        } else
         ok = lu_solve(A, m, I, m);
         for (int j = 0; j < d; j++) for (int r2 = 0; r2 < m; r2++) {
           float s = 0; for (int c2 = 0; c2 < m; c2++) s += I[(size_t)c2 * m + r2] * (float)rhs[(size_t)j * m + c2];
@@ -715,6 +727,10 @@ void* orc_create_mask(unsigned mask) {
 void* orc_create(int accurate) { return orc_create_mask(accurate ? 15u : 0u); }
 void orc_destroy(void* h) { delete (OracleBase*)h; }
 void orc_set_sgemm(void* fn) { g_sgemm = (sgemm_fn)fn; }
+void orc_set_lapack(void* getrf, void* getri, void* potrf, void* potri) {     // (liberty bits 5 / 6: lapack_inv.hpp)
+  lapack_inv::Table& t = lapack_inv::table();
+  t.getrf = (lapack_inv::getrf_fn)getrf; t.getri = (lapack_inv::getri_fn)getri; t.potrf = (lapack_inv::potrf_fn)potrf; t.potri = (lapack_inv::potri_fn)potri;
+}
 int orc_setup(void* h, const double* Z, int64_t N, int d, const int32_t* phi_i, const int32_t* phi_p, int B,
               const double* sigma, const double* theta, const double* lambda, int n_lambda, double alpha,
               int max_iter_kmeans, double eps_k, double eps_h, int K, double block_size, const int32_t* B_vec,

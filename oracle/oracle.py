@@ -21,8 +21,8 @@ _blas = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "harmony_oracle.cpp")
-    if force or not os.path.exists(_SO) or os.path.getmtime(src) > os.path.getmtime(_SO):
+    src = [os.path.join(_HERE, f) for f in ("harmony_oracle.cpp", "lapack_inv.hpp")]
+    if force or not os.path.exists(_SO) or max(os.path.getmtime(f) for f in src) > os.path.getmtime(_SO):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libharmony_oracle.so"])
     return _SO
 
@@ -82,6 +82,33 @@ def use_openblas(threads=1):
     return True
 
 
+def lapack_pointers():
+    """(sgetrf_, sgetri_, spotrf_, spotri_) of scipy's bundled OpenBLAS as void pointers, or None (oracle/lapack_inv.hpp)"""
+    global _blas
+    if _blas is None:
+        import scipy
+        cands = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so"))
+        if not cands:
+            return None
+        _blas = C.CDLL(cands[0])
+    try:
+        return [C.cast(getattr(_blas, "scipy_" + f), C.c_void_p) for f in ("sgetrf_", "sgetri_", "spotrf_", "spotri_")]
+    except AttributeError:
+        return None
+
+
+def use_lapack():
+    """Make liberty bits 5 / 6 (arma::inv through a real LAPACK) available to the oracle; False if no LAPACK is found."""
+    p = lapack_pointers()
+    if p is None:
+        return False
+    lib = load()
+    lib.orc_set_lapack.argtypes = [C.c_void_p] * 4
+    lib.orc_set_lapack.restype = None
+    lib.orc_set_lapack(*p)
+    return True
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -92,7 +119,7 @@ class OracleHarmony(object):
         fp64, clear = the reference's fp32).  accurate=True is mask 15, accurate=False (faithful) is mask 0.
         liberty: the places where Armadillo / BLAS -- not /root/reference -- fix the operation order, flipped one by one (bit 0 / 1 L1 sums
         with two / eight accumulators, 2 one rounded product per non-zero in the several-covariate apply, 3 fp32 Lloyd sums, 4 L2 norms in
-        double; harmony_oracle.cpp header)."""
+        double, 5 / 6 arma::inv through LAPACK's sgetrf + sgetri / spotrf + spotri -- after use_lapack(); harmony_oracle.cpp header)."""
         self._lib = load()
         self.mask = (15 if accurate else 0) if mask is None else int(mask)
         self._h = C.c_void_p(self._lib.orc_create_mask(self.mask))

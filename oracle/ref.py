@@ -49,6 +49,24 @@ def load(double=False):
     return _lib
 
 
+def use_lapack(mode):
+    """arma::inv of the single-precision build through a real LAPACK (scipy's OpenBLAS) instead of the stand-in's unblocked LU:
+    mode 1 = sgetrf + sgetri, 2 = spotrf + spotri + mirror, 0 = back to the stand-in (oracle/lapack_inv.hpp).  False if there is no LAPACK."""
+    from . import oracle as _orc
+    lib = load()
+    if mode:
+        p = _orc.lapack_pointers()
+        if p is None:
+            return False
+        lib.ref_set_lapack.argtypes = [C.c_void_p] * 4
+        lib.ref_set_lapack.restype = None
+        lib.ref_set_lapack(*p)
+    lib.ref_set_inv_mode.argtypes = [C.c_int]
+    lib.ref_set_inv_mode.restype = None
+    lib.ref_set_inv_mode(int(mode))
+    return True
+
+
 def _prototypes(lib):
     if True:
         dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)

@@ -37,6 +37,12 @@ template <class F> int guarded(Handle* H, F f) {
 }  // namespace
 
 extern "C" {
+// arma::inv through a real LAPACK instead of the stand-in's unblocked LU (oracle/lapack_inv.hpp; tests/test_oracle_ref.py)
+void ref_set_lapack(void* getrf, void* getri, void* potrf, void* potri) {
+  lapack_inv::Table& t = lapack_inv::table();
+  t.getrf = (lapack_inv::getrf_fn)getrf; t.getri = (lapack_inv::getri_fn)getri; t.potrf = (lapack_inv::potrf_fn)potrf; t.potri = (lapack_inv::potri_fn)potri;
+}
+void ref_set_inv_mode(int mode) { arma::shim::inv_mode() = mode; }
 void* ref_create() { return new Handle(); }
 void ref_destroy(void* p) { delete (Handle*)p; }
 const char* ref_last_error(void* p) { return ((Handle*)p)->err.c_str(); }

@@ -16,7 +16,8 @@
 //   sparse * sparse                               Gustavson: per output column, the right operand's non-zeros in ascending row order
 //   normalise(X, p, 0)                            column / norm_p(column), zero norm -> divide by 1; norms with one fp32 accumulator
 //   accu(vector)                                  two accumulators (even / odd elements), added at the end
-//   inv                                           unblocked fp32 LU with partial pivoting applied to the identity
+//   inv                                           unblocked fp32 LU with partial pivoting applied to the identity (or, on request of the
+//                                                 test harness, a real LAPACK: ../lapack_inv.hpp)
 //   kmeans(means, X, K, keep_existing, 1, ...)    one Lloyd iteration, fp64 member sums, an empty cluster keeps its mean
 //   randu / randi / shuffle                       R's stream as RcppArmadillo maps it (MT19937 after set.seed's scrambling; shuffle =
 //                                                 one randi per element in order + std::sort of (value, index) packets), or an injected
@@ -40,6 +41,8 @@
 #include <type_traits>
 #include <utility>
 #include <vector>
+
+#include "../lapack_inv.hpp"
 
 namespace arma {
 typedef unsigned long long uword;   // ARMA_64BIT_WORD (src/types.h:2)
@@ -461,10 +464,19 @@ template <class T, class A> Col<T> shuffle(const Base<T, A>& x) {
   for (uword i = 0; i < a.n_elem; i++) o.mem[i] = a.mem[pk[i].index];
   return o;
 }
-// inv: unblocked LU with partial pivoting on [A | I], row by row (the restatement the oracle documents for arma::inv)
+// inv: unblocked LU with partial pivoting on [A | I], row by row (the restatement the oracle documents for arma::inv) -- or, when the
+// test harness asked for it (shim::inv_mode(), ref_set_inv_mode) and injected one, through a real LAPACK in Armadillo's own call
+// sequences (../lapack_inv.hpp: 1 = sgetrf + sgetri, 2 = spotrf + spotri + mirror; fp32 only)
+namespace shim { inline int& inv_mode() { static int m = 0; return m; } }
 template <class T, class A> Mat<T> inv(const Base<T, A>& x) {
   Mat<T> a = unwrap(x);
   shim::need(a.n_rows == a.n_cols, "inv(): matrix must be square");
+  if constexpr (std::is_same<T, float>::value) {
+    if (shim::inv_mode() && lapack_inv::ready()) {
+      if (!lapack_inv::inv(a.mem, (int)a.n_rows, shim::inv_mode())) throw std::runtime_error("inv(): matrix is singular");
+      return a;
+    }
+  }
   const int n = (int)a.n_rows; Mat<T> b(n, n); for (int i = 0; i < n; i++) b.at(i, i) = T(1);
   T* Am = a.mem; T* Bm = b.mem;
   for (int c = 0; c < n; c++) {

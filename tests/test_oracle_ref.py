@@ -194,6 +194,44 @@ def test_with_several_covariates_the_apply_is_the_liberty_that_separates_them():
     assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
 
 
+@pytest.fixture
+def _lapack():
+    """arma::inv through the one real LAPACK of this image (OpenBLAS 0.3.28 inside scipy -- the release the reference's docs were built on),
+    injected into both libraries; the stand-in's own LU is restored afterwards (oracle/lapack_inv.hpp)"""
+    from oracle import oracle as orc
+    if not (orc.use_lapack() and oref.use_lapack(1)):
+        pytest.skip("no LAPACK (scipy's bundled OpenBLAS) found")
+    yield oref.use_lapack
+    oref.use_lapack(0)
+
+
+@needs_ref
+@pytest.mark.parametrize("mode,bit", [(1, 32), (2, 64)])
+def test_arma_inv_through_a_real_lapack(_lapack, mode, bit):
+    """src/harmony.cpp:573 `arma::inv(Phi_cov)` is the one place the header called unpinnable without the reference's BLAS.  With the
+    several-covariate ridge systems inverted by OpenBLAS 0.3.28's LAPACK in Armadillo's two call sequences -- sgetrf + sgetri
+    (auxlib::inv), spotrf + spotri + mirror (auxlib::inv_sympd) -- the reference's own sources and the oracle (liberty bit 5 / 6) still
+    hold bit-identical state after every call: two crossed covariates (the reference's test_two_variable.R fixture) and three nested
+    ones with clusters on the subset branch (systems of different sizes).  And the blocked LAPACK inverse moves a faithful run by
+    rounding noise only: < 1e-5 of Z_corr from the default restatement (unblocked LU), like every other liberty."""
+    _lapack(mode)
+    Z, meta = _cell_lines("cell_lines")
+    o, r = _pair(Z, meta, ["cell_type", "dataset"], 50, liberty=4 | bit, theta=[1, 1], options=harmony_options(max_iter_cluster=10, **NEVER))
+    assert _walk(o, r, 3) == 3
+    _lapack(0)
+    o0, r0 = _pair(Z, meta, ["cell_type", "dataset"], 50, liberty=4, theta=[1, 1], options=harmony_options(max_iter_cluster=10, **NEVER))
+    assert _walk(o0, r0, 3) == 3
+    a, b = o.getZcorr(), o0.getZcorr()
+    assert not np.array_equal(a, b)                          # (the LAPACK route really was taken)
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
+    assert np.abs(o.R - o0.R).max() < 1e-3
+    _lapack(mode)
+    Z, meta, _ = synth(6000, d=20, levels=(3, 6, 12), seed=5, nested=True)
+    o, r = _pair(Z, meta, list(meta), 40, liberty=4 | bit, options=harmony_options(batch_prop_cutoff=5e-3, **NEVER))
+    assert _walk(o, r, 3) == 3
+    assert o.subset_clusters > 0
+
+
 # ------------------------------------------------------------------------------------------------------------ committed golden vectors
 # tests/golden/ref_sources_*.npz: outputs of the reference's sources (over the shim) on the reference's bundled fixtures, written by
 # tools/make_ref_goldens.py in the build container.  They survive where neither /root/reference nor the built library exists.

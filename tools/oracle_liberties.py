@@ -19,6 +19,9 @@ from oracle.oracle import OracleHarmony  # noqa: E402
 
 BITS = {1: "L1 sums: two accumulators", 2: "L1 sums: eight strided accumulators", 4: "apply: one rounded product per non-zero",
         16: "L2 norms accumulated in double", 31 - 8: "all of them"}
+# several covariates only (src/harmony.cpp:573): arma::inv through OpenBLAS 0.3.28's LAPACK (scipy's copy), Armadillo's two call sequences
+BITS_INV = {32: "arma::inv = LAPACK sgetrf + sgetri (OpenBLAS 0.3.28)", 64: "arma::inv = LAPACK spotrf + spotri (OpenBLAS 0.3.28)",
+            4 | 64: "per-non-zero apply + LAPACK spotrf + spotri (what a current RcppArmadillo on OpenBLAS would run)"}
 
 
 def run(skw, Y0, liberty, seed=3):
@@ -59,8 +62,21 @@ for name, N, levels, K in cases:
     Y0 = np.asfortranarray(Z[rng.choice(N, K, replace=False)].T)
     base = run(skw, Y0, 0)
     rows = {}
-    for bit, what in BITS.items():
-        r = run(skw, Y0, bit)
+    bits = dict(BITS)
+    if len(levels) > 1:
+        from oracle import oracle as _orc
+        if _orc.use_lapack():
+            bits.update(BITS_INV)
+    bits["sgemm"] = "distance GEMM Y.t() * Z through OpenBLAS 0.3.28 sgemm (one thread)"
+    for bit, what in bits.items():
+        if bit == "sgemm":          # (:144,222 dense x dense: BLAS sgemm in the reference's binary; the oracle's default is the sequential dot product)
+            from oracle import oracle as _orc
+            if not _orc.use_openblas(1):
+                continue
+            r = run(skw, Y0, 0)
+            _orc.load().orc_set_sgemm(None)
+        else:
+            r = run(skw, Y0, bit)
         n = min(len(r["obj"]), len(base["obj"]))
         f, fc = flips(r["R"], base["R"], 1e-5)
         rows[what] = {"liberty": bit, "Z_rel": float(np.linalg.norm(r["Z"] - base["Z"]) / np.linalg.norm(base["Z"])),
