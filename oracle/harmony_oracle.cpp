@@ -64,6 +64,11 @@
 //              tries first for a matrix that looks symmetric positive definite, as this one is).  Default: the unblocked LU below.
 //              lapack_inv.hpp; the reference's own sources take the same two routes through the stand-in header (ref_set_inv_mode), and
 //              tests/test_oracle_ref.py requires the two to agree bit for bit there as well.
+//   bit 7 (128) every norm of a normalise() call exactly as Armadillo's op_norm forms it on a BLAS: two accumulators below 32 elements, the REAL
+//              sasum / snrm2 of OpenBLAS 0.3.28 from 32 on (lapack_inv.hpp, namespace blas1; injected by oracle.use_lapack()); and the head's
+//              column sums sum(R, 0) (:146,225 -- op_sum, not normalise) as arrayops::accumulate: two accumulators at every length.  Supersedes
+//              the modelled shapes of bits 0, 1 and 4.  Bits 2 + 6 + 7 with the distance GEMM through the same library's sgemm
+//              (oracle.use_openblas) is "what a current RcppArmadillo linked against OpenBLAS 0.3.28 runs": tools/oracle_liberties.py's last row.
 //   not switchable, stated: abs() in check_convergence (:185,194) -- with <cmath> in scope and a float argument, overload resolution
 //              takes std::abs(float) (exact match; ::abs(int) would need a conversion), so the quotient is a float expression, as here.
 //
@@ -202,10 +207,11 @@ void gemm_tn(int M, int N, int Kd, const float* A, const float* B, float* C) {
     }
 }
 
-template <class T> void normalise_cols_l2(T* X, int rows, int64_t cols, bool dacc = false) {
+template <class T> void normalise_cols_l2(T* X, int rows, int64_t cols, int dacc = 0) {
   for (int64_t c = 0; c < cols; c++) {
     T* x = X + c * rows; T nrm;
-    if (dacc) { double sd = 0; for (int r = 0; r < rows; r++) sd += (double)x[r] * (double)x[r]; nrm = (T)std::sqrt(sd); }   // (liberty bit 4: snrm2 in double)
+    if (dacc == 2 && std::is_same<T, float>::value && blas1::ready()) nrm = (T)blas1::norm2((const float*)x, rows);   // (liberty bit 7: Armadillo's op_norm on a real BLAS)
+    else if (dacc) { double sd = 0; for (int r = 0; r < rows; r++) sd += (double)x[r] * (double)x[r]; nrm = (T)std::sqrt(sd); }   // (liberty bit 4: snrm2 in double)
     else { T s = 0; for (int r = 0; r < rows; r++) s += x[r] * x[r]; nrm = std::sqrt(s); }
     if (nrm == 0) nrm = 1;
     for (int r = 0; r < rows; r++) x[r] /= nrm;
@@ -293,7 +299,14 @@ template <unsigned MASK> struct Oracle : OracleBase {
   int64_t subset_clusters = 0, skipped_clusters = 0;
   int liberty = 0;      // header, "LIBERTIES of the faithful mode"
   // the L1 norm of a column of R as normalise(X, 1, 0) forms it (all entries are >= 0: |r| = r)
+  int l2_mode() const { return (liberty & 128) ? 2 : ((liberty & 16) ? 1 : 0); }
+  // sum(R, 0) of the head (:146,225) is op_sum, not normalise: Armadillo's arrayops::accumulate = two accumulators at every length, no BLAS
+  float head_sum(const float* r, int n) const {
+    if (liberty & 128) { float a1 = 0.f, a2 = 0.f; int i = 0; for (; i + 1 < n; i += 2) { a1 += r[i]; a2 += r[i + 1]; } if (i < n) a1 += r[i]; return a1 + a2; }
+    return l1_sum(r, n);
+  }
   float l1_sum(const float* r, int n) const {
+    if ((liberty & 128) && blas1::ready()) return blas1::norm1(r, n);
     if (liberty & 1) { float a1 = 0.f, a2 = 0.f; int i = 0; for (; i + 1 < n; i += 2) { a1 += std::fabs(r[i]); a2 += std::fabs(r[i + 1]); } if (i < n) a1 += std::fabs(r[i]); return a1 + a2; }
     if (liberty & 2) { float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; i++) a[i & 7] += std::fabs(r[i]); return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7])); }
     float s = 0.f; for (int i = 0; i < n; i++) s += std::fabs(r[i]); return s;
@@ -308,7 +321,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
     if (N < 6) { err = "Refusing to run with less than 6 cells"; return 2; }  // :83-85
     Z_orig.resize((size_t)d * N);
     for (size_t i = 0; i < Z_orig.size(); i++) Z_orig[i] = (float)Z[i];          // conv_to :41
-    Z_corr = Z_orig; normalise_cols_l2(Z_corr.data(), d, N, (liberty & 16) != 0);   // :42
+    Z_corr = Z_orig; normalise_cols_l2(Z_corr.data(), d, N, l2_mode());   // :42
     B_vec.assign(B_vec_, B_vec_ + C);
     covariate_bounds.resize(C); std::partial_sum(B_vec.begin(), B_vec.end(), covariate_bounds.begin());
     if (covariate_bounds.back() != B) { err = "sum(B_vec) != nrow(Phi)"; return 3; }
@@ -402,7 +415,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
     for (int64_t n = 0; n < N; n++) {
       float* r = &R[n * K]; const float* dm = &dist[n * K];
       for (int k = 0; k < K; k++) r[k] = std::exp(-dm[k] / sigma[k]);
-      float s = l1_sum(r, K);
+      float s = head_sum(r, K);      // R.each_row() /= sum(R, 0)  (:146,225)
       if (s == 0.f) s = 1.f;
       for (int k = 0; k < K; k++) r[k] /= s;
     }
@@ -417,7 +430,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
     seed = seed_; rs_seeded = false;
     if (Y0) { Y.resize((size_t)d * K); for (size_t i = 0; i < Y.size(); i++) Y[i] = (float)Y0[i]; }
     else kmeans_centers(seed_);
-    normalise_cols_l2(Y.data(), d, K, (liberty & 16) != 0);
+    normalise_cols_l2(Y.data(), d, K, l2_mode());
     dist_R_EO();
     compute_objective();
     objective_harmony.push_back(objective_kmeans.back());
@@ -463,7 +476,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
 
   int cluster() override {  // :208-262
     if (objective_harmony.size() != 1) {
-      normalise_cols_l2(Z_corr.data(), d, N, (liberty & 16) != 0);
+      normalise_cols_l2(Z_corr.data(), d, N, l2_mode());
       dist_R_EO();
     }
     int iter;
@@ -662,7 +675,7 @@ template <unsigned MASK> struct Oracle : OracleBase {
       W.assign((size_t)m * d, 0.f); W_rows = m;
       for (size_t i = 0; i < W.size(); i++) W[i] = (float)Wk[i];
     }
-    normalise_cols_l2(Y.data(), d, K, (liberty & 16) != 0);  // :633
+    normalise_cols_l2(Y.data(), d, K, l2_mode());  // :633
     return 0;
   }
 
@@ -727,6 +740,7 @@ void* orc_create_mask(unsigned mask) {
 void* orc_create(int accurate) { return orc_create_mask(accurate ? 15u : 0u); }
 void orc_destroy(void* h) { delete (OracleBase*)h; }
 void orc_set_sgemm(void* fn) { g_sgemm = (sgemm_fn)fn; }
+void orc_set_blas1(void* asum, void* nrm2) { blas1::table().asum = (blas1::asum_fn)asum; blas1::table().nrm2 = (blas1::nrm2_fn)nrm2; }   // (liberty bit 7)
 void orc_set_lapack(void* getrf, void* getri, void* potrf, void* potri) {     // (liberty bits 5 / 6: lapack_inv.hpp)
   lapack_inv::Table& t = lapack_inv::table();
   t.getrf = (lapack_inv::getrf_fn)getrf; t.getri = (lapack_inv::getri_fn)getri; t.potrf = (lapack_inv::potrf_fn)potrf; t.potri = (lapack_inv::potri_fn)potri;

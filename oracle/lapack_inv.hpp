@@ -20,6 +20,7 @@
 // =============================================================================
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <vector>
 
@@ -61,3 +62,30 @@ inline bool sympd(float* A, int n) {
 }
 inline bool inv(float* A, int n, int mode) { return mode == 2 ? sympd(A, n) : general(A, n); }
 }  // namespace lapack_inv
+
+// norm(col, 1) / norm(col, 2) as Armadillo's op_norm forms them for a contiguous fp32 vector when it is built on a BLAS (restated from the
+// published source): fewer than 32 elements -> its own loop with TWO accumulators (elements 0, 2, 4, ... and 1, 3, 5, ..., added at the end);
+// 32 and more -> BLAS sasum / snrm2.  The BLAS entry points (cblas form, OpenBLAS 0.3.28 inside scipy) are injected like the LAPACK ones;
+// oracle liberty bit 7, ref_set_norm_mode.  normalise(X, p, 0) divides a column by this value (by 1 when it is 0), src/harmony.cpp:42,136,
+// 145,150,220,323,326,633.
+namespace blas1 {
+typedef float (*asum_fn)(int n, const float* x, int incx);
+typedef float (*nrm2_fn)(int n, const float* x, int incx);
+struct Table { asum_fn asum = nullptr; nrm2_fn nrm2 = nullptr; };
+inline Table& table() { static Table t; return t; }
+inline bool ready() { return table().asum && table().nrm2; }
+inline float norm1(const float* p, long long n) {
+  if (n >= 32) return table().asum((int)n, p, 1);
+  float a1 = 0.f, a2 = 0.f; long long i = 0;
+  for (; i + 1 < n; i += 2) { a1 += std::fabs(p[i]); a2 += std::fabs(p[i + 1]); }
+  if (i < n) a1 += std::fabs(p[i]);
+  return a1 + a2;
+}
+inline float norm2(const float* p, long long n) {
+  if (n >= 32) return table().nrm2((int)n, p, 1);
+  float a1 = 0.f, a2 = 0.f; long long i = 0;
+  for (; i + 1 < n; i += 2) { a1 += p[i] * p[i]; a2 += p[i + 1] * p[i + 1]; }
+  if (i < n) a1 += p[i] * p[i];
+  return std::sqrt(a1 + a2);          // (Armadillo retries with a scaled loop only when this is 0 or not finite: never on this path's unit-scale data)
+}
+}  // namespace blas1

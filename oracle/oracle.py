@@ -106,6 +106,13 @@ def use_lapack():
     lib.orc_set_lapack.argtypes = [C.c_void_p] * 4
     lib.orc_set_lapack.restype = None
     lib.orc_set_lapack(*p)
+    try:        # BLAS level 1 for liberty bit 7 (norms as Armadillo's op_norm forms them on a BLAS)
+        b1 = [C.cast(getattr(_blas, "scipy_cblas_" + f), C.c_void_p) for f in ("sasum", "snrm2")]
+        lib.orc_set_blas1.argtypes = [C.c_void_p] * 2
+        lib.orc_set_blas1.restype = None
+        lib.orc_set_blas1(*b1)
+    except AttributeError:
+        return False
     return True
 
 
@@ -119,7 +126,8 @@ class OracleHarmony(object):
         fp64, clear = the reference's fp32).  accurate=True is mask 15, accurate=False (faithful) is mask 0.
         liberty: the places where Armadillo / BLAS -- not /root/reference -- fix the operation order, flipped one by one (bit 0 / 1 L1 sums
         with two / eight accumulators, 2 one rounded product per non-zero in the several-covariate apply, 3 fp32 Lloyd sums, 4 L2 norms in
-        double, 5 / 6 arma::inv through LAPACK's sgetrf + sgetri / spotrf + spotri -- after use_lapack(); harmony_oracle.cpp header)."""
+        double, 5 / 6 arma::inv through LAPACK's sgetrf + sgetri / spotrf + spotri, 7 norms through Armadillo's op_norm on BLAS sasum / snrm2 -- after
+        use_lapack(); harmony_oracle.cpp header)."""
         self._lib = load()
         self.mask = (15 if accurate else 0) if mask is None else int(mask)
         self._h = C.c_void_p(self._lib.orc_create_mask(self.mask))

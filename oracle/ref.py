@@ -67,6 +67,24 @@ def use_lapack(mode):
     return True
 
 
+def use_blas_norms(on):
+    """norm(col, p) inside normalise() as Armadillo's op_norm forms it on a BLAS: two accumulators below 32 elements, scipy's OpenBLAS sasum /
+    snrm2 from 32 on (oracle/lapack_inv.hpp, blas1); False: back to the stand-in's single accumulator."""
+    from . import oracle as _orc
+    lib = load()
+    if on:
+        if _orc.lapack_pointers() is None:
+            return False
+        b1 = [C.cast(getattr(_orc._blas, "scipy_cblas_" + f), C.c_void_p) for f in ("sasum", "snrm2")]
+        lib.ref_set_blas1.argtypes = [C.c_void_p] * 2
+        lib.ref_set_blas1.restype = None
+        lib.ref_set_blas1(*b1)
+    lib.ref_set_norm_mode.argtypes = [C.c_int]
+    lib.ref_set_norm_mode.restype = None
+    lib.ref_set_norm_mode(1 if on else 0)
+    return True
+
+
 def _prototypes(lib):
     if True:
         dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)

@@ -43,6 +43,8 @@ void ref_set_lapack(void* getrf, void* getri, void* potrf, void* potri) {
   t.getrf = (lapack_inv::getrf_fn)getrf; t.getri = (lapack_inv::getri_fn)getri; t.potrf = (lapack_inv::potrf_fn)potrf; t.potri = (lapack_inv::potri_fn)potri;
 }
 void ref_set_inv_mode(int mode) { arma::shim::inv_mode() = mode; }
+void ref_set_blas1(void* asum, void* nrm2) { blas1::table().asum = (blas1::asum_fn)asum; blas1::table().nrm2 = (blas1::nrm2_fn)nrm2; }
+void ref_set_norm_mode(int mode) { arma::shim::norm_mode() = mode; }
 void* ref_create() { return new Handle(); }
 void ref_destroy(void* p) { delete (Handle*)p; }
 const char* ref_last_error(void* p) { return ((Handle*)p)->err.c_str(); }

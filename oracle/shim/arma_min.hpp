@@ -393,11 +393,24 @@ ARMA_SHIM_MAP(trunc_log, (!(v > T(0)) ? std::log(std::numeric_limits<T>::min()) 
 template <class T, class A, class S, ARMA_SHIM_ARITH(S)> Mat<T> pow(const Base<T, A>& x, S e) {
   const Mat<T>& a = unwrap(x); const T ev = T(e); Mat<T> o(a.n_rows, a.n_cols, fill::none); for (uword i = 0; i < a.n_elem; i++) o.mem[i] = std::pow(a.mem[i], ev); return o; }
 
+namespace shim { inline int& norm_mode() { static int m = 0; return m; } }    // 1: op_norm on a real BLAS (../lapack_inv.hpp, blas1; ref_set_norm_mode)
 // sum(X, 0): column sums (a row); sum(X, 1): row sums (a column), the columns added in order
 template <class T, class A> Mat<T> sum(const Base<T, A>& x, uword dim = 0) {
   const Mat<T>& a = unwrap(x);
   shim::need(dim <= 1, "sum(): dimension must be 0 or 1");
-  if (dim == 0) { Mat<T> o(1, a.n_cols); for (uword c = 0; c < a.n_cols; c++) { T s = T(0); const T* p = a.colptr(c); for (uword r = 0; r < a.n_rows; r++) s += p[r]; o.mem[c] = s; } return o; }
+  if (dim == 0) {
+    Mat<T> o(1, a.n_cols);
+    for (uword c = 0; c < a.n_cols; c++) {
+      const T* p = a.colptr(c);
+      if (shim::norm_mode()) {        // (ref_set_norm_mode: arrayops::accumulate -- two accumulators over the elements 0, 2, ... / 1, 3, ...)
+        T s1 = T(0), s2 = T(0); uword r = 0;
+        for (; r + 1 < a.n_rows; r += 2) { s1 += p[r]; s2 += p[r + 1]; }
+        if (r < a.n_rows) s1 += p[r];
+        o.mem[c] = s1 + s2;
+      } else { T s = T(0); for (uword r = 0; r < a.n_rows; r++) s += p[r]; o.mem[c] = s; }
+    }
+    return o;
+  }
   Mat<T> o(a.n_rows, 1);
   for (uword c = 0; c < a.n_cols; c++) { const T* p = a.colptr(c); for (uword r = 0; r < a.n_rows; r++) o.mem[r] += p[r]; }
   return o;
@@ -411,6 +424,9 @@ template <class T, class A> T accu(const Base<T, A>& x) {   // two accumulators 
 template <class T, class A> T as_scalar(const Base<T, A>& x) { const Mat<T>& a = unwrap(x); shim::need(a.n_elem == 1, "as_scalar(): expression must evaluate to exactly one element"); return a.mem[0]; }
 template <class S, ARMA_SHIM_ARITH(S)> S as_scalar(S s) { return s; }
 template <class T> T shim_norm(const T* p, uword n, int pp) {
+  if constexpr (std::is_same<T, float>::value) {
+    if (shim::norm_mode() && blas1::ready() && (pp == 1 || pp == 2)) return pp == 1 ? blas1::norm1(p, (long long)n) : blas1::norm2(p, (long long)n);
+  }
   T s = T(0);
   if (pp == 1) { for (uword i = 0; i < n; i++) s += std::abs(p[i]); return s; }
   shim::need(pp == 2, "norm(): only p = 1 and p = 2");

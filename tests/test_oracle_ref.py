@@ -232,6 +232,35 @@ def test_arma_inv_through_a_real_lapack(_lapack, mode, bit):
     assert o.subset_clusters > 0
 
 
+@needs_ref
+def test_norms_and_column_sums_as_armadillo_forms_them_on_a_real_blas(_lapack):
+    """normalise(X, p, 0) is norm(col, p): Armadillo's op_norm runs two accumulators below 32 elements and hands longer columns to BLAS sasum /
+    snrm2; sum(R, 0) of the head is arrayops::accumulate (two accumulators).  With exactly that -- OpenBLAS 0.3.28's sasum / snrm2 injected into
+    both libraries (oracle liberty bit 7, ref.use_blas_norms) -- the reference's own sources and the oracle hold bit-identical state after
+    every call: K = 50 >= 32 with d = 20 < 32 (the reference's own fixture), d = 50 >= 32 with K = 20 < 32, and the two-covariate fixture
+    with EVERYTHING the reference's binary would take from OpenBLAS at once (norms, column sums, arma::inv through spotrf + spotri, the
+    per-non-zero apply)."""
+    assert oref.use_blas_norms(True)
+    try:
+        Z, meta = _cell_lines("cell_lines_small")
+        o, r = _pair(Z, meta, "dataset", 50, theta=1, liberty=128, options=harmony_options(max_iter_cluster=10, **NEVER))
+        assert _walk(o, r, 4) == 4
+        Z2, meta2, _ = synth(3000, d=50, levels=(4,), seed=5)
+        o, r = _pair(Z2, meta2, list(meta2), 20, liberty=128, options=harmony_options(**NEVER))
+        assert _walk(o, r, 2) == 2
+        _lapack(2)
+        Z, meta = _cell_lines("cell_lines")
+        o, r = _pair(Z, meta, ["cell_type", "dataset"], 50, liberty=4 | 64 | 128, theta=[1, 1], options=harmony_options(max_iter_cluster=10, **NEVER))
+        assert _walk(o, r, 3) == 3
+    finally:
+        oref.use_blas_norms(False)
+    # the switch really changes the arithmetic, by rounding noise only
+    o0, r0 = _pair(Z, meta, ["cell_type", "dataset"], 50, liberty=4 | 64, theta=[1, 1], options=harmony_options(max_iter_cluster=10, **NEVER))
+    assert _walk(o0, r0, 3) == 3
+    a, b = o.getZcorr(), o0.getZcorr()
+    assert not np.array_equal(a, b) and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------------------ committed golden vectors
 # tests/golden/ref_sources_*.npz: outputs of the reference's sources (over the shim) on the reference's bundled fixtures, written by
 # tools/make_ref_goldens.py in the build container.  They survive where neither /root/reference nor the built library exists.

@@ -50,8 +50,8 @@ def flips(Ra, Rb, margin):
 
 
 cases = [("%dk_one_covariate_K100" % (n // 1000), n, (10,), 100) for n in (20000, 100000)] + [("20k_two_covariates_K60", 20000, (3, 4), 60)]
-if len(sys.argv) > 1:       # e.g. `1000k_one_covariate_K100` (BASELINE configs[2]; ~1 minute of CPU per run)
-    cases = [c for c in cases + [("1000k_one_covariate_K100", 1000000, (10,), 100), ("100k_three_nested_covariates_K200", 100000, (8, 64, 128), 200)] if c[0] in sys.argv[1:]]
+if len(sys.argv) > 1:       # e.g. `1000k_one_covariate_K100` (BASELINE configs[2]; ~1 minute of CPU per run); a second argument `new`: only the missing rows
+    cases = [c for c in cases + [("1000k_one_covariate_K100", 1000000, (10,), 100), ("100k_three_nested_covariates_K200", 100000, (8, 64, 128), 200)] if c[0] in sys.argv[1:2]]
 PATH = os.path.join(ROOT, "profiles", "r5_oracle_liberties.json")
 if os.path.exists(PATH):
     out = json.load(open(PATH))
@@ -67,13 +67,19 @@ for name, N, levels, K in cases:
         from oracle import oracle as _orc
         if _orc.use_lapack():
             bits.update(BITS_INV)
+    from oracle import oracle as _orc
+    if _orc.use_lapack():
+        bits[128] = "norms / column sums as Armadillo's op_norm / op_sum form them on OpenBLAS 0.3.28 (sasum, snrm2)"
     bits["sgemm"] = "distance GEMM Y.t() * Z through OpenBLAS 0.3.28 sgemm (one thread)"
+    bits["openblas"] = "EVERYTHING the reference's binary takes from OpenBLAS 0.3.28 at once: sgemm, sasum / snrm2%s" % (
+        ", spotrf + spotri, per-non-zero apply" if len(levels) > 1 else "")
+    if len(sys.argv) > 2 and sys.argv[2] == "new":      # only the rows the committed table does not hold yet
+        bits = {b: w for b, w in bits.items() if w not in out.get(name, {})}
     for bit, what in bits.items():
-        if bit == "sgemm":          # (:144,222 dense x dense: BLAS sgemm in the reference's binary; the oracle's default is the sequential dot product)
-            from oracle import oracle as _orc
-            if not _orc.use_openblas(1):
+        if bit in ("sgemm", "openblas"):          # (:144,222 dense x dense: BLAS sgemm in the reference's binary; the oracle's default is the sequential dot product)
+            if not _orc.use_openblas(1) or (bit == "openblas" and not _orc.use_lapack()):
                 continue
-            r = run(skw, Y0, 0)
+            r = run(skw, Y0, 0 if bit == "sgemm" else (128 | (4 | 64 if len(levels) > 1 else 0)))
             _orc.load().orc_set_sgemm(None)
         else:
             r = run(skw, Y0, bit)
@@ -84,6 +90,6 @@ for name, N, levels, K in cases:
                       "objective_rel_max": float(np.max(np.abs(r["obj"][:n] - base["obj"][:n]) / np.abs(base["obj"][:n]))),
                       "iterations": [r["it"], base["it"]]}
         print(name, what, rows[what], flush=True)
-    out[name] = rows
+    out[name] = dict(out.get(name, {}), **rows)
 with open(PATH, "w") as fh:
     json.dump(out, fh, indent=1)
