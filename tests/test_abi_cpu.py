@@ -283,3 +283,26 @@ def test_writable_fields_validate_their_values():
         assert lib.hmx_get(h, b"max_iter_kmeans", out, 1) == 1 and out[0] == 7.0
     finally:
         lib.hmx_destroy(h)
+
+
+def test_documented_switches_and_writable_fields_are_the_ones_in_the_code():
+    """INTEGRATION.md's table of environment switches and the header's list of writable fields against the library's sources, both ways:
+    every getenv("HMX_...") of the library is documented, every documented switch is still read, every writable field the header names
+    is a key the library knows (the round-4 verdict counted the switches; this keeps the documentation of what is left honest)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "harmony_amd", "csrc")
+    code = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)))
+    envs = set(re.findall(r'getenv\("(HMX_[A-Z0-9_]+)"\)', code))
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = integ[integ.index("## Environment switches"):]
+    live, removed = sec.split("*removed in round 5*")
+    doc = set(re.findall(r"`(HMX_[A-Z0-9_]+)", live)) | set(re.findall(r"`(HMX_[A-Z0-9_]+)", removed[removed.index("|\n") + 1:]))
+    assert envs == doc, (sorted(envs - doc), sorted(doc - envs))
+    gone = set(re.findall(r"`(HMX_[A-Z0-9_]+)", removed[:removed.index("|\n")]))
+    assert gone and not (gone & envs)                   # what the table calls removed really is
+    hdr = open(os.path.join(root, "include", "harmony_mi355x.h")).read()
+    w = hdr[hdr.index("/* writable fields:"):hdr.index("int hmx_set_int")]
+    keys = set(re.findall(r'"([a-z_:]+)"', w)) - {"randomness"}
+    assert len(keys) > 15
+    assert not [k for k in keys if '"%s"' % k not in code]
