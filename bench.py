@@ -128,15 +128,28 @@ def _reference_sources_cpu(d, K, levels, nested, seed, cells=40000):
         skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
         r = oref.RefHarmony(seed=1)
         r.setup(**skw)
-        t0 = time.time()
-        r.init_cluster_cpp()
-        it = 0
-        for it in range(1, 11):
-            r.cluster_cpp()
-            r.moe_correct_ridge_cpp()
-            if r.check_convergence(1):
-                break
-        dt = time.time() - t0
+        # the reference's sources print progress notes (Rcout -> stdout, e.g. a re-drawn seed in kmeans_centers): this process's stdout is
+        # reserved for the ONE JSON line, so file descriptor 1 points at stderr while they run
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            t0 = time.time()
+            r.init_cluster_cpp()
+            it = 0
+            for it in range(1, 11):
+                r.cluster_cpp()
+                r.moe_correct_ridge_cpp()
+                if r.check_convergence(1):
+                    break
+            dt = time.time() - t0
+        finally:
+            try:
+                oref.load().ref_flush_stdout()
+            except Exception:           # pragma: no cover
+                pass
+            os.dup2(keep, 1)
+            os.close(keep)
         return {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "reference",
                 "sample": "the reference's own engine sources (oracle/_ref, over oracle/shim's Armadillo stand-in: eager, no BLAS), %d cells x %d PCs, K=%d, "
                           "levels %s, to convergence (%d iterations, %.1f s)" % (cells, d, K, "x".join(map(str, levels)), it, dt)}

@@ -12,7 +12,9 @@
 // The entry points mirror oracle/harmony_oracle.cpp's orc_* (same argument lists) so that one Python wrapper shape drives both.
 // =============================================================================
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -45,6 +47,8 @@ void ref_set_lapack(void* getrf, void* getri, void* potrf, void* potri) {
 void ref_set_inv_mode(int mode) { arma::shim::inv_mode() = mode; }
 void ref_set_blas1(void* asum, void* nrm2) { blas1::table().asum = (blas1::asum_fn)asum; blas1::table().nrm2 = (blas1::nrm2_fn)nrm2; }
 void ref_set_norm_mode(int mode) { arma::shim::norm_mode() = mode; }
+// the reference prints notes through Rcout (= std::cout here): let a caller that owns stdout empty the buffer while it has redirected fd 1
+void ref_flush_stdout() { std::cout.flush(); std::fflush(stdout); }
 void* ref_create() { return new Handle(); }
 void ref_destroy(void* p) { delete (Handle*)p; }
 const char* ref_last_error(void* p) { return ((Handle*)p)->err.c_str(); }
