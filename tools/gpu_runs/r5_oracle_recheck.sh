@@ -15,3 +15,4 @@ import json
 j = json.loads(open("gpurun_out/r5z/bench.json").read().strip().splitlines()[-1])
 print(j["ms_per_step"], j["cpu_baseline"]["value"], j["cpu_baseline"].get("reference_sources"), len(open("gpurun_out/r5z/bench.json").read().strip().splitlines()))
 PY
+timeout 60 python tools/openblas_point_probe.py > gpurun_out/r5z/probe.log 2>&1; echo probe rc=$?; tail -c 1500 gpurun_out/r5z/probe.log
