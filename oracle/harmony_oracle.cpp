@@ -23,8 +23,12 @@
 //       three covariates, the subset and skip branches, fixed lambda, vector sigma, tau, tiny inputs).  That pins every line of control
 //       flow and every expression order restated below to the reference's source.
 //   (2) the reference's test invariants on its bundled fixtures (tests/test_oracle.py).
-// STILL UNPINNED: the arithmetic INSIDE Armadillo's kernels (sum, norm, the products, inv, kmeans) -- the stand-in restates them exactly
-// as this file does ("Third-party arithmetic" and "LIBERTIES" below), so pin (1) cannot see a misreading of Armadillo shared by both.
+// STILL UNPINNED: the arithmetic INSIDE Armadillo's own loops (op_sum, accumulate, the short-vector norms, dense x sparse, sparse x sparse,
+// kmeans) -- the stand-in restates them exactly as this file does ("Third-party arithmetic" and "LIBERTIES" below), so pin (1) cannot see
+// a misreading of Armadillo shared by both.  What Armadillo takes from BLAS / LAPACK is no longer in that class: the one real BLAS on this
+// machine (OpenBLAS 0.3.28 inside scipy, the release the reference's docs were built on) can be injected into both libraries for sgemm,
+// sasum, snrm2, sgetrf + sgetri and spotrf + spotri (liberty bits 5 - 7, lapack_inv.hpp), the two still agree bit for bit, and the run
+// moves by 2e-6 .. 8e-6 of Z_corr -- the width of every other liberty (profiles/r5_oracle_liberties.json).
 //
 // Third-party arithmetic whose source is NOT under /root/reference (RcppArmadillo,
 // unpinned version; DESCRIPTION:54) is restated by its published semantics:
