@@ -330,3 +330,46 @@ def test_reference_arithmetic_with_the_hosts_shuffles(cell_lines):
     s = _report(g, c)
     print("ref_arith, injected orders:", s)
     assert s["Z_rel"] <= 1e-5 and s["O_rel"] <= 1e-5 and s["clear_flips"] == 0 and s["obj_rel"] <= 2e-5, s
+
+
+@pytest.mark.timeout(600, method="thread")
+def test_reference_arithmetic_against_the_openblas_point(cell_lines):
+    """The product is tuned to the oracle's DEFAULT point of the faithful interval (the operation orders the oracle header fixes).  The other
+    point that matters is what the reference's binary runs when RcppArmadillo sits on OpenBLAS: norms and column sums as Armadillo's
+    op_norm / op_sum form them (two accumulators below 32 elements, sasum / snrm2 above), arma::inv as spotrf + spotri, one rounded product per
+    non-zero in the several-covariate apply, the distance GEMM through sgemm -- all from the real OpenBLAS 0.3.28 inside scipy (oracle
+    liberty bits 2 + 6 + 7; the reference's own sources take the same routes and equal the oracle bit for bit: tests/test_oracle_ref.py).
+    The GPU's reference-arithmetic mode has to be as close to THAT point as the two points are to each other: same centres, same
+    shuffles, to convergence; one covariate at 100k cells, two crossed covariates (the reference's fixture), three nested covariates.
+    Measured on the final tree (profiles/r5_gpu_vs_openblas_point.json): 2.1e-6 / 2.0e-6 / 5.9e-6 against 2.0e-6 / 2.3e-6 / 5.9e-6 between the
+    points, no assignment flip at a margin of 1e-5."""
+    if not (orc.use_lapack() and orc.use_openblas(1)):
+        pytest.skip("scipy's bundled OpenBLAS not found")
+    cases = [(synth(100000, d=50, levels=(10,), seed=7)[:2], 100, 10, 1e-5),
+             ((cell_lines["pcs"], {"dataset": cell_lines["dataset_levels"][cell_lines["dataset"]],
+                                   "cell_type": cell_lines["cell_type_levels"][cell_lines["cell_type"]]}), 20, 4, 1e-5),
+             (synth(40000, d=50, levels=(4, 12, 24), seed=5, nested=True)[:2], 60, 4, 3e-5)]
+    try:
+        for (Z, meta), K, max_iter, tol in cases:
+            vu = list(meta)
+            skw, _ = prepare_setup_args(Z, meta, vu, nclust=K)
+            g = Harmony(seed=3, ref_arith=1)
+            g.setup(**skw)
+            Y0 = g.kmeans_centers()
+            g.init_cluster_cpp(Y0)
+            ig = _iterate(g, max_iter)
+            c = OracleHarmony(mask=0, seed=3, liberty=128 | (4 | 64 if len(vu) > 1 else 0))
+            c.setup(**skw)
+            c.init_cluster_cpp(Y0)
+            ic = _iterate(c, max_iter)
+            bad = np.where(g.R.argmax(axis=0) != c.R.argmax(axis=0))[0]
+            srt = np.sort(c.R[:, bad], axis=0) if bad.size else np.zeros((2, 0))
+            og, oc = np.asarray(g.objective_kmeans), np.asarray(c.objective_kmeans)
+            s = dict(Z_rel=relfro(g.getZcorr(), c.getZcorr()), R_maxabs=float(np.abs(g.R - c.R).max()), flips=int(bad.size),
+                     clear_flips=int(((srt[-1] - srt[-2]) >= 1e-5).sum()) if bad.size else 0, obj_len=(len(og), len(oc)))
+            print("ref_arith vs the OpenBLAS point, %d covariate(s):" % len(vu), s)
+            assert ig == ic and len(og) == len(oc), (ig, ic, s)
+            assert float(np.max(np.abs(og - oc) / np.abs(oc))) <= 1e-4, s
+            assert s["Z_rel"] <= tol and s["clear_flips"] == 0, s
+    finally:
+        orc.use_openblas(4)
