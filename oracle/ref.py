@@ -67,6 +67,26 @@ def use_lapack(mode):
     return True
 
 
+def use_sgemm(on, threads=1):
+    """the distance GEMM Y.t() * Z_corr of the single-precision build through scipy's OpenBLAS sgemm('T', 'N') -- as Armadillo's glue_times calls
+    it, and as oracle.use_openblas() routes the oracle's; False: back to the stand-in's sequential dot products."""
+    from . import oracle as _orc
+    lib = load()
+    lib.ref_set_sgemm.argtypes = [C.c_void_p]
+    lib.ref_set_sgemm.restype = None
+    if not on:
+        lib.ref_set_sgemm(None)
+        return True
+    if _orc.lapack_pointers() is None:
+        return False
+    try:
+        _orc._blas.scipy_openblas_set_num_threads(int(threads))
+    except AttributeError:
+        pass
+    lib.ref_set_sgemm(C.cast(_orc._blas.scipy_cblas_sgemm, C.c_void_p))
+    return True
+
+
 def use_blas_norms(on):
     """norm(col, p) inside normalise() as Armadillo's op_norm forms it on a BLAS: two accumulators below 32 elements, scipy's OpenBLAS sasum /
     snrm2 from 32 on (oracle/lapack_inv.hpp, blas1); False: back to the stand-in's single accumulator."""

@@ -47,6 +47,7 @@ void ref_set_lapack(void* getrf, void* getri, void* potrf, void* potri) {
 void ref_set_inv_mode(int mode) { arma::shim::inv_mode() = mode; }
 void ref_set_blas1(void* asum, void* nrm2) { blas1::table().asum = (blas1::asum_fn)asum; blas1::table().nrm2 = (blas1::nrm2_fn)nrm2; }
 void ref_set_norm_mode(int mode) { arma::shim::norm_mode() = mode; }
+void ref_set_sgemm(void* fn) { arma::shim::sgemm_ptr() = (arma::shim::sgemm_fn)fn; }     // cblas_sgemm for Y.t() * Z_corr, or NULL
 // the reference prints notes through Rcout (= std::cout here): let a caller that owns stdout empty the buffer while it has redirected fd 1
 void ref_flush_stdout() { std::cout.flush(); std::fflush(stdout); }
 void* ref_create() { return new Handle(); }

@@ -366,13 +366,25 @@ template <class T, class A, class S, ARMA_SHIM_ARITH(S)> Mat<uword> operator>(co
 template <class T, class A, class S, ARMA_SHIM_ARITH(S)> Mat<uword> operator<(const Base<T, A>& x, S s) {
   const Mat<T>& a = unwrap(x); Mat<uword> o(a.n_rows, a.n_cols, fill::none); for (uword i = 0; i < a.n_elem; i++) o.mem[i] = a.mem[i] < T(s) ? 1 : 0; return o; }
 
-// dense * dense: every entry one sequential dot product (k ascending, from 0)
+// dense * dense: every entry one sequential dot product (k ascending, from 0) -- or, when the test harness injected one (ref_set_sgemm), a real
+// BLAS sgemm for the matrix-matrix case (M > 1: Y.t() * Z_corr, src/harmony.cpp:141,221 -- Armadillo's glue_times hands it to sgemm('T', 'N')
+// on Y itself; the row-vector products of the seeding, utils.cpp:28, are gemv calls in Armadillo and stay this loop)
+namespace shim {
+typedef void (*sgemm_fn)(int order, int transa, int transb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc);
+inline sgemm_fn& sgemm_ptr() { static sgemm_fn f = nullptr; return f; }
+}
 template <class T, class A, class B> Mat<T> operator*(const Base<T, A>& x, const Base<T, B>& y) {
   const Mat<T>& a = unwrap(x); const Mat<T>& b = unwrap(y);
   shim::need(a.n_cols == b.n_rows, "matrix multiplication: incompatible dimensions");
   const uword M = a.n_rows, N = b.n_cols, Kd = a.n_cols;
   const Mat<T> at = a.t();                                   // rows of A contiguous: the same sums, friendlier strides
   Mat<T> o(M, N, fill::none);
+  if constexpr (std::is_same<T, float>::value) {
+    if (shim::sgemm_ptr() && M > 1 && Kd > 1) {
+      shim::sgemm_ptr()(102 /*ColMajor*/, 112 /*Trans*/, 111 /*NoTrans*/, (int)M, (int)N, (int)Kd, 1.0f, at.mem, (int)Kd, b.mem, (int)Kd, 0.0f, o.mem, (int)M);
+      return o;
+    }
+  }
   for (uword n = 0; n < N; n++) { const T* bc = b.colptr(n);
     for (uword m = 0; m < M; m++) { const T* ar = at.colptr(m); T s = T(0); for (uword k = 0; k < Kd; k++) s += ar[k] * bc[k]; o.mem[n * M + m] = s; } }
   return o;

@@ -238,8 +238,9 @@ def test_norms_and_column_sums_as_armadillo_forms_them_on_a_real_blas(_lapack):
     snrm2; sum(R, 0) of the head is arrayops::accumulate (two accumulators).  With exactly that -- OpenBLAS 0.3.28's sasum / snrm2 injected into
     both libraries (oracle liberty bit 7, ref.use_blas_norms) -- the reference's own sources and the oracle hold bit-identical state after
     every call: K = 50 >= 32 with d = 20 < 32 (the reference's own fixture), d = 50 >= 32 with K = 20 < 32, and the two-covariate fixture
-    with EVERYTHING the reference's binary would take from OpenBLAS at once (norms, column sums, arma::inv through spotrf + spotri, the
-    per-non-zero apply)."""
+    with EVERYTHING the reference's binary would take from OpenBLAS at once (the distance GEMM through sgemm, norms, column sums, arma::inv
+    through spotrf + spotri, the per-non-zero apply; only the seeding's row-vector products -- gemv calls in Armadillo, outside every GPU
+    comparison because the centres are shared -- stay sequential dot products)."""
     assert oref.use_blas_norms(True)
     try:
         Z, meta = _cell_lines("cell_lines_small")
@@ -249,16 +250,48 @@ def test_norms_and_column_sums_as_armadillo_forms_them_on_a_real_blas(_lapack):
         o, r = _pair(Z2, meta2, list(meta2), 20, liberty=128, options=harmony_options(**NEVER))
         assert _walk(o, r, 2) == 2
         _lapack(2)
+        from oracle import oracle as orc
+        assert orc.use_openblas(1) and oref.use_sgemm(True)       # ... and the distance GEMM Y.t() * Z_corr through sgemm('T', 'N') on both sides
         Z, meta = _cell_lines("cell_lines")
         o, r = _pair(Z, meta, ["cell_type", "dataset"], 50, liberty=4 | 64 | 128, theta=[1, 1], options=harmony_options(max_iter_cluster=10, **NEVER))
         assert _walk(o, r, 3) == 3
     finally:
         oref.use_blas_norms(False)
+        oref.use_sgemm(False)
+        from oracle import oracle as orc
+        orc.load().orc_set_sgemm(None)
     # the switch really changes the arithmetic, by rounding noise only
     o0, r0 = _pair(Z, meta, ["cell_type", "dataset"], 50, liberty=4 | 64, theta=[1, 1], options=harmony_options(max_iter_cluster=10, **NEVER))
     assert _walk(o0, r0, 3) == 3
     a, b = o.getZcorr(), o0.getZcorr()
     assert not np.array_equal(a, b) and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
+
+
+@needs_ref
+def test_distance_gemm_through_a_real_sgemm():
+    """dist_mat = 2 (1 - Y.t() * Z_corr) (src/harmony.cpp:141,221): Armadillo's glue_times hands the product to BLAS sgemm('T', 'N') on Y itself.
+    With OpenBLAS 0.3.28's sgemm injected into both libraries the reference's sources and the oracle still agree bit for bit (K = 50 / d = 20
+    on the reference's fixture; K = 100 / d = 50 at 20k cells: blocked kernels, edge tiles)."""
+    from oracle import oracle as orc
+    if not (orc.use_openblas(1) and oref.use_sgemm(True)):
+        pytest.skip("no BLAS (scipy's bundled OpenBLAS) found")
+    try:
+        Z, meta = _cell_lines("cell_lines_small")
+        o, r = _pair(Z, meta, "dataset", 50, theta=1, options=harmony_options(max_iter_cluster=10, **NEVER))
+        assert _walk(o, r, 3) == 3
+        Z, meta, _ = synth(20000, d=50, levels=(5,), seed=3)
+        o, r = _pair(Z, meta, "cov0", 100, options=harmony_options(**NEVER))
+        o.init_cluster_cpp()
+        d_blas = o.dist_mat.copy()
+        o, r = _pair(Z, meta, "cov0", 100, options=harmony_options(**NEVER))
+        assert _walk(o, r, 2) == 2
+    finally:
+        oref.use_sgemm(False)
+        orc.load().orc_set_sgemm(None)
+    o0, r0 = _pair(Z, meta, "cov0", 100, options=harmony_options(**NEVER))
+    o0.init_cluster_cpp()
+    assert not np.array_equal(o0.dist_mat, d_blas)                                                  # the BLAS route really was taken ...
+    assert np.abs(o0.dist_mat - d_blas).max() < 1e-5                                                # ... and differs by rounding only
 
 
 # ------------------------------------------------------------------------------------------------------------ committed golden vectors
