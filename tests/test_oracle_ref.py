@@ -194,6 +194,44 @@ def test_with_several_covariates_the_apply_is_the_liberty_that_separates_them():
     assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
 
 
+def _random_case(case):
+    """One configuration drawn from `case`'s own generator: sizes, covariate structure and every numeric option of the path."""
+    g = np.random.default_rng(1000 + case)
+    C = int(g.integers(1, 4))
+    nested = bool(C == 3 and g.integers(0, 2))
+    levels = tuple(sorted(int(x) for x in g.integers(2, 7, size=C))) if nested else tuple(int(x) for x in g.integers(2, 6, size=C))
+    N, d, K = int(g.integers(45, 1500)), int(g.integers(3, 41)), int(g.integers(2, 41))
+    Z, meta, _ = synth(N, d=d, n_types=int(g.integers(2, 8)), levels=levels, seed=case, nested=nested)
+    if g.integers(0, 4) == 0:
+        Z = Z * 1e-3                                            # tiny norms, like the reference's own fixture
+    kw = dict(theta=[float(x) for x in g.choice([0.0, 0.5, 1.0, 2.0, 4.0], size=C)],
+              sigma=float(g.choice([0.05, 0.1, 0.3])) if g.integers(0, 3) else g.uniform(0.05, 0.4, size=K),
+              options=harmony_options(alpha=float(g.choice([0.1, 0.2, 0.5])), tau=float(g.choice([0, 0, 3, 20])),
+                                      block_size=float(g.choice([0.05, 0.05, 0.13, 0.34, 1.0])), max_iter_cluster=int(g.integers(1, 8)),
+                                      epsilon_cluster=float(g.choice([1e-3, 1e-5, 0.05])), epsilon_harmony=float(g.choice([1e-2, 1e-4, -1e9])),
+                                      batch_prop_cutoff=float(g.choice([1e-5, 1e-5, 5e-3, 3e-2]))))
+    mode = int(g.integers(0, 3))
+    if mode == 1:
+        kw["lambda_"] = float(g.choice([0.5, 1.0, 3.0]))
+    elif mode == 2:
+        kw["lambda_"] = [float(x) for x in g.uniform(0.3, 2.0, size=C)]
+    return Z, meta, K, kw, int(g.integers(1, 2 ** 31 - 1))
+
+
+@needs_ref
+@pytest.mark.parametrize("case", range(60))
+def test_random_configurations_walk_in_lockstep(case):
+    """60 configurations nobody chose by hand -- 45 to 1500 cells, 3 to 40 dimensions, 2 to 40 clusters, one to three covariates (crossed or
+    nested, 2 to 6 levels each), theta incl. 0, scalar or per-cluster sigma, estimated / one fixed / per-covariate lambda, alpha, tau, block
+    sizes up to ONE block per round, 1 to 7 rounds per clustering with three window tolerances, three early-stop tolerances, four
+    cut-offs, tiny-norm inputs, an arbitrary set.seed: the reference's own sources and the oracle hold bit-identical state after every
+    call of up to four harmony iterations and take the same convergence decisions."""
+    Z, meta, K, kw, seed = _random_case(case)
+    o, r = _pair(Z, meta, list(meta), K, seed=seed, liberty=4, **kw)
+    n = _walk(o, r, 4)
+    assert 1 <= n <= 4 and np.array_equal(o.kmeans_rounds, r.kmeans_rounds)
+
+
 @pytest.fixture
 def _lapack():
     """arma::inv through the one real LAPACK of this image (OpenBLAS 0.3.28 inside scipy -- the release the reference's docs were built on),
