@@ -8,7 +8,9 @@
 // the reference's docs were built on that very OpenBLAS release).  Python injects its entry points (oracle.use_lapack(),
 // ref.use_lapack()); nothing links against it.
 //
-// Call sequences restated from Armadillo's published auxlib (not on disk; from its documentation and source as published):
+// Call sequences restated from Armadillo's published auxlib (not on disk: written down from knowledge of the published source, so the details
+// that cannot be checked here are named -- the workspace size only matters above ~64 rows, where it decides between sgetri's blocked and
+// unblocked forms; the ridge systems of this path have B + 1 = 4 .. 201 rows, the subset branch's a few dozen):
 //   mode 1  auxlib::inv        sgetrf(n, n, A) ; sgetri(n, A, ipiv, work, lwork) with lwork = max(16, n), raised to the workspace query's
 //                              proposal when n > 16
 //   mode 2  auxlib::inv_sympd  what inv() takes first when the matrix "looks" symmetric positive definite (sym_helper::guess_sympd;
