@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in ("hmx_kernels.hip", "hmx_tile_bf.hip", "hmx_seq.hip", "hmx_api.cpp")]
 # (hmx_tile_bf.hip is hmx_kernels.hip's tile kernel built a second time with the split-bf16 distance GEMM: it includes that file)
 _INC = [os.path.join(HERE, "csrc", f) for f in ("hmx_k_stream.inc", "hmx_k_tile.inc", "hmx_k_correct.inc", "hmx_k_launch.inc")]      # the kernels, by section (included by hmx_kernels.hip)
-EXTRA_DEP = {"hmx_kernels.hip": _INC, "hmx_tile_bf.hip": [os.path.join(HERE, "csrc", "hmx_kernels.hip")] + _INC}
+_API_INC = [os.path.join(HERE, "csrc", "hmx_api_%s.inc" % f) for f in ("seam", "kmeans", "refarith", "update", "ridge", "p2p", "setup", "diag")]    # the host orchestration, by section (included by hmx_api.cpp)
+EXTRA_DEP = {"hmx_kernels.hip": _INC, "hmx_tile_bf.hip": [os.path.join(HERE, "csrc", "hmx_kernels.hip")] + _INC, "hmx_api.cpp": _API_INC}
 HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "csrc", "hmx_rrng.h"), os.path.join(HERE, "..", "include", "harmony_mi355x.h")]
 OUT = os.path.join(HERE, "lib", "libharmony_mi355x.so")
 
@@ -35,7 +36,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(p) > t for p in SRC + HDR + _INC)
+    return any(os.path.getmtime(p) > t for p in SRC + HDR + _INC + _API_INC)
 
 
 def build(force=False, verbose=True, trace=False):
