@@ -1,7 +1,9 @@
 ## harmony_mi355x.R -- R-side stand-in for the Rcpp module object (NOT RUN HERE: no R in the build container).
-## Drop this file into the reference's R/ directory, remove `loadModule("harmony_module", TRUE)`
-## (R/harmony-package.R:13) and change ONE line of R/ui.R (269):
-##     harmonyObj <- new(harmony)      ->      harmonyObj <- new_harmony_mi355x()
+## Recommended use: as the R file of the companion package `harmonymi355x` (r/make_companion_package.sh assembles it); the reference package
+## then changes ONE line, R/ui.R:269 (r/ui_R_269.sed):
+##     harmonyObj <- new(harmony)      ->      harmonyObj <- if (requireNamespace("harmonymi355x", quietly = TRUE) && ...) harmonymi355x::new_harmony_mi355x() else new(harmony)
+## (In-package alternative: drop this file into the reference's R/ directory, remove `loadModule("harmony_module", TRUE)`
+##  (R/harmony-package.R:13), `harmonyObj <- new_harmony_mi355x()` -- INTEGRATION.md says what else that implies.)
 ## Everything else -- RunHarmony.default (R/ui.R), harmonize() (R/utils.R:15-46), HarmonyConvergencePlot
 ## (R/utils.R:50-81), the Seurat / SingleCellExperiment methods (R/RunHarmony.R) -- runs unchanged, because the
 ## returned environment exposes the same `$` names as class_<harmony> (src/harmony.cpp:675-707).

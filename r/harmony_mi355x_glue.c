@@ -162,7 +162,17 @@ static const R_CallMethodDef CallEntries[] = {
   {"C_hmx_get", (DL_FUNC)&C_hmx_get, 2},
   {NULL, NULL, 0}
 };
-void R_init_harmony(DllInfo* dll) {                                       /* replaces _rcpp_module_boot_harmony_module */
+/* R calls R_init_<name of the DLL> when the package's shared object is loaded.  Default: the glue is the whole DLL of a package named
+ * `harmony` (it then replaces RcppExports.cpp's R_init_harmony and with it _rcpp_module_boot_harmony_module).  Recommended instead:
+ * the companion package r/make_companion_package.sh assembles (-DHMX_R_PACKAGE=harmonymi355x): the reference package keeps its own
+ * DLL -- its other Rcpp exports, scaleRows_dgc / kmeans_centers / find_lambda_cpp (src/RcppExports.cpp:14-62), stay registered -- and
+ * R/ui.R:269 asks the companion for the object.  INTEGRATION.md. */
+#ifndef HMX_R_PACKAGE
+#define HMX_R_PACKAGE harmony
+#endif
+#define HMX_R_INIT_2(pkg) R_init_##pkg
+#define HMX_R_INIT_1(pkg) HMX_R_INIT_2(pkg)
+void HMX_R_INIT_1(HMX_R_PACKAGE)(DllInfo* dll) {
   R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
   R_useDynamicSymbols(dll, FALSE);
 }

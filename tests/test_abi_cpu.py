@@ -306,3 +306,60 @@ def test_documented_switches_and_writable_fields_are_the_ones_in_the_code():
     keys = set(re.findall(r'"([a-z_:]+)"', w)) - {"randomness"}
     assert len(keys) > 15
     assert not [k for k in keys if '"%s"' % k not in code]
+
+
+def test_r_companion_package_assembles_and_registers_under_its_own_name(tmp_path):
+    """The recommended binding: r/make_companion_package.sh assembles the R package `harmonymi355x` from the repository's
+    single sources.  No R here -- so: the tree has what R CMD INSTALL needs (DESCRIPTION, NAMESPACE with useDynLib + the export, R/, src/ with
+    Makevars pointing at this checkout), and the glue compiled with the package's own flags defines R_init_harmonymi355x (the name R looks
+    for when it loads harmonymi355x.so), not R_init_harmony -- the reference package keeps its own DLL and registration."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "harmonymi355x"
+    p = subprocess.run(["bash", os.path.join(root, "r", "make_companion_package.sh"), str(out)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "R/ui.R:269" in p.stdout
+    have = sorted(os.path.relpath(os.path.join(d, f), out) for d, _, fs in os.walk(out) for f in fs)
+    assert have == ["DESCRIPTION", "NAMESPACE", "R/harmony_mi355x.R", "src/Makevars", "src/harmony_mi355x_glue.c"]
+    ns = (out / "NAMESPACE").read_text()
+    assert "useDynLib(harmonymi355x, .registration = TRUE)" in ns and "export(new_harmony_mi355x)" in ns
+    assert "Package: harmonymi355x" in (out / "DESCRIPTION").read_text()
+    mk = (out / "src" / "Makevars").read_text()
+    assert "HMX_ROOT = " + root in mk and "-lharmony_mi355x" in mk and "@HMX_ROOT@" not in mk
+    flags = re.search(r"PKG_CPPFLAGS = (.*)", mk).group(1).replace("$(HMX_ROOT)", root).split()
+    assert "-DHMX_R_PACKAGE=harmonymi355x" in flags
+    obj = tmp_path / "glue.o"
+    p = subprocess.run([shutil.which("gcc"), "-std=c11", "-c", "-fPIC", "-I" + os.path.join(root, "tests", "stubs")] + flags +
+                       [str(out / "src" / "harmony_mi355x_glue.c"), "-o", str(obj)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    syms = subprocess.run(["nm", "--defined-only", str(obj)], capture_output=True, text=True).stdout
+    assert " T R_init_harmonymi355x" in syms and "R_init_harmony\n" not in syms.replace("R_init_harmonymi355x", "")
+    # every routine the R file calls is in the table the glue registers
+    rsrc = (out / "R" / "harmony_mi355x.R").read_text()
+    csrc = (out / "src" / "harmony_mi355x_glue.c").read_text()
+    called = set(re.findall(r'"(C_hmx_[a-z0-9_]+)"', rsrc))
+    registered = set(re.findall(r'\{"(C_hmx_[a-z0-9_]+)", \(DL_FUNC\)', csrc))
+    assert called and called <= registered, sorted(called - registered)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/R/ui.R"), reason="the reference package is not on this machine")
+def test_the_one_line_edit_applies_to_the_reference_package(tmp_path):
+    """INTEGRATION.md's claim, executed on the reference's own file: r/ui_R_269.sed changes exactly ONE line of R/ui.R -- line 269,
+    `harmonyObj <- new(harmony)` -- and leaves the reference's engine as the fallback.  And the reason the companion package is the
+    recommended route: the reference's DLL registers three more routines than the module (src/RcppExports.cpp:60-62), one of which
+    (scaleRows_dgc) its own R code calls (R/utils.R:93) -- a glue that REPLACED that DLL's registration would break them."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = open("/root/reference/R/ui.R").read().split("\n")
+    work = tmp_path / "ui.R"
+    work.write_text("\n".join(ref))
+    assert subprocess.run(["sed", "-i", "-f", os.path.join(root, "r", "ui_R_269.sed"), str(work)]).returncode == 0
+    new = work.read_text().split("\n")
+    diff = [i + 1 for i, (a, b) in enumerate(zip(ref, new)) if a != b]
+    assert len(ref) == len(new) and diff == [269]
+    assert ref[268].strip() == "harmonyObj <- new(harmony)"
+    assert "harmonymi355x::new_harmony_mi355x()" in new[268] and new[268].rstrip().endswith("else new(harmony)")
+    exports = open("/root/reference/src/RcppExports.cpp").read()
+    assert all(("_harmony_" + f) in exports for f in ("kmeans_centers", "scaleRows_dgc", "find_lambda_cpp"))
+    assert "scaleRows_dgc(" in open("/root/reference/R/utils.R").read()
