@@ -143,8 +143,8 @@ def RunHarmony(data_mat, meta_data, vars_use=None, theta=None, sigma=0.1, lambda
 
     `lambda` is a Python keyword, so the ridge penalty is `lambda_` (``**{"lambda": x}`` also works);
     `.options` is `options`.  `ncores` is accepted and ignored (the reference uses it for BLAS threads,
-    R/ui.R:114-128).  Returns the corrected embedding with the orientation of the input (cells x PCs if
-    the input was cells x PCs -- the reference returns t(Z_corr)), or the Harmony object.
+    R/ui.R:114-128).  Returns the corrected embedding as cells x PCs whatever the orientation of the input was -- the
+    reference returns t(Z_corr) unconditionally (R/ui.R:292-295) --, or the Harmony object.
     `seed` + `rng="R"`: draw the centroid seeds and the per-round shuffles as `set.seed(seed); RunHarmony(...)` does in R
     (MT19937, RcppArmadillo's draw order); default: the library's counter-based generator keyed by `seed`.
     """
