@@ -363,3 +363,33 @@ def test_the_one_line_edit_applies_to_the_reference_package(tmp_path):
     exports = open("/root/reference/src/RcppExports.cpp").read()
     assert all(("_harmony_" + f) in exports for f in ("kmeans_centers", "scaleRows_dgc", "find_lambda_cpp"))
     assert "scaleRows_dgc(" in open("/root/reference/R/utils.R").read()
+
+
+def test_methods_called_out_of_order_fail_cleanly():
+    """The module object's methods are callable in any order after construction (the reference keeps ran_setup / ran_init
+    flags but does not enforce them -- an early cluster_cpp reads empty matrices).  The C ABI enforces them: every entry point called on a
+    fresh or a NULL handle returns a status (HMX_ERR_STATE = 6 / HMX_ERR_ARG = 1 / -1 for the sizing getters) and a message, never a
+    crash -- no device is touched, so this runs without a GPU."""
+    import ctypes as C
+    lib = _lib.load()
+    h = C.c_void_p(lib.hmx_create())
+    buf, i64, u8 = (C.c_double * 16)(), (C.c_int64 * 16)(), (C.c_uint8 * 1024)()
+    err = lambda: lib.hmx_last_error(h).decode()
+    try:
+        for call, msg in ((lambda: lib.hmx_init_cluster(h, None), "setup first"), (lambda: lib.hmx_kmeans_centers(h, buf), "setup first"),
+                          (lambda: lib.hmx_cluster(h), "init_cluster first"), (lambda: lib.hmx_moe_correct_ridge(h), "init_cluster first"),
+                          (lambda: lib.hmx_compute_objective(h), "init_cluster first"), (lambda: lib.hmx_push_update_order(h, i64), "setup first"),
+                          (lambda: lib.hmx_restart(h), "setup first"), (lambda: lib.hmx_p2p_connect(h, 0, 2, u8), "hmx_p2p_export first"),
+                          (lambda: lib.hmx_p2p_selftest(h), "hmx_p2p_connect first"), (lambda: lib.hmx_p2p_enable(h, 1), "hmx_p2p_connect first"),
+                          (lambda: lib.hmx_comm_allreduce_host(h, buf, 1, 0), "hmx_comm_init first")):
+            assert call() == 6 and msg in err(), err()
+        for t in (0, 1):
+            assert lib.hmx_check_convergence(h, t) < 0 and "not enough objective values" in err()
+        assert lib.hmx_get_matrix(h, b"Z_corr", buf, 0, 0, 16) == -1
+        assert lib.hmx_get(h, b"R", buf, 16) == -1 and lib.hmx_get(h, b"Lambda", buf, 16) == -1
+        assert lib.hmx_get(h, b"N", buf, 16) == 1 and buf[0] == 0          # scalar fields of an empty object: zero, like new(harmony)'s
+        assert lib.hmx_cluster(None) == 1 and lib.hmx_get(None, b"R", buf, 16) == -1 and lib.hmx_set_int(None, b"seed", 1) == 1
+        assert lib.hmx_last_error(None) == b"null handle"
+    finally:
+        lib.hmx_destroy(h)
+    lib.hmx_destroy(None)                                                       # harmless
