@@ -433,3 +433,52 @@ def test_the_accurate_oracle_is_the_reference_in_double_precision():
     assert a["Z_rel"] <= 1e-6 and a["clear_flips"] == 0 and a["R_maxabs"] <= 5e-5, a
     assert f["Z_rel"] <= 1e-5 and f["clear_flips"] == 0, f                     # (shared centroids: Z_corr normalised twice on the reference's side, an ulp)
     assert own["Z_rel"] >= 20 * a["Z_rel"], (own, a)
+
+
+@needs_ref
+def test_accurate_oracle_against_the_double_precision_reference_over_random_configurations():
+    """The same question as above over the 60 randomly drawn configurations of test_random_configurations_walk_in_lockstep (shared centroids,
+    the reference's shuffles injected from the documented generator, four harmony iterations): the accurate oracle -- the parity target of the
+    product's default mode -- stays within 1e-5 of the reference's sources built in double precision (median 1.3e-7; the reference's own
+    single-precision build: median 5e-6), with no clear assignment flip, WHEREVER the two made the same control-flow decisions.  The one thing
+    that can separate them is a knife-edge decision: the double-precision build still sums its objective in float (my_accu, src/utils.cpp:67-75;
+    the series are std::vector<float>, src/harmony.h:54), the accurate oracle in double, so a windowed clustering check (src/harmony.cpp:250-257)
+    that lands within fp32 noise of epsilon_cluster can stop one round apart -- one case of the 60 (epsilon_cluster = 1e-5), and there the
+    difference appears exactly at that round.  At most two such cases are tolerated, and they must show different kmeans_rounds."""
+    from oracle.oracle import feistel_order
+
+    def walk(obj, Y0, seed, N, inject):
+        obj.init_cluster_cpp(Y0)
+        done = 0
+        for it in range(1, 5):
+            if inject:
+                obj.clear_update_orders()
+                for r in range(8):                               # (max_iter_cluster <= 7 in these configurations)
+                    obj.push_update_order(feistel_order(seed, done + r, N))
+            assert obj.cluster_cpp() == 0
+            done = int(np.sum(obj.kmeans_rounds))
+            obj.moe_correct_ridge_cpp()
+            if obj.check_convergence(1):
+                break
+        return it
+
+    dist, knife = [], 0
+    for case in range(60):
+        Z, meta, K, kw, seed = _random_case(case)
+        skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K, **kw)
+        o0 = OracleHarmony(mask=15, seed=seed)
+        o0.setup(**skw)
+        o0.init_cluster_cpp()
+        Y0 = o0.Y.copy()
+        acc, r64 = OracleHarmony(mask=15, seed=seed), oref.RefHarmony(seed=seed, double=True)
+        acc.setup(**skw)
+        r64.setup(**skw)
+        ia, ir = walk(acc, Y0, seed, Z.shape[0], False), walk(r64, Y0, seed, Z.shape[0], True)
+        if ia != ir or not np.array_equal(acc.kmeans_rounds, r64.kmeans_rounds):
+            knife += 1
+            continue
+        a = _distance(acc, r64)
+        assert a["Z_rel"] <= 1e-5 and a["clear_flips"] == 0, (case, a)
+        dist.append(a["Z_rel"])
+    assert knife <= 2 and len(dist) >= 58
+    assert np.median(dist) <= 5e-7, np.median(dist)
