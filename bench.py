@@ -3,10 +3,12 @@
 
 Default workload (BASELINE.json configs[2], the one the metric is quoted on and that fits one GPU): synthetic
 1M cells x 50 PCs, K=100, 10 batches, reference defaults (sigma 0.1, theta 2, lambda auto, block.size 0.05,
-max.iter.cluster 4, epsilon 1e-3 / 1e-2, max_iter 10).  With --gpus N every rank holds --cells-per-gpu cells (weak
-scaling; 8 ranks ~ configs[3]) and the accumulators are all-reduced over RCCL.  `--gpus N` without a launcher
-(WORLD_SIZE unset) re-launches itself under torch.distributed.run with N ranks; the line's n_gpus always equals --gpus
-or the run exits non-zero.
+max.iter.cluster 4, epsilon 1e-3 / 1e-2, max_iter 10).  `--gpus N` (N > 1) with no size on the command line runs BASELINE
+configs[3] -- 10M cells x 50 PCs, K=100, 20 batches IN TOTAL, cell-sharded over the N GPUs ("scaling": "strong": north_star's
+">= 6x at 8 GPUs vs 1" is a statement about that workload), accumulators all-reduced over RCCL / exchanged through the peers'
+inboxes; the weak-scaling companion (1M cells on every GPU) is the line's `also.weak_scaling_1M_per_gpu`, or the main line when
+--cells-per-gpu is given.  `--gpus N` without a launcher (WORLD_SIZE unset) re-launches itself under torch.distributed.run with N
+ranks; the line's n_gpus always equals --gpus or the run exits non-zero.
 
 Other driver-reproducible modes:
     --cells-per-gpu 10000000 --batches 20          north_star target: 10M x 50 x K=100 on ONE GPU (configs[3]'s size)
@@ -486,6 +488,23 @@ def _free_port():
     return p
 
 
+def apply_size_defaults(a):
+    """Defaults by N: one GPU = BASELINE configs[2] (1M cells, 10 batches); N > 1 with no size on the command line = BASELINE configs[3] -- 10M cells
+    x 50 PCs, K = 100, 20 batches IN TOTAL, cell-sharded over the N GPUs: north_star's ">= 6x cells/s at 8 GPUs vs 1" is a strong-scaling statement
+    on that workload.  Weak scaling (--cells-per-gpu given, or the `also.weak_scaling_1M_per_gpu` leg of the default N > 1 line) keeps 1M cells on
+    every GPU."""
+    a.default_multi = a.gpus > 1 and a.workload == "c3" and a.cells_per_gpu is None and a.total_cells == 0
+    if a.default_multi:
+        a.total_cells = 10000000
+        if a.batches is None:
+            a.batches = 20
+    if a.cells_per_gpu is None:
+        a.cells_per_gpu = 1000000
+    if a.batches is None:
+        a.batches = 10
+    return a
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -493,13 +512,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"], help="c3: one covariate (--batches levels), K=--clusters; "
                     "c5: configs[4] shape, K=200, nested covariates 8 > 64 > 128")
-    ap.add_argument("--cells-per-gpu", type=int, default=1000000)
-    ap.add_argument("--total-cells", type=int, default=0, help="strong scaling: this many cells in TOTAL, sharded over --gpus (overrides --cells-per-gpu)")
+    ap.add_argument("--cells-per-gpu", type=int, default=None, help="weak scaling: this many cells on EVERY GPU (default at --gpus 1: 1000000 = configs[2])")
+    ap.add_argument("--total-cells", type=int, default=0, help="strong scaling: this many cells in TOTAL, sharded over --gpus (overrides --cells-per-gpu); "
+                    "default at --gpus N > 1 when no size is given: 10000000 with --batches 20 = BASELINE configs[3]")
     ap.add_argument("--also", default=None, help="extra legs at N=1, comma separated: ref (reference arithmetic on the main workload), 10M, share (1.25M cells / 20 batches: one GPU's part of configs[3] on 8), c5, pbmc "
                     "(configs[1] at its stated size, with its own CPU oracle timing); default 'ref,10M,share,c5,pbmc' for the default workload on one GPU, 'none' otherwise")
     ap.add_argument("--pcs", type=int, default=50)
     ap.add_argument("--clusters", type=int, default=None)
-    ap.add_argument("--batches", type=int, default=10)
+    ap.add_argument("--batches", type=int, default=None, help="levels of the one covariate (default 10 = configs[2]; 20 with the configs[3] default of --gpus N > 1)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="cells for the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--no-e2e", action="store_true", help="skip the T_e2e measurement (ingest + egress over PCIe)")
@@ -509,6 +529,7 @@ def main():
     ap.add_argument("--bootstrap", default="torch", choices=["torch", "file"], help="torch: torch.distributed bootstraps the communicator (default); "
                     "file: no torch in the process -- unique id through a file, hmx_comm_init, host reductions through the library")
     a = ap.parse_args()
+    apply_size_defaults(a)
 
     if a.bootstrap == "file":
         return main_file_bootstrap(a)
@@ -552,118 +573,124 @@ def main():
         raise SystemExit("--total-cells must be a multiple of --gpus")
     n, d = (a.total_cells // world if strong else a.cells_per_gpu), a.pcs
     N = n * world
-    Z, meta, _ = synth(n, d=d, levels=levels, seed=a.seed, shard=rank, nested=nested)
-    vars_use = list(meta)
-    # harmony_amd is loaded AFTER torch initialised its HIP runtime: both then share ONE runtime in the process,
-    # so torch streams, zero-copy tensor views of the library's buffers and RCCL all interoperate.
-    obj = Harmony(device=local_rank, seed=1)
-    obj.set_stream(torch.cuda.current_stream().cuda_stream)
-    N_b = None
-    comm_kind = "none"
-    if world > 1:
-        warm = torch.ones(1, device=dev)
-        dist.all_reduce(warm)                         # torch loads + initialises its RCCL; the library binds to the same one
-        torch.cuda.synchronize()
-        ok = 0
-        if os.environ.get("HMX_BENCH_COMM", "rccl") == "rccl":
-            # built-in communicator: ncclAllReduce issued by the C library on its own stream -- no Python per collective
-            uid = [Harmony.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0, device=dev)
-            # ncclCommInitRank runs in a watchdog thread: if the bootstrap of the extra communicator never returns on this
-            # node, every rank falls back to the torch.distributed hook instead of hanging the whole job
-            import threading
-            res = {}
-            # hmx_comm_init also connects the ranks' inboxes and runs the transport self-test (the path a torch-free C / R host takes);
-            # the torch.distributed bootstrap below is only used where that did not switch the peer-to-peer chain on
+    def build_object(n, N, levels, nested, K):
+        """one Harmony object holding this rank's n cells of an N-cell job: communicator (built-in RCCL, else the torch.distributed hook), the peers' inboxes
+        with their self-test, global level sizes, setup -- the main workload and, at N > 1, the weak-scaling leg go through the same path"""
+        Z, meta, _ = synth(n, d=d, levels=levels, seed=a.seed, shard=rank, nested=nested)
+        vars_use = list(meta)
+        # harmony_amd is loaded AFTER torch initialised its HIP runtime: both then share ONE runtime in the process,
+        # so torch streams, zero-copy tensor views of the library's buffers and RCCL all interoperate.
+        obj = Harmony(device=local_rank, seed=1)
+        obj.set_stream(torch.cuda.current_stream().cuda_stream)
+        N_b = None
+        comm_kind = "none"
+        if world > 1:
+            warm = torch.ones(1, device=dev)
+            dist.all_reduce(warm)                         # torch loads + initialises its RCCL; the library binds to the same one
+            torch.cuda.synchronize()
+            ok = 0
+            if os.environ.get("HMX_BENCH_COMM", "rccl") == "rccl":
+                # built-in communicator: ncclAllReduce issued by the C library on its own stream -- no Python per collective
+                uid = [Harmony.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0, device=dev)
+                # ncclCommInitRank runs in a watchdog thread: if the bootstrap of the extra communicator never returns on this
+                # node, every rank falls back to the torch.distributed hook instead of hanging the whole job
+                import threading
+                res = {}
+                # hmx_comm_init also connects the ranks' inboxes and runs the transport self-test (the path a torch-free C / R host takes);
+                # the torch.distributed bootstrap below is only used where that did not switch the peer-to-peer chain on
 
-            def _init():
-                try:
-                    obj.comm_init(rank, world, uid[0])
-                    obj.set_shard(rank, world, rank * n, N, None)
-                    res["ok"] = 1
-                except Exception as e:                # pragma: no cover
-                    res["err"] = e
+                def _init():
+                    try:
+                        obj.comm_init(rank, world, uid[0])
+                        obj.set_shard(rank, world, rank * n, N, None)
+                        res["ok"] = 1
+                    except Exception as e:                # pragma: no cover
+                        res["err"] = e
 
-            th = threading.Thread(target=_init, daemon=True)
-            th.start()
-            th.join(timeout=float(os.environ.get("HMX_COMM_INIT_TIMEOUT", "120")))
-            ok = 1 if res.get("ok") else 0
-            if not ok:                                # pragma: no cover
-                print("rank %d: built-in RCCL communicator failed (%s); using the torch.distributed hook"
-                      % (rank, res.get("err", "ncclCommInitRank timed out")), file=sys.stderr)
-            flag = torch.tensor([ok], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        if ok:
-            comm_kind = "RCCL over xGMI, ncclAllReduce from the C library (communicator bootstrapped through torch.distributed)"
-        else:
-            from harmony_amd.dist import TorchAllReduce
-            obj = Harmony(device=local_rank, seed=1)
-            obj.set_stream(torch.cuda.current_stream().cuda_stream)
-            obj.set_shard(rank, world, rank * n, N, TorchAllReduce(device=dev))
-            comm_kind = "torch.distributed %s all_reduce hook%s" % (a.backend, " (RCCL over xGMI)" if a.backend == "nccl" else "")
-        # Peer-to-peer block chain: the 20 dependent K x B sums of a clustering round happen INSIDE the persistent launch (every
-        # GPU writes its table into every peer's inbox over xGMI) instead of 20 launches + 20 all-reduces.  The inbox handles
-        # travel through torch.distributed; it is switched on only if the transport self-test passed on EVERY rank.
-        p2p_note = obj.p2p_status
-        builtin_p2p = bool(ok) and torch.tensor([1 if obj._scalar("p2p") else 0], device=dev)
-        if ok:
-            dist.all_reduce(builtin_p2p, op=dist.ReduceOp.MIN)
-            builtin_p2p = bool(builtin_p2p.item())
-        if os.environ.get("HMX_BENCH_P2P", "1") == "0":
-            obj.p2p_enable(False)
-            p2p_note = "switched off (HMX_BENCH_P2P=0)"
-        elif builtin_p2p:
-            p2p_note = "bootstrapped by hmx_comm_init: " + obj.p2p_status
-        elif world <= 8:
-            def agree(flag):
-                t = torch.tensor([1 if flag else 0], device=dev if a.backend == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                return bool(t.item())
-            peers_ok = True
-            if torch.cuda.device_count() < world:
-                os.environ["HMX_CHAIN_WGS"] = str(max(8, 240 // world))    # smoke tests: the ranks' chains share one GPU
-            else:                                     # every GPU of the job must be able to map every other's memory
-                peers_ok = all(g == local_rank or torch.cuda.can_device_access_peer(local_rank, g) for g in range(world))
-            handle = None
-            try:
-                if peers_ok:
-                    handle = obj.p2p_export()
-                else:
-                    p2p_note = "no peer access between the GPUs of this job"
-            except Exception as e:                    # pragma: no cover
-                handle, p2p_note = None, "export failed: %s" % e
-            handles = [None] * world
-            dist.all_gather_object(handles, handle)
-            good = all(h is not None for h in handles)
-            if good:
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("HMX_COMM_INIT_TIMEOUT", "120")))
+                ok = 1 if res.get("ok") else 0
+                if not ok:                                # pragma: no cover
+                    print("rank %d: built-in RCCL communicator failed (%s); using the torch.distributed hook"
+                          % (rank, res.get("err", "ncclCommInitRank timed out")), file=sys.stderr)
+                flag = torch.tensor([ok], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                comm_kind = "RCCL over xGMI, ncclAllReduce from the C library (communicator bootstrapped through torch.distributed)"
+            else:
+                from harmony_amd.dist import TorchAllReduce
+                obj = Harmony(device=local_rank, seed=1)
+                obj.set_stream(torch.cuda.current_stream().cuda_stream)
+                obj.set_shard(rank, world, rank * n, N, TorchAllReduce(device=dev))
+                comm_kind = "torch.distributed %s all_reduce hook%s" % (a.backend, " (RCCL over xGMI)" if a.backend == "nccl" else "")
+            # Peer-to-peer block chain: the 20 dependent K x B sums of a clustering round happen INSIDE the persistent launch (every
+            # GPU writes its table into every peer's inbox over xGMI) instead of 20 launches + 20 all-reduces.  The inbox handles
+            # travel through torch.distributed; it is switched on only if the transport self-test passed on EVERY rank.
+            p2p_note = obj.p2p_status
+            builtin_p2p = bool(ok) and torch.tensor([1 if obj._scalar("p2p") else 0], device=dev)
+            if ok:
+                dist.all_reduce(builtin_p2p, op=dist.ReduceOp.MIN)
+                builtin_p2p = bool(builtin_p2p.item())
+            if os.environ.get("HMX_BENCH_P2P", "1") == "0":
+                obj.p2p_enable(False)
+                p2p_note = "switched off (HMX_BENCH_P2P=0)"
+            elif builtin_p2p:
+                p2p_note = "bootstrapped by hmx_comm_init: " + obj.p2p_status
+            elif world <= 8:
+                def agree(flag):
+                    t = torch.tensor([1 if flag else 0], device=dev if a.backend == "nccl" else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    return bool(t.item())
+                peers_ok = True
+                if torch.cuda.device_count() < world:
+                    os.environ["HMX_CHAIN_WGS"] = str(max(8, 240 // world))    # smoke tests: the ranks' chains share one GPU
+                else:                                     # every GPU of the job must be able to map every other's memory
+                    peers_ok = all(g == local_rank or torch.cuda.can_device_access_peer(local_rank, g) for g in range(world))
+                handle = None
                 try:
-                    obj.p2p_connect(rank, world, handles)
-                except Exception as e:                # pragma: no cover
-                    good, p2p_note = False, "connect failed: %s" % e
-            good = agree(good)
-            if good:
-                dist.barrier()
-                good = agree(obj.p2p_selftest())
-                p2p_note = obj.p2p_status
-            if good:
-                obj.p2p_enable(True)
-            elif rank == 0:                           # pragma: no cover
-                print("peer-to-peer chain not available (%s): one launch + one all-reduce per block" % p2p_note, file=sys.stderr)
-        comm_kind += "; block chain: " + ("peer-to-peer inboxes inside the persistent launch (%s)" % p2p_note
-                                          if obj._scalar("p2p") else "one launch + one all-reduce per block (%s)" % p2p_note)
-        N_b = []
-        for v, L in zip(vars_use, levels):
-            cnt = torch.from_numpy(np.bincount(meta[v], minlength=L).astype(np.int64)).to(dev)
-            dist.all_reduce(cnt)
-            N_b.append(cnt.cpu().numpy().astype(float))
-        N_b = np.concatenate(N_b)
-    skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=K, N_b=N_b, levels={v: np.arange(L) for v, L in zip(vars_use, levels)})
-    t_setup = time.perf_counter()
-    obj.setup(**skw)
-    t_setup = time.perf_counter() - t_setup
-    ingest_ms = obj.timer("ingest_Z")     # H2D of Z (N*d*8 B from pageable host memory) + fp32 conversion, inside setup
-    del Z                                 # (skw keeps the d x N matrix the library was given)
+                    if peers_ok:
+                        handle = obj.p2p_export()
+                    else:
+                        p2p_note = "no peer access between the GPUs of this job"
+                except Exception as e:                    # pragma: no cover
+                    handle, p2p_note = None, "export failed: %s" % e
+                handles = [None] * world
+                dist.all_gather_object(handles, handle)
+                good = all(h is not None for h in handles)
+                if good:
+                    try:
+                        obj.p2p_connect(rank, world, handles)
+                    except Exception as e:                # pragma: no cover
+                        good, p2p_note = False, "connect failed: %s" % e
+                good = agree(good)
+                if good:
+                    dist.barrier()
+                    good = agree(obj.p2p_selftest())
+                    p2p_note = obj.p2p_status
+                if good:
+                    obj.p2p_enable(True)
+                elif rank == 0:                           # pragma: no cover
+                    print("peer-to-peer chain not available (%s): one launch + one all-reduce per block" % p2p_note, file=sys.stderr)
+            comm_kind += "; block chain: " + ("peer-to-peer inboxes inside the persistent launch (%s)" % p2p_note
+                                              if obj._scalar("p2p") else "one launch + one all-reduce per block (%s)" % p2p_note)
+            N_b = []
+            for v, L in zip(vars_use, levels):
+                cnt = torch.from_numpy(np.bincount(meta[v], minlength=L).astype(np.int64)).to(dev)
+                dist.all_reduce(cnt)
+                N_b.append(cnt.cpu().numpy().astype(float))
+            N_b = np.concatenate(N_b)
+        skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=K, N_b=N_b, levels={v: np.arange(L) for v, L in zip(vars_use, levels)})
+        t_setup = time.perf_counter()
+        obj.setup(**skw)
+        t_setup = time.perf_counter() - t_setup
+        ingest_ms = obj.timer("ingest_Z")     # H2D of Z (N*d*8 B from pageable host memory) + fp32 conversion, inside setup
+        del Z                                 # (skw keeps the d x N matrix the library was given)
+        return obj, skw, comm_kind, t_setup, ingest_ms
+
+    obj, skw, comm_kind, t_setup, ingest_ms = build_object(n, N, levels, nested, K)
 
     def sync():
         torch.cuda.synchronize()
@@ -774,11 +801,13 @@ def main():
     kname = ("k_tile<%d,4|5,2,%s,%s> -- the persistent block chain: ONE launch = one round of update_R (%d block steps, every cell once); variant 5 (no R stores) for rounds whose R rows nobody reads"
              % (nct, "true" if obj._scalar("usig") else "false", bf, int(obj._scalar("n_blocks")))) if on_chain else \
             ("k_tile<%d,0,%d,%s,%s> -- one launch = the block update of one block of update_R" % (nct, int(obj._scalar("upd_wps")), "true" if obj._scalar("usig") else "false", bf))
-    roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
-                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "mfma_busy_frac": mfma_util,
-                "achieved_is": "NOMINAL algorithmic bytes: 4d + 4K per cell and round (read the embedding row, write the R row) over the HIP-event time of the launches",
-                "achieved_weighted_by_variant": {"achieved": achieved_moved, "frac": achieved_moved / 8000.0, "share_of_rounds_without_R_stores": share_noR,
-                                                 "note": "rounds whose R rows nobody reads store none (4d bytes per cell): the bytes the timed launches had to move"},
+    roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved_moved, "peak": 8000.0,
+                "unit": "GB/s", "frac": achieved_moved / 8000.0, "traffic": traffic, "mfma_busy_frac": mfma_util,
+                "achieved_is": "algorithmic bytes the timed launches HAD to move, over the HIP-event time of the launches: 4d per cell and round (read the embedding row) + 4K (write "
+                               "the R row) only for the rounds that store their R rows -- %.0f%% of the timed rounds keep them in registers because nobody reads them (DESIGN 4.5)" % (100 * share_noR),
+                "share_of_rounds_without_R_stores": share_noR,
+                "nominal": {"achieved": achieved, "frac": achieved / 8000.0,
+                            "note": "SURVEY 8(d)'s formulation -- every round reads the embedding row and writes the R row, 4d + 4K per cell: the figure rounds 1-5 reported as `frac`"},
                 "distance_gemm": "split bf16: 6 x v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block on three exact bf16 parts per fp32 operand" if bf == "true" else "v_mfma_f32_16x16x4_f32",
                 "traffic_and_mfma_busy_are": (("collected by THIS invocation (--pmc: three separate rocprofv3 --pmc passes over tools/prof_update.py just before the timed run; %s)" % pm_note) if pmc_now
                                               else ("replayed from profiles/pmc_traffic_update_kernel.json (separate rocprofv3 --pmc passes over this kernel, "
@@ -850,6 +879,42 @@ def main():
                    "gpu_phase_ms_per_step": gpu_phase, "chain_us_per_block_step": chain, "e2e": e2e},
         "roofline": roofline,
     }
+    if world > 1:
+        out["config"]["baseline_config"] = ("configs[3]: 10M cells x 50 PCs, K=100, 20 batches, cell-sharded (the default of --gpus N > 1)" if (N, d, K, levels) == (10000000, 50, 100, (20,))
+                                            else "configs[4] shape" if a.workload == "c5" else "user-sized")
+        out["parity_mode"] = ("default: exact accumulators, identical for every shard count (integer sums); parity target = the reference's own sources built with its "
+                              "-DHARMONY_SCALAR_DOUBLE switch (INTEGRATION.md, 'Which result a sharded run returns'); reference arithmetic is a one-GPU mode")
+        try:      # DESIGN 5.2's prediction for this very line, made before any run crossed two devices: the hardware run falsifies or confirms it
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r5_scaling_prediction.json")))
+            key = "configs3" if (N, d, K, levels) == (10000000, 50, 100, (20,)) else ("configs4" if a.workload == "c5" and N == 5000000 else None)
+            if key and str(world) in pj[key]:
+                e = pj[key][str(world)]
+                out["predicted"] = {"ms_per_step": e["predicted_ms"], "speedup_vs_1_gpu": e["speedup_vs_1"], "one_rank_share_without_exchanges_ms": e["share_ms"],
+                                    "source": "profiles/r5_scaling_prediction.json (tools/scaling_prediction.py: per-rank shares measured on ONE GPU + measured one-device exchange costs)"}
+        except Exception:
+            pass
+        if a.default_multi and (a.also or "weak") != "none":
+            # the weak-scaling companion of the default N > 1 line: configs[2]'s 1M cells x 10 batches on EVERY GPU
+            try:
+                del obj
+                n2 = 1000000
+                o2, _, ck2, _, _ = build_object(n2, n2 * world, (10,), False, 100)
+                for _ in range(2):
+                    run_to_convergence(o2)
+                sync()
+                t0 = time.perf_counter()
+                its2 = [run_to_convergence(o2) for _ in range(a.steps)]
+                sync()
+                dt2 = time.perf_counter() - t0
+                t = torch.tensor([dt2], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+                out["also"] = {"weak_scaling_1M_per_gpu": {"workload": "synthetic %d cells x 50 PCs, K=100, 10 batches, %d cells/GPU" % (n2 * world, n2), "scaling": "weak",
+                                                           "ms_per_step": 1e3 * dt2 / a.steps, "cells_per_s": n2 * world / (dt2 / a.steps), "harmony_iterations": its2,
+                                                           "comm": comm_stats(o2), "parallelism": ck2}}
+                del o2
+            except Exception as e:     # pragma: no cover  (an extra leg never costs the main line)
+                out["also"] = {"weak_scaling_1M_per_gpu": {"error": repr(e)}}
     hp = headline_parity(n, d, K, levels) if world == 1 else None
     if hp:
         out.update({"parity_mode": hp["parity_mode"], "Z_rel_vs_accurate": hp["Z_rel_vs_accurate"], "Z_rel_vs_faithful": hp["Z_rel_vs_faithful"], "parity": hp})

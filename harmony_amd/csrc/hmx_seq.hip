@@ -646,7 +646,7 @@ __global__ void k_seq_ridge_store(Dev D, const float* __restrict__ total) {
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------
 void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* poslev, int nlist, const SeqSeg* segs, int seg0, int nsegs, const float* start,
                    float* end, int zero_start, unsigned* conv_zero) {
-  if (nsegs <= 0) return;
+  if (nsegs <= 0) { if (conv_zero) (void)hipMemsetAsync(conv_zero, 0, 2 * sizeof(unsigned), L.stream); return; }      // (no pass: the statistics words its scan adds to are still zeroed)
   if (D.B <= 32) {                         // level rows in registers (more levels: in LDS, the round-3 form)
     const dim3 grid((nsegs + 3) / 4, (D.K + 63) / 64);
     if (D.B <= 16) hipLaunchKernelGGL((k_seq_oe_pass<true, 16>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
@@ -661,13 +661,13 @@ void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* po
 // plain list sums: W = K lane-chains per segment (row 0 of the kernel above only)
 void l_seq_sum_pass(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const float* start, float* end,
                     int zero_start, unsigned* conv_zero) {
-  if (nsegs <= 0) return;
+  if (nsegs <= 0) { if (conv_zero) (void)hipMemsetAsync(conv_zero, 0, 2 * sizeof(unsigned), L.stream); return; }      // (no pass: the statistics words its scan adds to are still zeroed)
   hipLaunchKernelGGL((k_seq_oe_pass<false, 0>), dim3((nsegs + 3) / 4, (D.K + 63) / 64), dim3(256), 0, L.stream, D.R, D.K, 0, 0, list, nullptr, 0, D.combo, D.qlev, segs,
                      seg0, nsegs, start, end, zero_start, conv_zero);
 }
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const int* listq, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start, unsigned* conv_zero) {
-  if (nsegs <= 0) return;
+  if (nsegs <= 0) { if (conv_zero) (void)hipMemsetAsync(conv_zero, 0, 2 * sizeof(unsigned), L.stream); return; }      // (no pass: the statistics words its scan adds to are still zeroed)
   // one wave per 8 clusters.  Round 5: at most TWELVE waves per workgroup -- at 80 VGPRs a CU holds 24 waves, i.e. two 12-wave workgroups where a
   // 13-wave one (K = 100) left the rest of the CU empty; the clusters beyond 96 go to a second, small workgroup of the same segment (grid.y)
   // (measured at K = 100, 1M cells: ridge statistics 20.9 -> 19.7 ms per run)

@@ -29,8 +29,8 @@ def build(force=False):
     """(Re)build where the reference's sources exist; elsewhere use the file that travelled with the tree."""
     if os.path.exists(os.path.join(_REF_SRC, "harmony.cpp")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "_ref", "REF=" + _REF_SRC])
-    if not os.path.exists(_SO) or not os.path.exists(_SO64):
-        raise RuntimeError("oracle/_ref/libharmony_ref*.so absent and /root/reference is not here to build them from")
+    if not os.path.exists(_SO):
+        raise RuntimeError("oracle/_ref/libharmony_ref.so absent and /root/reference is not here to build it from")
     return _SO
 
 
@@ -40,6 +40,8 @@ def load(double=False):
     if double:
         if _lib64 is None:
             build()
+            if not os.path.exists(_SO64):
+                raise RuntimeError("oracle/_ref/libharmony_ref_f64.so absent and /root/reference is not here to build it from")
             _lib64 = _prototypes(C.CDLL(_SO64))
             assert _lib64.ref_scalar_bytes() == 8
         return _lib64

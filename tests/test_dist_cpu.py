@@ -133,3 +133,25 @@ def test_sharded_argument_preparation_gloo_world2():
         assert all(np.array_equal(m[k], shards[rank][1][k]) for k in m)
         assert np.array_equal(N_b, np.concatenate([np.bincount(meta[k], minlength=L) for k, L in zip(meta, (3, 40))]))
     assert not np.array_equal(whole["theta"], np.full(43, 2.0))    # tau really scaled it
+
+
+def test_bench_defaults_by_gpu_count():
+    """bench.py's size defaults: one GPU = BASELINE configs[2]; --gpus N > 1 with no size = configs[3] (10M cells, 20 batches, strong
+    scaling); an explicit --cells-per-gpu keeps weak scaling; an explicit --total-cells / --batches is respected."""
+    import argparse
+    import bench
+    def ns(**kw):
+        a = argparse.Namespace(gpus=1, workload="c3", cells_per_gpu=None, total_cells=0, batches=None)
+        a.__dict__.update(kw)
+        return bench.apply_size_defaults(a)
+    a = ns()
+    assert (a.cells_per_gpu, a.total_cells, a.batches, a.default_multi) == (1000000, 0, 10, False)
+    for g in (2, 4, 8):
+        a = ns(gpus=g)
+        assert (a.total_cells, a.batches, a.default_multi) == (10000000, 20, True) and a.total_cells % g == 0
+    a = ns(gpus=8, cells_per_gpu=1000000)
+    assert (a.total_cells, a.batches, a.default_multi) == (0, 10, False)
+    a = ns(gpus=4, total_cells=4000000, batches=10)
+    assert (a.total_cells, a.batches, a.default_multi) == (4000000, 10, False)
+    a = ns(gpus=8, workload="c5")
+    assert (a.total_cells, a.default_multi) == (0, False)

@@ -408,6 +408,31 @@ def test_elided_R_stores_change_nothing(mode, monkeypatch):
     np.testing.assert_array_equal(a[0], b[0])
 
 
+def test_objective_in_reference_arithmetic_never_reads_elided_rows(monkeypatch):
+    """obj_arith alone (exact O / E tables, so the round-to-round carry stays on): the round's objective is summed from the R rows
+    themselves (src/utils.cpp:67-75 over R % dist, R % log R, ...), so a round must store them even where the next round would not read
+    them (the elision of hmx_api_update.inc ignored obj_arith and the objective of a call's first rounds came from stale rows).
+    Default against HMX_R_STORE=1: the objective series must be bit-identical, and no round may have elided its stores."""
+    monkeypatch.setenv("HMX_SOLD_CARRY", "1")
+    Z, meta, _ = synth(30000, d=50, levels=(10,), seed=23)
+    K, seed = 100, 9
+    out = []
+    for store in ("0", "1"):
+        monkeypatch.setenv("HMX_R_STORE", store)
+        skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=K)
+        g = Harmony(seed=seed, obj_arith=1)
+        g.setup(**skw)
+        g.init_cluster_cpp()
+        for it in range(3):
+            assert g.cluster_cpp() == 0
+            g.moe_correct_ridge_cpp()
+        assert int(g._scalar("sold_carry")) == 1
+        assert int(g._scalar("rounds_without_R")) == 0
+        out.append((np.array(g.objective_kmeans), np.array(g.objective_kmeans_dist), np.array(g.objective_kmeans_entropy), g.getZcorr()))
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_builtin_rccl_communicator_single_rank():
     """The built-in communicator (hmx_comm_init -> ncclCommInitRank, ncclAllReduce issued by the C library on its own
     stream) with a 1-rank communicator and forced collectives reproduces the plain run.  torch-first subprocess: the

@@ -779,6 +779,28 @@ def test_bench_bootstraps_without_torch():
     assert line["n_gpus"] == 1 and line["value"] > 0 and "no torch" in line["config"]["bootstrap"] and line["roofline"]["frac"] > 0, line
 
 
+@pytest.mark.timeout(1500, method="thread")
+def test_bench_two_ranks_default_is_configs3_strong_scaling():
+    """`bench.py --gpus 2` with no size on the command line IS BASELINE configs[3] (10M cells x 50 PCs, K = 100, 20 batches in total, cell-sharded,
+    "scaling": "strong"), carries DESIGN 5.2's prediction for that line and the weak-scaling companion under `also`.  Two ranks
+    share this box's one GPU over gloo: a protocol check of the line, not a scaling number."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HMX_BENCH_PREROLL="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--no-e2e"],
+                       capture_output=True, text=True, timeout=1400, stdin=subprocess.DEVNULL, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0, line
+    assert line["config"]["baseline_config"].startswith("configs[3]") and "10000000 cells" in line["config"]["workload"], line["config"]
+    assert line["config"]["shard_check"]["O_identical_on_all_ranks"], line["config"]
+    assert line["predicted"]["ms_per_step"][0] > 0 and line["config"]["comm"] is not None, line
+    weak = line["also"]["weak_scaling_1M_per_gpu"]
+    assert weak.get("scaling") == "weak" and weak["cells_per_s"] > 0, weak
+    print("bench --gpus 2 (two ranks sharing one GPU, gloo): %.1f ms per step at configs[3], predicted on two GPUs %s; weak leg %.1f ms"
+          % (line["ms_per_step"], line["predicted"]["ms_per_step"], weak["ms_per_step"]))
+
+
 def test_torch_free_c_host_with_builtin_rccl(tmp_path):
     """examples/comm_example.c: a process WITHOUT torch (the R / plain-C host) brings up the built-in RCCL communicator from the
     system librccl with the unique id shipped through a file, and runs the sharded code path with forced collectives
