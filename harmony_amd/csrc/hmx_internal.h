@@ -319,7 +319,12 @@ void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float*
 int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
 // arrays 1 and 2 of the objective (entropy, cross-entropy) as sequential sums straight from R: same segments, starts / ends / partials as l_seq_arr_pass's arrays 1, 2
 void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial);
-void l_obj_store(const Launch& L, const float* total, double* obj);
+// round 6: the three chains in ONE launch, segments in registers, the scans between the passes inside the launch (k_seq_obj_fused, hmx_seq.hip)
+size_t seq_obj_fused_slot_words(long long nt);
+int seq_obj_fused_nsegs(long long nt);
+bool l_seq_obj_fused(const Launch& L, const Dev& D, int mode, const float* T, long long stride, const float* M, const int* olev, long long nt, int npass, int zero_start,
+                     float* starts, float* total, unsigned* stats, unsigned long long* slots, unsigned epoch);
+void l_obj_store(const Launch& L, const float* total, double* obj, const unsigned* xerr = nullptr);      // (xerr: a fused launch's exchange error word -> obj[5])
 bool l_obj_terms_mfma(const Launch& L, const Dev& D, const float* M, float* T, long long stride, int all3);
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M);
 void l_seq_inset(const Launch& L, const Dev& D, const float* Of, const int* cov_bounds, float cutoff, unsigned char* inset);

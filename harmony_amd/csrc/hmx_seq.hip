@@ -358,6 +358,292 @@ __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __res
   if (threadIdx.x == 0) { partial[(size_t)gridDim.x + blockIdx.x] = bsum[0][0]; partial[(size_t)2 * gridDim.x + blockIdx.x] = bsum[1][0]; }
 }
 
+// ---- (d) round 6: the objective's three chains in ONE launch -----------------------------------------------------------------------
+// The passes above re-read their 400 MB term arrays for every pass of the fixed-point iteration (2.7 passes x 0.33 ms per evaluation at 1M
+// cells, 21 evaluations per run).  Here a thread keeps its segment -- 32 consecutive terms of each of the three chains -- in REGISTERS, so a
+// further pass costs 96 adds instead of a sweep over HBM; what the scan kernels did between the passes happens inside the launch:
+//   * workgroup: the deltas (end - start, fp64 on fp32-representable values) are scanned over the wave (shuffles) and the 8 waves (LDS);
+//   * grid: every workgroup takes a TICKET (its rank in start order: whoever holds a lower ticket is running or done -- no assumption about
+//     dispatch order) and publishes its three aggregates as self-validating 8-byte granules {tag, 32 bits} (written through, read around L1 /
+//     the other XCDs' L2s: no fence, no flag -- MI355X_MICROARCH.md, the transport the block chain and the peer inboxes use); tag = (launch
+//     epoch, stage), so nothing is ever reset.  Two levels: a workgroup sums the aggregates of the lower tickets of its group of 64 (one
+//     lane each) and the totals of the groups in front of it (published by each group's last member) -- it never waits for a higher ticket,
+//     so the wait graph is acyclic whatever is resident.  One stage per pass; every stage has its own slots (a slow reader of stage p must
+//     not find stage p + 2 there).  Every spin is bounded by the wall clock and raises X.err instead of hanging the GPU.
+// MODE 0: three term arrays T[c][nt] (the probe hmx_debug_seq_arr, and the fallback when all three arrays are materialised);
+// MODE 1: T[0] = R % dist from k_obj_terms_mfma; the entropy and cross-entropy terms are formed from the cells' R rows (through invperm; level
+//         codes in original cell order, `olev`) with exactly the roundings of k_obj_terms / k_seq_objr_pass.  K % 4 == 0.
+// stats: [0] starts that still moved in the last stage, [1 + c] the largest move of a start of chain c (float bits), [4 + c] the chain totals (float
+//        bits), [7] error word, [8] the ticket counter -- zeroed by the host in front of the launch (one 64-byte memset).
+struct SeqXchg { unsigned long long* slotA; unsigned long long* slotG; unsigned epoch; int ngroups; int dbg; };
+__device__ __forceinline__ void xg_put3(unsigned long long* slot, const int lane, const unsigned tag, const double a0, const double a1, const double a2) {
+  if (lane < 6) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(lane < 2 ? a0 : lane < 4 ? a1 : a2);
+    const unsigned half = (lane & 1) ? (unsigned)(bits & 0xffffffffull) : (unsigned)(bits >> 32);
+    __hip_atomic_store(slot + lane, ((unsigned long long)tag << 32) | (unsigned long long)half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void xg_get3(const unsigned long long* slot, const unsigned tag, double& a0, double& a1, double& a2, unsigned* err) {
+  unsigned long long g[6];
+  const unsigned long long t_in = wall_clock64();
+  bool ok = false;
+  for (int spins = 0; !ok; spins++) {
+    ok = true;
+#pragma unroll
+    for (int q = 0; q < 6; q++) { g[q] = __hip_atomic_load(slot + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && (unsigned)(g[q] >> 32) == tag; }
+    if (ok) break;
+    if ((spins & 63) == 63 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t_in > 200000000ull)) { atomicExch(err, 9u); break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  a0 = __longlong_as_double((long long)(((g[0] & 0xffffffffull) << 32) | (g[1] & 0xffffffffull)));
+  a1 = __longlong_as_double((long long)(((g[2] & 0xffffffffull) << 32) | (g[3] & 0xffffffffull)));
+  a2 = __longlong_as_double((long long)(((g[4] & 0xffffffffull) << 32) | (g[5] & 0xffffffffull)));
+}
+__device__ __forceinline__ double wave_sum_d(double v) {      // butterfly: both partners form the same sum at every step -> all lanes end bit-identical
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// the two halves of a stage's exchange for workgroup `w` (ticket order), run by two different waves at the same time:
+//   mates: publish the own aggregate; sum the aggregates of the lower tickets of the group of 64 (one lane each); the group's last member also publishes
+//          the group's total;   groups: sum the totals of the groups in front (one lane each, 64 at a time)
+__device__ __forceinline__ void xg_mates3(const SeqXchg& X, const int stage, const int w, const int nwg, const int lane, const double A0, const double A1, const double A2,
+                                          double& p0, double& p1, double& p2, unsigned* err) {
+  const unsigned tag = (X.epoch << 4) | (unsigned)stage;
+  const int g = w >> 6, j = w & 63;
+  xg_put3(X.slotA + ((size_t)stage * nwg + w) * 8, lane, tag, A0, A1, A2);
+  p0 = 0.0; p1 = 0.0; p2 = 0.0;
+  if (lane < j) xg_get3(X.slotA + ((size_t)stage * nwg + (size_t)g * 64 + lane) * 8, tag, p0, p1, p2, err);
+  p0 = wave_sum_d(p0); p1 = wave_sum_d(p1); p2 = wave_sum_d(p2);
+  if (j == 63 || w == nwg - 1) xg_put3(X.slotG + ((size_t)stage * X.ngroups + g) * 8, lane, tag, p0 + A0, p1 + A1, p2 + A2);
+}
+__device__ __forceinline__ void xg_groups3(const SeqXchg& X, const int stage, const int w, const int lane, double& q0, double& q1, double& q2, unsigned* err) {
+  const unsigned tag = (X.epoch << 4) | (unsigned)stage;
+  const int g = w >> 6;
+  q0 = 0.0; q1 = 0.0; q2 = 0.0;
+  for (int g0 = 0; g0 < g; g0 += 64) {
+    if (g0 + lane < g) { double t0, t1, t2; xg_get3(X.slotG + ((size_t)stage * X.ngroups + g0 + lane) * 8, tag, t0, t1, t2, err); q0 += t0; q1 += t1; q2 += t2; }
+  }
+  q0 = wave_sum_d(q0); q1 = wave_sum_d(q1); q2 = wave_sum_d(q2);
+}
+// inclusive scan of a double over the wave without LDS traffic: DPP row shifts inside the rows of 16, then row_bcast15 / row_bcast31 across them
+// (an invalid source lane or a masked row contributes the `old` operand, +0.0)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_d(const double v) {
+  const long long bts = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bts & 0xffffffffll), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bts >> 32), CTRL, ROWMASK, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_scan_d(double v) {
+  v += dpp_d<0x111, 0xF>(v); v += dpp_d<0x112, 0xF>(v); v += dpp_d<0x114, 0xF>(v); v += dpp_d<0x118, 0xF>(v);
+  v += dpp_d<0x142, 0xA>(v); v += dpp_d<0x143, 0xC>(v);
+  return v;
+}
+constexpr int OBJF_TPT = 32, OBJF_THREADS = 256, OBJF_WAVES = OBJF_THREADS / 64, OBJF_MAXSTAGE = 8;
+// a wave's 64 x 32 consecutive terms, loaded COALESCED -- load q of lane l fetches the 16 bytes at term 4 (64 q + l) of the wave's window, a kilobyte per
+// instruction -- and dealt to the lanes that own them through LDS (an 8 x 8 transpose of 16-byte items per group of 8 lanes; item (row L, slot r) lives at
+// slot r ^ (L & 7) of its row: writes and reads are conflict-free).  (The first version let every lane read its own 128-byte line: eight waves of such
+// loads thrash the L1, 1.1 ms per evaluation against 0.22 ms for the same bytes in k_seq_arr_pass.)
+template <class LOAD> __device__ __forceinline__ void objf_deal(float* __restrict__ lbuf, const int lane, LOAD load16, float (&out)[OBJF_TPT]) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) v[q] = load16(q * 64 + lane);
+  f4* const L4 = reinterpret_cast<f4*>(lbuf);
+#pragma unroll
+  for (int q = 0; q < 8; q++) { const int i = q * 64 + lane, row = i >> 3, r = i & 7; L4[row * 8 + (r ^ (row & 7))] = v[q]; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int r = 0; r < 8; r++) { const f4 x = L4[lane * 8 + (r ^ (lane & 7))]; out[4 * r] = x[0]; out[4 * r + 1] = x[1]; out[4 * r + 2] = x[2]; out[4 * r + 3] = x[3]; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int MODE, bool LDSTAB>
+__global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const float* __restrict__ T, long long stride, const float* __restrict__ M, const int* __restrict__ olev,
+                                                                   long long nt, int nsegs, int npass, int zero_start, float* __restrict__ starts,
+                                                                   unsigned* __restrict__ stats, double* __restrict__ wgagg, SeqXchg X) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ double wtot[OBJF_WAVES][3];
+  __shared__ double xin[3], xgr[3];
+  __shared__ unsigned wgid;
+  extern __shared__ __attribute__((aligned(16))) float lds_[];      // [waves][64 x 32] deal buffers, then (MODE 1, LDSTAB) [B][K] M and [K] sigma
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* const lbuf = lds_ + (size_t)wave * 64 * OBJF_TPT;
+  float* const ltab = lds_ + (size_t)OBJF_WAVES * 64 * OBJF_TPT;
+  if (tid == 0) wgid = (X.dbg & 4) ? blockIdx.x : atomicAdd(stats + 8, 1u);
+  if constexpr (MODE == 1 && LDSTAB) {
+    for (int i = tid; i < D.B * D.K; i += OBJF_THREADS) ltab[i] = M[i];
+    for (int i = tid; i < D.K; i += OBJF_THREADS) ltab[D.B * D.K + i] = D.sigma[i];
+  }
+  __syncthreads();
+  const int w = (int)wgid, nwg = (int)gridDim.x;
+  const int seg = w * OBJF_THREADS + tid;
+  const bool live = seg < nsegs;
+  const long long tw = ((long long)w * OBJF_THREADS + wave * 64) * OBJF_TPT;      // first term of this wave's window
+  const long long t0 = (long long)seg * OBJF_TPT;                                   // first term of this lane's segment
+  float a[OBJF_TPT], b[OBJF_TPT], c[OBJF_TPT];
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto plain = [&](const float* __restrict__ arr) {      // 16 bytes of a term array at item i of the window; beyond the end: zeros (a ragged end term by term)
+    return [=](const int i) -> f4 {
+      const long long t = tw + 4 * (long long)i;
+      if (t + 3 < nt) return *reinterpret_cast<const f4*>(arr + t);
+      f4 x = zero4;
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (t + u < nt) x[u] = arr[t + u];
+      return x;
+    };
+  };
+  if constexpr (MODE == 0) {
+    objf_deal(lbuf, lane, plain(T), a);
+    objf_deal(lbuf, lane, plain(T + (size_t)stride), b);
+    objf_deal(lbuf, lane, plain(T + 2 * (size_t)stride), c);
+  } else {
+    const int K = D.K, C = D.C, n = D.n;
+    objf_deal(lbuf, lane, plain(T), a);
+    // the same items of R: term t belongs to original cell t / K, cluster t % K -> row invperm[cell] of R (K % 4 == 0: an item never straddles a row)
+    objf_deal(lbuf, lane, [&](const int i) -> f4 {
+      const long long t = tw + 4 * (long long)i;
+      if (t >= nt) return zero4;
+      const int cell = (int)(t / K), k = (int)(t - (long long)cell * K);
+      return *reinterpret_cast<const f4*>(D.R + (size_t)D.invperm[cell] * K + k); }, b);
+    const float lmin = __builtin_amdgcn_logf(FLT_MIN) * 0.69314718055994530942f;
+    const float* const lsig = ltab + D.B * K;
+    int cell = (int)(t0 / K), k = (int)(t0 - (long long)cell * K);
+#pragma unroll
+    for (int j = 0; j < OBJF_TPT / 4; j++) {
+      const bool ok = live && t0 + 4 * j < nt;
+      const int cs = min(cell, n - 1), ks = min(k, K - 4);
+      f4 g4, m4 = zero4;
+      if constexpr (LDSTAB) g4 = *reinterpret_cast<const f4*>(lsig + ks); else g4 = *reinterpret_cast<const f4*>(D.sigma + ks);
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) {
+        if (cc < C) {
+          const int lev = olev[(size_t)cc * n + cs];
+          f4 mm;
+          if constexpr (LDSTAB) mm = *reinterpret_cast<const f4*>(ltab + lev * K + ks); else mm = *reinterpret_cast<const f4*>(M + (size_t)lev * K + ks);
+#pragma unroll
+          for (int i = 0; i < 4; i++) m4[i] = __fadd_rn(m4[i], mm[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float r = b[4 * j + i], sg = g4[i];
+        const float lg = (r > 0.0f) ? __fmul_rn(__builtin_amdgcn_logf(r), 0.69314718055994530942f) : lmin;      // arma::trunc_log
+        b[4 * j + i] = ok ? __fmul_rn(__fmul_rn(r, lg), sg) : 0.0f;
+        c[4 * j + i] = ok ? __fmul_rn(__fmul_rn(r, sg), m4[i]) : 0.0f;
+      }
+      k += 4; if (k >= K) { k -= K; cell++; }
+    }
+  }
+  const bool clk = (X.dbg & 8) && tid == 0;
+  unsigned long long tk0 = 0, tk1 = 0;
+  if (clk) { tk0 = wall_clock64(); }
+  float st0 = 0.0f, st1 = 0.0f, st2 = 0.0f, pv0 = 0.0f, pv1 = 0.0f, pv2 = 0.0f;
+  if (!zero_start && live) { st0 = starts[seg]; st1 = starts[(size_t)nsegs + seg]; st2 = starts[2 * (size_t)nsegs + seg]; }
+  for (int p = 0; p < npass; p++) {
+    float s0 = st0, s1 = st1, s2 = st2;
+#pragma unroll
+    for (int i = 0; i < OBJF_TPT; i++) { s0 = __fadd_rn(s0, a[i]); s1 = __fadd_rn(s1, b[i]); s2 = __fadd_rn(s2, c[i]); }      // (a masked term is +0: it leaves the accumulator as it is)
+    const double d0 = live ? (double)s0 - (double)st0 : 0.0, d1 = live ? (double)s1 - (double)st1 : 0.0, d2 = live ? (double)s2 - (double)st2 : 0.0;
+    if (clk) { tk1 = wall_clock64(); atomicAdd(stats + 9 + (p == 0 ? 0 : 1), (unsigned)(tk1 - tk0)); tk0 = tk1; }      // [9] first pass, [10] later passes
+    const double i0 = wave_scan_d(d0), i1 = wave_scan_d(d1), i2 = wave_scan_d(d2);
+    if (lane == 63) { wtot[wave][0] = i0; wtot[wave][1] = i1; wtot[wave][2] = i2; }
+    double e0 = dpp_d<0x138, 0xF>(i0), e1 = dpp_d<0x138, 0xF>(i1), e2 = dpp_d<0x138, 0xF>(i2);      // wave_shr:1 -> the exclusive prefix (lane 0: +0)
+    __syncthreads();
+    double A0 = 0.0, A1 = 0.0, A2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < OBJF_WAVES; u++) {
+      const double v0 = wtot[u][0], v1 = wtot[u][1], v2 = wtot[u][2];
+      if (u == wave) { e0 += A0; e1 += A1; e2 += A2; }      // (the waves in front of this one)
+      A0 += v0; A1 += v1; A2 += v2;
+    }
+    if (clk) { tk1 = wall_clock64(); atomicAdd(stats + 11, (unsigned)(tk1 - tk0)); tk0 = tk1; }      // [11] workgroup scan
+    if (p == npass - 1) {
+      // the LAST pass needs no exchange: nobody restarts from its result inside this launch.  The workgroup leaves its aggregate and the start its first
+      // segment ran from (this pass and the one before); k_seq_objf_close sums the aggregates in ticket order -> chain totals, and sees how far
+      // the workgroups' starts would still move.  The segment starts of this pass are what the next evaluation starts warm from.
+      if (live) { starts[seg] = st0; starts[(size_t)nsegs + seg] = st1; starts[2 * (size_t)nsegs + seg] = st2; }
+      if (tid == 0) {      // component-major records [7][nwg] of 8 bytes: the closing kernel reads them coalesced
+        const size_t nw_ = (size_t)nwg;
+        wgagg[w] = A0; wgagg[nw_ + w] = A1; wgagg[2 * nw_ + w] = A2;
+        auto pack = [](const float x, const float y) { return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(y) << 32) | (unsigned long long)__float_as_uint(x))); };
+        wgagg[3 * nw_ + w] = pack(st0, pv0); wgagg[4 * nw_ + w] = pack(st1, pv1); wgagg[5 * nw_ + w] = pack(st2, pv2);
+        // flags: the starts of this pass were iterated ones (not zeros by construction) | so were the ones of the pass before
+        wgagg[6 * nw_ + w] = __longlong_as_double((long long)(((npass > 1 || !zero_start) ? 1ull : 0ull) | (npass > 1 ? 2ull : 0ull)));
+      }
+      break;
+    }
+    if (!(X.dbg & 1)) {
+      if (wave == 0) { double p0, p1, p2; xg_mates3(X, p, w, nwg, lane, A0, A1, A2, p0, p1, p2, stats + 7); if (lane == 0) { xin[0] = p0; xin[1] = p1; xin[2] = p2; } }
+      else if (wave == 1) { double q0, q1, q2; xg_groups3(X, p, w, lane, q0, q1, q2, stats + 7); if (lane == 0) { xgr[0] = q0; xgr[1] = q1; xgr[2] = q2; } }
+    } else if (tid == 0) { xin[0] = xin[1] = xin[2] = 0.0; xgr[0] = xgr[1] = xgr[2] = 0.0; }
+    __syncthreads();
+    if (clk) { tk1 = wall_clock64(); atomicAdd(stats + 12, (unsigned)(tk1 - tk0)); tk0 = tk1; }      // [12] exchange
+    const double b0 = xgr[0] + xin[0], b1 = xgr[1] + xin[1], b2 = xgr[2] + xin[2];
+    pv0 = st0; pv1 = st1; pv2 = st2;
+    st0 = (float)(b0 + e0); st1 = (float)(b1 + e1); st2 = (float)(b2 + e2);
+    __syncthreads();          // (wtot / xin / xgr are rewritten by the next pass)
+    if (clk) { tk1 = wall_clock64(); atomicAdd(stats + 13, (unsigned)(tk1 - tk0)); tk0 = tk1; }      // [13] new starts
+  }
+}
+// closes a fused launch: the workgroups' aggregates of the last pass, in ticket order -> the chain totals; and, per workgroup, the start its first segment
+// WOULD take next (the sum of the aggregates in front of it) against the one it ran from in the last pass and in the pass before:
+//   stats[0] workgroups whose start still moves, stats[1 + c] the largest such move of chain c, stats[9 + c] the largest move one pass earlier (float bits;
+//   0 when that pass started from zeros), stats[4 + c] the chain totals (float bits)
+// A grid of workgroups of 1024 records each, one record per thread (coalesced component-major reads; one workgroup walking 12k records needed 57 us on its
+// one CU's address unit): a workgroup first sums the aggregates in FRONT of its records -- thread-strided, then a fixed tree -- which makes the
+// few workgroups independent of each other; stats[0..3], [9..11] are combined with atomics (zeroed by the launcher's memset).
+__global__ __launch_bounds__(1024) void k_seq_objf_close(const double* __restrict__ wgagg, int nwg, float* __restrict__ total, unsigned* __restrict__ stats) {
+  __shared__ double part[3][1024];
+  __shared__ double wsum[3][16];
+  __shared__ unsigned smm[16]; __shared__ float sx[6][16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const size_t nw_ = (size_t)nwg;
+  const int lo = blockIdx.x * 1024, i = lo + t;
+  const bool last_wg = blockIdx.x == gridDim.x - 1;
+  double f0 = 0.0, f1 = 0.0, f2 = 0.0;                  // records in front of this workgroup's (the last workgroup: ALL the others -> the totals)
+  for (int j = t; j < lo; j += 1024) { f0 += wgagg[j]; f1 += wgagg[nw_ + j]; f2 += wgagg[2 * nw_ + j]; }
+  part[0][t] = f0; part[1][t] = f1; part[2][t] = f2;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (t < o) { part[0][t] += part[0][t + o]; part[1][t] += part[1][t + o]; part[2][t] += part[2][t + o]; } __syncthreads(); }
+  const double base0 = part[0][0], base1 = part[1][0], base2 = part[2][0];
+  const bool live = i < nwg;
+  const double v0 = live ? wgagg[i] : 0.0, v1 = live ? wgagg[nw_ + i] : 0.0, v2 = live ? wgagg[2 * nw_ + i] : 0.0;
+  const double i0 = wave_scan_d(v0), i1 = wave_scan_d(v1), i2 = wave_scan_d(v2);
+  if (lane == 63) { wsum[0][wv] = i0; wsum[1][wv] = i1; wsum[2][wv] = i2; }
+  __syncthreads();
+  double w0 = 0.0, w1 = 0.0, w2 = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int u = 0; u < 16; u++) { if (u == wv) { w0 = a0; w1 = a1; w2 = a2; } a0 += wsum[0][u]; a1 += wsum[1][u]; a2 += wsum[2][u]; }
+  const double r[3] = {base0 + w0 + (i0 - v0), base1 + w1 + (i1 - v1), base2 + w2 + (i2 - v2)};      // the sum in front of record i
+  unsigned mm = 0; float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const unsigned long long fl = (unsigned long long)__double_as_longlong(wgagg[6 * nw_ + i]);
+    if (fl & 1ull) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const unsigned long long pk = (unsigned long long)__double_as_longlong(wgagg[(3 + c) * nw_ + i]);
+        const float nn = (float)r[c], last = __uint_as_float((unsigned)(pk & 0xffffffffull)), prev = __uint_as_float((unsigned)(pk >> 32));
+        if (__float_as_uint(nn) != __float_as_uint(last)) { mm++; x[c] = fabsf(nn - last); }
+        if (fl & 2ull) x[3 + c] = fabsf(last - prev);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { mm += __shfl_xor(mm, m, 64); for (int c = 0; c < 6; c++) x[c] = fmaxf(x[c], __shfl_xor(x[c], m, 64)); }
+  if (lane == 0) { smm[wv] = mm; for (int c = 0; c < 6; c++) sx[c][wv] = x[c]; }
+  __syncthreads();
+  if (t == 0) {
+    unsigned sm = 0; float y[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 16; u++) { sm += smm[u]; for (int c = 0; c < 6; c++) y[c] = fmaxf(y[c], sx[c][u]); }
+    if (sm) atomicAdd(stats, sm);
+    for (int c = 0; c < 3; c++) { if (y[c] > 0.f) atomicMax(stats + 1 + c, __float_as_uint(y[c])); if (y[3 + c] > 0.f) atomicMax(stats + 9 + c, __float_as_uint(y[3 + c])); }
+    if (last_wg) {
+      const float t0 = (float)(base0 + a0), t1 = (float)(base1 + a1), t2 = (float)(base2 + a2);
+      total[0] = t0; total[1] = t1; total[2] = t2;
+      stats[4] = __float_as_uint(t0); stats[5] = __float_as_uint(t1); stats[6] = __float_as_uint(t2);
+    }
+  }
+}
+
 // ---- scans: start[s] <- sum of (end - start) over the chain's segments before s ------------------------------------------------
 // lanes = lane-chains (w), 16 waves split the chain's segments; the differences and their partial sums are fp64 operations on values
 // that fp32 can hold: exact.  mismatch counts the (segment, lane-chain) pairs whose new start differs from the one the pass used.
@@ -591,8 +877,9 @@ __global__ void k_obj_mtable(Dev D, const float* __restrict__ Of, const float* _
   M[i] = D.theta[b] * logf((o + e + 1.0f) / ((2.0f * e) + 1.0f));
 }
 // the three totals -> the objective snapshot obj[2..4]
-__global__ void k_obj_store(const float* __restrict__ total, double* __restrict__ obj) {
-  if (threadIdx.x == 0) { obj[2] = (double)total[0]; obj[3] = (double)total[1]; obj[4] = (double)total[2]; }      // (obj[5]: the chain's error word, left alone)
+__global__ void k_obj_store(const float* __restrict__ total, double* __restrict__ obj, const unsigned* __restrict__ xerr) {
+  if (threadIdx.x == 0) { obj[2] = (double)total[0]; obj[3] = (double)total[1]; obj[4] = (double)total[2];      // (obj[5]: the error word of in-launch exchanges)
+                          if (xerr && *xerr) obj[5] = (double)(*xerr & 15u); }
 }
 // cross-entropy term from the fp32 tables when only the tables follow the reference (oe_arith without obj_arith): obj[0..1] hold the
 // exact per-cell sums, the cross term is sum_kb sigma_k M[b][k] O[b][k]
@@ -708,7 +995,34 @@ void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nt
   else
     hipLaunchKernelGGL(k_seq_objr_pass<false>, dim3((nsegs + 255) / 256), dim3(256), 0, L.stream, D, M, nterms, Lseg, nsegs, start, end, zero_start, partial);
 }
-void l_obj_store(const Launch& L, const float* total, double* obj) { hipLaunchKernelGGL(k_obj_store, dim3(1), dim3(64), 0, L.stream, total, obj); }
+// the objective's three chains in one launch (k_seq_obj_fused).  mode 0: T = three term arrays at `stride`; mode 1: T = R % dist, the other two chains from R.
+// slots: [OBJF_MAXSTAGE][nwg + ngroups][8] granules, zeroed once at allocation; `epoch` must differ from launch to launch.  Returns false when the shape is
+// outside the kernel's envelope (K % 4, more than four covariates, more passes than slot sets): the caller falls back to the pass / scan launches.
+size_t seq_obj_fused_slot_words(long long nt) {      // granule slots [OBJF_MAXSTAGE][nwg + ngroups][8] + the workgroups' closing records [nwg][8]
+  const int nsegs = (int)((nt + OBJF_TPT - 1) / OBJF_TPT), nwg = (nsegs + OBJF_THREADS - 1) / OBJF_THREADS, ng = (nwg + 63) / 64;
+  return (size_t)OBJF_MAXSTAGE * ((size_t)nwg + ng) * 8 + (size_t)nwg * 8;
+}
+int seq_obj_fused_nsegs(long long nt) { return (int)((nt + OBJF_TPT - 1) / OBJF_TPT); }
+bool l_seq_obj_fused(const Launch& L, const Dev& D, int mode, const float* T, long long stride, const float* M, const int* olev, long long nt, int npass, int zero_start,
+                     float* starts, float* total, unsigned* stats, unsigned long long* slots, unsigned epoch) {
+  if (npass < 1 || npass > OBJF_MAXSTAGE || nt < 4) return false;
+  if (mode == 1 && (D.K % 4 != 0 || D.C > 4 || !olev)) return false;
+  const int nsegs = seq_obj_fused_nsegs(nt), nwg = (nsegs + OBJF_THREADS - 1) / OBJF_THREADS, ng = (nwg + 63) / 64;
+  SeqXchg X; X.slotA = slots; X.slotG = slots + (size_t)OBJF_MAXSTAGE * nwg * 8; X.epoch = epoch & 0x0fffffffu; X.ngroups = ng;
+  { const char* e = getenv("HMX_OBJF_DBG"); X.dbg = e ? atoi(e) : 0; }
+  double* const wgagg = reinterpret_cast<double*>(slots + (size_t)OBJF_MAXSTAGE * ((size_t)nwg + ng) * 8);
+  (void)hipMemsetAsync(stats, 0, 16 * sizeof(unsigned), L.stream);
+  const size_t deal = (size_t)OBJF_WAVES * 64 * OBJF_TPT * sizeof(float);
+  if (mode == 0) hipLaunchKernelGGL((k_seq_obj_fused<0, false>), dim3(nwg), dim3(OBJF_THREADS), deal, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);
+  else {
+    const size_t tab = ((size_t)D.B * D.K + D.K) * sizeof(float);
+    if (tab <= 24 * 1024) hipLaunchKernelGGL((k_seq_obj_fused<1, true>), dim3(nwg), dim3(OBJF_THREADS), deal + tab, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);
+    else hipLaunchKernelGGL((k_seq_obj_fused<1, false>), dim3(nwg), dim3(OBJF_THREADS), deal, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);
+  }
+  hipLaunchKernelGGL(k_seq_objf_close, dim3((nwg + 1023) / 1024), dim3(1024), 0, L.stream, wgagg, nwg, total, stats);
+  return true;
+}
+void l_obj_store(const Launch& L, const float* total, double* obj, const unsigned* xerr) { hipLaunchKernelGGL(k_obj_store, dim3(1), dim3(64), 0, L.stream, total, obj, xerr); }
 void l_obj_cross_f32(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M) {
   const int n = D.B * D.K;
   hipLaunchKernelGGL(k_obj_mtable, dim3((n + 255) / 256), dim3(256), 0, L.stream, D, Of, Ef, M);

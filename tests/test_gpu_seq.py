@@ -112,6 +112,26 @@ def test_restarted_sums_over_term_arrays_reach_the_sequential_loop():
         if passes == 32:
             assert np.array_equal(tot[:2].view(np.uint32), want[:2].view(np.uint32)), log
     print("restarted sums over term arrays (passes, rel. error per chain, segment starts still moving, largest relative move):", log)
+    # round 6: the one-launch form (k_seq_obj_fused: segments of 32 terms in registers, the scans between the passes through the in-launch exchange of
+    # workgroup aggregates) -- the same fixed point, reached the same way; several launches when more than 8 passes are asked for
+    log = []
+    for nn in (n, 1000, 36):
+        Tn = np.ascontiguousarray(T[:, :nn])
+        wn = np.array([_seq32(Tn[i])[-1] for i in range(3)], np.float32)
+        for passes in (2, 3, 5, 8, 32):
+            tot = np.empty(3, np.float32)
+            mm, res = C.c_int64(-1), C.c_double(-1)
+            st = _lib.load().hmx_debug_seq_arr(_fp(Tn), nn, 3, 0, passes, _fp(tot), C.byref(mm), C.byref(res))
+            assert st == 0
+            rel = np.abs(tot.astype(np.float64) - wn) / np.abs(wn)
+            log.append((nn, passes, rel.tolist(), mm.value, res.value))
+            if passes == 2:
+                assert rel[0] <= 2e-5 and rel[1] <= 2e-5, log
+            if passes == 3:
+                assert rel[0] <= 1e-6 and rel[1] <= 1e-6, log
+            if passes == 32:
+                assert np.array_equal(tot[:2].view(np.uint32), wn[:2].view(np.uint32)), log
+    print("the same in one launch (terms, passes, rel. error per chain, starts still moving, largest relative move):", log)
 
 
 def _iterate(obj, max_iter=10):
