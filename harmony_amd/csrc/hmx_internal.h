@@ -306,6 +306,9 @@ void l_ref_posord(const Launch& L, const Dev& D, uint64_t seed, uint64_t round, 
 // (listq: the combination of every entry of `list`, or nullptr -- the kernel then looks it up through D.combo, one more dependent load per batch)
 void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const int* listq, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
                       const float* start, float* end, int zero_start, unsigned* conv_zero);
+bool l_seq_ridge_pass_kl(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
+                         const float* start, float* end, int zero_start, unsigned* conv_zero);
+void l_seq_ridge_rows2lanes(const Launch& L, const float* in, float* out, int nchains, int K, int d);
 // (partial: [narr][ceil(nsegs / 256)] doubles, the deltas of every workgroup's 256 segments -- k_seq_scan1's bases)
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
                     int zero_start, double* partial, unsigned* conv_zero);

@@ -225,6 +225,90 @@ __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict
     if (k0 + kk < K) end[((size_t)seg * K + k0 + kk) * 64 + lane] = s[kk >> 1][kk & 1];
 }
 
+// (b') round 6: the same chains with lane = CLUSTER.  k_seq_ridge_pass (lane = PC) pays one v_readlane per (cell, cluster) to bring R_ki into a scalar
+//      operand and runs 13 waves of 8 clusters over every cell: 538 M wave-instructions per pass at 1M cells, 0.87 of its 1.1 ms pure VALU issue
+//      (profiles/r5_ref_arith_pmc_sq.txt).  Here a lane owns cluster k and holds the d + 1 accumulators of ITS (k, j) chains in registers (j < d: sum_i
+//      fl(z_ij R_ki); j = d: the mass sum_i R_ki, as fl(1 * R_ki)): R_ki is the lane's own coalesced load, the in-set flag its own byte, and the cell's
+//      embedding row is the wave-UNIFORM operand -- it comes through the scalar cache (s_load) and feeds v_pk_mul_f32 / v_pk_add_f32 from SGPR pairs, two
+//      PCs per instruction, each product rounded before it is added (no contraction: :592).  2 x NP VALU instructions per (cell, 64 clusters) and no
+//      cross-lane traffic at all.  Same chains, same order, same roundings as k_seq_ridge_pass: the totals are bit-identical.
+//      start / end: [segment][d + 1][K] (row j contiguous over the clusters: coalesced); k_seq_ridge_rows2lanes hands the chain totals to the consumers in
+//      k_seq_ridge_pass's [chain][K][64] layout.
+template <int ZS4>      // the embedding rows hold exactly 4 ZS4 floats (zs; zero beyond d)
+__global__ __launch_bounds__(256) void k_seq_ridge_pass_kl(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo, int K, int d, int KP8,
+                                                           const int* __restrict__ list, const SeqSeg* __restrict__ segs, int seg0, int nsegs, const unsigned char* __restrict__ inset,
+                                                           const float* __restrict__ start, float* __restrict__ end, int zero_start, unsigned* __restrict__ conv_zero) {
+#pragma clang fp contract(off)
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  constexpr int ZS = 4 * ZS4, NP = 2 * ZS4;
+  if (conv_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) conv_zero[threadIdx.x] = 0u;
+  // the waves that walk the SAME cells (the cluster groups of a segment) sit in one workgroup: the second one finds the rows in the CU's scalar cache
+  // (the scalar miss path is what bounds this kernel: one group per workgroup 0.92 ms per pass at 1M cells)
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int ngr = (K + 63) >> 6, gpw = ngr >= 4 ? 4 : ngr >= 2 ? 2 : 1, spw = 4 / gpw;       // cluster groups / segments per workgroup
+  const int sl = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * spw + wib / gpw));
+  const int grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * gpw + wib % gpw));
+  if (sl >= nsegs || grp >= ngr) return;
+  const int seg = seg0 + sl;
+  const int k = grp * 64 + lane, ks = min(k, K - 1);
+  const SeqSeg sg = segs[seg];
+  const size_t so = (size_t)seg * (d + 1) * K + ks;
+  const bool warm = !zero_start && k < K;
+  // accumulators: pair p = PCs 2 p, 2 p + 1 (slots beyond d: the rows' zero padding -- they add +0 and are never stored); the mass on its own
+  f32x2 acc[NP];
+  float mass = warm ? start[so + (size_t)d * K] : 0.0f;
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const float a0 = start[so + (size_t)min(2 * p, d) * K], a1 = start[so + (size_t)min(2 * p + 1, d) * K];      // (unconditional, clamped loads: no branch per row)
+    acc[p][0] = (warm && 2 * p < d) ? a0 : 0.0f; acc[p][1] = (warm && 2 * p + 1 < d) ? a1 : 0.0f;
+  }
+  for (int base = 0; base < sg.cnt; base += 64) {
+    const int nc = min(64, sg.cnt - base);
+    const int ci = sg.off + min(base + lane, sg.cnt - 1);
+    const int myc = list ? list[ci] : ci;
+    const int myq = combo[myc];
+    // the lane's own R value and in-set flag of the NEXT cell are requested while this cell's 2 NP packed operations run
+    int cell = __builtin_amdgcn_readlane(myc, 0), q = __builtin_amdgcn_readlane(myq, 0);
+    float rn = R[(size_t)cell * K + ks];
+    unsigned char fn = inset[(size_t)q * KP8 + ks];
+    for (int u = 0; u < nc; u++) {
+      const float r = rn * (fn ? 1.0f : 0.0f);                          // (a product, not a select around the load)
+      const f32x4_* __restrict__ zp = reinterpret_cast<const f32x4_*>(Zo + (size_t)cell * ZS);      // wave-uniform: the row comes through the scalar cache
+      const int un = min(u + 1, nc - 1);
+      cell = __builtin_amdgcn_readlane(myc, un); q = __builtin_amdgcn_readlane(myq, un);
+      rn = R[(size_t)cell * K + ks]; fn = inset[(size_t)q * KP8 + ks];
+      const f32x2 rr = {r, r};
+      f32x4_ zq[ZS4];
+#pragma unroll
+      for (int i = 0; i < ZS4; i++) zq[i] = zp[i];
+#pragma unroll
+      for (int i = 0; i < ZS4; i++) {
+        const f32x2 za = {zq[i][0], zq[i][1]}, zb = {zq[i][2], zq[i][3]};
+        acc[2 * i] = acc[2 * i] + za * rr;
+        acc[2 * i + 1] = acc[2 * i + 1] + zb * rr;
+      }
+      mass = __fadd_rn(mass, r);
+    }
+  }
+  if (k < K) {
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      if (2 * p < d) end[so + (size_t)(2 * p) * K] = acc[p][0];
+      if (2 * p + 1 < d) end[so + (size_t)(2 * p + 1) * K] = acc[p][1];
+    }
+    end[so + (size_t)d * K] = mass;
+  }
+  (void)ZS;
+}
+// chain totals [chain][d + 1][K] -> [chain][K][64] (lane j < d: the PCs, lane 63: the mass; the lanes between: 0)
+__global__ void k_seq_ridge_rows2lanes(const float* __restrict__ in, float* __restrict__ out, int nchains, int K, int d) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)nchains * K * 64) return;
+  const int j = (int)(i & 63); const size_t ck = i >> 6; const int k = (int)(ck % K); const size_t chain = ck / K;
+  const int row = j < d ? j : (j == 63 ? d : -1);
+  out[i] = row >= 0 ? in[(chain * (size_t)(d + 1) + row) * K + k] : 0.0f;
+}
+
 // (c) a contiguous array of terms (the objective's three K*N-term chains, one array each): thread = segment of L terms.
 //     Round 4: a thread reads one whole 128-byte line (32 terms) per step, the next line already in flight while the 32 dependent adds of
 //     this one run (round 3: 64 bytes per step and no prefetch -- with one wave per SIMD every step exposed a full memory latency).
@@ -961,6 +1045,27 @@ void l_seq_ridge_pass(const Launch& L, const Dev& D, const int* list, const int*
   const int kg = (D.K + 7) / 8, wpg = kg < 12 ? kg : 12;
   hipLaunchKernelGGL(k_seq_ridge_pass<8>, dim3(nsegs, (kg + wpg - 1) / wpg), dim3(64 * wpg), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, D.zs, (D.K + 7) / 8 * 8, list, listq, segs,
                      seg0, inset, start, end, zero_start, conv_zero);
+}
+// lane = cluster form (round 6): start / end hold [segment][d + 1][K]; false for embedding rows of more than 64 floats
+bool l_seq_ridge_pass_kl(const Launch& L, const Dev& D, const int* list, const SeqSeg* segs, int seg0, int nsegs, const unsigned char* inset,
+                         const float* start, float* end, int zero_start, unsigned* conv_zero) {
+  if (D.zs > 64 || D.zs % 4 != 0 || D.d > D.zs) return false;
+  if (nsegs <= 0) { if (conv_zero) (void)hipMemsetAsync(conv_zero, 0, 2 * sizeof(unsigned), L.stream); return true; }
+  const int ngr = (D.K + 63) / 64, gpw = ngr >= 4 ? 4 : ngr >= 2 ? 2 : 1, spw = 4 / gpw;
+  const dim3 grid((nsegs + spw - 1) / spw, (ngr + gpw - 1) / gpw);
+  const int KP8 = (D.K + 7) / 8 * 8;
+#define HMX_RPKL(Z4) case Z4: hipLaunchKernelGGL((k_seq_ridge_pass_kl<Z4>), grid, dim3(256), 0, L.stream, D.R, D.Zo, D.combo, D.K, D.d, KP8, list, segs, seg0, nsegs, inset, start, end, zero_start, conv_zero); break;
+  switch (D.zs / 4) {
+    HMX_RPKL(1) HMX_RPKL(2) HMX_RPKL(3) HMX_RPKL(4) HMX_RPKL(5) HMX_RPKL(6) HMX_RPKL(7) HMX_RPKL(8) HMX_RPKL(9) HMX_RPKL(10) HMX_RPKL(11) HMX_RPKL(12) HMX_RPKL(13) HMX_RPKL(14)
+    HMX_RPKL(15) HMX_RPKL(16)
+    default: return false;
+  }
+#undef HMX_RPKL
+  return true;
+}
+void l_seq_ridge_rows2lanes(const Launch& L, const float* in, float* out, int nchains, int K, int d) {
+  const size_t n = (size_t)nchains * K * 64;
+  hipLaunchKernelGGL(k_seq_ridge_rows2lanes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, L.stream, in, out, nchains, K, d);
 }
 void l_seq_arr_pass(const Launch& L, const float* T, long long n, long long stride, int narr, int Lseg, int nsegs, const float* start, float* end,
                     int zero_start, double* partial, unsigned* conv_zero) {
