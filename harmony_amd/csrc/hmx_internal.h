@@ -26,6 +26,7 @@ struct Dev {
   int n;            // local cells
   int d, K, B, C, Q;
   int B0;           // number of levels of covariate 0 (rowsum(R) = sum of its O columns)
+  int cov_end[4];   // cumulative level counts of the first four covariates (B beyond the last one): which covariates a range of levels belongs to
   int upd_cpw;      // cells per wave in the update kernel
   int KP;           // K rounded up to a multiple of 64
   int zs;           // row stride of Zo/Zc in floats: d rounded up to a multiple of 4 (16-byte rows), pads are 0

@@ -143,6 +143,100 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   }
 }
 
+// (a') round 6: MANY levels (B > 32: BASELINE configs[4] has 200 in three nested covariates).  The LDS rows of the form above cost a dependent LDS
+//      read-modify-write per (cell, covariate) -- 452 us per pass over a 50k-cell block, 55 % of a reference-arithmetic run at that shape -- and, with
+//      (1 + B) K = 40 200 lane-chains per 128-cell segment, more workspace traffic than the block's R rows.  Here the levels are dealt to LEVEL GROUPS of 32:
+//      wave g of a workgroup owns the rows of levels [32 g, 32 g + 32) in REGISTERS (the fast path above), all waves of the workgroup walk the same
+//      (segment, 64 clusters) -- the R values come from L1 for all but the first -- and a cell's level is a wave-uniform compare + branch per covariate:
+//      the row is touched by the one wave that owns it.  Row 0 (every cell) belongs to group 0.  Segments are long (512 cells: a quarter of the
+//      workspace traffic; the adds per wave stay short because a wave only meets the cells of its own levels).
+__global__ __launch_bounds__(512) void k_seq_oe_pass_lg(const float* __restrict__ R, int K, int B, int C, const int* __restrict__ list,
+                                                        const int* __restrict__ poslev, int nlist, const int* __restrict__ combo, const int* __restrict__ qlev,
+                                                        const SeqSeg* __restrict__ segs, int seg0, int nsegs, int4 cb,
+                                                        const float* __restrict__ start, float* __restrict__ end, int zero_start, unsigned* __restrict__ conv_zero) {
+  if (conv_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) conv_zero[threadIdx.x] = 0u;
+  const int lane = threadIdx.x & 63;
+  const int lg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));         // level group of this wave
+  const int b_lo = 32 * lg;
+  if (b_lo >= B) return;
+  int cmask = 0;                     // covariates (of the first four) with a level in [b_lo, b_lo + 32): cb = their cumulative ends
+  { int lo = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { const int hi = c == 0 ? cb.x : c == 1 ? cb.y : c == 2 ? cb.z : cb.w; if (c < C && lo < b_lo + 32 && hi > b_lo) cmask |= 1 << c; lo = hi; } }
+  cmask = __builtin_amdgcn_readfirstlane(cmask);
+  const int seg = seg0 + blockIdx.x;
+  const int k = blockIdx.y * 64 + lane, ks = min(k, K - 1);
+  const SeqSeg sg = segs[seg];
+  const size_t so = (size_t)seg * (1 + B) * K + ks;
+  float s0 = (zero_start || k >= K || lg != 0) ? 0.0f : start[so];
+  LvRows<32> lv;
+#pragma unroll
+  for (int b = 0; b < 32; b++) lv.v[b >> 4][b & 15] = (zero_start || k >= K || b_lo + b >= B) ? 0.0f : start[so + (size_t)(1 + min(b_lo + b, B - 1)) * K];
+  struct Ids { int myc, myq, lev[4]; };
+  auto fetch_ids = [&](const int base) __attribute__((always_inline)) {
+    Ids I; I.myq = 0; I.lev[0] = I.lev[1] = I.lev[2] = I.lev[3] = 0;
+    const int ci = sg.off + min(base + lane, sg.cnt - 1);
+    I.myc = list ? list[min(ci, sg.off + sg.cnt - 1)] : ci;
+    if (poslev && C <= 4) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) I.lev[c] = poslev[(size_t)min(c, C - 1) * nlist + ci];
+    } else {
+      I.myq = combo[I.myc];
+#pragma unroll
+      for (int c = 0; c < 4; c++) I.lev[c] = qlev[I.myq * C + min(c, C - 1)];
+    }
+    return I;
+  };
+  auto fetch_r = [&](const Ids& I, float (&r)[64]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 64; u++) {
+      const int cell = __builtin_amdgcn_readlane(I.myc, u);
+      r[u] = R[(size_t)cell * K + ks];
+    }
+  };
+  Ids idc = fetch_ids(0), idn = fetch_ids(64);
+  float rc[64], rn[64];
+  fetch_r(idc, rc);
+  for (int base = 0; base < sg.cnt; base += 64) {
+    const int nc = min(64, sg.cnt - base);
+    const bool more = base + 64 < sg.cnt;
+    if (more) fetch_r(idn, rn);
+    const Ids idnn = fetch_ids(base + 128);
+    if (lg == 0) {
+#pragma unroll
+      for (int u = 0; u < 64; u++) if (u < nc) s0 = __fadd_rn(s0, rc[u]);
+    }
+    // covariate by covariate (a row belongs to ONE covariate: the order of its own cells is all that matters), and only the covariates whose levels
+    // meet this wave's 32: one compare per cell for most waves instead of one per (cell, covariate)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (c < C && ((cmask >> c) & 1)) {
+#pragma unroll
+        for (int u = 0; u < 64; u++) {
+          if (u < nc) {
+            const int b = __builtin_amdgcn_readlane(idc.lev[c], u) - b_lo;
+            if (b >= 0 && b < 32) lv_add<32>(lv, b, rc[u]);
+          }
+        }
+      }
+    }
+    for (int c = 4; c < C; c++) {
+      for (int u = 0; u < nc; u++) {
+        const int b = __builtin_amdgcn_readfirstlane(qlev[__builtin_amdgcn_readlane(idc.myq, u) * C + c]) - b_lo;
+        if (b >= 0 && b < 32) lv_add<32>(lv, b, rc[u]);
+      }
+    }
+    idc = idn; idn = idnn;
+#pragma unroll
+    for (int u = 0; u < 64; u++) rc[u] = rn[u];
+  }
+  if (k < K) {
+    if (lg == 0) end[so] = s0;
+#pragma unroll
+    for (int b = 0; b < 32; b++) if (b_lo + b < B) end[so + (size_t)(1 + b_lo + b) * K] = lv.v[b >> 4][b & 15];
+  }
+}
+
 // (b) ridge statistics of KPW = 8 clusters per wave: W = K * 64 lane-chains per segment.  lane j < d: sum_i fl(z_ij * R_ki)
 //     (Z_tmp = Z_orig % R_k is rounded to fp32 first, src/harmony.cpp:592); lane 63: sum_i R_ki (the matching entry of
 //     Phi* diag(R_k) Phi*^T, :567).  A cell enters cluster k's regression only if one of its levels is kept for k (:400,456-460):
@@ -1022,6 +1116,13 @@ void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* po
     const dim3 grid((nsegs + 3) / 4, (D.K + 63) / 64);
     if (D.B <= 16) hipLaunchKernelGGL((k_seq_oe_pass<true, 16>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
     else hipLaunchKernelGGL((k_seq_oe_pass<true, 32>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
+    return;
+  }
+  if (D.B <= 256) {                        // level groups of 32, rows in registers (round 6; B <= 8 x 32: one wave per group)
+    int4 cb = {D.B, D.B, D.B, D.B};                 // cumulative level counts of the first four covariates (from the combinations' level codes: D.cov_end)
+    cb.x = D.cov_end[0]; cb.y = D.cov_end[1]; cb.z = D.cov_end[2]; cb.w = D.cov_end[3];
+    hipLaunchKernelGGL(k_seq_oe_pass_lg, dim3(nsegs, (D.K + 63) / 64), dim3(64 * ((D.B + 31) / 32)), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0,
+                       nsegs, cb, start, end, zero_start, conv_zero);
     return;
   }
   int wpb = 4;                                           // waves per workgroup, limited by the level rows in LDS
