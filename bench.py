@@ -107,11 +107,13 @@ def cpu_baseline(cells, d, K, levels, nested, seed):
             break
     v1, it, dt, blas = out["one"]
     va, _, dta, _ = out["all"]
-    return {"value": v1, "unit": "cells/s", "cores": 1, "kind": "port", "reference_sources": _reference_sources_cpu(d, K, levels, nested, seed),
+    return {"value": v1, "unit": "cells/s", "cores": 1, "kind": "port", "value_measured_on": "%d-cell sample of the workload (--cpu-sample; --cpu-full times the full size, ~1 min at 1M)" % cells,
+            "reference_sources": _reference_sources_cpu(d, K, levels, nested, seed),
             "sample": "oracle (faithful fp32%s), %d cells x %d PCs, K=%d, levels %s, to convergence (%d iterations, %.1f s); the "
                       "algorithm is O(N) per iteration, so cells/s at the full size is the same figure up to the iteration count"
                       % (", OpenBLAS sgemm" if blas else "", cells, d, K, "x".join(map(str, levels)), it, dt),
-            "all_cores": {"value": va, "cores": ncpu, "seconds": dta},
+            "all_cores": {"value": va, "cores": ncpu, "seconds": dta,
+                          "note": "only the distance GEMM is threaded (as in the reference with ncores > 1, R/ui.R:123-128): the sequential accumulators dominate, more cores do not help"},
             "host_cores_available": ncpu, "full_size": _full_size_cpu(),
             "gpu_reference_arith_vs_this_run": ref_check}
 
@@ -205,16 +207,47 @@ def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps,
     ach = upd_cells * (4.0 * d + 4.0 * K) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     out = {"workload": label,
            "ms_per_step": ms, "cells_per_s": n / (ms * 1e-3), "harmony_iterations": its, "steps": steps, "gpu_phase_ms_per_step": ph, "gpu_phase_from": "one extra untimed run with per-phase events",
-           "block_chain": chain, "avg_block_step_us": 1e3 * upd_ms / upd_steps,
+           "block_chain": chain and not hkw.get("ref_arith"), "avg_block_step_us": 1e3 * upd_ms / upd_steps,
            # the leg's own dominant kernel (the E-step update of update_R, as on the main line): algorithmic bytes (4d + 4K per cell and
            # round) over its HIP-event time on the library's stream
-           "roofline": {"kernel": ("k_tile<%d,4,...> persistent block chain" if chain else "k_tile<%d,0,...> one launch per block step") % ((K + 15) // 16),
+           "roofline": {"kernel": ("k_tile<%d,4|5,...> persistent block chain" if (chain and not hkw.get("ref_arith")) else "k_tile<%d,0,...> one launch per block step") % ((K + 15) // 16),
                         "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                         "kernel_time_share": upd_ms / (ms * steps) if ms > 0 else None},
            "roofline_run_frac": run_bytes / (ms * 1e-3) / 8e12}
     if hkw:
         out["mode"] = hkw
         out["seq_residual"] = o._scalar("seq:residual")
+    if hkw.get("ref_arith"):
+        # The reference-arithmetic leg is not the tile kernel's leg: its time goes into the restarted sequential sums.  Roofline of its
+        # own dominant phase, from the per-phase HIP-event brackets of the extra untimed run: algorithmic bytes = what the sums of that phase have to read.
+        # (`passes` per group from the object: O/E, objective, ridge, level pairs; "seq:oe_cell_passes" = cells x passes the O / E sums walked since setup.)
+        runs_total = warmup + steps + 1
+        passes = [float(x) for x in o._get("seq:group_passes")]
+        evals = [float(x) for x in o._get("seq:group_runs")]
+        oe_cells = float(o._scalar("seq:oe_cell_passes")) / runs_total
+        C_ = len(levels)
+        phases = {
+            "EO_update": {"kernels": "k_seq_oe_pass + k_seq_scan (+ k_oe_fold): a block's (all blocks') O / E sums in the round's shuffled order, src/harmony.cpp:312-313,329-330",
+                          "alg_bytes": oe_cells * 4.0 * K, "what": "the R rows of the cells a pass walks (4K per cell and pass)"},
+            "objective": {"kernels": "k_obj_terms_mfma + k_seq_obj_fused + k_seq_objf_close: compute_objective's three my_accu chains, src/utils.cpp:67-75",
+                          "alg_bytes": evals[1] / runs_total * float(n) * (4.0 * d + 16.0 * K),
+                          "what": "per evaluation: embedding + R rows in, R % dist out (terms), then R % dist + R rows in once (the passes run from registers)"},
+            "ridge_statistics": {"kernels": "k_seq_ridge_pass_kl + k_seq_scan: Phi* diag(R_k) Z^T as sequential sums, src/harmony.cpp:592-608",
+                                 "alg_bytes": passes[2] / runs_total * float(n) * (1.0 + C_) * (4.0 * d + 4.0 * K), "what": "per pass every cell once per chain it is in (all cells + one level per covariate): its embedding row and its R row"},
+        }
+        dom = max(phases, key=lambda kk: ph.get(kk, 0.0))
+        for kk, v in phases.items():
+            t_ms = ph.get(kk, 0.0)
+            v["gpu_ms_per_step"] = t_ms
+            v["achieved"] = v["alg_bytes"] / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+            v["frac"] = v["achieved"] / 8000.0
+            v["share_of_step"] = t_ms / ms if ms > 0 else None
+        out["roofline_tile_kernel"] = out["roofline"]          # (the E-step update kernel of this leg: 9-10 % of its time)
+        out["roofline"] = {"kernel": phases[dom]["kernels"], "phase": dom, "bound": "hbm (latency-bound in practice: chains of dependent small launches)", "achieved": phases[dom]["achieved"],
+                           "peak": 8000.0, "unit": "GB/s", "frac": phases[dom]["frac"], "traffic": None, "kernel_time_share": phases[dom]["share_of_step"],
+                           "achieved_is": "algorithmic bytes of the phase (%s) over its GPU time from HIP-event brackets around the phase (one extra untimed run)" % phases[dom]["what"],
+                           "by_phase": {kk: {q: v[q] for q in ("gpu_ms_per_step", "achieved", "frac", "share_of_step")} for kk, v in phases.items()},
+                           "passes_per_step": {"O/E": passes[0] / runs_total, "objective": passes[1] / runs_total, "ridge": passes[2] / runs_total, "level_pairs": passes[3] / runs_total}}
     del o
     return out
 
@@ -521,6 +554,7 @@ def main():
     ap.add_argument("--clusters", type=int, default=None)
     ap.add_argument("--batches", type=int, default=None, help="levels of the one covariate (default 10 = configs[2]; 20 with the configs[3] default of --gpus N > 1)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="cells for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline at the FULL workload size in this run (~1 min at 1M cells) instead of replaying the committed figure")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--no-e2e", action="store_true", help="skip the T_e2e measurement (ingest + egress over PCIe)")
     ap.add_argument("--pmc", action="store_true", help="N = 1: collect the dominant kernel's HBM traffic and MFMA-busy counters with rocprofv3 first (three separate "
@@ -951,7 +985,7 @@ def main():
             out["value_reference_arith"] = ra["cells_per_s"]
             out["ms_per_step_reference_arith"] = ra["ms_per_step"]
     if rank == 0 and world == 1 and a.cpu_sample > 0:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, d, K, levels, nested, a.seed)
+        out["cpu_baseline"] = cpu_baseline(n if a.cpu_full else a.cpu_sample, d, K, levels, nested, a.seed)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

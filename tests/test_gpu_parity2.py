@@ -339,6 +339,120 @@ def test_r_compatible_stream_end_to_end(case, cell_lines):
     assert relfro(g2.Y, g.Y) > 1e-3
 
 
+def _run_shards_as_threads(Z, meta, vars_use, G, K, seed, Y0, max_iter=10):
+    """G handles (one thread each) holding contiguous cell shards of ONE job on this GPU: the production sharded code path, the all-reduce hook a thread
+    rendezvous (as tests/test_gpu_parity.py::_run_sharded; any covariate structure, shared initial centroids).  Returns Z_corr (d x N), R (K x N),
+    kmeans_rounds, harmony iterations."""
+    import ctypes
+    import threading
+    from harmony_amd.dist import shard_bounds
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipDeviceSynchronize.argtypes = []
+    N = Z.shape[0]
+    vars_use = [vars_use] if isinstance(vars_use, str) else list(vars_use)
+    bounds = shard_bounds(N, G)
+    barrier = threading.Barrier(G)
+    slots, results, errors = [None] * G, [None] * G, []
+    nlev = {v: int(np.max(meta[v])) + 1 for v in vars_use}
+    N_b = np.concatenate([np.bincount(meta[v], minlength=nlev[v]).astype(float) for v in vars_use])
+
+    def hook_for(rank):
+        def hook(user, buf, count, dtype, stream):
+            assert hip.hipDeviceSynchronize() == 0
+            host = np.empty(count, dtype=np.float64 if dtype == 1 else np.int64)
+            assert hip.hipMemcpy(host.ctypes.data, buf, host.nbytes, 2) == 0
+            slots[rank] = host
+            barrier.wait()
+            st = np.stack(slots)
+            red = st.min(axis=0) if dtype == 2 else st.sum(axis=0)
+            barrier.wait()
+            assert hip.hipMemcpy(buf, red.ctypes.data, red.nbytes, 1) == 0
+            barrier.wait()
+            return 0
+        return hook
+
+    def work(rank):
+        try:
+            lo, hi = bounds[rank]
+            m = {k: v[lo:hi] for k, v in meta.items()}
+            skw, _ = prepare_setup_args(Z[lo:hi], m, vars_use, nclust=K, N_b=N_b, levels={v: np.arange(nlev[v]) for v in vars_use})
+            g = Harmony(seed=seed)
+            g.set_shard(rank, G, lo, N, hook_for(rank))
+            g.setup(**skw)
+            g.init_cluster_cpp(Y0)
+            it = 0
+            for it in range(1, max_iter + 1):
+                assert g.cluster_cpp() == 0
+                g.moe_correct_ridge_cpp()
+                if g.check_convergence(1):
+                    break
+            results[rank] = (g.getZcorr(), g.R, np.array(g.kmeans_rounds), it)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
+    return (np.concatenate([r[0] for r in results], axis=1), np.concatenate([r[1] for r in results], axis=1), results[0][2], results[0][3])
+
+
+@pytest.mark.timeout(1500, method="thread")
+@pytest.mark.parametrize("case", ["configs3_share", "configs4_shape"])
+def test_sharded_runs_return_the_reference_in_double_precision(case):
+    """WHICH result a multi-GPU run returns ("Which result a sharded run returns").  The reference's fp32 accumulators are
+    sequential sums over ALL cells in orders that interleave the shards cell by cell (a block's shuffled order, src/harmony.cpp:285-313), so their rounding
+    cannot be formed shard-locally; a sharded run therefore targets what the reference's own sources compute when built with the reference's own precision
+    switch (-DHARMONY_SCALAR_DOUBLE, src/types.h:5-9): exact accumulators, identical for every shard count.  Two shards of one job on this GPU (the
+    production sharded path) against oracle/_ref/libharmony_ref_f64.so, same centroids, same shuffles, to convergence, at the two 8-GPU configs' shapes:
+    configs[3]'s per-rank share scaled by ten (125k cells x 50 PCs, K = 100, 20 batches; the full 1.25M share with HMX_SLOW=1) and configs[4]'s shape
+    (K = 200, three nested covariates 8 > 64 > 128)."""
+    from oracle import ref as oref
+    if not oref.available():
+        pytest.skip("oracle/_ref/libharmony_ref_f64.so did not travel with the tree")
+    from oracle.oracle import feistel_order
+    seed = 3
+    if case == "configs3_share":
+        N, K = (1250000 if os.environ.get("HMX_SLOW") == "1" else 125000), 100
+        Z, meta, _ = synth(N, d=50, levels=(20,), seed=7)
+    else:
+        N, K = 30000, 200
+        Z, meta, _ = synth(N, d=50, levels=(8, 64, 128), seed=7, nested=True)
+    vars_use = list(meta)
+    skw, _ = prepare_setup_args(Z, meta, vars_use, nclust=K)
+    one = Harmony(seed=seed)
+    one.setup(**skw)
+    Y0 = one.kmeans_centers()
+    one.init_cluster_cpp(Y0)
+    i1 = _iterate(one)
+    Zs, Rs, rounds_s, i_s = _run_shards_as_threads(Z, meta, vars_use, 2, K, seed, Y0)
+    r = oref.RefHarmony(seed=seed, double=True)
+    r.setup(**skw)
+    r.init_cluster_cpp(Y0)
+    done, i64 = 0, 0
+    for i64 in range(1, 11):
+        r.clear_update_orders()
+        for k in range(4):
+            r.push_update_order(feistel_order(seed, done + k, N))
+        assert r.cluster_cpp() == 0
+        done = int(np.sum(r.kmeans_rounds))
+        r.moe_correct_ridge_cpp()
+        if r.check_convergence(1):
+            break
+    Z64, R64 = r.getZcorr(), r.R
+    s = dict(case=case, cells=N, sharded_vs_reference_double=relfro(Zs, Z64), one_gpu_vs_reference_double=relfro(one.getZcorr(), Z64), sharded_vs_one_gpu=relfro(Zs, one.getZcorr()),
+             R_maxabs=float(np.abs(Rs - R64).max()), clear_flips=_flips(Rs, R64, 1e-5)[1], iterations=(i_s, i1, i64))
+    print("two shards vs the reference's sources in double precision:", s)
+    assert i_s == i64 == i1 and np.array_equal(rounds_s, r.kmeans_rounds), s
+    assert s["sharded_vs_reference_double"] <= 5e-6 and s["clear_flips"] == 0 and s["R_maxabs"] <= 1e-4, s
+    assert s["sharded_vs_one_gpu"] <= 1e-6, s
+
+
 # ---------------------------------------------------------------- the default mode against the reference's own sources in double precision
 def test_default_mode_against_the_reference_in_double_precision():
     """oracle/_ref/libharmony_ref_f64.so: the reference's own harmony.cpp / utils.cpp built with the reference's own precision switch
