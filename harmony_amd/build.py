@@ -15,7 +15,7 @@ SRC = [os.path.join(HERE, "csrc", f) for f in ("hmx_kernels.hip", "hmx_tile_bf.h
 _INC = [os.path.join(HERE, "csrc", f) for f in ("hmx_k_stream.inc", "hmx_k_tile.inc", "hmx_k_correct.inc", "hmx_k_launch.inc")]      # the kernels, by section (included by hmx_kernels.hip)
 _API_INC = [os.path.join(HERE, "csrc", "hmx_api_%s.inc" % f) for f in ("seam", "kmeans", "refarith", "update", "ridge", "p2p", "setup", "diag")]    # the host orchestration, by section (included by hmx_api.cpp)
 EXTRA_DEP = {"hmx_kernels.hip": _INC, "hmx_tile_bf.hip": [os.path.join(HERE, "csrc", "hmx_kernels.hip")] + _INC, "hmx_api.cpp": _API_INC}
-HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "csrc", "hmx_rrng.h"), os.path.join(HERE, "..", "include", "harmony_mi355x.h")]
+HDR = [os.path.join(HERE, "csrc", "hmx_internal.h"), os.path.join(HERE, "csrc", "hmx_rrng.h"), os.path.join(HERE, "..", "include", "harmony_mi355x.h"), os.path.join(HERE, "..", "include", "harmony_mi355x_lab.h")]
 OUT = os.path.join(HERE, "lib", "libharmony_mi355x.so")
 
 

@@ -2,7 +2,7 @@
 // Mirrors the reference's `harmony` object (src/harmony.h:20-70): same methods, same
 // per-call operation order, but every pass over the cells is a gfx950
 // kernel (hmx_kernels.hip) and all per-cell state stays in HBM between calls.
-#include "../../include/harmony_mi355x.h"
+#include "../../include/harmony_mi355x_lab.h"      // (the reference interface + the probes / tuning declarations: the library defines both)
 #include "hmx_internal.h"
 #include "hmx_rrng.h"
 

@@ -46,12 +46,15 @@ namespace hmx {
 // write of the cell before, the compiler cannot prove the rows differ -- cost 150-200: a 128-cell segment took 20 us, 10 of them there.
 // (vector-typed rows: a dynamic but UNIFORM element index is register-indexed addressing -- s_set_gpr_idx / v_movrel --, three instructions;
 //  a switch over 32 cases inside the 64-cell unrolled loop kept hipcc from unrolling it and sent the R values to scratch)
+// (round 6: 32 rows as ONE 32-element vector -- two 16-element vectors behind `if (b < 16)` made hipcc copy the whole second vector around every indexed add)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int NLV> struct LvRows { f32x16 v[NLV > 0 ? NLV / 16 : 1]; };
-template <int NLV> __device__ __forceinline__ void lv_add(LvRows<NLV>& lv, const int b, const float r) {
-  if constexpr (NLV == 16) lv.v[0][b] = __fadd_rn(lv.v[0][b], r);
-  else if constexpr (NLV == 32) { if (b < 16) lv.v[0][b] = __fadd_rn(lv.v[0][b], r); else lv.v[1][b - 16] = __fadd_rn(lv.v[1][b - 16], r); }
-}
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+template <int NLV> struct LvVec { typedef f32x16 type; };
+template <> struct LvVec<32> { typedef f32x32 type; };
+template <int NLV> struct LvRows {
+  typename LvVec<NLV>::type w;
+};
+template <int NLV> __device__ __forceinline__ void lv_add(LvRows<NLV>& lv, const int b, const float r) { lv.w[b] = __fadd_rn(lv.w[b], r); }
 template <bool ROWS, int NLV = 0>
 __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R, int K, int B, int C, const int* __restrict__ list,
                                                      const int* __restrict__ poslev, int nlist,
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   LvRows<NLV> lv;
   if constexpr (ROWS && NLV > 0) {
 #pragma unroll
-    for (int b = 0; b < NLV; b++) lv.v[b >> 4][b & 15] = (zero_start || k >= K || b >= B) ? 0.0f : start[so + (size_t)(1 + min(b, B - 1)) * K];
+    for (int b = 0; b < NLV; b++) lv.w[b] = (zero_start || k >= K || b >= B) ? 0.0f : start[so + (size_t)(1 + min(b, B - 1)) * K];
   } else if constexpr (ROWS) for (int b = 0; b < B; b++) acc[b * 64] = (zero_start || k >= K) ? 0.0f : start[so + (size_t)(1 + b) * K];
   // software pipeline over the batches of 64 cells: the ids (cell, level codes) of batch b + 2 and the 64 R loads of batch b + 1 are in
   // flight while batch b is added up -- a segment of 128 cells costs two memory round trips instead of four
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
     end[so] = s0;
     if constexpr (ROWS && NLV > 0) {
 #pragma unroll
-      for (int b = 0; b < NLV; b++) if (b < B) end[so + (size_t)(1 + b) * K] = lv.v[b >> 4][b & 15];
+      for (int b = 0; b < NLV; b++) if (b < B) end[so + (size_t)(1 + b) * K] = lv.w[b];
     } else if constexpr (ROWS) for (int b = 0; b < B; b++) end[so + (size_t)(1 + b) * K] = acc[b * 64];
   }
 }
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(512) void k_seq_oe_pass_lg(const float* __restrict_
   float s0 = (zero_start || k >= K || lg != 0) ? 0.0f : start[so];
   LvRows<32> lv;
 #pragma unroll
-  for (int b = 0; b < 32; b++) lv.v[b >> 4][b & 15] = (zero_start || k >= K || b_lo + b >= B) ? 0.0f : start[so + (size_t)(1 + min(b_lo + b, B - 1)) * K];
+  for (int b = 0; b < 32; b++) lv.w[b] = (zero_start || k >= K || b_lo + b >= B) ? 0.0f : start[so + (size_t)(1 + min(b_lo + b, B - 1)) * K];
   struct Ids { int myc, myq, lev[4]; };
   auto fetch_ids = [&](const int base) __attribute__((always_inline)) {
     Ids I; I.myq = 0; I.lev[0] = I.lev[1] = I.lev[2] = I.lev[3] = 0;
@@ -220,10 +223,13 @@ __global__ __launch_bounds__(512) void k_seq_oe_pass_lg(const float* __restrict_
         }
       }
     }
-    for (int c = 4; c < C; c++) {
-      for (int u = 0; u < nc; u++) {
-        const int b = __builtin_amdgcn_readfirstlane(qlev[__builtin_amdgcn_readlane(idc.myq, u) * C + c]) - b_lo;
-        if (b >= 0 && b < 32) lv_add<32>(lv, b, rc[u]);
+    for (int c = 4; c < C; c++) {       // (more than four covariates: level codes straight from the table; u unrolled -- a dynamic index would send rc to scratch)
+#pragma unroll
+      for (int u = 0; u < 64; u++) {
+        if (u < nc) {
+          const int b = __builtin_amdgcn_readfirstlane(qlev[__builtin_amdgcn_readlane(idc.myq, u) * C + c]) - b_lo;
+          if (b >= 0 && b < 32) lv_add<32>(lv, b, rc[u]);
+        }
       }
     }
     idc = idn; idn = idnn;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(512) void k_seq_oe_pass_lg(const float* __restrict_
   if (k < K) {
     if (lg == 0) end[so] = s0;
 #pragma unroll
-    for (int b = 0; b < 32; b++) if (b_lo + b < B) end[so + (size_t)(1 + b_lo + b) * K] = lv.v[b >> 4][b & 15];
+    for (int b = 0; b < 32; b++) if (b_lo + b < B) end[so + (size_t)(1 + b_lo + b) * K] = lv.w[b];
   }
 }
 
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __res
 //         codes in original cell order, `olev`) with exactly the roundings of k_obj_terms / k_seq_objr_pass.  K % 4 == 0.
 // stats: [0] starts that still moved in the last stage, [1 + c] the largest move of a start of chain c (float bits), [4 + c] the chain totals (float
 //        bits), [7] error word, [8] the ticket counter -- zeroed by the host in front of the launch (one 64-byte memset).
-struct SeqXchg { unsigned long long* slotA; unsigned long long* slotG; unsigned epoch; int ngroups; int dbg; };
+struct SeqXchg { unsigned long long* slotA; unsigned long long* slotG; unsigned epoch; int ngroups; };
 __device__ __forceinline__ void xg_put3(unsigned long long* slot, const int lane, const unsigned tag, const double a0, const double a1, const double a2) {
   if (lane < 6) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(lane < 2 ? a0 : lane < 4 ? a1 : a2);
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* const lbuf = lds_ + (size_t)wave * 64 * OBJF_TPT;
   float* const ltab = lds_ + (size_t)OBJF_WAVES * 64 * OBJF_TPT;
-  if (tid == 0) wgid = (X.dbg & 4) ? blockIdx.x : atomicAdd(stats + 8, 1u);
+  if (tid == 0) wgid = atomicAdd(stats + 8, 1u);
   if constexpr (MODE == 1 && LDSTAB) {
     for (int i = tid; i < D.B * D.K; i += OBJF_THREADS) ltab[i] = M[i];
     for (int i = tid; i < D.K; i += OBJF_THREADS) ltab[D.B * D.K + i] = D.sigma[i];
@@ -712,9 +718,6 @@ __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const 
       k += 4; if (k >= K) { k -= K; cell++; }
     }
   }
-  const bool clk = (X.dbg & 8) && tid == 0;
-  unsigned long long tk0 = 0, tk1 = 0;
-  if (clk) { tk0 = wall_clock64(); }
   float st0 = 0.0f, st1 = 0.0f, st2 = 0.0f, pv0 = 0.0f, pv1 = 0.0f, pv2 = 0.0f;
   if (!zero_start && live) { st0 = starts[seg]; st1 = starts[(size_t)nsegs + seg]; st2 = starts[2 * (size_t)nsegs + seg]; }
   for (int p = 0; p < npass; p++) {
@@ -722,7 +725,6 @@ __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const 
 #pragma unroll
     for (int i = 0; i < OBJF_TPT; i++) { s0 = __fadd_rn(s0, a[i]); s1 = __fadd_rn(s1, b[i]); s2 = __fadd_rn(s2, c[i]); }      // (a masked term is +0: it leaves the accumulator as it is)
     const double d0 = live ? (double)s0 - (double)st0 : 0.0, d1 = live ? (double)s1 - (double)st1 : 0.0, d2 = live ? (double)s2 - (double)st2 : 0.0;
-    if (clk) { tk1 = wall_clock64(); atomicAdd(stats + 9 + (p == 0 ? 0 : 1), (unsigned)(tk1 - tk0)); tk0 = tk1; }      // [9] first pass, [10] later passes
     const double i0 = wave_scan_d(d0), i1 = wave_scan_d(d1), i2 = wave_scan_d(d2);
     if (lane == 63) { wtot[wave][0] = i0; wtot[wave][1] = i1; wtot[wave][2] = i2; }
     double e0 = dpp_d<0x138, 0xF>(i0), e1 = dpp_d<0x138, 0xF>(i1), e2 = dpp_d<0x138, 0xF>(i2);      // wave_shr:1 -> the exclusive prefix (lane 0: +0)
@@ -734,7 +736,6 @@ __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const 
       if (u == wave) { e0 += A0; e1 += A1; e2 += A2; }      // (the waves in front of this one)
       A0 += v0; A1 += v1; A2 += v2;
     }
-    if (clk) { tk1 = wall_clock64(); atomicAdd(stats + 11, (unsigned)(tk1 - tk0)); tk0 = tk1; }      // [11] workgroup scan
     if (p == npass - 1) {
       // the LAST pass needs no exchange: nobody restarts from its result inside this launch.  The workgroup leaves its aggregate and the start its first
       // segment ran from (this pass and the one before); k_seq_objf_close sums the aggregates in ticket order -> chain totals, and sees how far
@@ -750,17 +751,13 @@ __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const 
       }
       break;
     }
-    if (!(X.dbg & 1)) {
-      if (wave == 0) { double p0, p1, p2; xg_mates3(X, p, w, nwg, lane, A0, A1, A2, p0, p1, p2, stats + 7); if (lane == 0) { xin[0] = p0; xin[1] = p1; xin[2] = p2; } }
-      else if (wave == 1) { double q0, q1, q2; xg_groups3(X, p, w, lane, q0, q1, q2, stats + 7); if (lane == 0) { xgr[0] = q0; xgr[1] = q1; xgr[2] = q2; } }
-    } else if (tid == 0) { xin[0] = xin[1] = xin[2] = 0.0; xgr[0] = xgr[1] = xgr[2] = 0.0; }
+    if (wave == 0) { double p0, p1, p2; xg_mates3(X, p, w, nwg, lane, A0, A1, A2, p0, p1, p2, stats + 7); if (lane == 0) { xin[0] = p0; xin[1] = p1; xin[2] = p2; } }
+    else if (wave == 1) { double q0, q1, q2; xg_groups3(X, p, w, lane, q0, q1, q2, stats + 7); if (lane == 0) { xgr[0] = q0; xgr[1] = q1; xgr[2] = q2; } }
     __syncthreads();
-    if (clk) { tk1 = wall_clock64(); atomicAdd(stats + 12, (unsigned)(tk1 - tk0)); tk0 = tk1; }      // [12] exchange
     const double b0 = xgr[0] + xin[0], b1 = xgr[1] + xin[1], b2 = xgr[2] + xin[2];
     pv0 = st0; pv1 = st1; pv2 = st2;
     st0 = (float)(b0 + e0); st1 = (float)(b1 + e1); st2 = (float)(b2 + e2);
     __syncthreads();          // (wtot / xin / xgr are rewritten by the next pass)
-    if (clk) { tk1 = wall_clock64(); atomicAdd(stats + 13, (unsigned)(tk1 - tk0)); tk0 = tk1; }      // [13] new starts
   }
 }
 // closes a fused launch: the workgroups' aggregates of the last pass, in ticket order -> the chain totals; and, per workgroup, the start its first segment
@@ -1215,7 +1212,6 @@ bool l_seq_obj_fused(const Launch& L, const Dev& D, int mode, const float* T, lo
   if (mode == 1 && (D.K % 4 != 0 || D.C > 4 || !olev)) return false;
   const int nsegs = seq_obj_fused_nsegs(nt), nwg = (nsegs + OBJF_THREADS - 1) / OBJF_THREADS, ng = (nwg + 63) / 64;
   SeqXchg X; X.slotA = slots; X.slotG = slots + (size_t)OBJF_MAXSTAGE * nwg * 8; X.epoch = epoch & 0x0fffffffu; X.ngroups = ng;
-  { const char* e = getenv("HMX_OBJF_DBG"); X.dbg = e ? atoi(e) : 0; }
   double* const wgagg = reinterpret_cast<double*>(slots + (size_t)OBJF_MAXSTAGE * ((size_t)nwg + ng) * 8);
   (void)hipMemsetAsync(stats, 0, 16 * sizeof(unsigned), L.stream);
   const size_t deal = (size_t)OBJF_WAVES * 64 * OBJF_TPT * sizeof(float);

@@ -128,21 +128,11 @@ int64_t hmx_get(hmx_ctx* ctx, const char* field, double* out, int64_t cap);
  * hmx_get(ctx, "Z_corr", ...) is this with (F64, HOST). */
 int64_t hmx_get_matrix(hmx_ctx* ctx, const char* field, void* out, int32_t dtype, int32_t location, int64_t cap);
 /* writable fields: "max_iter_kmeans" (vignettes/detailedWalkthrough.Rmd:364), "seed",
- * "device" (before setup), "profile" (HIP-event timing of the update kernel, see below),
+ * "device" (before setup), "profile" (HIP-event timing of the update kernel, see "measurement"),
  * "rng" (0 counter-based generator | 1 R-compatible stream, see "randomness"),
- * "ridge_arith" / "oe_arith" / "obj_arith" / "solve_arith" / "ref_arith", "seq_passes" / "seq_warm_passes" / "seq_tol_ppb" / "seq_strict" /
- * "seq_stats" / "seq_max_passes" (see "reference arithmetic" below),
- * "stale_dist" (before setup; see hmx_compute_objective).
- * Tuning / fallback selectors (tests and measurements; the defaults are the measured best):
- *   fields "grid", "upd_wps" (before setup), "upd_tpw", "upd_cpw", "upd_impl", "comm_force";
- *   environment, read by hmx_setup: HMX_GRID, HMX_NREP, HMX_UPD_WPS (2|4), HMX_USIG=0 (general-sigma kernels),
- *   HMX_UPD_THREADS, HMX_UPD_MAXBLOCKS, HMX_STATIC_MAXBLOCKS, HMX_UPD_TPW, HMX_UPD_CPW, HMX_FUSED_FOLD=0, HMX_FOLD_IMPL=split,
- *   HMX_OLDSUM_IMPL=gather|stream1, HMX_UPDATE_IMPL=v1, HMX_TILE_IMPL=v1, HMX_MOE_IMPL=v1 (first-generation kernels),
- *   HMX_DOT=f32 (tile kernels: fp32-MFMA distance GEMM only; default: the split-bf16 build wherever its LDS image fits -- same
- *   fp32 accuracy);
- *   host matrices (hmx_setup / hmx_get_matrix with HMX_HOST): HMX_XFER=pin (register the caller's buffer instead of moving it
- *   through the process-wide ring of page-locked slots), HMX_XFER_THREADS (host threads that fill / drain the ring, default 8),
- *   HMX_PIN=0 (plain pageable copies). */
+ * "ref_arith" (before setup; see "arithmetic"), "stale_dist" (before setup; see hmx_compute_objective).
+ * The tuning / fallback selectors and the settings of the reference-arithmetic machinery are laboratory equipment, not part of the
+ * reference's interface: include/harmony_mi355x_lab.h lists them. */
 int hmx_set_int(hmx_ctx* ctx, const char* field, int64_t value);
 
 /* ---- randomness ------------------------------------------------------------------------
@@ -171,14 +161,6 @@ uint64_t hmx_feistel_pos(uint64_t seed, uint64_t round, uint64_t N, uint64_t g);
  * builds a round's block order from it without sorting (round 4). */
 uint64_t hmx_feistel_cell(uint64_t seed, uint64_t round, uint64_t N, uint64_t pos);
 int hmx_set_uniform_source(hmx_ctx* ctx, double (*unif_rand)(void* user), void* user);
-/* probes of the R-compatible stream (host only, no device needed; used by the CPU tests) */
-void hmx_r_runif(uint32_t seed, int32_t n, double* out);            /* set.seed(seed); runif(n)                      */
-void hmx_r_shuffle(uint32_t seed, int64_t N, int64_t* out);         /* set.seed(seed); arma::shuffle(0..N-1)         */
-void hmx_mt19937_by_array(const uint32_t* key, int32_t len, int32_t n, uint32_t* out);  /* MT19937 known-answer vector */
-float hmx_u01(uint64_t seed, uint64_t stream, uint64_t idx);
-/* probe (host only): which cluster MFMA column c of cluster tile ct holds when a launch uses nct cluster tiles (the tile kernels
- * deal a lane consecutive clusters so that its R values are adjacent in memory) */
-int32_t hmx_cluster_of_column(int32_t nct, int32_t ct, int32_t c);
 int hmx_push_update_order(hmx_ctx* ctx, const int64_t* update_order);
 
 /* ---- multi-GPU: one handle per process/GPU, cells sharded contiguously --------------------
@@ -229,32 +211,15 @@ int hmx_set_stream(hmx_ctx* ctx, void* hip_stream);
  * (Progress::check_abort(), src/harmony.cpp:233,355); non-zero return aborts */
 int hmx_set_abort_poll(hmx_ctx* ctx, int (*poll)(void*), void* user);
 
-/* ---- reference arithmetic --------------------------------------------------------------------------------
- * By default every cross-cell accumulator is exact (64-bit fixed point / fp64 in a fixed order).  The reference accumulates in
- * fp32, one term after the other; at 10^6 cells that is a visible, systematic bias (terms below half an ulp of a grown
- * accumulator are dropped).  Four switches (hmx_set_int, before hmx_setup; one GPU) make the library reproduce it, group by group:
- *   "ridge_arith"  Phi* diag(R_k) Phi*^T and Phi* diag(R_k) Z^T as sequential fp32 sums over the cells  (src/harmony.cpp:567,599-608)
- *   "oe_arith"     O, E as fp32 tables: block sums in the round's shuffled order, -= / += drift       (:149-150,312-313,329-330)
- *   "obj_arith"    compute_objective's three K*N-term my_accu sums                                       (src/utils.cpp:67-75)
- *   "solve_arith"  the closed-form fp32 arrowhead inverse of the one-covariate ridge system               (src/harmony.cpp:575-586)
- *   "ref_arith"    all four.
- * The sequential sums are computed as RESTARTED sequential sums (segments in parallel, their starting values by fixed-point
- * iteration; at the fixed point the result is bit-identical to the one-after-the-other loop).  Settings (hmx_set_int):
- *   "seq_passes" passes of a sum that starts from zero (default 2), "seq_warm_passes" passes of a sum that starts from the starts of its
- *   last evaluation (default 2); long chains (>= 200k cells, the objective's K N terms) continue until the largest move of a start in the last
- *   scan is below "seq_tol_ppb" parts per billion of the largest start of its lane group (default 10000 = 1e-5; at most "seq_max_passes");
- *   "seq_strict" = 1: EVERY sum is iterated until no start moves any more -- the bit-exact fixed point (slow: ~1.2 s per run at 1M cells).
- *   Measured at BASELINE configs[2] (profiles/r5_strict_probe_1M_*.json): the default, six passes and the strict fixed point all end
- *   1.9e-6 .. 2.1e-6 from the faithful oracle and as far from EACH OTHER -- the faithful fp32 trajectory itself moves by that much under any
- *   ulp-level change (profiles/r5_oracle_liberties.json).
- *   hmx_get "seq:mismatch" / "seq:residual" = how many segment starts still moved in the last scans and by how much, relatively (long chains
- *   always; the short per-block sums only with "seq_stats" = 1); "seq:group_passes" / "seq:group_runs" = passes / evaluations per group (O/E,
- *   objective, ridge, level pairs); "seq:unsettled" = sums that hit seq_max_passes.
- * Probes of that machinery on caller-provided data (device needed): */
-int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level, int32_t B, const int32_t* list, int64_t nlist,
-                     const int32_t* chain_off, const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals,
-                     int64_t* mismatch, double* residual);
-int hmx_debug_seq_arr(const float* T, int64_t n, int32_t narr, int32_t seg_terms, int32_t passes, float* total, int64_t* mismatch, double* residual);
+/* ---- arithmetic -------------------------------------------------------------------------------------------------
+ * By default every cross-cell accumulator is exact (64-bit fixed point / fp64 in a fixed order): the result is what the reference's
+ * own sources compute when built with their own precision switch (-DHARMONY_SCALAR_DOUBLE, src/types.h:5-9), on one GPU or sharded
+ * (identical for every shard count).  The reference as it ships accumulates in fp32, one term after the other (src/utils.cpp:67-75,
+ * src/harmony.cpp:312-313,329-330,567,592-608); at 10^6 cells that is a visible, systematic bias.
+ * hmx_set_int(ctx, "ref_arith", 1) before hmx_setup (one GPU) reproduces that arithmetic -- the O / E tables with their -= / += drift, the
+ * objective's my_accu sums, the ridge statistics, the closed-form fp32 inverse -- as restarted sequential sums and follows
+ * the CPU package's numbers to 2e-6 in Z_corr.  The accumulator groups can be switched one by one and the iteration of the restarted sums
+ * tuned: include/harmony_mi355x_lab.h. */
 
 /* ---- measurement ----------------------------------------------------------------------------
  * HIP-event timing of the dominant kernel on the library's stream: after

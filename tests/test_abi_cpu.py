@@ -17,8 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
-    hdr = open(os.path.join(ROOT, "include", "harmony_mi355x.h")).read()
-    declared = set(re.findall(r"\b(hmx_[a-z0-9_]+)\s*\(", hdr)) - {"hmx_allreduce_fn"}
+    # the reference's interface (harmony_mi355x.h) and the laboratory equipment (harmony_mi355x_lab.h: probes, tuning) -- together everything the library exports
+    pub = set(re.findall(r"\b(hmx_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "harmony_mi355x.h")).read())) - {"hmx_allreduce_fn"}
+    lab = set(re.findall(r"\b(hmx_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "harmony_mi355x_lab.h")).read())) - {"hmx_allreduce_fn", "hmx_setup", "hmx_get_matrix", "hmx_set_int", "hmx_compute_objective"}
+    assert not (pub & lab) and not [n for n in pub if "debug" in n], (pub & lab)
+    assert len(pub) <= 32, sorted(pub)             # (the module's methods and fields, randomness, multi-GPU: no probes)
+    declared = pub | lab
     assert declared, "no declarations parsed"
     for name in sorted(declared):
         assert hasattr(lib, name), "missing export: " + name
@@ -303,7 +307,9 @@ def test_documented_switches_and_writable_fields_are_the_ones_in_the_code():
     assert gone and not (gone & envs)                   # what the table calls removed really is
     hdr = open(os.path.join(root, "include", "harmony_mi355x.h")).read()
     w = hdr[hdr.index("/* writable fields:"):hdr.index("int hmx_set_int")]
-    keys = set(re.findall(r'"([a-z_:]+)"', w)) - {"randomness"}
+    lab = open(os.path.join(root, "include", "harmony_mi355x_lab.h")).read()
+    w += lab[lab.index("writable fields:"):lab.index("environment, read by hmx_setup")]
+    keys = set(re.findall(r'"([a-z_:]+)"', w)) - {"randomness", "measurement", "arithmetic", "reference arithmetic"}
     assert len(keys) > 15
     assert not [k for k in keys if '"%s"' % k not in code]
 

@@ -49,6 +49,9 @@ def test_only_the_documented_kernels_use_scratch(objs):
                 if name == "k_seq_scan":
                     assert r[".vgpr_spill_count"] <= 8
                     continue
+                if name.startswith("k_seq_obj_fused<"):       # (round 6: held to three waves per SIMD -- 168 registers -- at the price of a few spilled ones)
+                    assert r[".vgpr_spill_count"] <= 12
+                    continue
                 m = re.match(r"k_tile<(\d+), (\d+),", name)
                 assert m, "%s: %s spills %d VGPRs" % (o, name, r[".vgpr_spill_count"])
                 nct, mode = int(m.group(1)), int(m.group(2))

@@ -34,7 +34,7 @@ f = (glob.glob("/tmp/prof_d/**/*kernel_stats.csv", recursive=True) + glob.glob("
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:22]:
-    print("   %-58s calls %6s avg %9.1f us  total %8.2f ms  %5.1f%%" % (r["Name"][:58], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
+    print("   %-58s calls %6s avg %9.1f us (min %.1f max %.1f)  total %8.2f ms  %5.1f%%" % (r["Name"][:58], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
 PY
 cp $(find /tmp/prof_d -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r6_d_kernel_stats.csv
 cat $R/gpurun_out/r6_d.txt
