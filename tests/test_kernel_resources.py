@@ -88,7 +88,7 @@ def test_distance_gemm_instructions():
 
 
 def test_committed_table_is_the_table_of_this_build():
-    """profiles/r5_kernel_resources.txt is regenerated by `python tools/kernel_resources.py --write`"""
-    p = os.path.join(ROOT, "profiles", "r5_kernel_resources.txt")
+    """profiles/r6_kernel_resources.txt is regenerated by `python tools/kernel_resources.py --write`"""
+    p = os.path.join(ROOT, "profiles", "r6_kernel_resources.txt")
     assert os.path.exists(p)
     assert open(p).read() == kr.table()

@@ -2,7 +2,7 @@
 from the code objects' own metadata (llvm-readelf --notes) -- plus the MFMA instruction counts of each object's disassembly.  Needs no GPU.
 
     python tools/kernel_resources.py                 # table on stdout
-    python tools/kernel_resources.py --write          # also profiles/r5_kernel_resources.txt
+    python tools/kernel_resources.py --write          # also profiles/r6_kernel_resources.txt
 
 tests/test_kernel_resources.py pins the figures DESIGN.md quotes (registers / spills of the chain kernels, MFMA flavour of the distance
 GEMM) to the objects of the build, so that the document cannot drift from the code again.
@@ -99,4 +99,4 @@ if __name__ == "__main__":
     t = table()
     sys.stdout.write(t)
     if "--write" in sys.argv:
-        open(os.path.join(ROOT, "profiles", "r5_kernel_resources.txt"), "w").write(t)
+        open(os.path.join(ROOT, "profiles", "r6_kernel_resources.txt"), "w").write(t)
