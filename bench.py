@@ -164,7 +164,7 @@ def _reference_sources_cpu(d, K, levels, nested, seed, cells=40000):
 def _full_size_cpu():
     """the same oracle at the FULL configs[2] size, from the committed parity table (profiles/, a builder run: ~1 minute of CPU)"""
     try:
-        j = json.load(open(next(f for f in (os.path.join(ROOT, "profiles", "%s_parity_table_1000000.json" % t) for t in ("r5", "r4", "r3")) if os.path.exists(f))))
+        j = json.load(open(next(f for f in (os.path.join(ROOT, "profiles", "%s_parity_table_1000000.json" % t) for t in ("r6", "r5", "r4", "r3")) if os.path.exists(f))))
         s = j["seconds"]["oracle_faithful"]
         return {"cells": j["workload"]["cells"], "seconds": s, "value": j["workload"]["cells"] / s, "unit": "cells/s",
                 "source": "profiles/r*_parity_table_1000000.json of the latest round (tests/test_gpu_parity2.py::test_arithmetic_gap_table[1000000]; 4 BLAS threads, "
@@ -298,7 +298,7 @@ def headline_parity(n, d, K, levels):
     """where the HEADLINE mode (exact accumulators) stands against both oracle arithmetics at this exact workload, replayed from the committed
     parity table of the round (tests/test_gpu_parity2.py::test_arithmetic_gap_table, a driver-run GPU test) -- so that nobody reads `value` as
     a faithful-arithmetic number: the mode that follows the reference's fp32 arithmetic is `also.reference_arith`"""
-    for tag in ("r5", "r4", "r3"):
+    for tag in ("r6", "r5", "r4", "r3"):
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", "%s_parity_table_%d.json" % (tag, n))))
         except Exception:
