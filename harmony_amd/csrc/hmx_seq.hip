@@ -146,6 +146,99 @@ __global__ __launch_bounds__(256) void k_seq_oe_pass(const float* __restrict__ R
   }
 }
 
+// (a'') round 6: the same sums LEVEL BY LEVEL.  In the loop above every (cell, covariate) costs a read-modify-write of a register chosen at run time --
+//      v_readlane, s_set_gpr_idx_on, v_mov, off, v_add, on, v_mov, off, between scalar branches on u < nc and c < C: ~190 cycles per cell, 10 of the 18 us
+//      of a pass over a 50k-cell block (phase clocks of a traced wave: ids 0.6, first 64 R loads 2.9, issue of the next batch 1.6, the adds 10.2 us).  A row's
+//      chain only fixes the order of ITS OWN cells, so a batch of 64 cells is taken row by row instead: the lanes hold the cells' level codes, one
+//      v_cmp per level gives the 64-bit mask of the row's cells (wave-uniform), and the row -- a register chosen at COMPILE time -- adds them in ascending
+//      position; what is chosen at run time is only the R value READ (one indexed v_mov).  Same chains, same order inside every chain: bit-identical totals.
+template <int NLV>
+__global__ __launch_bounds__(256) void k_seq_oe_pass_bl(const float* __restrict__ R, int K, int B, int C, const int* __restrict__ list,
+                                                        const int* __restrict__ poslev, int nlist, const int* __restrict__ combo, const int* __restrict__ qlev,
+                                                        const SeqSeg* __restrict__ segs, int seg0, int nsegs,
+                                                        const float* __restrict__ start, float* __restrict__ end, int zero_start, unsigned* __restrict__ conv_zero) {
+  if (conv_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) conv_zero[threadIdx.x] = 0u;
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int sl = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wib));
+  if (sl >= nsegs) return;
+  const int seg = seg0 + sl;
+  const int k = blockIdx.y * 64 + lane, ks = min(k, K - 1);
+  const SeqSeg sg = segs[seg];
+  const size_t so = (size_t)seg * (1 + B) * K + ks;
+  float s0 = (zero_start || k >= K) ? 0.0f : start[so];
+  LvRows<NLV> lv;
+#pragma unroll
+  for (int b = 0; b < NLV; b++) lv.w[b] = (zero_start || k >= K || b >= B) ? 0.0f : start[so + (size_t)(1 + min(b, B - 1)) * K];
+  struct Ids { int myc, lev[4]; };
+  auto fetch_ids = [&](const int base) __attribute__((always_inline)) {
+    Ids I;
+    const int ci = sg.off + min(base + lane, sg.cnt - 1);
+    I.myc = list ? list[min(ci, sg.off + sg.cnt - 1)] : ci;
+    if (poslev) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) I.lev[c] = poslev[(size_t)min(c, C - 1) * nlist + ci];
+    } else {
+      const int myq = combo[I.myc];
+#pragma unroll
+      for (int c = 0; c < 4; c++) I.lev[c] = qlev[myq * C + min(c, C - 1)];
+    }
+    return I;
+  };
+  auto fetch_r = [&](const Ids& I, f32x32& lo, f32x32& hi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 32; u++) {
+      lo[u] = R[(size_t)__builtin_amdgcn_readlane(I.myc, u) * K + ks];            // (lanes past the end hold the segment's last cell: a valid row)
+      hi[u] = R[(size_t)__builtin_amdgcn_readlane(I.myc, 32 + u) * K + ks];
+    }
+  };
+  Ids idc = fetch_ids(0), idn = fetch_ids(64);
+  f32x32 cl, chh, nl, nh;
+  fetch_r(idc, cl, chh);
+  for (int base = 0; base < sg.cnt; base += 64) {
+    const int nc = min(64, sg.cnt - base);
+    const unsigned long long vm = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
+    const bool more = base + 64 < sg.cnt;
+    if (more) fetch_r(idn, nl, nh);
+    const Ids idnn = fetch_ids(base + 128);
+    if (nc == 64) {
+#pragma unroll
+      for (int u = 0; u < 32; u++) s0 = __fadd_rn(s0, cl[u]);
+#pragma unroll
+      for (int u = 0; u < 32; u++) s0 = __fadd_rn(s0, chh[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 32; u++) if (u < nc) s0 = __fadd_rn(s0, cl[u]);
+#pragma unroll
+      for (int u = 0; u < 32; u++) if (32 + u < nc) s0 = __fadd_rn(s0, chh[u]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (c < C) {
+        const int levc = idc.lev[c];
+#pragma unroll
+        for (int b = 0; b < NLV; b++) {
+          if (b < B) {
+            const unsigned long long m = __ballot(levc == b) & vm;
+            if (m) {
+              unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+              float a = lv.w[b];
+              while (mlo) { const int u = __builtin_ctz(mlo); mlo &= mlo - 1u; a = __fadd_rn(a, cl[u]); }
+              while (mhi) { const int u = __builtin_ctz(mhi); mhi &= mhi - 1u; a = __fadd_rn(a, chh[u]); }
+              lv.w[b] = a;
+            }
+          }
+        }
+      }
+    }
+    idc = idn; idn = idnn; cl = nl; chh = nh;
+  }
+  if (k < K) {
+    end[so] = s0;
+#pragma unroll
+    for (int b = 0; b < NLV; b++) if (b < B) end[so + (size_t)(1 + b) * K] = lv.w[b];
+  }
+}
+
 // (a') round 6: MANY levels (B > 32: BASELINE configs[4] has 200 in three nested covariates).  The LDS rows of the form above cost a dependent LDS
 //      read-modify-write per (cell, covariate) -- 452 us per pass over a 50k-cell block, 55 % of a reference-arithmetic run at that shape -- and, with
 //      (1 + B) K = 40 200 lane-chains per 128-cell segment, more workspace traffic than the block's R rows.  Here the levels are dealt to LEVEL GROUPS of 32:
@@ -190,51 +283,56 @@ __global__ __launch_bounds__(512) void k_seq_oe_pass_lg(const float* __restrict_
     }
     return I;
   };
-  auto fetch_r = [&](const Ids& I, float (&r)[64]) __attribute__((always_inline)) {
+  auto fetch_r = [&](const Ids& I, f32x32& lo, f32x32& hi) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 64; u++) {
-      const int cell = __builtin_amdgcn_readlane(I.myc, u);
-      r[u] = R[(size_t)cell * K + ks];
+    for (int u = 0; u < 32; u++) {
+      lo[u] = R[(size_t)__builtin_amdgcn_readlane(I.myc, u) * K + ks];
+      hi[u] = R[(size_t)__builtin_amdgcn_readlane(I.myc, 32 + u) * K + ks];
     }
   };
   Ids idc = fetch_ids(0), idn = fetch_ids(64);
-  float rc[64], rn[64];
-  fetch_r(idc, rc);
+  f32x32 cl, chh, nl, nh;
+  fetch_r(idc, cl, chh);
   for (int base = 0; base < sg.cnt; base += 64) {
     const int nc = min(64, sg.cnt - base);
+    const unsigned long long vm = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
     const bool more = base + 64 < sg.cnt;
-    if (more) fetch_r(idn, rn);
+    if (more) fetch_r(idn, nl, nh);
     const Ids idnn = fetch_ids(base + 128);
     if (lg == 0) {
 #pragma unroll
-      for (int u = 0; u < 64; u++) if (u < nc) s0 = __fadd_rn(s0, rc[u]);
+      for (int u = 0; u < 32; u++) if (u < nc) s0 = __fadd_rn(s0, cl[u]);
+#pragma unroll
+      for (int u = 0; u < 32; u++) if (32 + u < nc) s0 = __fadd_rn(s0, chh[u]);
     }
-    // covariate by covariate (a row belongs to ONE covariate: the order of its own cells is all that matters), and only the covariates whose levels
-    // meet this wave's 32: one compare per cell for most waves instead of one per (cell, covariate)
+    // row by row (k_seq_oe_pass_bl): the covariates whose levels meet this wave's 32, one v_cmp per row and covariate, the row's cells added in ascending position
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       if (c < C && ((cmask >> c) & 1)) {
+        const int levc = idc.lev[c] - b_lo;
 #pragma unroll
-        for (int u = 0; u < 64; u++) {
-          if (u < nc) {
-            const int b = __builtin_amdgcn_readlane(idc.lev[c], u) - b_lo;
-            if (b >= 0 && b < 32) lv_add<32>(lv, b, rc[u]);
+        for (int b = 0; b < 32; b++) {
+          const unsigned long long m = __ballot(levc == b) & vm;
+          if (m) {
+            unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+            float a = lv.w[b];
+            while (mlo) { const int u = __builtin_ctz(mlo); mlo &= mlo - 1u; a = __fadd_rn(a, cl[u]); }
+            while (mhi) { const int u = __builtin_ctz(mhi); mhi &= mhi - 1u; a = __fadd_rn(a, chh[u]); }
+            lv.w[b] = a;
           }
         }
       }
     }
-    for (int c = 4; c < C; c++) {       // (more than four covariates: level codes straight from the table; u unrolled -- a dynamic index would send rc to scratch)
+    for (int c = 4; c < C; c++) {       // (more than four covariates: level codes straight from the table, cell by cell)
 #pragma unroll
       for (int u = 0; u < 64; u++) {
         if (u < nc) {
           const int b = __builtin_amdgcn_readfirstlane(qlev[__builtin_amdgcn_readlane(idc.myq, u) * C + c]) - b_lo;
-          if (b >= 0 && b < 32) lv_add<32>(lv, b, rc[u]);
+          if (b >= 0 && b < 32) lv_add<32>(lv, b, u < 32 ? cl[u & 31] : chh[u & 31]);
         }
       }
     }
-    idc = idn; idn = idnn;
-#pragma unroll
-    for (int u = 0; u < 64; u++) rc[u] = rn[u];
+    idc = idn; idn = idnn; cl = nl; chh = nh;
   }
   if (k < K) {
     if (lg == 0) end[so] = s0;
@@ -1109,7 +1207,13 @@ __global__ void k_seq_ridge_store(Dev D, const float* __restrict__ total) {
 void l_seq_oe_pass(const Launch& L, const Dev& D, const int* list, const int* poslev, int nlist, const SeqSeg* segs, int seg0, int nsegs, const float* start,
                    float* end, int zero_start, unsigned* conv_zero) {
   if (nsegs <= 0) { if (conv_zero) (void)hipMemsetAsync(conv_zero, 0, 2 * sizeof(unsigned), L.stream); return; }      // (no pass: the statistics words its scan adds to are still zeroed)
-  if (D.B <= 32) {                         // level rows in registers (more levels: in LDS, the round-3 form)
+  if (D.B <= 32 && D.C <= 4) {             // level rows in registers, a batch taken level by level (round 6)
+    const dim3 grid((nsegs + 3) / 4, (D.K + 63) / 64);
+    if (D.B <= 16) hipLaunchKernelGGL((k_seq_oe_pass_bl<16>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
+    else hipLaunchKernelGGL((k_seq_oe_pass_bl<32>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
+    return;
+  }
+  if (D.B <= 32) {                         // level rows in registers, cell by cell (more than four covariates; more levels: in LDS, the round-3 form)
     const dim3 grid((nsegs + 3) / 4, (D.K + 63) / 64);
     if (D.B <= 16) hipLaunchKernelGGL((k_seq_oe_pass<true, 16>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
     else hipLaunchKernelGGL((k_seq_oe_pass<true, 32>), grid, dim3(256), 0, L.stream, D.R, D.K, D.B, D.C, list, poslev, nlist, D.combo, D.qlev, segs, seg0, nsegs, start, end, zero_start, conv_zero);
