@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512) void k_seq_oe_pass_lg(const float* __restrict_
 //     (no contraction: the reference multiplies, rounds, then adds).  10 VALU instructions per (cell, 8 clusters) instead of ~30.
 //     (Round 5 tried a software pipeline over the batches -- ids two ahead through a static combination list `listq`, raw R / flags one ahead, all 64
 //      rows of a batch in flight together: 128 VGPRs, 1.20 -> 1.46 ms per pass.  The form below stays; `listq` is accepted and unused.  Two workgroups
-//      per CU at 72 VGPRs: 21 -> 35 ms per run.  Both measured on the final code, tools/gpu_runs/r5_probe2.sh.)
+//      per CU at 72 VGPRs: 21 -> 35 ms per run.  Both measured on the final code of round 5.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int KPW>
 __global__ __launch_bounds__(1024) void k_seq_ridge_pass(const float* __restrict__ R, const float* __restrict__ Zo, const int* __restrict__ combo,

@@ -156,7 +156,7 @@ def test_config5_shape_200k():
 def test_chain_with_three_and_more_tiles_per_wave_equals_launch_per_step(monkeypatch):
     """3M cells: the persistent chain's waves own three and more tiles of a block -- the tile loop in front of the deferred epilogues, rows
     of the LAST tile stored behind the arrival (the suite's other chain cases stop at two tiles per wave) -- against the launch-per-step
-    kernels on the same data: same kernels' arithmetic, integer O sums => bit-identical (tools/gpu_runs/r3_chain3m.sh is the same check)."""
+    kernels on the same data: same kernels' arithmetic, integer O sums => bit-identical."""
     Z, meta, _ = synth(3000000, d=50, levels=(10,), seed=11)
     skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
     out, Y0 = [], None

@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-5 evidence for profiles/: default bench (plain, with its extra legs; and under rocprofv3 kernel stats), PMC passes (separate,
+# The round's evidence for profiles/ (TAG=r6 by default: TAG=r7 bash tools/final_profiles.sh ... in the next round): default bench (plain, with its extra legs; and under rocprofv3 kernel stats), PMC passes (separate,
 # --kernel-trace only), the round timeline, the reference-arithmetic mode's kernel table, configs[4] at full size, the two-rank
-# protocol runs on this one GPU.  Writes gpurun_out/r5fin/; tools/pmc_summary_r5.py turns it into profiles/r5_*.
+# protocol runs on this one GPU.  Writes gpurun_out/${TAG}fin/; tools/pmc_summary.py $TAG turns it into profiles/${TAG}_*.
 # PART=a: bench lines + kernel stats + timeline + PMC;  PART=b: reference arithmetic, configs[4] shape, 10M, two ranks.
 exec </dev/null
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5fin; mkdir -p $O
+TAG=${TAG:-r6}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG}fin; mkdir -p $O
 PART=${1:-ab}
 cd /tmp && export TMPDIR=/tmp
 if [[ $PART == *c* ]]; then     # full-size oracle tables of the two 8-GPU configs (CPU-bound: 15-20 minutes of oracle threads), in the background of the other parts
@@ -32,6 +33,7 @@ fi
 if [[ $PART == *b* ]]; then
 cd /tmp
 timeout 300 python $R/tools/ref_arith_profile.py > $O/ref_profile.json 2> $O/ref_profile.err
+timeout 300 python $R/tools/ref_arith_profile.py --c5 > $O/ref_profile_c5.json 2> $O/ref_profile_c5.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/refstats -o r -- python $R/tools/ref_arith_profile.py --steps 1 > /dev/null 2> $O/ref_rocprof.err
 cp $O/refstats/r_kernel_stats.csv $O/ref_kernel_stats.csv 2>/dev/null; rm -rf $O/refstats
 timeout 600 python $R/bench.py --cpu-sample 0 --workload c5 --cells-per-gpu 5000000 --steps 2 --warmup 1 --no-e2e --also none > $O/bench_c5_5M.json 2> $O/bench_c5_5M.err

@@ -1,4 +1,4 @@
-"""round 6 A/B: the reference-arithmetic mode with the round-6 kernel forms switched off / on ("seq_fused" bits): time per run, phases, and how far the results
+"""A/B (python tools/gpu_runs/ref_arith_ab.py on the GPU box; AB_SET="0,5" settings of "seq_fused", AB_CELLS, AB_C5=1 for configs[4]'s shape): the reference-arithmetic mode with the round-6 kernel forms switched off / on ("seq_fused" bits): time per run, phases, and how far the results
 of the two settings are from each other (the lane = cluster ridge pass must be BIT-identical to the round-5 kernel: same chains, same roundings)."""
 import sys, time, json, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

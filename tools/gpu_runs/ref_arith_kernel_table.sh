@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: kernel table of the reference-arithmetic mode at BASELINE configs[2] (rocprofv3 --kernel-trace --stats), fused objective on
+# kernel table of the reference-arithmetic mode (rocprofv3 --kernel-trace --stats) at BASELINE configs[2]; LEG_CELLS=n, LEG_SET="seq_fused=0" (the round-5 kernels) ...
+# -> gpurun_out/ref_arith_kernel_table.txt, ref_arith_kernel_stats.csv
 exec </dev/null
 R=$GRAFT_REPO_ROOT; cd $R || exit 1
 mkdir -p gpurun_out
@@ -27,8 +28,8 @@ PY
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_d
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_d -o p -- python /tmp/leg2.py > /tmp/leg2.out 2>&1
-grep '^{' /tmp/leg2.out > $R/gpurun_out/r6_d.txt
-python - <<'PY' >> $R/gpurun_out/r6_d.txt
+grep '^{' /tmp/leg2.out > $R/gpurun_out/ref_arith_kernel_table.txt
+python - <<'PY' >> $R/gpurun_out/ref_arith_kernel_table.txt
 import csv, glob
 f = (glob.glob("/tmp/prof_d/**/*kernel_stats.csv", recursive=True) + glob.glob("/tmp/prof_d/*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
@@ -36,5 +37,5 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:22]:
     print("   %-58s calls %6s avg %9.1f us (min %.1f max %.1f)  total %8.2f ms  %5.1f%%" % (r["Name"][:58], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
 PY
-cp $(find /tmp/prof_d -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r6_d_kernel_stats.csv
-cat $R/gpurun_out/r6_d.txt
+cp $(find /tmp/prof_d -name "*kernel_stats.csv" | head -1) $R/gpurun_out/ref_arith_kernel_stats.csv
+cat $R/gpurun_out/ref_arith_kernel_table.txt

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where the reference-arithmetic mode spends its time: one synthetic workload (default BASELINE configs[2]: 1M x 50, K = 100, 10
 batches), `ref_arith = 1`, to convergence; prints wall time per run, GPU time per phase (HIP events) and the host timers.
-Run it under `rocprofv3 --kernel-trace --stats` for the per-kernel table (tools/gpu_runs/r3_ref_profile.sh)."""
+Run it under `rocprofv3 --kernel-trace --stats` for the per-kernel table (tools/final_profiles.sh, part b)."""
 import argparse
 import json
 import os
@@ -18,9 +18,14 @@ ap.add_argument("--cells", type=int, default=1000000)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--passes", type=int, default=0, help="seq_passes (0: the library's default, 2 since round 5)")
 ap.add_argument("--mode", default="ref_arith")
+ap.add_argument("--c5", action="store_true", help="BASELINE configs[4]'s shape: K = 200, three nested covariates 8 > 64 > 128")
 a = ap.parse_args()
-Z, meta, _ = synth(a.cells, d=50, levels=(10,), seed=7)
-skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
+if a.c5:
+    Z, meta, _ = synth(a.cells, d=50, levels=(8, 64, 128), seed=7, nested=True)
+    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=200)
+else:
+    Z, meta, _ = synth(a.cells, d=50, levels=(10,), seed=7)
+    skw, _ = prepare_setup_args(Z, meta, "cov0", nclust=100)
 g = Harmony(seed=1, **({a.mode: 1} if a.mode != "default" else {}))
 if a.passes:
     g._set("seq_passes", a.passes)
@@ -49,6 +54,6 @@ phases = {k: round(g._scalar("gputimer:" + k) / a.steps, 3) for k in
           ("kmeans_centers", "cluster_head", "randomize", "EO_update", "Rcells_update", "objective", "correct_ridge_loop", "ridge_statistics",
            "arma_inv", "update_Zcorr")}
 host = {k: round(g.timer(k) / (a.steps + 1), 3) for k in ("init_cluster", "cluster", "update_R", "moe_correct_ridge")}
-print(json.dumps({"mode": a.mode, "cells": a.cells, "passes": a.passes, "iterations": its, "ms_per_run_incl_egress": 1e3 * dt / a.steps,
+print(json.dumps({"mode": a.mode, "shape": "configs[4]" if a.c5 else "configs[2]", "cells": a.cells, "passes": a.passes, "iterations": its, "ms_per_run_incl_egress": 1e3 * dt / a.steps,
                   "gpu_phase_ms_per_run": phases, "host_wall_ms_per_run": host, "seq_residual": g._scalar("seq:residual"),
-                  "seq_runs": g._scalar("seq:runs")}))
+                  "seq_runs": g._scalar("seq:runs"), "passes_per_group": [float(x) for x in g._get("seq:group_passes")], "evaluations_per_group": [float(x) for x in g._get("seq:group_runs")]}))
