@@ -345,8 +345,7 @@ int hmx_moe_correct_ridge(hmx_ctx* ctx) {  // src/harmony.cpp:345-638
   }
   { PhaseScope pall(ctx, "correct_ridge_loop");
   { PhaseScope ph(ctx, "ridge_statistics");   // reference timers Phi_Rk + Phi_cov + Z_tmp + Z_intercept + batch_exprod: ONE pass here
-    HIPCHK(hipMemsetAsync(D.Sq, 0, sizeof(double) * (size_t)Q * d * K, ctx->L.stream));
-    HIPCHK(hipMemsetAsync(D.nq, 0, sizeof(double) * (size_t)Q * K, ctx->L.stream));
+    l_zero4(ctx->L, D.Sq, (size_t)Q * d * K, D.nq, (size_t)Q * K, nullptr, 0, nullptr, 0); KCHK();      // (one launch instead of two memsets)
     if (seq) CHK(seq_ridge_stats(ctx));
     else if (D.moe_mfma) { l_moe_stats_mfma(ctx->L, D); KCHK(); } else { l_moe_stats(ctx->L, D); KCHK(); }
     CHK(allreduce(ctx, D.Sq, (int64_t)Q * d * K, 1));

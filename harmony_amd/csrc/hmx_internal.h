@@ -197,6 +197,7 @@ struct Launch {
 void l_convert_in(const Launch& L, const void* src, int f32, float* dst, const int* invperm, int n, int d, int zs);
 void l_convert_out(const Launch& L, const float* src, void* dst, int f32, const int* invperm, int n, int w, int ws);
 void l_copy(const Launch& L, const float* src, float* dst, size_t count);
+void l_zero4(const Launch& L, void* a, size_t na, void* b, size_t nb, void* c, size_t nc, void* d, size_t nd);      // up to four buffers of 8-byte words, one launch
 void l_normalize(const Launch& L, float* Z, int n, int d, int zs);
 void l_normalize_from(const Launch& L, const float* src, float* dst, int n, int d, int zs);
 // mode 0: head (write R, accumulate O_fx, objective partials); mode 1: objective only (read R)

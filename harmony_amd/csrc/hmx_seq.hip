@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void k_seq_objr_pass(Dev D, const float* __res
 //         codes in original cell order, `olev`) with exactly the roundings of k_obj_terms / k_seq_objr_pass.  K % 4 == 0.
 // stats: [0] starts that still moved in the last stage, [1 + c] the largest move of a start of chain c (float bits), [4 + c] the chain totals (float
 //        bits), [7] error word, [8] the ticket counter -- zeroed by the host in front of the launch (one 64-byte memset).
-struct SeqXchg { unsigned long long* slotA; unsigned long long* slotG; unsigned epoch; int ngroups; };
+struct SeqXchg { unsigned long long* slotA; unsigned long long* slotG; unsigned long long* slotS; unsigned epoch; int ngroups, nsuper; };
 __device__ __forceinline__ void xg_put3(unsigned long long* slot, const int lane, const unsigned tag, const double a0, const double a1, const double a2) {
   if (lane < 6) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(lane < 2 ? a0 : lane < 4 ? a1 : a2);
@@ -699,14 +699,19 @@ __device__ __forceinline__ void xg_mates3(const SeqXchg& X, const int stage, con
   p0 = wave_sum_d(p0); p1 = wave_sum_d(p1); p2 = wave_sum_d(p2);
   if (j == 63 || w == nwg - 1) xg_put3(X.slotG + ((size_t)stage * X.ngroups + g) * 8, lane, tag, p0 + A0, p1 + A1, p2 + A2);
 }
-__device__ __forceinline__ void xg_groups3(const SeqXchg& X, const int stage, const int w, const int lane, double& q0, double& q1, double& q2, unsigned* err) {
+// (three levels since the 10M-cell runs: groups of 64 workgroups, super-groups of 64 groups.  qi: the totals of the groups in front INSIDE this
+//  workgroup's super-group; qs: the totals of the super-groups in front -- published by each super-group's last workgroup, 4096 tickets ago or more)
+__device__ __forceinline__ void xg_groups3(const SeqXchg& X, const int stage, const int w, const int lane, double& qi0, double& qi1, double& qi2,
+                                           double& qs0, double& qs1, double& qs2, unsigned* err) {
   const unsigned tag = (X.epoch << 4) | (unsigned)stage;
-  const int g = w >> 6;
-  q0 = 0.0; q1 = 0.0; q2 = 0.0;
-  for (int g0 = 0; g0 < g; g0 += 64) {
-    if (g0 + lane < g) { double t0, t1, t2; xg_get3(X.slotG + ((size_t)stage * X.ngroups + g0 + lane) * 8, tag, t0, t1, t2, err); q0 += t0; q1 += t1; q2 += t2; }
+  const int g = w >> 6, sg = g >> 6, g_lo = sg << 6;
+  qi0 = 0.0; qi1 = 0.0; qi2 = 0.0; qs0 = 0.0; qs1 = 0.0; qs2 = 0.0;
+  if (g_lo + lane < g) xg_get3(X.slotG + ((size_t)stage * X.ngroups + g_lo + lane) * 8, tag, qi0, qi1, qi2, err);
+  for (int s0 = 0; s0 < sg; s0 += 64) {
+    if (s0 + lane < sg) { double t0, t1, t2; xg_get3(X.slotS + ((size_t)stage * X.nsuper + s0 + lane) * 8, tag, t0, t1, t2, err); qs0 += t0; qs1 += t1; qs2 += t2; }
   }
-  q0 = wave_sum_d(q0); q1 = wave_sum_d(q1); q2 = wave_sum_d(q2);
+  qi0 = wave_sum_d(qi0); qi1 = wave_sum_d(qi1); qi2 = wave_sum_d(qi2);
+  qs0 = wave_sum_d(qs0); qs1 = wave_sum_d(qs1); qs2 = wave_sum_d(qs2);
 }
 // inclusive scan of a double over the wave without LDS traffic: DPP row shifts inside the rows of 16, then row_bcast15 / row_bcast31 across them
 // (an invalid source lane or a masked row contributes the `old` operand, +0.0)
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const 
                                                                    unsigned* __restrict__ stats, double* __restrict__ wgagg, SeqXchg X) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ double wtot[OBJF_WAVES][3];
-  __shared__ double xin[3], xgr[3];
+  __shared__ double xin[3], xgr[3], xsu[3];
   __shared__ unsigned wgid;
   extern __shared__ __attribute__((aligned(16))) float lds_[];      // [waves][64 x 32] deal buffers, then (MODE 1, LDSTAB) [B][K] M and [K] sigma
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -850,9 +855,12 @@ __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const 
       break;
     }
     if (wave == 0) { double p0, p1, p2; xg_mates3(X, p, w, nwg, lane, A0, A1, A2, p0, p1, p2, stats + 7); if (lane == 0) { xin[0] = p0; xin[1] = p1; xin[2] = p2; } }
-    else if (wave == 1) { double q0, q1, q2; xg_groups3(X, p, w, lane, q0, q1, q2, stats + 7); if (lane == 0) { xgr[0] = q0; xgr[1] = q1; xgr[2] = q2; } }
+    else if (wave == 1) { double q0, q1, q2, u0, u1, u2; xg_groups3(X, p, w, lane, q0, q1, q2, u0, u1, u2, stats + 7);
+                          if (lane == 0) { xgr[0] = q0; xgr[1] = q1; xgr[2] = q2; xsu[0] = u0; xsu[1] = u1; xsu[2] = u2; } }
     __syncthreads();
-    const double b0 = xgr[0] + xin[0], b1 = xgr[1] + xin[1], b2 = xgr[2] + xin[2];
+    if (wave == 0 && ((w & 4095) == 4095 || w == nwg - 1) && X.nsuper > 1)      // the last workgroup of a super-group: its total = the groups in front inside it + this group
+      xg_put3(X.slotS + ((size_t)p * X.nsuper + (w >> 12)) * 8, lane, (X.epoch << 4) | (unsigned)p, xgr[0] + xin[0] + A0, xgr[1] + xin[1] + A1, xgr[2] + xin[2] + A2);
+    const double b0 = xsu[0] + xgr[0] + xin[0], b1 = xsu[1] + xgr[1] + xin[1], b2 = xsu[2] + xgr[2] + xin[2];
     pv0 = st0; pv1 = st1; pv2 = st2;
     st0 = (float)(b0 + e0); st1 = (float)(b1 + e1); st2 = (float)(b2 + e2);
     __syncthreads();          // (wtot / xin / xgr are rewritten by the next pass)
@@ -1307,7 +1315,7 @@ void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nt
 // outside the kernel's envelope (K % 4, more than four covariates, more passes than slot sets): the caller falls back to the pass / scan launches.
 size_t seq_obj_fused_slot_words(long long nt) {      // granule slots [OBJF_MAXSTAGE][nwg + ngroups][8] + the workgroups' closing records [nwg][8]
   const int nsegs = (int)((nt + OBJF_TPT - 1) / OBJF_TPT), nwg = (nsegs + OBJF_THREADS - 1) / OBJF_THREADS, ng = (nwg + 63) / 64;
-  return (size_t)OBJF_MAXSTAGE * ((size_t)nwg + ng) * 8 + (size_t)nwg * 8;
+  return (size_t)OBJF_MAXSTAGE * ((size_t)nwg + ng + (ng + 63) / 64) * 8 + (size_t)nwg * 8;
 }
 int seq_obj_fused_nsegs(long long nt) { return (int)((nt + OBJF_TPT - 1) / OBJF_TPT); }
 bool l_seq_obj_fused(const Launch& L, const Dev& D, int mode, const float* T, long long stride, const float* M, const int* olev, long long nt, int npass, int zero_start,
@@ -1315,8 +1323,9 @@ bool l_seq_obj_fused(const Launch& L, const Dev& D, int mode, const float* T, lo
   if (npass < 1 || npass > OBJF_MAXSTAGE || nt < 4) return false;
   if (mode == 1 && (D.K % 4 != 0 || D.C > 4 || !olev)) return false;
   const int nsegs = seq_obj_fused_nsegs(nt), nwg = (nsegs + OBJF_THREADS - 1) / OBJF_THREADS, ng = (nwg + 63) / 64;
-  SeqXchg X; X.slotA = slots; X.slotG = slots + (size_t)OBJF_MAXSTAGE * nwg * 8; X.epoch = epoch & 0x0fffffffu; X.ngroups = ng;
-  double* const wgagg = reinterpret_cast<double*>(slots + (size_t)OBJF_MAXSTAGE * ((size_t)nwg + ng) * 8);
+  const int nsup = (ng + 63) / 64;
+  SeqXchg X; X.slotA = slots; X.slotG = slots + (size_t)OBJF_MAXSTAGE * nwg * 8; X.slotS = X.slotG + (size_t)OBJF_MAXSTAGE * ng * 8; X.epoch = epoch & 0x0fffffffu; X.ngroups = ng; X.nsuper = nsup;
+  double* const wgagg = reinterpret_cast<double*>(slots + (size_t)OBJF_MAXSTAGE * ((size_t)nwg + ng + nsup) * 8);
   (void)hipMemsetAsync(stats, 0, 16 * sizeof(unsigned), L.stream);
   const size_t deal = (size_t)OBJF_WAVES * 64 * OBJF_TPT * sizeof(float);
   if (mode == 0) hipLaunchKernelGGL((k_seq_obj_fused<0, false>), dim3(nwg), dim3(OBJF_THREADS), deal, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);

@@ -134,6 +134,27 @@ def test_restarted_sums_over_term_arrays_reach_the_sequential_loop():
     print("the same in one launch (terms, passes, rel. error per chain, starts still moving, largest relative move):", log)
 
 
+def test_one_launch_sums_across_super_groups():
+    """k_seq_obj_fused's exchange has three levels (groups of 64 workgroups, super-groups of 64 groups): 40M terms per chain are 4883 workgroups, i.e. two
+    super-groups -- the totals must still follow the one-after-the-other loop (the 10M-cell runs have 30 super-groups)."""
+    rng = np.random.default_rng(11)
+    n = 40_000_000
+    a = rng.random(n, dtype=np.float32) * rng.choice(np.array([1e-6, 1e-3, 1.0], np.float32), size=n)
+    b = -(rng.random(n, dtype=np.float32) ** 8)
+    c = (rng.random(n, dtype=np.float32) * np.float32(1e-4)).astype(np.float32)
+    T = np.ascontiguousarray(np.stack([a, b, c]), dtype=np.float32)
+    want = np.array([_seq32(T[i])[-1] for i in range(3)], np.float32)
+    log = []
+    for passes in (3, 8):
+        tot = np.empty(3, np.float32)
+        mm, res = C.c_int64(-1), C.c_double(-1)
+        assert _lib.load().hmx_debug_seq_arr(_fp(T), n, 3, 0, passes, _fp(tot), C.byref(mm), C.byref(res)) == 0
+        rel = np.abs(tot.astype(np.float64) - want) / np.abs(want)
+        log.append((passes, rel.tolist(), mm.value, res.value))
+    print("one-launch sums over 40M terms per chain (passes, rel. error per chain, workgroups still moving, largest relative move):", log)
+    assert max(log[0][1]) <= 1e-3 and max(log[1][1]) <= 2e-6, log          # (three passes: the negative chain of 40M terms saturates and is still 2e-4 away; eight: on the loop)
+
+
 def _iterate(obj, max_iter=10):
     it = 0
     for it in range(1, max_iter + 1):
