@@ -210,7 +210,8 @@ def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps,
            "block_chain": chain and not hkw.get("ref_arith"), "avg_block_step_us": 1e3 * upd_ms / upd_steps,
            # the leg's own dominant kernel (the E-step update of update_R, as on the main line): algorithmic bytes (4d + 4K per cell and
            # round) over its HIP-event time on the library's stream
-           "roofline": {"kernel": ("k_tile<%d,4|5,...> persistent block chain" if (chain and not hkw.get("ref_arith")) else "k_tile<%d,0,...> one launch per block step") % ((K + 15) // 16),
+           "roofline": {"kernel": ("k_tile<7,6,...> persistent block chain by wave pairs (two halves of the clusters, several folder workgroups)" if (chain and K > 112 and not hkw.get("ref_arith")) else
+                                   ("k_tile<%d,4|5,...> persistent block chain" if (chain and not hkw.get("ref_arith")) else "k_tile<%d,0,...> one launch per block step") % ((K + 15) // 16)),
                         "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                         "kernel_time_share": upd_ms / (ms * steps) if ms > 0 else None},
            "roofline_run_frac": run_bytes / (ms * 1e-3) / 8e12}

@@ -105,6 +105,11 @@ struct Dev {
   int obj_stale;               // compute_objective on the stale snapshot (stale_dist): Yt / Zc are not the ones the MFMA images were built from
   int rvec;                    // K % 4 == 0: R rows are 16-byte aligned, the tile kernels store them with vector stores
   int chain_wps;               // waves per SIMD of the chain kernel: 2 (two accumulator sets)
+  // wave-pair chain (k_tile MODE 6; 112 < K <= 224, BASELINE configs[4]: K = 200): the clusters are split in two halves [0, KH) and [KH, K), the two
+  // waves of a pair run the K <= 112 worker on one half each and exchange the halves of a row's normalisation sum through LDS; the table is folded by
+  // chain_folders workgroups (chain_kw clusters each), the penalty table is read per level from `pen` in memory (write-through stores, drained flag)
+  int chain_pair, KH, chain_folders, chain_kw;
+  unsigned short* Yimg3p;      // [2 halves][NCTP][NS2][part][lane][8 bf16]: the split-bf16 centroid image of each half in the layout of NCTP = ceil(KH / 16) cluster tiles
   // peer-to-peer block chain (sharded runs, one process per GPU on a node): p2p_inbox[g] = rank g's inbox as mapped into THIS
   // process (fine-grained device memory shared through HIP IPC), [2 parities][8 sources][P2P_CAP entries][2 granules]
   int p2p_world, p2p_rank;
@@ -268,6 +273,14 @@ __host__ __device__ inline void bfimg_store(unsigned short* img, int nct, int ns
   unsigned short p[3];
   bf3_split(y, p);
   for (int part = 0; part < 3; part++) img[bfimg_index(nct, ns2, j, k, part)] = p[part];
+}
+// both split-bf16 images of the centroids (the second one only where the wave-pair chain runs)
+__host__ __device__ inline void bfimg_store_all(const Dev& D, int j, int k, float y) {
+  bfimg_store(D.Yimg3, D.NCT, D.NS2, j, k, y);
+  if (D.Yimg3p) {
+    const int nctp = (D.KH + 15) >> 4, h = k >= D.KH ? 1 : 0;
+    bfimg_store(D.Yimg3p + (size_t)h * nctp * D.NS2 * 3 * 512, nctp, D.NS2, j, h ? k - D.KH : k, y);
+  }
 }
 constexpr int P2P_CAP = 65536;                       // K x B entries an inbox holds per (plane, source): 200 clusters x 200 levels (BASELINE configs[4]) fit
 // an inbox = [4 planes][8 sources][P2P_CAP entries][2 granules]: planes 0 / 1 = the block chain's exchanges (alternating by exchange

@@ -20,6 +20,11 @@
 #ifndef HMX_CHAIN_PRE2
 #define HMX_CHAIN_PRE2 1      // the chain runs the MFMAs of a wave's second tile of a block ahead of the flag too
 #endif
+#ifndef HMX_PAIR_PRE2
+// the wave-pair chain (MODE 6) hoists ONE tile's MFMAs ahead of the flag: with the second accumulator set live across the flag as well the kernel needs 87
+// spilled registers instead of 13 and a block step at K = 200 takes 44.8 instead of 42.6 us (profiles/r6_pair_chain_tuning.txt)
+#define HMX_PAIR_PRE2(PAIR) (!(PAIR))
+#endif
 #ifndef HMX_CHAIN_BALANCE
 #define HMX_CHAIN_BALANCE 1
 #endif

@@ -178,6 +178,36 @@ def test_chain_with_three_and_more_tiles_per_wave_equals_launch_per_step(monkeyp
     assert relfro(Z1, Z0) < 1e-6 and float(np.max(np.abs(o1 - o0) / np.abs(o0))) < 1e-6
 
 
+@pytest.mark.parametrize("N", [60000, 1300000])
+def test_wave_pair_chain_equals_launch_per_step(monkeypatch, N):
+    """BASELINE configs[4]'s shape (K = 200, 8 > 64 > 128 nested levels): the block chain by wave pairs (k_tile MODE 6, round 6: two halves of the clusters on the
+    two waves of a pair, a row's normalisation sum exchanged through LDS, several folder workgroups, the penalty rows from memory) against the
+    launch-per-step kernels on the same data.  60k cells: at most one tile per pair and block, streams without a tile; 1.3M cells: four and five tiles
+    per pair -- the tile loop, the deferred last epilogue, and (fifth tile) the penalty rows fetched outside the wave's LDS cache.  The two paths add the halves
+    of a row sum in a different order: R agrees to the last bits, the integer tables to 1e-6, nothing is bit-identical."""
+    Z, meta, _ = synth(N, d=50, levels=(8, 64, 128), seed=11, nested=True)
+    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=200)
+    out, Y0 = [], None
+    for pair in ("1", "0"):
+        monkeypatch.setenv("HMX_CHAIN_PAIR", pair)
+        g = Harmony(seed=3)
+        g.setup(**skw)
+        if Y0 is None:
+            Y0 = g.kmeans_centers()
+        g.init_cluster_cpp(Y0)
+        for _ in range(2):
+            assert g.cluster_cpp() == 0
+            g.moe_correct_ridge_cpp()
+        out.append((int(g._scalar("chain_pair")), int(g._scalar("chain")), g.getZcorr().copy(), np.array(g.objective_kmeans), np.array(g.O), g.getR().copy() if N <= 100000 else None))
+        del g
+    (p1, c1, Z1, o1, O1, R1), (p0, c0, Z0, o0, O0, R0) = out
+    assert p1 == 1 and c1 == 1 and p0 == 0 and c0 == 0
+    assert len(o1) == len(o0) and float(np.max(np.abs(o1 - o0) / np.abs(o0))) < 1e-6
+    assert relfro(Z1, Z0) < 1e-6 and np.allclose(O1, O0, rtol=1e-5, atol=1e-3)
+    if R1 is not None:
+        assert float(np.max(np.abs(R1 - R0))) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [dict(N=30000, K=100, levels=(10,)), dict(N=20000, K=60, levels=(3, 4)), dict(N=9000, K=24, levels=(5,))])
 @pytest.mark.parametrize("chain", ["1", "0"])
 def test_carried_old_contributions_equal_a_fresh_pass(monkeypatch, shape, chain):
@@ -875,8 +905,9 @@ def test_two_processes_peer_to_peer_chain():
 
 
 def test_two_processes_configs4_shape_through_the_inboxes():
-    """BASELINE configs[4]'s shape on two ranks (K = 200, 8 > 64 > 128 nested levels, 40k cells): no persistent chain above K = 112, so every
-    block step's K x B table is an inbox all-reduce of its own, and the ridge statistics (Q K (d + 1) doubles, far above the 65536 entries
+    """BASELINE configs[4]'s shape on two ranks (K = 200, 8 > 64 > 128 nested levels, 40k cells): round 6 -- the block chain by wave pairs (k_tile MODE 6), the
+    folders of the two ranks exchange every block step's slice of the K x B table through the inboxes INSIDE the launch (rounds 2-5: one launch and one inbox
+    all-reduce per block step); the ridge statistics (Q K (d + 1) doubles, far above the 65536 entries
     of the one-shot form) take the inboxes' reduce-scatter + all-gather windows (round 5) -- what is left on the hook is the setup's handful.
     Rank 0 checks against the unsharded run."""
     import subprocess
@@ -890,6 +921,7 @@ def test_two_processes_configs4_shape_through_the_inboxes():
     print(p.stdout[-400:])
     assert int(p.stdout.split("collectives/rank=")[1].split()[0]) <= 12, p.stdout[-400:]
     assert int(p.stdout.split("big_windows/rank=")[1].split()[0]) > 0, p.stdout[-400:]
+    assert "chain=1" in p.stdout, p.stdout[-400:]      # (round 6: the block steps run inside the wave-pair chain, their tables exchanged through the inboxes in the launch)
 
 
 def test_bench_bootstraps_without_torch():

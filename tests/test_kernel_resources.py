@@ -49,13 +49,13 @@ def test_only_the_documented_kernels_use_scratch(objs):
                 if name == "k_seq_scan":
                     assert r[".vgpr_spill_count"] <= 8
                     continue
-                if name.startswith("k_seq_obj_fused<"):       # (round 6: held to three waves per SIMD -- 168 registers -- at the price of a few spilled ones)
-                    assert r[".vgpr_spill_count"] <= 12
+                if name.startswith("k_seq_obj_fused<"):       # (round 6: held to three waves per SIMD -- 168 registers -- at the price of a few spilled ones; 20 with the three-level exchange)
+                    assert r[".vgpr_spill_count"] <= 24
                     continue
                 m = re.match(r"k_tile<(\d+), (\d+),", name)
                 assert m, "%s: %s spills %d VGPRs" % (o, name, r[".vgpr_spill_count"])
                 nct, mode = int(m.group(1)), int(m.group(2))
-                assert (mode in (4, 5) and nct >= 6) or (mode == 0 and nct >= 12) or (mode == 1 and nct >= 14), (o, name, r[".vgpr_spill_count"])
+                assert (mode in (4, 5, 6) and nct >= 6) or (mode == 0 and nct >= 12) or (mode == 1 and nct >= 14), (o, name, r[".vgpr_spill_count"])      # (mode 6: the wave-pair chain, 17)
                 assert r[".vgpr_spill_count"] <= 150, (o, name)
     # the kernels of the headline configuration (K = 100: 7 cluster tiles, split-bf16 build)
     bf = objs["hmx_tile_bf"]

@@ -23,8 +23,8 @@ ap.add_argument("--p2p", action="store_true", help="sum the block contributions 
                 "(hmx_p2p_*; the handles travel through torch.distributed) instead of one all-reduce per block")
 ap.add_argument("--carry", action="store_true", help="force the round-to-round carry of the old contributions (HMX_SOLD_CARRY=1)")
 ap.add_argument("--split", type=float, default=0.0, help="two ranks: rank 0 holds this fraction of the cells (unequal shards)")
-ap.add_argument("--workload", default="c3", choices=["c3", "c5"], help="c5: BASELINE configs[4]'s shape (K = 200, nested covariates 8 > 64 > 128): block steps one launch each "
-                "(no chain above K = 112), ridge statistics of Q K (d + 1) > 65536 entries -- the inboxes' reduce-scatter + all-gather path")
+ap.add_argument("--workload", default="c3", choices=["c3", "c5"], help="c5: BASELINE configs[4]'s shape (K = 200, nested covariates 8 > 64 > 128): the block chain by wave pairs "
+                "(k_tile MODE 6; HMX_CHAIN_PAIR=0: one launch + one inbox all-reduce per block step), ridge statistics of Q K (d + 1) > 65536 entries -- the inboxes' reduce-scatter + all-gather path")
 ap.add_argument("--chain-max-tpw", default=None, help="HMX_CHAIN_MAX_TPW: tiles per wave up to which a rank would pick the persistent chain")
 a = ap.parse_args()
 if a.carry:
