@@ -920,12 +920,13 @@ def main():
         out["parity_mode"] = ("default: exact accumulators, identical for every shard count (integer sums); parity target = the reference's own sources built with its "
                               "-DHARMONY_SCALAR_DOUBLE switch (INTEGRATION.md, 'Which result a sharded run returns'); reference arithmetic is a one-GPU mode")
         try:      # DESIGN 5.2's prediction for this very line, made before any run crossed two devices: the hardware run falsifies or confirms it
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r5_scaling_prediction.json")))
+            pfile = next(f for f in ("r6_scaling_prediction.json", "r5_scaling_prediction.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pj = json.load(open(os.path.join(ROOT, "profiles", pfile)))
             key = "configs3" if (N, d, K, levels) == (10000000, 50, 100, (20,)) else ("configs4" if a.workload == "c5" and N == 5000000 else None)
             if key and str(world) in pj[key]:
                 e = pj[key][str(world)]
                 out["predicted"] = {"ms_per_step": e["predicted_ms"], "speedup_vs_1_gpu": e["speedup_vs_1"], "one_rank_share_without_exchanges_ms": e["share_ms"],
-                                    "source": "profiles/r5_scaling_prediction.json (tools/scaling_prediction.py: per-rank shares measured on ONE GPU + measured one-device exchange costs)"}
+                                    "source": "profiles/%s (tools/scaling_prediction.py: per-rank shares measured on ONE GPU + measured one-device exchange costs)" % pfile}
         except Exception:
             pass
         if a.default_multi and (a.also or "weak") != "none":

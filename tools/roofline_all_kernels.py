@@ -1,16 +1,19 @@
 #!/usr/bin/env python
 """Every kernel of the default bench run against the HBM roofline -- not only the dominant one the bench line prices.
 
-Input: profiles/r5_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py` on the final code: 1M cells x 50 PCs, K = 100,
+Input: profiles/<tag>_kernel_stats.csv (tag: r6 by default) (rocprofv3 --kernel-trace --stats of `python bench.py` on the final code: 1M cells x 50 PCs, K = 100,
 10 batches, fp32; 23 runs to convergence in the trace).  For every kernel that touches N-sized arrays: ALGORITHMIC bytes per launch (SURVEY
 8(d)'s per-cell figures x the cells one launch processes -- compulsory traffic only: what has to be read or written once, side inputs of a
 few bytes per cell counted where they are the kernel's whole job), average launch duration, achieved GB/s, fraction of the 8 TB/s peak,
-share of the run.  Output: profiles/r5_roofline_all_kernels.json + a markdown table on stdout.  No GPU needed.
+share of the run.  Output: profiles/<tag>_roofline_all_kernels.json + a markdown table on stdout.  No GPU needed.
 """
 import csv
 import json
 import os
 import re
+import sys
+
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r6"      # python tools/roofline_all_kernels.py [tag]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N, d, K, B = 1000000, 50, 100, 10
@@ -35,7 +38,7 @@ PER_CELL = [
 
 def main():
     rows, total_ns = [], 0.0
-    with open(os.path.join(ROOT, "profiles", "r5_kernel_stats.csv")) as fh:
+    with open(os.path.join(ROOT, "profiles", TAG + "_kernel_stats.csv")) as fh:
         stats = list(csv.DictReader(fh))
     total_ns = sum(float(r["TotalDurationNs"]) for r in stats)
     for r in stats:
@@ -58,8 +61,8 @@ def main():
         else:
             row["counts"] = "K x B / K x d tables, scans, solves: latency-bound small launches (no N-sized traffic)"
         rows.append(row)
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_summary.json")))["kernels"]
-    for r in rows:                      # measured HBM bytes per launch (rocprofv3 --pmc, separate passes, gfx950 FETCH_SIZE correction: r5_pmc_summary.json)
+    pmc = json.load(open(os.path.join(ROOT, "profiles", TAG + "_pmc_summary.json")))["kernels"]
+    for r in rows:                      # measured HBM bytes per launch (rocprofv3 --pmc, separate passes, gfx950 FETCH_SIZE correction: <tag>_pmc_summary.json)
         m = pmc.get("hmx::" + r["kernel"])
         if m:
             r["hbm_bytes_measured"] = m["hbm_total_bytes"]
@@ -68,11 +71,11 @@ def main():
             if "alg_bytes_per_launch" in r:
                 r["traffic_over_algorithmic"] = round(m["hbm_total_bytes"] / r["alg_bytes_per_launch"], 2)
     priced = [r for r in rows if "frac_of_8TBps" in r]
-    out = {"workload": "1M cells x 50 PCs, K = 100, 10 batches, fp32 (bench.py default, profiles/r5_kernel_stats.csv)", "peak_GBps": PEAK,
+    out = {"workload": "1M cells x 50 PCs, K = 100, 10 batches, fp32 (bench.py default, profiles/%s_kernel_stats.csv)" % TAG, "peak_GBps": PEAK,
            "kernels": rows,
            "time_weighted_frac_of_priced_kernels": round(sum(r["frac_of_8TBps"] * r["share_of_gpu_time"] for r in priced) / sum(r["share_of_gpu_time"] for r in priced), 3),
            "share_of_gpu_time_priced": round(sum(r["share_of_gpu_time"] for r in priced), 3)}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r5_roofline_all_kernels.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_roofline_all_kernels.json"), "w"), indent=1)
     print("| kernel | what one launch has to move | B / cell | avg µs | algorithmic GB/s | **of 8 TB/s** | measured HBM MB (PMC) | measured / algorithmic | measured of 8 TB/s | share of GPU time |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """a falsifiable prediction of the multi-GPU runs this project could never measure (one GPU per box).  Inputs, all measured on ONE
 MI355X and committed under profiles/ (tools/final_profiles_r5.sh):
-  r5_bench_shares.json        time to convergence of ONE rank's share of configs[3] (10M cells / G, 20 batches) and configs[4] (5M / G, K = 200,
+  <tag>_bench_shares.json        time to convergence of ONE rank's share of configs[3] (10M cells / G, 20 batches) and configs[4] (5M / G, K = 200,
                               200 levels) for G = 2, 4, 8, without any exchange (`bench.py --also shares`; G = 1: r5_bench_default.json's also.10M_one_gpu
                               and r5_bench_c5_5M.json)
-  r5_bench_2ranks_one_gpu_*   two ranks SHARING this GPU with the in-launch exchange / inbox collectives: exchange + collective cost per step on one device
-  r5_bench_default.json       p2p self-test figure (us per exchange step) and collective counts (config.comm of the 2-rank lines)
+  <tag>_bench_2ranks_one_gpu_*   two ranks SHARING this GPU with the in-launch exchange / inbox collectives: exchange + collective cost per step on one device
+  <tag>_bench_default.json       p2p self-test figure (us per exchange step) and collective counts (config.comm of the 2-rank lines)
 Model per rank:  T(G) = T_share(N / G) + n_exchange * t_x + n_small * t_small + n_big * t_big(G)
   configs[3] (K = 100: persistent chain, the per-block sum INSIDE the launch): n_exchange = rounds * (nb + 2) folder exchanges; t_x = the measured one-device
       figure (lower bound) and 5 us (assumed xGMI round trip of a write-through granule + poll); n_small inbox all-reduces at ~12 us (one launch, one trip)
@@ -13,13 +13,14 @@ Model per rank:  T(G) = T_share(N / G) + n_exchange * t_x + n_small * t_small + 
       as (T_2ranks - 2 T_share(500k)) / block steps; big buffers (ridge statistics 1.3M entries per correction, old sums 800k per round) as reduce-scatter +
       all-gather windows: bytes per link = 2 (G - 1) / G * 16 B * entries / G ... / 50 GB/s effective per direction and link (assumed: a third of the 153 GB/s peak
       for 16-byte granule traffic)
-Writes profiles/r5_scaling_prediction.json and prints the markdown table."""
+Writes profiles/<tag>_scaling_prediction.json and prints the markdown table."""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r6"      # python tools/scaling_prediction.py [tag]
 
 
 def line(fn):
@@ -29,10 +30,10 @@ def line(fn):
         return None
 
 
-sh, dflt, c5full = line("r5_bench_shares.json"), line("r5_bench_default.json"), line("r5_bench_c5_5M.json")
-two_c3, two_c5 = line("r5_bench_2ranks_one_gpu_p2p_chain.json"), line("r5_bench_2ranks_one_gpu_configs4_shape.json")
+sh, dflt, c5full = line(TAG + "_bench_shares.json"), line(TAG + "_bench_default.json"), line(TAG + "_bench_c5_5M.json")
+two_c3, two_c5 = line(TAG + "_bench_2ranks_one_gpu_p2p_chain.json"), line(TAG + "_bench_2ranks_one_gpu_configs4_shape.json")
 if not sh or not dflt:
-    sys.exit("profiles/r5_bench_shares.json / r5_bench_default.json missing: run tools/final_profiles_r5.sh first")
+    sys.exit("profiles/%s_bench_shares.json / %s_bench_default.json missing: run tools/final_profiles.sh + tools/pmc_summary.py first" % (TAG, TAG))
 legs = sh["also"]
 out = {"assumptions": {"t_x_us": [None, 5.0], "t_small_us": 12.0, "link_GBps_effective": 50.0}, "configs3": {}, "configs4": {}}
 tx_meas = None
@@ -71,13 +72,27 @@ out["assumptions"]["configs4_us_per_block_step_allreduce_shared_gpu"] = t_step_a
 for G, (ms, it) in rows4.items():
     rounds = it * 4
     steps = rounds * nb
+    key = {2: "configs4_share_2500k", 4: "configs4_share_1250k", 8: "configs4_share_625k"}.get(G)
+    chain = bool(key and legs[key].get("block_chain"))          # round 6: the share runs its rounds in the wave-pair chain (k_tile MODE 6): block steps exchanged in the launch
+    if chain and G > 1:
+        # in-launch exchange per block step (the configs[3] model: nb + 1 exchanges per round of t_x each), no old-sums collective (the folders exchange
+        # new(j - 1) - old_local(j)); the ridge statistics stay reduce-scatter + all-gather windows
+        n_x = rounds * (nb + 1)
+        big_entries = it * 1.3e6
+        t_big = 1e3 * (2.0 * (G - 1) / G * 16.0 * big_entries / G) / (50.0e9)
+        lo, hi = ms + 1e-3 * n_x * tx_meas + t_big, ms + 1e-3 * n_x * 5.0 + t_big
+        out["configs4"][G] = {"share_ms": ms, "iterations": it, "block_chain": True, "in_launch_exchanges": n_x, "block_step_allreduces": 0, "us_per_step_allreduce": 0.0,
+                              "big_window_ms": t_big, "predicted_ms": hi, "predicted_ms_range": [lo, hi], "speedup_vs_1": (rows4[1][0] / hi) if 1 in rows4 else None}
+        continue
     big_entries = it * 1.3e6 + rounds * 0.8e6                     # ridge statistics per correction + old sums per round
     t_big = 0.0 if G == 1 else 1e3 * (2.0 * (G - 1) / G * 16.0 * big_entries / G) / (50.0e9)      # ms: bytes over one link / effective rate
-    t_ar = (t_step_ar if t_step_ar is not None else 40.0)
+    # (round 6: the two-rank configs[4] run itself is on the wave-pair chain now and no longer measures a per-step collective: shares above the chain's
+    #  envelope are priced with round 5's measurement, 39.5 us per host-launched inbox all-reduce of the 40 000-entry table)
+    t_ar = (t_step_ar if (t_step_ar is not None and t_step_ar >= 5.0) else 39.5)
     pred = ms + (1e-3 * steps * t_ar + t_big if G > 1 else 0.0)
-    out["configs4"][G] = {"share_ms": ms, "iterations": it, "block_step_allreduces": steps if G > 1 else 0, "us_per_step_allreduce": t_ar if G > 1 else 0,
+    out["configs4"][G] = {"share_ms": ms, "iterations": it, "block_chain": False, "block_step_allreduces": steps if G > 1 else 0, "us_per_step_allreduce": t_ar if G > 1 else 0,
                           "big_window_ms": t_big, "predicted_ms": pred, "speedup_vs_1": (rows4[1][0] / pred) if 1 in rows4 else None}
-json.dump(out, open(os.path.join(P, "r5_scaling_prediction.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, TAG + "_scaling_prediction.json"), "w"), indent=1)
 print("| config | G | cells per rank | one rank's share, no exchange (measured) | exchanges / collectives per run | predicted ms per step | predicted speed-up vs 1 GPU |")
 print("|---|---|---|---|---|---|---|")
 for G in sorted(out["configs3"]):
@@ -86,6 +101,6 @@ for G in sorted(out["configs3"]):
           % (G, 10.0 / G, r["share_ms"], r["iterations"], r["exchanges"], r["small_allreduces"], r["predicted_ms"][0], r["predicted_ms"][1], r["speedup_vs_1"][0], r["speedup_vs_1"][1]))
 for G in sorted(out["configs4"]):
     r = out["configs4"][G]
-    print("| configs[4] 5M x 50, K=200, 200 levels | %d | %.3fM | %.1f ms (%d it.) | %d per-step inbox all-reduces (%.0f us each) + %.2f ms of reduce-scatter / all-gather windows | %.1f | %s |"
-          % (G, 5.0 / G, r["share_ms"], r["iterations"], r["block_step_allreduces"], r["us_per_step_allreduce"], r["big_window_ms"], r["predicted_ms"],
-             ("%.2f" % r["speedup_vs_1"]) if r["speedup_vs_1"] else "-"))
+    how = ("%d in-launch exchanges (wave-pair chain)" % r["in_launch_exchanges"]) if r.get("block_chain") else ("%d per-step inbox all-reduces (%.0f us each)" % (r["block_step_allreduces"], r["us_per_step_allreduce"]))
+    print("| configs[4] 5M x 50, K=200, 200 levels | %d | %.3fM | %.1f ms (%d it.) | %s + %.2f ms of reduce-scatter / all-gather windows | %.1f | %s |"
+          % (G, 5.0 / G, r["share_ms"], r["iterations"], how, r["big_window_ms"], r["predicted_ms"], ("%.2f" % r["speedup_vs_1"]) if r["speedup_vs_1"] else "-"))
