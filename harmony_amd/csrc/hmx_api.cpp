@@ -312,6 +312,9 @@ int hmx_cluster(hmx_ctx* ctx) {  // src/harmony.cpp:208-262
     CHK(head_pass(ctx, true));
   }
   int iter;
+  ctx->objD_valid = false;
+  struct RoundLoop { hmx_ctx* c; ~RoundLoop() { c->in_cluster_rounds = false; c->objD_valid = false; } } round_loop{ctx};      // (dist_mat of this call serves its rounds' objective evaluations only)
+  ctx->in_cluster_rounds = true;
   for (iter = 0; iter < ctx->max_iter_kmeans; iter++) {
     if (ctx->poll && ctx->poll(ctx->poll_user)) return HMX_ABORTED;  // :233-234
     ctx->last_round_hint = (iter == ctx->max_iter_kmeans - 1);         // (nothing follows the last round that could use its R sums)

@@ -334,7 +334,7 @@ void l_seq_scan1(const Launch& L, int narr, int nsegs, const float* start_in, co
 void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float* tot_add, const float* tot_sub, float* pen, int head);
 // returns the number of term arrays materialised in T: 1 (T[0] = R % dist only: the MFMA kernel; the passes recompute the other two from R,
 // l_seq_objr_pass) or 3 (the cluster-lane fallback kernel: K % 4 != 0, rows of more than 67 PCs, the stale-distance snapshot)
-int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride);
+int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride, int dist_mode = 0);
 // arrays 1 and 2 of the objective (entropy, cross-entropy) as sequential sums straight from R: same segments, starts / ends / partials as l_seq_arr_pass's arrays 1, 2
 void l_seq_objr_pass(const Launch& L, const Dev& D, const float* M, long long nterms, int Lseg, int nsegs, const float* start, float* end, int zero_start, double* partial);
 // round 6: the three chains in ONE launch, segments in registers, the scans between the passes inside the launch (k_seq_obj_fused, hmx_seq.hip)

@@ -744,7 +744,7 @@ template <class LOAD> __device__ __forceinline__ void objf_deal(float* __restric
   for (int r = 0; r < 8; r++) { const f4 x = L4[lane * 8 + (r ^ (lane & 7))]; out[4 * r] = x[0]; out[4 * r + 1] = x[1]; out[4 * r + 2] = x[2]; out[4 * r + 3] = x[3]; }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <int MODE, bool LDSTAB>
+template <int MODE, bool LDSTAB, bool DIST = false>      // DIST (MODE 1): T holds dist_mat, the first chain's terms R % dist are formed here (one rounding, as k_obj_terms_mfma forms them)
 __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const float* __restrict__ T, long long stride, const float* __restrict__ M, const int* __restrict__ olev,
                                                                    long long nt, int nsegs, int npass, int zero_start, float* __restrict__ starts,
                                                                    unsigned* __restrict__ stats, double* __restrict__ wgagg, SeqXchg X) {
@@ -815,6 +815,7 @@ __global__ __launch_bounds__(OBJF_THREADS, 3) void k_seq_obj_fused(Dev D, const 
       for (int i = 0; i < 4; i++) {
         const float r = b[4 * j + i], sg = g4[i];
         const float lg = (r > 0.0f) ? __fmul_rn(__builtin_amdgcn_logf(r), 0.69314718055994530942f) : lmin;      // arma::trunc_log
+        if constexpr (DIST) a[4 * j + i] = ok ? __fmul_rn(r, a[4 * j + i]) : 0.0f;
         b[4 * j + i] = ok ? __fmul_rn(__fmul_rn(r, lg), sg) : 0.0f;
         c[4 * j + i] = ok ? __fmul_rn(__fmul_rn(r, sg), m4[i]) : 0.0f;
       }
@@ -1295,9 +1296,13 @@ void l_oe_fold(const Launch& L, const Dev& D, float* Of, float* Ef, const float*
   const int n = D.B * D.K;
   hipLaunchKernelGGL(k_oe_fold, dim3((n + 255) / 256), dim3(256), 0, L.stream, Of, Ef, tot_add, tot_sub, D.Pr_b, D.theta, pen, D.B, D.K, head);
 }
-int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride) {
+int l_obj_terms(const Launch& L, const Dev& D, const float* Of, const float* Ef, float* M, float* T, long long stride, int dist_mode) {
+  // dist_mode (round 6): 1 = T[0 .. stride) <- dist_mat itself (returns 2; 0 and nothing written where the MFMA kernel does not apply), 2 = the M table only
+  // (the caller holds this call's dist_mat already: returns 2)
   const int n = D.B * D.K;
   hipLaunchKernelGGL(k_obj_mtable, dim3((n + 255) / 256), dim3(256), 0, L.stream, D, Of, Ef, M);
+  if (dist_mode == 2) return 2;
+  if (dist_mode == 1) return l_obj_terms_mfma(L, D, M, T, stride, 2) ? 2 : 0;
   if (l_obj_terms_mfma(L, D, M, T, stride, 0)) return 1;          // distances on the matrix cores, 16-byte rows (hmx_k_correct.inc): T[0] only
   int blocks = (D.n + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_obj_terms, dim3(blocks), dim3(256), (size_t)D.d * D.KP * sizeof(float), L.stream, D, M, T, stride);
@@ -1321,7 +1326,7 @@ int seq_obj_fused_nsegs(long long nt) { return (int)((nt + OBJF_TPT - 1) / OBJF_
 bool l_seq_obj_fused(const Launch& L, const Dev& D, int mode, const float* T, long long stride, const float* M, const int* olev, long long nt, int npass, int zero_start,
                      float* starts, float* total, unsigned* stats, unsigned long long* slots, unsigned epoch) {
   if (npass < 1 || npass > OBJF_MAXSTAGE || nt < 4) return false;
-  if (mode == 1 && (D.K % 4 != 0 || D.C > 4 || !olev)) return false;
+  if (mode >= 1 && (D.K % 4 != 0 || D.C > 4 || !olev)) return false;      // (mode 2: T = dist_mat, see k_seq_obj_fused<., ., DIST>)
   const int nsegs = seq_obj_fused_nsegs(nt), nwg = (nsegs + OBJF_THREADS - 1) / OBJF_THREADS, ng = (nwg + 63) / 64;
   const int nsup = (ng + 63) / 64;
   SeqXchg X; X.slotA = slots; X.slotG = slots + (size_t)OBJF_MAXSTAGE * nwg * 8; X.slotS = X.slotG + (size_t)OBJF_MAXSTAGE * ng * 8; X.epoch = epoch & 0x0fffffffu; X.ngroups = ng; X.nsuper = nsup;
@@ -1331,6 +1336,10 @@ bool l_seq_obj_fused(const Launch& L, const Dev& D, int mode, const float* T, lo
   if (mode == 0) hipLaunchKernelGGL((k_seq_obj_fused<0, false>), dim3(nwg), dim3(OBJF_THREADS), deal, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);
   else {
     const size_t tab = ((size_t)D.B * D.K + D.K) * sizeof(float);
+    if (mode == 2) {
+      if (tab <= 24 * 1024) hipLaunchKernelGGL((k_seq_obj_fused<1, true, true>), dim3(nwg), dim3(OBJF_THREADS), deal + tab, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);
+      else hipLaunchKernelGGL((k_seq_obj_fused<1, false, true>), dim3(nwg), dim3(OBJF_THREADS), deal, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);
+    } else
     if (tab <= 24 * 1024) hipLaunchKernelGGL((k_seq_obj_fused<1, true>), dim3(nwg), dim3(OBJF_THREADS), deal + tab, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);
     else hipLaunchKernelGGL((k_seq_obj_fused<1, false>), dim3(nwg), dim3(OBJF_THREADS), deal, L.stream, D, T, stride, M, olev, nt, nsegs, npass, zero_start, starts, stats, wgagg, X);
   }

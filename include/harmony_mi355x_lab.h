@@ -61,8 +61,9 @@ int32_t hmx_cluster_of_column(int32_t nct, int32_t ct, int32_t c);
  *   hmx_get "seq:mismatch" / "seq:residual" = how many segment starts still moved in the last scans and by how much, relatively (long chains
  *   always; the short per-block sums only with "seq_stats" = 1); "seq:group_passes" / "seq:group_runs" = passes / evaluations per group (O/E,
  *   objective, ridge, level pairs); "seq:unsettled" = sums that hit seq_max_passes.
- *   "seq_fused" (round 6, default 5 = both on): bit 0 the objective's three chains in ONE launch (k_seq_obj_fused: segments of 32 terms in registers, the
- *   passes and the scans between them inside the launch); bit 2 the ridge pass with lane = cluster (k_seq_ridge_pass_kl).  0: the round-5 kernels.
+ *   "seq_fused" (round 6, default 13 = all on): bit 0 the objective's three chains in ONE launch (k_seq_obj_fused: segments of 32 terms in registers, the
+ *   passes and the scans between them inside the launch); bit 2 the ridge pass with lane = cluster (k_seq_ridge_pass_kl); bit 3 dist_mat of a cluster_cpp
+ *   call computed by its first objective evaluation and kept for the others (R % dist formed inside the fused launch).  0: the round-5 kernels.
  * Probes of that machinery on caller-provided data (device needed; hmx_debug_seq_arr with seg_terms = 0 and three arrays: the one-launch form): */
 int hmx_debug_seq_oe(const float* R, int64_t n, int32_t K, const int32_t* level, int32_t B, const int32_t* list, int64_t nlist,
                      const int32_t* chain_off, const int32_t* chain_cnt, int32_t nchains, int32_t seg_cells, int32_t passes, float* totals,

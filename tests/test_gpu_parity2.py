@@ -795,10 +795,22 @@ def test_config5_5M_against_the_oracle():
     assert ga["Z_rel"] <= 2e-5 and ga["argmax_diff_margin_ge_1e-5"] == 0 and ga["iterations"][0] == ga["iterations"][1] and ga["kmeans_rounds_equal"], ga
     assert ga["objective_rel_max"] <= 1e-4, ga
     assert ga["subset_clusters_per_iteration"][0] == ga["subset_clusters_per_iteration"][1], ga
-    assert rf["Z_rel"] <= 1e-4 and rf["iterations"][0] == rf["iterations"][1], rf
-    # the pair's clear flips against the oracle's own width at this size (VERDICT r5 #1b: 309 clear flips at 5M were reported, not bounded)
+    assert rf["iterations"][0] == rf["iterations"][1], rf
+    # the pair's distance and clear flips against the oracle's own width at this size (VERDICT r5 #1b: 309 clear flips at 5M were reported, not bounded)
     lib = rows["oracle_faithful_liberty1_vs_oracle_faithful"]
+    assert lib["iterations"][0] == lib["iterations"][1], lib
     assert rf["Z_rel"] <= 3 * lib["Z_rel"] + 2e-6 and rf["argmax_diff_margin_ge_1e-5"] <= 3 * lib["argmax_diff_margin_ge_1e-5"] + 5 * 5, (rf, lib)
+    if lib["subset_clusters_per_iteration"][0] == lib["subset_clusters_per_iteration"][1]:
+        # where the oracle agrees with itself on which clusters take the batch-subset ridge path: north_star's 1e-4, and the same clusters on the GPU
+        assert rf["Z_rel"] <= 1e-4 and rf["subset_clusters_per_iteration"][0] == rf["subset_clusters_per_iteration"][1], rf
+    else:
+        # Round 6, second builder run (another box: another OpenBLAS kernel under the oracle's sgemm): the faithful oracle kept 27 clusters on the subset path in the
+        # first correction, its own liberty variant 29, the GPU 31 -- a level's O[k, b] / N_b sits on the cutoff (src/harmony.cpp:368-402) and fp32 sums over 5M
+        # cells decide it differently in every legal order; ALL pairs then differ by 1.4e-3 .. 1.8e-3 (profiles/r6_parity_c5_5M.json: GPU 1.41e-3 / 12 409 clear
+        # flips, the oracle against itself 1.76e-3 / 10 734).  The round's first run (profiles/r6_parity_c5_5M_first_run.json) had all three at 31 and the pair at
+        # 1.0e-5 / 192 against the oracle's own 1.0e-5 / 247.  Bounded by the liberty row above; the subset-cluster count within the spread the oracle itself shows.
+        spread = abs(lib["subset_clusters_per_iteration"][0][0] - lib["subset_clusters_per_iteration"][1][0])
+        assert abs(rf["subset_clusters_per_iteration"][0][0] - rf["subset_clusters_per_iteration"][1][0]) <= 2 * spread + 2, (rf, lib)
 
 
 # ---------------------------------------------------------------- the sharded path through two PROCESSES

@@ -285,6 +285,29 @@ def test_reference_arithmetic_against_the_golden_vectors_of_the_reference_source
     assert s["Z_rel"] <= tol and s["clear_flips"] == 0 and s["obj_rel"] <= 1e-4 and s["Y_rel"] <= 1e-4 and s["O_rel"] <= 1e-4, s
 
 
+@pytest.mark.parametrize("shape", [dict(N=60000, K=100, levels=(10,)), dict(N=30000, K=40, levels=(3, 4))])
+def test_kept_distances_give_the_same_objective_bits(shape):
+    """Round 6: inside a cluster_cpp call dist_mat is computed by the first objective evaluation and kept for the call's other rounds (Y and Z_corr do not
+    change between them); R % dist is then formed inside the one-launch sums with the single rounding of the terms kernel.  Same terms, same chains: the
+    objective series and everything that follows from it -- round counts, Z_corr -- are BIT-identical to the run that recomputes the distances every round
+    ("seq_fused" bit 3 off)."""
+    Z, meta, _ = synth(shape["N"], d=50, levels=shape["levels"], seed=5)
+    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=shape["K"])
+    out, Y0 = [], None
+    for fused in (13, 5):
+        g = Harmony(seed=2, ref_arith=1)
+        g._set("seq_fused", fused)
+        g.setup(**skw)
+        if Y0 is None:
+            Y0 = g.kmeans_centers()
+        g.init_cluster_cpp(Y0)
+        it = _iterate(g, 3)
+        out.append((it, np.array(g.objective_kmeans), list(g.kmeans_rounds), g.getZcorr().copy()))
+        del g
+    (i1, o1, r1, z1), (i0, o0, r0, z0) = out
+    assert i1 == i0 and r1 == r0 and np.array_equal(o1, o0) and np.array_equal(z1, z0)
+
+
 def test_reference_arithmetic_groups_can_be_switched_one_by_one(cell_lines_small):
     """each switch alone against the oracle with the matching arithmetic mask (oracle bit set = fp64: mask = 15 minus the group)"""
     meta = {"dataset": cell_lines_small["dataset_levels"][cell_lines_small["dataset"]]}
