@@ -49,8 +49,8 @@ def test_only_the_documented_kernels_use_scratch(objs):
                 if name == "k_seq_scan":
                     assert r[".vgpr_spill_count"] <= 8
                     continue
-                if name.startswith("k_seq_obj_fused<"):       # (round 6: held to three waves per SIMD -- 168 registers -- at the price of a few spilled ones; 20 with the three-level exchange)
-                    assert r[".vgpr_spill_count"] <= 24
+                if name.startswith("k_seq_obj_fused<"):       # (round 6: held to three waves per SIMD -- 168 registers -- at the price of a few spilled ones; 20 with the three-level exchange, 32 in the variant that forms R % dist itself)
+                    assert r[".vgpr_spill_count"] <= 36
                     continue
                 m = re.match(r"k_tile<(\d+), (\d+),", name)
                 assert m, "%s: %s spills %d VGPRs" % (o, name, r[".vgpr_spill_count"])
