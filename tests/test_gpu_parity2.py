@@ -287,7 +287,7 @@ def test_sort_free_shuffle_equals_the_counting_sort(monkeypatch, shape):
     np.testing.assert_allclose(ja, jb, rtol=1e-7)
 
 
-@pytest.mark.parametrize("K", [12, 60, 64, 104, 116, 128, 148, 192, 200, 256])
+@pytest.mark.parametrize("K", [12, 60, 64, 104, 116, 128, 148, 192, 196, 200, 208, 224, 256])      # (196 .. 224: the wave-pair chain, halves of 100 + 96, 100 + 100, 104 + 104, 112 + 112 clusters)
 def test_every_cluster_tile_shape(K):
     """The tile kernels deal clusters to MFMA columns in quads (a lane's columns are consecutive clusters: 16 / 12 / 8 / 4-byte R
     stores, 16-byte penalty reads, one contribution atomic per 64 clusters).  Cluster counts that end inside a full quad, inside
