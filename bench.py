@@ -14,7 +14,7 @@ Other driver-reproducible modes:
     --cells-per-gpu 10000000 --batches 20          north_star target: 10M x 50 x K=100 on ONE GPU (configs[3]'s size)
     --workload c5 [--cells-per-gpu N]              configs[4] shape: K=200, 3 nested covariates 8 > 64 > 128 (200 levels)
     --total-cells 10000000 --batches 20 --gpus N   STRONG scaling: configs[3] = 10M cells in total, sharded over the N GPUs
-    --also ref,10M,share,c5,pbmc (default at N=1; "none"; "shares": the per-rank shares of the 8-GPU configs at G = 2 / 4 / 8)  extra legs of the same invocation, reported under "also": the reference-arithmetic
+    --also ref,10M,share,c5,pbmc (default at N=1 incl. ref2 = "ref_arith" 2; "none"; "shares": the per-rank shares of the 8-GPU configs at G = 2 / 4 / 8)  extra legs of the same invocation, reported under "also": the reference-arithmetic
                                                    mode on the main workload, 10M cells on this one GPU, the configs[4] shape at 1M,
                                                    configs[1] (pbmc, 30k cells) with its own CPU-oracle timing and parity check
 
@@ -207,11 +207,11 @@ def bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, seed, steps,
     ach = upd_cells * (4.0 * d + 4.0 * K) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     out = {"workload": label,
            "ms_per_step": ms, "cells_per_s": n / (ms * 1e-3), "harmony_iterations": its, "steps": steps, "gpu_phase_ms_per_step": ph, "gpu_phase_from": "one extra untimed run with per-phase events",
-           "block_chain": chain and not hkw.get("ref_arith"), "avg_block_step_us": 1e3 * upd_ms / upd_steps,
+           "block_chain": chain and hkw.get("ref_arith") != 1, "avg_block_step_us": 1e3 * upd_ms / upd_steps,
            # the leg's own dominant kernel (the E-step update of update_R, as on the main line): algorithmic bytes (4d + 4K per cell and
            # round) over its HIP-event time on the library's stream
-           "roofline": {"kernel": ("k_tile<7,6,...> persistent block chain by wave pairs (two halves of the clusters, several folder workgroups)" if (chain and K > 112 and not hkw.get("ref_arith")) else
-                                   ("k_tile<%d,4|5,...> persistent block chain" if (chain and not hkw.get("ref_arith")) else "k_tile<%d,0,...> one launch per block step") % ((K + 15) // 16)),
+           "roofline": {"kernel": ("k_tile<7,6,...> persistent block chain by wave pairs (two halves of the clusters, several folder workgroups)" if (chain and K > 112 and hkw.get("ref_arith") != 1) else
+                                   ("k_tile<%d,4|5,...> persistent block chain" if (chain and hkw.get("ref_arith") != 1) else "k_tile<%d,0,...> one launch per block step") % ((K + 15) // 16)),
                         "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                         "kernel_time_share": upd_ms / (ms * steps) if ms > 0 else None},
            "roofline_run_frac": run_bytes / (ms * 1e-3) / 8e12}
@@ -315,6 +315,12 @@ def headline_parity(n, d, K, levels):
                 "reference_arith_mode": {"Z_rel_vs_faithful": pr["gpu_ref_arith_vs_oracle_faithful"]["Z_rel"],
                                          "clear_flips_vs_faithful": pr["gpu_ref_arith_vs_oracle_faithful"]["argmax_diff_margin_ge_1e-5"],
                                          "timed_as": "also.reference_arith"},
+                "reference_arith_2_mode": ({"Z_rel_vs_faithful": pr["gpu_ref_arith2_vs_oracle_faithful"]["Z_rel"],
+                                            "clear_flips_vs_faithful": pr["gpu_ref_arith2_vs_oracle_faithful"]["argmax_diff_margin_ge_1e-5"],
+                                            "flips_at_margin_1e-4_vs_faithful": pr["gpu_ref_arith2_vs_oracle_faithful"]["argmax_diff_margin_ge_1e-4"],
+                                            "iterations": pr["gpu_ref_arith2_vs_oracle_faithful"]["iterations"],
+                                            "is": "ref_arith = 2: the reference's accumulators for the objective, the ridge statistics and the inverse; exact O / E tables",
+                                            "timed_as": "also.reference_arith_2"} if "gpu_ref_arith2_vs_oracle_faithful" in pr else None),
                 "the_reference_itself_faithful_vs_accurate": pr["oracle_faithful_vs_oracle_accurate"]["Z_rel"],
                 "oracle_pinned_to": "the reference's own src/harmony.cpp / utils.cpp / timer.cpp compiled in place over oracle/shim (a stand-in for the Armadillo / "
                                     "Rcpp headers): the faithful oracle equals them bit for bit (tests/test_oracle_ref.py, tests/golden/ref_sources_*.npz); "
@@ -955,7 +961,7 @@ def main():
     if hp:
         out.update({"parity_mode": hp["parity_mode"], "Z_rel_vs_accurate": hp["Z_rel_vs_accurate"], "Z_rel_vs_faithful": hp["Z_rel_vs_faithful"], "parity": hp})
     default_main = world == 1 and a.workload == "c3" and n == 1000000 and levels == (10,) and K == 100 and d == 50
-    also = a.also if a.also is not None else ("ref,10M,share,c5,pbmc" if default_main else "none")
+    also = a.also if a.also is not None else ("ref,ref2,10M,share,c5,pbmc" if default_main else "none")
     if world == 1 and also != "none":
         # extra legs of this invocation (never part of `value`): each one is a full run to convergence from HBM-resident inputs
         del obj
@@ -965,6 +971,9 @@ def main():
                 if leg == "ref":       # every accumulator group in the reference's fp32 operation order on the main workload
                     legs["reference_arith"] = bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, a.seed, 2, 1, sync, ref_arith=1)
                     legs["reference_arith"]["parity"] = "vs the faithful oracle: cpu_baseline.gpu_reference_arith_vs_this_run (live, sample) and profiles/r5_parity_table_*.json (full size: gpu_ref_arith_vs_oracle_faithful)"
+                elif leg == "ref2":    # ref_arith = 2 (round 6): every group but the O / E tables -- inside north_star's 1e-4 of the fp32 reference (parity.reference_arith_2_mode), update_R in the block chain
+                    legs["reference_arith_2"] = bench_leg(Harmony, prepare_setup_args, n, d, K, levels, nested, a.seed, 2, 1, sync, ref_arith=2)
+                    legs["reference_arith_2"]["parity"] = "vs the faithful oracle: profiles/r6_parity_table_*.json (gpu_ref_arith2_vs_oracle_faithful: 1e-4 asserted, same iteration counts)"
                 elif leg == "10M":     # north_star's target size on ONE GPU: 10M x 50, K = 100, 20 batches (configs[3]'s total size)
                     legs["10M_one_gpu"] = bench_leg(Harmony, prepare_setup_args, 10000000, 50, 100, (20,), False, a.seed, 2, 1, sync)
                 elif leg == "share":   # one GPU's share of configs[3] on an 8-GPU node: 1.25M cells of the 10M, 20 batches
@@ -986,6 +995,10 @@ def main():
         if isinstance(ra, dict) and "cells_per_s" in ra:      # the mode whose arithmetic is the reference's, next to the headline (VERDICT r4 #1c)
             out["value_reference_arith"] = ra["cells_per_s"]
             out["ms_per_step_reference_arith"] = ra["ms_per_step"]
+        r2 = legs.get("reference_arith_2")
+        if isinstance(r2, dict) and "cells_per_s" in r2:
+            out["value_reference_arith_2"] = r2["cells_per_s"]
+            out["ms_per_step_reference_arith_2"] = r2["ms_per_step"]
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(n if a.cpu_full else a.cpu_sample, d, K, levels, nested, a.seed)
     elif rank == 0:

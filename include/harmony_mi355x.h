@@ -218,8 +218,9 @@ int hmx_set_abort_poll(hmx_ctx* ctx, int (*poll)(void*), void* user);
  * src/harmony.cpp:312-313,329-330,567,592-608); at 10^6 cells that is a visible, systematic bias.
  * hmx_set_int(ctx, "ref_arith", 1) before hmx_setup (one GPU) reproduces that arithmetic -- the O / E tables with their -= / += drift, the
  * objective's my_accu sums, the ridge statistics, the closed-form fp32 inverse -- as restarted sequential sums and follows
- * the CPU package's numbers to 2e-6 in Z_corr.  The accumulator groups can be switched one by one and the iteration of the restarted sums
- * tuned: include/harmony_mi355x_lab.h. */
+ * the CPU package's numbers to 2e-6 in Z_corr.  "ref_arith" = 2 keeps the O / E tables exact and reproduces the other three groups (the ones
+ * that move the result): 4e-5 .. 6e-5 from the CPU package at 10^6 .. 2 10^6 cells, inside the 1e-4 contract, at a bit over half the time.  The
+ * accumulator groups can be switched one by one and the iteration of the restarted sums tuned: include/harmony_mi355x_lab.h. */
 
 /* ---- measurement ----------------------------------------------------------------------------
  * HIP-event timing of the dominant kernel on the library's stream: after

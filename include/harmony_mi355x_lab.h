@@ -47,7 +47,7 @@ int32_t hmx_cluster_of_column(int32_t nct, int32_t ct, int32_t c);
  *   "oe_arith"     O, E as fp32 tables: block sums in the round's shuffled order, -= / += drift       (:149-150,312-313,329-330)
  *   "obj_arith"    compute_objective's three K*N-term my_accu sums                                       (src/utils.cpp:67-75)
  *   "solve_arith"  the closed-form fp32 arrowhead inverse of the one-covariate ridge system               (src/harmony.cpp:575-586)
- *   "ref_arith"    all four.
+ *   "ref_arith"    1: all four; 2: all but "oe_arith" (the groups that move the result; update_R in the persistent block chain).
  * The sequential sums are computed as RESTARTED sequential sums (segments in parallel, their starting values by fixed-point
  * iteration; at the fixed point the result is bit-identical to the one-after-the-other loop).  Settings (hmx_set_int):
  *   "seq_passes" passes of a sum that starts from zero (default 2), "seq_warm_passes" passes of a sum that starts from the starts of its

@@ -278,7 +278,7 @@ def test_writable_fields_validate_their_values():
               "max_iter_kmeans": 7, "seed": 42}
         for f, v in ok.items():
             assert lib.hmx_set_int(h, f.encode(), v) == 0, (f, lib.hmx_last_error(h))
-        bad = {"seq_passes": 1, "seq_warm_passes": 0, "seq_tol_ppb": -1, "seq_max_passes": 1000, "ref_arith": 2, "rng": 3, "no_such_field": 1}
+        bad = {"seq_passes": 1, "seq_warm_passes": 0, "seq_tol_ppb": -1, "seq_max_passes": 1000, "ref_arith": 3, "rng": 3, "no_such_field": 1}
         for f, v in bad.items():
             assert lib.hmx_set_int(h, f.encode(), v) != 0, f
             assert len(lib.hmx_last_error(h)) > 0

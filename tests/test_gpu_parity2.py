@@ -58,7 +58,7 @@ def test_arithmetic_gap_table(N):
     res, timing = {}, {}
 
     def gpu(name, ref_arith):
-        o = g if ref_arith == 0 else Harmony(seed=seed, ref_arith=1)
+        o = g if ref_arith == 0 else Harmony(seed=seed, ref_arith=ref_arith)
         if ref_arith:
             o._set("seq_stats", 1)
             o.setup(**skw)
@@ -84,6 +84,7 @@ def test_arithmetic_gap_table(N):
     [t.start() for t in th]
     gpu("gpu", 0)
     gpu("gpu_ref_arith", 1)
+    gpu("gpu_ref_arith2", 2)       # (round 6) "ref_arith" = 2: the reference's accumulators for the objective, the ridge statistics and the inverse, exact O / E tables
     [t.join() for t in th]
     if N == 1000000:       # BASELINE configs[2]: the width of "faithful" itself, measured next to the GPU -- the same oracle with ONE of its liberties flipped
         # (L1 sums with Armadillo's two accumulators, oracle header; on its own AFTER the other two: a third concurrent caller of the
@@ -92,7 +93,7 @@ def test_arithmetic_gap_table(N):
     assert {"gpu", "gpu_ref_arith", "oracle_accurate", "oracle_faithful"} <= set(res)
     rows = {}
     pairs = [("gpu", "oracle_accurate"), ("gpu", "oracle_faithful"), ("gpu_ref_arith", "oracle_faithful"),
-             ("gpu_ref_arith", "oracle_accurate"), ("oracle_faithful", "oracle_accurate")]
+             ("gpu_ref_arith", "oracle_accurate"), ("oracle_faithful", "oracle_accurate"), ("gpu_ref_arith2", "oracle_faithful"), ("gpu_ref_arith2", "gpu_ref_arith")]
     if "oracle_faithful_liberty1" in res:
         pairs.append(("oracle_faithful_liberty1", "oracle_faithful"))
     for a, b in pairs:
@@ -136,6 +137,12 @@ def test_arithmetic_gap_table(N):
     if "oracle_faithful_liberty1_vs_oracle_faithful" in rows:      # the GPU is as close to the oracle as the oracle is to itself
         lf = rows["oracle_faithful_liberty1_vs_oracle_faithful"]
         assert rf["Z_rel"] <= 3 * lf["Z_rel"], (rf, lf)       # (max |dR| is one cell of one small cluster on both sides: reported, 5e-5 .. 1.4e-3 across liberties and centres)
+    # (3) "ref_arith" = 2 -- every group but the O / E tables: north_star's 1e-4 against the faithful oracle with the same iteration counts; what the exact tables
+    # leave (the reference's -= / += drift of O and E) is 4e-6 at 100k cells, 4e-5 at 1M, 6e-5 at 2M.  Hard assignments: reported (the drift it does not follow moves
+    # R by a few 1e-4: clear flips in the tens at 1M), bounded at N / 10^4.
+    r2 = rows["gpu_ref_arith2_vs_oracle_faithful"]
+    assert r2["Z_rel"] <= 1e-4 and r2["iterations"][0] == r2["iterations"][1] and r2["objective_rel_max"] <= 1e-3, r2
+    assert r2["argmax_diff_margin_ge_1e-4"] <= max(2, N // 10000), r2
     # (gf -- default GPU vs the reference's fp32 drift -- is REPORTED, not asserted: it is the reference's N-dependent bias)
     assert gf["iterations"][0] == gf["iterations"][1], gf
 

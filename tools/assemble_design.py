@@ -49,6 +49,10 @@ if d:
         vals["REF_MS"] = fmt(ra["ms_per_step"], 1)
         vals["REF_CPS"] = fmt(ra["cells_per_s"] / 1e6, 1)
         vals["PHASES_REF"] = ", ".join("%s %s" % (k, fmt(v, 1)) for k, v in ra["gpu_phase_ms_per_step"].items())
+    r2 = also.get("reference_arith_2")
+    if r2 and "ms_per_step" in r2:
+        vals["REF2_MS"] = fmt(r2["ms_per_step"], 1)
+        vals["REF2_CPS"] = fmt(r2["cells_per_s"] / 1e6, 1)
     for key, leg in (("10M", "10M_one_gpu"), ("SHARE", "configs3_share_1p25M"), ("C5_1M", "c5_shape_1M"), ("PBMC", "pbmc30k")):
         if leg in also and "ms_per_step" in also[leg]:
             vals[key + "_MS"] = fmt(also[leg]["ms_per_step"], 1)
