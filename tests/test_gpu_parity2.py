@@ -721,10 +721,11 @@ def test_config5_shape_1M_to_convergence():
     Z, meta, _ = synth(1_000_000, d=50, levels=(8, 64, 128), seed=11, nested=True)
     # (round 6: + the faithful oracle with ONE of its own sums taken in another order Armadillo is free to choose -- L1 sums with two accumulators,
     #  liberty bit 0: how wide "faithful" is at THIS shape, the yardstick of the reference-arithmetic pair's flips)
-    res, timing = _run_pair_to_convergence(Z, meta, 200, 5, {"gpu": {}, "gpu_ref_arith": {"ref_arith": 1}},
+    res, timing = _run_pair_to_convergence(Z, meta, 200, 5, {"gpu": {}, "gpu_ref_arith": {"ref_arith": 1}, "gpu_ref_arith2": {"ref_arith": 2}},
                                            {"oracle_accurate": 15, "oracle_faithful": 0, "oracle_faithful_liberty1": (0, 1)})
     rows = {"gpu_vs_oracle_accurate": _pair_row(res["gpu"], res["oracle_accurate"]), "gpu_vs_oracle_faithful": _pair_row(res["gpu"], res["oracle_faithful"]),
             "gpu_ref_arith_vs_oracle_faithful": _pair_row(res["gpu_ref_arith"], res["oracle_faithful"]),
+            "gpu_ref_arith2_vs_oracle_faithful": _pair_row(res["gpu_ref_arith2"], res["oracle_faithful"]),
             "oracle_faithful_liberty1_vs_oracle_faithful": _pair_row(res["oracle_faithful_liberty1"], res["oracle_faithful"]),
             "oracle_faithful_vs_oracle_accurate": _pair_row(res["oracle_faithful"], res["oracle_accurate"])}
     out = {"workload": {"cells": 1000000, "pcs": 50, "clusters": 200, "levels": [8, 64, 128], "nested": True}, "seconds": timing, "pairs": rows}
@@ -751,6 +752,9 @@ def test_config5_shape_1M_to_convergence():
     assert rf["Z_rel"] <= 3 * lib["Z_rel"] + 2e-6 and rf["argmax_diff_margin_ge_1e-5"] <= 3 * lib["argmax_diff_margin_ge_1e-5"] + 5, (rf, lib)
     gf = rows["gpu_vs_oracle_faithful"]      # reported: the default mode against the reference's fp32 drift at this shape
     assert gf["iterations"][0] == gf["iterations"][1], gf
+    # "ref_arith" = 2 at this shape (round 6): every group but the O / E tables -- north_star's 1e-4 against the faithful oracle, same iterations and subset clusters
+    r2 = rows["gpu_ref_arith2_vs_oracle_faithful"]
+    assert r2["Z_rel"] <= 1e-4 and r2["iterations"][0] == r2["iterations"][1] and r2["subset_clusters_per_iteration"][0] == r2["subset_clusters_per_iteration"][1], r2
 
 
 @pytest.mark.timeout(3000, method="thread")
