@@ -185,16 +185,16 @@ def test_chain_with_three_and_more_tiles_per_wave_equals_launch_per_step(monkeyp
     assert relfro(Z1, Z0) < 1e-6 and float(np.max(np.abs(o1 - o0) / np.abs(o0))) < 1e-6
 
 
-@pytest.mark.parametrize("N,levels", [(60000, (8, 64, 128)), (1300000, (8, 64, 128)), (300000, (10,))])
-def test_wave_pair_chain_equals_launch_per_step(monkeypatch, N, levels):
+@pytest.mark.parametrize("N,levels,K", [(60000, (8, 64, 128), 200), (1300000, (8, 64, 128), 200), (300000, (10,), 200), (250000, (6, 5), 116), (400000, (10,), 152), (500000, (4, 30), 180)])
+def test_wave_pair_chain_equals_launch_per_step(monkeypatch, N, levels, K):
     """BASELINE configs[4]'s shape (K = 200, 8 > 64 > 128 nested levels): the block chain by wave pairs (k_tile MODE 6, round 6: two halves of the clusters on the
     two waves of a pair, a row's normalisation sum exchanged through LDS, several folder workgroups, the penalty rows from memory) against the
     launch-per-step kernels on the same data.  60k cells: at most one tile per pair and block, streams without a tile; 1.3M cells: four and five tiles
     per pair -- the tile loop, the deferred last epilogue, and (fifth tile) the penalty rows fetched outside the wave's LDS cache.  The two paths add the halves
     of a row sum in a different order: R agrees to the last bits, the integer tables to 1e-6, nothing is bit-identical.  300k cells with ONE covariate of 10
     levels: the round-to-round carry of the old contributions is on (tiles keyed by the next block, rounds without R stores) inside the wave-pair chain."""
-    Z, meta, _ = synth(N, d=50, levels=levels, seed=11, nested=len(levels) > 1)
-    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=200)
+    Z, meta, _ = synth(N, d=50, levels=levels, seed=11, nested=len(levels) == 3)
+    skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)      # (K = 116 / 152 / 180: halves of 4 / 5 / 6 cluster tiles)
     out, Y0 = [], None
     for pair in ("1", "0"):
         monkeypatch.setenv("HMX_CHAIN_PAIR", pair)
@@ -207,7 +207,7 @@ def test_wave_pair_chain_equals_launch_per_step(monkeypatch, N, levels):
             assert g.cluster_cpp() == 0
             g.moe_correct_ridge_cpp()
         out.append((int(g._scalar("chain_pair")), int(g._scalar("chain")), g.getZcorr().copy(), np.array(g.objective_kmeans), np.array(g.O), g.getR().copy() if N <= 100000 else None))
-        if len(levels) == 1:
+        if levels == (10,) and K == 200:
             assert g._scalar("sold_carry") == 1
         del g
     (p1, c1, Z1, o1, O1, R1), (p0, c0, Z0, o0, O0, R0) = out
