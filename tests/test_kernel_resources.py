@@ -55,7 +55,8 @@ def test_only_the_documented_kernels_use_scratch(objs):
                 m = re.match(r"k_tile<(\d+), (\d+),", name)
                 assert m, "%s: %s spills %d VGPRs" % (o, name, r[".vgpr_spill_count"])
                 nct, mode = int(m.group(1)), int(m.group(2))
-                assert (mode in (4, 5, 6) and nct >= 6) or (mode == 0 and nct >= 12) or (mode == 1 and nct >= 14), (o, name, r[".vgpr_spill_count"])      # (mode 6: the wave-pair chain, 17)
+                # (mode 6, the wave-pair chain: 17 spilled registers at 7 cluster tiles per half; the 4- to 6-tile variants spill none and keep a 32-byte stack slot)
+                assert (mode in (4, 5) and nct >= 6) or (mode == 6 and (nct >= 7 or r[".vgpr_spill_count"] == 0)) or (mode == 0 and nct >= 12) or (mode == 1 and nct >= 14), (o, name, r[".vgpr_spill_count"])
                 assert r[".vgpr_spill_count"] <= 150, (o, name)
     # the kernels of the headline configuration (K = 100: 7 cluster tiles, split-bf16 build)
     bf = objs["hmx_tile_bf"]
