@@ -817,8 +817,8 @@ def test_config5_5M_against_the_oracle():
     else:
         # Round 6, second builder run (another box: another OpenBLAS kernel under the oracle's sgemm): the faithful oracle kept 27 clusters on the subset path in the
         # first correction, its own liberty variant 29, the GPU 31 -- a level's O[k, b] / N_b sits on the cutoff (src/harmony.cpp:368-402) and fp32 sums over 5M
-        # cells decide it differently in every legal order; ALL pairs then differ by 1.4e-3 .. 1.8e-3 (profiles/r6_parity_c5_5M.json: GPU 1.41e-3 / 12 409 clear
-        # flips, the oracle against itself 1.76e-3 / 10 734).  The round's first run (profiles/r6_parity_c5_5M_first_run.json) had all three at 31 and the pair at
+        # cells decide it differently in every legal order; ALL pairs then differ by 1.4e-3 .. 1.8e-3 (profiles/r6_parity_c5_5M_second_run.json: GPU 1.41e-3 / 12 409
+        # clear flips, the oracle against itself 1.76e-3 / 10 734).  The round's first and third run (profiles/r6_parity_c5_5M.json) had all three at 31 and the pair at
         # 1.0e-5 / 192 against the oracle's own 1.0e-5 / 247.  Bounded by the liberty row above; the subset-cluster count within the spread the oracle itself shows.
         spread = abs(lib["subset_clusters_per_iteration"][0][0] - lib["subset_clusters_per_iteration"][1][0])
         assert abs(rf["subset_clusters_per_iteration"][0][0] - rf["subset_clusters_per_iteration"][1][0]) <= 2 * spread + 2, (rf, lib)
