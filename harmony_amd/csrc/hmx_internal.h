@@ -154,6 +154,7 @@ struct Dev {
   double* nq;       // [Q][K]     sum_i R_ki
   // deterministic statistics pass (k_moe_stats_q): per-(workgroup, combination run) partial slots, reduced in fixed order
   int st_dma, st_nwg, st_cpw;       // enabled, workgroups, 16-cell tiles per workgroup
+  int st_halves, st_KH;             // 2: K in (128, 224] -- the pass runs once per half of the clusters ([0, st_KH) / [st_KH, K), blockIdx.y), each with <= 8 cluster tiles
   double* st_part;                  // [slots][K*d + K]
   int* st_slot0;                    // [st_nwg] first slot of every workgroup
   int* st_qptr; int* st_qslots;     // CSR: slots of every combination in ascending (= cell) order
