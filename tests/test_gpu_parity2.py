@@ -664,7 +664,7 @@ def test_update_order_must_be_a_permutation(cell_lines_small):
 
 def _run_pair_to_convergence(Z, meta, K, seed, gpu_kw, masks, max_iter=10, blas_threads=4):
     """one GPU handle and one oracle per arithmetic mask on the same problem (shared k-means centres, shared documented shuffles), each to
-    convergence; the oracles run in threads next to the GPU.  Returns {name: dict(Z, R, it, obj, rounds, subset)}."""
+    convergence; the first two oracles run in threads next to the GPU, further ones after them.  Returns {name: dict(Z, R, it, obj, rounds, subset)}."""
     skw, _ = prepare_setup_args(Z, meta, list(meta), nclust=K)
     res, timing = {}, {}
     g0 = Harmony(seed=seed)
@@ -691,14 +691,20 @@ def _run_pair_to_convergence(Z, meta, K, seed, gpu_kw, masks, max_iter=10, blas_
         drive(name, o)
 
     orc.use_openblas(blas_threads)
+    # AT MOST TWO oracles call the bundled OpenBLAS at a time.  With three concurrent callers one or two of them came back with a different trajectory -- on some
+    # boxes only: the 5M table's second builder run (two faithful oracles off by 1.4e-3 .. 1.8e-3, the accurate one fine) and a run of the 1M-shape test in which
+    # the fp64-accumulator oracle itself moved by 3.6e-3 against every GPU variant and against its own earlier runs (round 6; test_arithmetic_gap_table had met
+    # the same with its third oracle in round 5 and runs it on its own).  The others follow one by one.
     th = [threading.Thread(target=cpu, args=((nm,) + (mk if isinstance(mk, tuple) else (mk, 0)))) for nm, mk in masks.items()]      # (mask, or (mask, liberty bits))
-    [t.start() for t in th]
+    [t.start() for t in th[:2]]
     for nm, kw in gpu_kw.items():
         o = Harmony(seed=seed, **kw)
         o.setup(**skw)
         drive(nm, o)
         del o
-    [t.join() for t in th]
+    [t.join() for t in th[:2]]
+    for t in th[2:]:
+        t.start(); t.join()
     return res, timing
 
 
@@ -815,11 +821,9 @@ def test_config5_5M_against_the_oracle():
         # where the oracle agrees with itself on which clusters take the batch-subset ridge path: north_star's 1e-4, and the same clusters on the GPU
         assert rf["Z_rel"] <= 1e-4 and rf["subset_clusters_per_iteration"][0] == rf["subset_clusters_per_iteration"][1], rf
     else:
-        # Round 6, second builder run (another box: another OpenBLAS kernel under the oracle's sgemm): the faithful oracle kept 27 clusters on the subset path in the
-        # first correction, its own liberty variant 29, the GPU 31 -- a level's O[k, b] / N_b sits on the cutoff (src/harmony.cpp:368-402) and fp32 sums over 5M
-        # cells decide it differently in every legal order; ALL pairs then differ by 1.4e-3 .. 1.8e-3 (profiles/r6_parity_c5_5M_second_run.json: GPU 1.41e-3 / 12 409
-        # clear flips, the oracle against itself 1.76e-3 / 10 734).  The round's first and third run (profiles/r6_parity_c5_5M.json) had all three at 31 and the pair at
-        # 1.0e-5 / 192 against the oracle's own 1.0e-5 / 247.  Bounded by the liberty row above; the subset-cluster count within the spread the oracle itself shows.
+        # (Round 6, second builder run: the faithful oracle kept 27 clusters on the subset path in the first correction, its liberty variant 29, the GPU 31, ALL pairs
+        #  1.4e-3 .. 1.8e-3 apart -- profiles/r6_parity_c5_5M_second_run.json.  Read as a knife edge of the reference's arithmetic at first; it was three oracle threads
+        #  in the bundled OpenBLAS at once, see _run_pair_to_convergence.  The branch stays as the bound for an oracle that disagrees with itself.)
         spread = abs(lib["subset_clusters_per_iteration"][0][0] - lib["subset_clusters_per_iteration"][1][0])
         assert abs(rf["subset_clusters_per_iteration"][0][0] - rf["subset_clusters_per_iteration"][1][0]) <= 2 * spread + 2, (rf, lib)
 
