@@ -1,3 +1,6 @@
+"""configs[4]'s shape (K = 200, 8 > 64 > 128 levels) through two corrections on the GPU with the statistics kernel and the chain switched -- default /
+HMX_MOE_STATS=atomic / HMX_CHAIN_PAIR=0 -- and the three variants against each other: Z_corr, O, objective series, subset clusters per correction (python
+tools/gpu_runs/gpu_variants_check.py on the GPU box).  The check that cleared the GPU when an oracle run came back different."""
 import sys, os, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -18,7 +21,7 @@ sys.path.insert(0, "/root/repo/tests")
 res = {}
 for n in (200000, 1000000):
     for name, env in (("default", {}), ("atomic", {"HMX_MOE_STATS": "atomic"}), ("nopair", {"HMX_CHAIN_PAIR": "0"})):
-        f = "/tmp/dbg_%s_%d.npz" % (name, n)
+        f = "/tmp/variant_%s_%d.npz" % (name, n)
         r = subprocess.run([sys.executable, __file__, str(n), f], env=dict(os.environ, PYTHONPATH=os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"), **env), capture_output=True, text=True)
         if r.returncode: print(name, r.stderr[-500:])
         res[(name, n)] = np.load(f)
